@@ -1,0 +1,164 @@
+/*
+ * gpe.h — C-ABI of libgpengine.so, the MI355X (gfx950) GP posterior engine.
+ *
+ * This is the drop-in boundary for the hot path of resibots/limbo's
+ * `limbo::model::GP<Params, Kernel, Mean, HPOpt>` (reference file
+ * src/limbo/model/gp.hpp).  The reference has no FFI of its own (it is a
+ * header-only C++ template over Eigen), so every entry point below names the
+ * reference member function / Eigen call-site it replaces.  The C++ drop-in
+ * template in include/limbo_amd/ is the only intended caller besides the test
+ * and benchmark harnesses.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - host pointers are caller-owned; the library copies (H2D/D2H) unless the
+ *     function name ends in `_device`, in which case the pointer is a HIP
+ *     device pointer on the handle's device.
+ *   - matrices are COLUMN-MAJOR (Eigen::MatrixXd default) unless the name says
+ *     `rowmajor`; sample matrices are row-major N x D (one sample per row,
+ *     i.e. the concatenation of limbo's std::vector<Eigen::VectorXd>).
+ *   - every function returns an int status: 0 = ok; >0 = 1-based index of the
+ *     first non-positive Cholesky pivot (the reference never checks
+ *     Eigen::LLT::info(), gp.hpp:565 — the C++ wrapper mirrors that and just
+ *     records it); <0 = GPE_ERR_*.
+ *   - hyper-parameters are in limbo's log-space (kernel/kernel.hpp:104-123).
+ *   - one handle = one GP = one HIP stream; different handles may be driven
+ *     from different host threads concurrently; const queries on one handle
+ *     are serialised by an internal mutex.
+ */
+#ifndef GPE_H
+#define GPE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpe_ctx* gpe_handle;
+
+enum gpe_status {
+    GPE_OK = 0,
+    GPE_ERR_ARG = -1,      /* bad argument / shape (reference: assert) */
+    GPE_ERR_STATE = -2,    /* call order (e.g. log_lik before compute) */
+    GPE_ERR_HIP = -3,      /* HIP runtime error, see gpe_last_error()   */
+    GPE_ERR_NOMEM = -4,
+    GPE_ERR_UNSUPPORTED = -5
+};
+
+/* kernel functors with device code.
+ * SE_ARD    kernel/squared_exp_ard.hpp:138-151 (k = 0 only)  theta = [log l_1..log l_D, log sigma_f]
+ * MATERN52  kernel/matern_five_halves.hpp:104-113            theta = [log l, log sigma_f]
+ * MATERN32  kernel/matern_three_halves.hpp                   theta = [log l, log sigma_f]
+ * EXP       kernel/exp.hpp                                   theta = [log l, log sigma_f]
+ * HOST_K    any user functor: K is built on the host by the C++ wrapper and
+ *           uploaded with gpe_set_K_host(); factorisation/solves stay on device.
+ */
+enum gpe_kernel_kind {
+    GPE_KERNEL_SE_ARD = 0,
+    GPE_KERNEL_MATERN52 = 1,
+    GPE_KERNEL_MATERN32 = 2,
+    GPE_KERNEL_EXP = 3,
+    GPE_KERNEL_HOST_K = 4
+};
+
+/* ---- lifetime ------------------------------------------------------------ */
+int gpe_create(int device_id, gpe_handle* out);
+/* deep copy (value semantics of limbo::model::GP, e.g. kernel_lf_opt.hpp:79) */
+int gpe_clone(gpe_handle src, gpe_handle* out);
+int gpe_destroy(gpe_handle h);
+const char* gpe_last_error(gpe_handle h);
+const char* gpe_version(void);
+
+/* ---- data & hyper-parameters -------------------------------------------- */
+/* gp.hpp:105-111 + :537-548.  X: N x D row-major.  obs_mean = Y - m(X), N x P
+ * column-major; the mean functor is evaluated on the host by the caller
+ * (it receives the GP itself, mean/data.hpp:59-63). */
+int gpe_set_data(gpe_handle h, const double* X_rowmajor, int64_t N, int D,
+                 const double* obs_mean, int P);
+/* same, from device memory already resident on the handle's device */
+int gpe_set_data_device(gpe_handle h, const double* dX_rowmajor, int64_t N, int D,
+                        const double* d_obs_mean, int P);
+/* kernel.hpp:116-123 set_h_params + the per-kernel set_params.  log_theta has
+ * n_theta entries (without the optional noise parameter); noise is sigma_n^2
+ * (Params::kernel::noise(), or exp(2 p_noise) when optimize_noise). */
+int gpe_set_kernel(gpe_handle h, int kind, const double* log_theta, int n_theta, double noise);
+/* HOST_K fallback: full symmetric K (N x N, ld >= N), noise already on the diagonal */
+int gpe_set_K_host(gpe_handle h, const double* K, int64_t ldk);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* gp.hpp:550-571 `_compute_full_kernel`: K (kernel build, +noise+1e-8 on the
+ * diagonal) -> L = chol(K) (replaces Eigen::LLT, gp.hpp:565) -> alpha
+ * (gp.hpp:605-611).  Everything stays in HBM. */
+int gpe_compute(gpe_handle h);
+/* gp.hpp:241-252 recompute(update_obs_mean, false): new obs_mean, same L */
+int gpe_update_alpha(gpe_handle h, const double* obs_mean);
+/* gp.hpp:126-152 + :573-603: append one sample; obs_mean is the FULL new
+ * (N+1) x P matrix (mean::Data moves every row when a sample is added).  On an
+ * empty handle D and P set the dimensions (gp.hpp:128-137); otherwise they
+ * must match (gp.hpp:139-140 assert -> GPE_ERR_ARG). */
+int gpe_add_sample(gpe_handle h, const double* x, int D, const double* obs_mean, int P);
+/* gp.hpp:267-282 compute_log_lik */
+int gpe_log_lik(gpe_handle h, double* out);
+/* gp.hpp:254-264 compute_inv_kernel (K^-1 from L, cached until K changes) */
+int gpe_compute_inv_kernel(gpe_handle h);
+/* gp.hpp:285-311 compute_kernel_grad_log_lik (+ kernel.hpp:86-96 noise term).
+ * grad has n_theta (+1 if optimize_noise) entries. */
+int gpe_log_lik_grad(gpe_handle h, double* grad, int n_grad, int optimize_noise);
+/* model/gp/kernel_lf_opt.hpp:77-92 KernelLFOptimization::operator() in one
+ * call, without the reference's per-evaluation deep copy: set theta (and
+ * noise), recompute(false), log-lik and (optionally) its gradient. */
+int gpe_hp_objective(gpe_handle h, int kind, const double* log_theta, int n_theta,
+                     double noise, int optimize_noise, int want_grad,
+                     double* log_lik, double* grad);
+/* gp.hpp:613-632 for a batch of M points (row-major M x D):
+ *   kta[m + M*p] = k(X, v_m)^T alpha_p          (add m(v) on the host, :615)
+ *   var[m]       = k(v_m, v_m) - ||L^-1 k*||^2  (clamp and +noise on the host, :166,:623)
+ * either output may be NULL. */
+int gpe_query_batch(gpe_handle h, const double* Xq_rowmajor, int64_t M,
+                    double* kta, double* var);
+
+/* ---- accessors (host mirrors for matrixL()/alpha()/save/load) ------------ */
+int gpe_nb_samples(gpe_handle h, int64_t* N);
+int gpe_get_L(gpe_handle h, double* L, int64_t ld);          /* lower, upper part zeroed (gp.hpp:411) */
+int gpe_set_L(gpe_handle h, const double* L, int64_t ld);    /* load(..., recompute=false) gp.hpp:506-509 */
+int gpe_get_alpha(gpe_handle h, double* alpha);              /* N x P */
+int gpe_set_alpha(gpe_handle h, const double* alpha);
+int gpe_get_Kinv(gpe_handle h, double* Kinv, int64_t ld);    /* full symmetric */
+int gpe_get_K(gpe_handle h, double* K, int64_t ld);          /* rebuilds K; for tests */
+
+/* ---- independent GPs: multi_gp.hpp:124-126, parallel_repeater.hpp:86-105 -- */
+/* run gpe_compute on G handles (same device): kernels of different GPs are
+ * interleaved on the device instead of being serialised. */
+int gpe_batch_compute(gpe_handle* hs, int G, int* status);
+int gpe_batch_log_lik(gpe_handle* hs, int G, double* out);
+
+/* ---- instrumentation ----------------------------------------------------- */
+/* HIP stream the handle launches on (hipStream_t as void*) */
+int gpe_get_stream(gpe_handle h, void** stream);
+int gpe_synchronize(gpe_handle h);
+/* when on, gpe_compute brackets every phase with HIP events on the handle's
+ * stream; read back with gpe_get_phase_ms (sums since the last reset). */
+enum gpe_phase {
+    GPE_PH_KERNEL_BUILD = 0,
+    GPE_PH_POTRF_PANEL = 1,
+    GPE_PH_POTRF_UPDATE = 2,   /* trailing SYRK/GEMM (fp64 MFMA) */
+    GPE_PH_SOLVE = 3,
+    GPE_PH_LOGLIK = 4,
+    GPE_PH_INV = 5,
+    GPE_PH_GRAD = 6,
+    GPE_PH_QUERY = 7,
+    GPE_PH_COUNT = 8
+};
+int gpe_set_profiling(gpe_handle h, int on);
+int gpe_get_phase_ms(gpe_handle h, double* ms, int64_t* launches, double* flops, int n);
+int gpe_reset_phase_ms(gpe_handle h);
+/* fp64 MFMA peak micro-benchmark (v_mfma_f64_16x16x4_f64), TFLOP/s */
+int gpe_mfma_f64_peak(int device_id, double* tflops);
+/* HBM write-stream micro-benchmark, GB/s */
+int gpe_hbm_stream_peak(int device_id, double* gbs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPE_H */

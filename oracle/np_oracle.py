@@ -1,0 +1,348 @@
+"""Independent numpy/scipy (LAPACK) and mpmath restatements of limbo's GP path.
+
+TEST INFRASTRUCTURE ONLY — imported from tests/ and oracle/make_golden.py, never by the
+product.  Written independently of gp_oracle.c (vectorised / LAPACK / arbitrary precision
+instead of scalar loops) so that the two can cross-validate each other; each function cites
+the reference file:line (relative to /root/reference) whose semantics it follows.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SE_ARD, MATERN52, MATERN32, EXP = 0, 1, 2, 3
+
+
+# --------------------------------------------------------------------------- numpy / LAPACK
+def kernel_cross(kind, X1, X2, theta):
+    """k(x1_i, x2_j) without noise.  squared_exp_ard.hpp:138-151 (k=0),
+    matern_five_halves.hpp:104-113, matern_three_halves.hpp:101-107, exp.hpp:97-102."""
+    X1 = np.asarray(X1, float)
+    X2 = np.asarray(X2, float)
+    theta = np.asarray(theta, float)
+    D = X1.shape[1]
+    if kind == SE_ARD:
+        ell = np.exp(theta[:D])
+        sf2 = np.exp(2.0 * theta[D])
+        q = (X1[:, None, :] - X2[None, :, :]) / ell
+        return sf2 * np.exp(-0.5 * np.sum(q * q, axis=2))
+    l = np.exp(theta[0])
+    sf2 = np.exp(2.0 * theta[1])
+    diff = X1[:, None, :] - X2[None, :, :]
+    s = np.sum(diff * diff, axis=2)
+    if kind == MATERN52:
+        d = np.sqrt(s)
+        t1 = np.sqrt(5.0) * d / l
+        t2 = 5.0 * (d * d) / (3.0 * l * l)
+        return sf2 * (1 + t1 + t2) * np.exp(-t1)
+    if kind == MATERN32:
+        t = np.sqrt(3.0) * np.sqrt(s) / l
+        return sf2 * (1 + t) * np.exp(-t)
+    return sf2 * np.exp(-0.5 * s / (l * l))
+
+
+def kernel_matrix(kind, X, theta, noise):
+    """gp.hpp:550-562 with BaseKernel::operator() (kernel.hpp:81-84): +noise+1e-8 on i==j."""
+    K = kernel_cross(kind, X, X, theta)
+    K = np.tril(K) + np.tril(K, -1).T  # the reference mirrors the lower triangle
+    K[np.diag_indices_from(K)] += noise + 1e-8
+    return K
+
+
+def kernel_grad_tensor(kind, X, theta):
+    """dk/dtheta_t for all pairs: (T, N, N).  squared_exp_ard.hpp:127-135,
+    matern_five_halves.hpp:115-133, matern_three_halves.hpp:109-121, exp.hpp:104-113."""
+    X = np.asarray(X, float)
+    theta = np.asarray(theta, float)
+    N, D = X.shape
+    if kind == SE_ARD:
+        ell = np.exp(theta[:D])
+        sf2 = np.exp(2.0 * theta[D])
+        q = (X[:, None, :] - X[None, :, :]) / ell
+        z = q * q
+        k = sf2 * np.exp(-0.5 * z.sum(axis=2))
+        G = np.empty((D + 1, N, N))
+        for d in range(D):
+            G[d] = z[:, :, d] * k
+        G[D] = 2 * k
+        return G
+    l = np.exp(theta[0])
+    sf2 = np.exp(2.0 * theta[1])
+    diff = X[:, None, :] - X[None, :, :]
+    s = np.sum(diff * diff, axis=2)
+    G = np.empty((2, N, N))
+    if kind == MATERN52:
+        d = np.sqrt(s)
+        t1 = np.sqrt(5.0) * d / l
+        t2 = 5.0 * (d * d) / (3.0 * l * l)
+        r = np.exp(-t1)
+        G[0] = sf2 * (r * t1 * (1 + t1 + t2) + (-t1 - 2.0 * t2) * r)
+        G[1] = 2 * sf2 * (1 + t1 + t2) * r
+    elif kind == MATERN32:
+        t = np.sqrt(3.0) * np.sqrt(s) / l
+        r = np.exp(-t)
+        G[0] = sf2 * (-t * r + (1 + t) * t * r)
+        G[1] = 2 * sf2 * (1 + t) * r
+    else:
+        r = s / (l * l)
+        k = sf2 * np.exp(-0.5 * r)
+        G[0] = r * k
+        G[1] = 2 * k
+    return G
+
+
+def gp_fit(kind, X, obs_mean, theta, noise):
+    """compute(): K, L, alpha (gp.hpp:550-571, :605-611) via LAPACK dpotrf/dtrtrs."""
+    import scipy.linalg as sla
+
+    obs_mean = np.asarray(obs_mean, float)
+    if obs_mean.ndim == 1:
+        obs_mean = obs_mean[:, None]
+    K = kernel_matrix(kind, X, theta, noise)
+    L = sla.cholesky(K, lower=True)
+    y = sla.solve_triangular(L, obs_mean, lower=True)
+    alpha = sla.solve_triangular(L, y, lower=True, trans="T")
+    return K, L, alpha
+
+
+def log_lik(L, obs_mean, alpha):
+    """gp.hpp:267-282 (P-quirk: logdet and n log 2pi not multiplied by P)."""
+    obs_mean = np.asarray(obs_mean, float).reshape(L.shape[0], -1)
+    n = L.shape[0]
+    logdet = 2.0 * np.sum(np.log(np.diag(L)))
+    a = np.sum(obs_mean * alpha)
+    return -0.5 * a - 0.5 * logdet - 0.5 * n * np.log(2 * np.pi)
+
+
+def inv_kernel(L):
+    """gp.hpp:254-264."""
+    import scipy.linalg as sla
+
+    n = L.shape[0]
+    Li = sla.solve_triangular(L, np.eye(n), lower=True)
+    return Li.T @ Li
+
+
+def log_lik_grad(kind, X, theta, noise, L, alpha, optimize_noise=False):
+    """gp.hpp:285-311 + kernel.hpp:86-96: sum over i>=j with 1/2 on the diagonal."""
+    Kinv = inv_kernel(L)
+    W = alpha @ alpha.T - Kinv
+    G = kernel_grad_tensor(kind, X, theta)
+    n = L.shape[0]
+    tri = np.tril(np.ones((n, n)))
+    tri[np.diag_indices(n)] = 0.5
+    g = [np.sum(W * tri * G[t]) for t in range(G.shape[0])]
+    if optimize_noise:
+        g.append(np.sum(np.diag(W) * 0.5 * 2.0 * noise))
+    return np.array(g)
+
+
+def query(kind, X, theta, L, alpha, Xq):
+    """gp.hpp:613-632: returns (k*^T alpha [M,P], k(v,v) - ||L^-1 k*||^2 [M])."""
+    import scipy.linalg as sla
+
+    Ks = kernel_cross(kind, X, Xq, theta)  # N x M, no noise (kernel.hpp:81 defaults i=-1,j=-2)
+    kta = Ks.T @ alpha
+    Z = sla.solve_triangular(L, Ks, lower=True)
+    kvv = np.array([kernel_cross(kind, Xq[m:m + 1], Xq[m:m + 1], theta)[0, 0] for m in range(Xq.shape[0])])
+    return kta, kvv - np.sum(Z * Z, axis=0)
+
+
+def finish_query(kta, var_raw, mean_at_v, noise):
+    """What the C++ wrapper applies on the host: mu = k^T alpha + m(v) (gp.hpp:615);
+    sigma^2 = (res <= eps ? 0 : res) + noise (gp.hpp:623, :166)."""
+    eps = np.finfo(float).eps
+    var = np.where(var_raw <= eps, 0.0, var_raw) + noise
+    return kta + mean_at_v, var
+
+
+# --------------------------------------------------------------------------- mpmath ground truth
+def mp_gp(kind, X, obs_mean, theta, noise, Xq=None, optimize_noise=False, dps=50):
+    """50-digit evaluation of the same formulas (exact-arithmetic stand-in for 'what the
+    reference computes up to fp64 rounding').  Small N only (O(N^3) in Python)."""
+    import mpmath as mp
+
+    mp.mp.dps = dps
+    X = np.asarray(X, float)
+    obs_mean = np.asarray(obs_mean, float).reshape(X.shape[0], -1)
+    N, D = X.shape
+    P = obs_mean.shape[1]
+    th = [mp.mpf(float(t)) for t in theta]
+    nz = mp.mpf(float(noise))
+
+    def kf(a, b):
+        if kind == SE_ARD:
+            z = mp.mpf(0)
+            for d in range(D):
+                q = (mp.mpf(float(a[d])) - mp.mpf(float(b[d]))) / mp.exp(th[d])
+                z += q * q
+            return mp.exp(2 * th[D]) * mp.exp(-z / 2)
+        l = mp.exp(th[0])
+        sf2 = mp.exp(2 * th[1])
+        s = mp.mpf(0)
+        for d in range(D):
+            q = mp.mpf(float(a[d])) - mp.mpf(float(b[d]))
+            s += q * q
+        if kind == MATERN52:
+            dd = mp.sqrt(s)
+            t1 = mp.sqrt(5) * dd / l
+            t2 = 5 * s / (3 * l * l)
+            return sf2 * (1 + t1 + t2) * mp.exp(-t1)
+        if kind == MATERN32:
+            t = mp.sqrt(3) * mp.sqrt(s) / l
+            return sf2 * (1 + t) * mp.exp(-t)
+        return sf2 * mp.exp(-s / (2 * l * l))
+
+    def gf(a, b):
+        if kind == SE_ARD:
+            zs = []
+            for d in range(D):
+                q = (mp.mpf(float(a[d])) - mp.mpf(float(b[d]))) / mp.exp(th[d])
+                zs.append(q * q)
+            k = mp.exp(2 * th[D]) * mp.exp(-sum(zs) / 2)
+            return [z * k for z in zs] + [2 * k]
+        l = mp.exp(th[0])
+        sf2 = mp.exp(2 * th[1])
+        s = mp.mpf(0)
+        for d in range(D):
+            q = mp.mpf(float(a[d])) - mp.mpf(float(b[d]))
+            s += q * q
+        if kind == MATERN52:
+            dd = mp.sqrt(s)
+            t1 = mp.sqrt(5) * dd / l
+            t2 = 5 * s / (3 * l * l)
+            r = mp.exp(-t1)
+            return [sf2 * (r * t1 * (1 + t1 + t2) + (-t1 - 2 * t2) * r), 2 * sf2 * (1 + t1 + t2) * r]
+        if kind == MATERN32:
+            t = mp.sqrt(3) * mp.sqrt(s) / l
+            r = mp.exp(-t)
+            return [sf2 * (-t * r + (1 + t) * t * r), 2 * sf2 * (1 + t) * r]
+        r = s / (l * l)
+        k = sf2 * mp.exp(-r / 2)
+        return [r * k, 2 * k]
+
+    K = mp.zeros(N, N)
+    for i in range(N):
+        for j in range(i + 1):
+            v = kf(X[i], X[j])
+            if i == j:
+                v += nz + mp.mpf("1e-8")
+            K[i, j] = v
+            K[j, i] = v
+    L = mp.cholesky(K)
+    B = mp.matrix(N, P)
+    for i in range(N):
+        for p in range(P):
+            B[i, p] = mp.mpf(float(obs_mean[i, p]))
+    Y = mp.lu_solve(L, B) if False else _mp_trsm(L, B, lower=True)
+    A = _mp_trsm(L.T, Y, lower=False)
+    logdet = 2 * sum(mp.log(L[i, i]) for i in range(N))
+    a = sum(B[i, p] * A[i, p] for i in range(N) for p in range(P))
+    ll = -a / 2 - logdet / 2 - mp.mpf(N) / 2 * mp.log(2 * mp.pi)
+    # K^-1
+    Li = _mp_trsm(L, mp.eye(N), lower=True)
+    Kinv = Li.T * Li
+    T = len(th) + (1 if optimize_noise else 0)
+    grad = [mp.mpf(0)] * T
+    for i in range(N):
+        for j in range(i + 1):
+            w = sum(A[i, p] * A[j, p] for p in range(P)) - Kinv[i, j]
+            g = gf(X[i], X[j])
+            if optimize_noise:
+                g = g + [2 * nz if i == j else mp.mpf(0)]
+            f = mp.mpf("0.5") if i == j else mp.mpf(1)
+            for t in range(T):
+                grad[t] += w * g[t] * f
+    out = {
+        "K": _mp2np(K), "L": _mp2np(L), "alpha": _mp2np(A), "log_lik": float(ll),
+        "Kinv": _mp2np(Kinv), "grad": np.array([float(g) for g in grad]),
+    }
+    if Xq is not None:
+        Xq = np.asarray(Xq, float)
+        M = Xq.shape[0]
+        kta = np.zeros((M, P))
+        var = np.zeros(M)
+        for m in range(M):
+            ks = mp.matrix(N, 1)
+            for i in range(N):
+                ks[i, 0] = kf(X[i], Xq[m])
+            z = _mp_trsm(L, ks, lower=True)
+            for p in range(P):
+                kta[m, p] = float(sum(ks[i, 0] * A[i, p] for i in range(N)))
+            var[m] = float(kf(Xq[m], Xq[m]) - sum(z[i, 0] * z[i, 0] for i in range(N)))
+        out["kta"] = kta
+        out["var_raw"] = var
+    return out
+
+
+def _mp_trsm(T, B, lower=True):
+    import mpmath as mp
+
+    n = T.rows
+    X = B.copy()
+    rng = range(n) if lower else range(n - 1, -1, -1)
+    for c in range(B.cols):
+        for i in rng:
+            s = X[i, c]
+            ks = range(i) if lower else range(i + 1, n)
+            for k in ks:
+                s -= T[i, k] * X[k, c]
+            X[i, c] = s / T[i, i]
+    return X
+
+
+def _mp2np(M):
+    return np.array([[float(M[i, j]) for j in range(M.cols)] for i in range(M.rows)])
+
+
+# --------------------------------------------------------------------------- synthetic data
+def hartmann6(X):
+    """src/benchmarks/regression/test_functions.hpp:343-366."""
+    a = np.array([[10, 3, 17, 3.5, 1.7, 8], [0.05, 10, 17, 0.1, 8, 14], [3, 3.5, 1.7, 10, 17, 8],
+                  [17, 8, 0.05, 10, 0.1, 14]])
+    p = np.array([[0.1312, 0.1696, 0.5569, 0.0124, 0.8283, 0.5886], [0.2329, 0.4135, 0.8307, 0.3736, 0.1004, 0.9991],
+                  [0.2348, 0.1451, 0.3522, 0.2883, 0.3047, 0.665], [0.4047, 0.8828, 0.8732, 0.5743, 0.1091, 0.0381]])
+    al = np.array([1.0, 1.2, 3.0, 3.2])
+    X = np.atleast_2d(X)
+    s = np.einsum("ij,nij->ni", a, (X[:, None, :] - p[None]) ** 2)
+    return (al * np.exp(-s)).sum(axis=1)
+
+
+def rastrigin(X):
+    """src/benchmarks/regression/test_functions.hpp:50-66 (A = 10)."""
+    X = np.atleast_2d(X)
+    return 10.0 * X.shape[1] + np.sum(X * X - 10.0 * np.cos(2 * np.pi * X), axis=1)
+
+
+def make_problem(config, seed=None, N=None, D=None, P=1):
+    """Synthetic (X, y) per SURVEY.md §8(d).  numpy default_rng(20260925 + config index)
+    replaces the reference's entropy-seeded RNG (tools/random_generator.hpp:83).
+    Noise rule: y += N(0, (std(y)/20)^2) (waf_tools/benchmark_template.cpp:112-120)."""
+    idx = {"c1": 1, "c2": 2, "c3": 3, "c4": 4, "c5": 5}[config]
+    rng = np.random.default_rng(20260925 + idx if seed is None else seed)
+    if config == "c1":
+        N = N or 200
+        D = D or 2
+        X = rng.uniform(-5.12, 5.12, size=(N, D))
+        y = rastrigin(X)
+    elif config in ("c2", "c4", "c5"):
+        N = N or (4096 if config == "c2" else 2048)
+        D = 6
+        X = rng.uniform(0.0, 1.0, size=(N, D))
+        y = hartmann6(X)
+    else:
+        N = N or 16384
+        D = D or 12
+        X = rng.uniform(0.0, 1.0, size=(N, D))
+        y = np.cos(2 * X).sum(axis=1)
+    y = y + rng.normal(0.0, np.std(y, ddof=1) / 20.0, size=N)
+    Y = y[:, None]
+    if P > 1:
+        Y = np.concatenate([Y] + [(y * rng.uniform(0.5, 1.5) + rng.normal(0, 0.05, N))[:, None] for _ in range(P - 1)], axis=1)
+    return X, Y
+
+
+def obs_mean_data(Y):
+    """mean::Data (mean/data.hpp:59-63) + gp.hpp:111,:537-548: obs_mean = Y - colwise mean."""
+    Y = np.asarray(Y, float).reshape(len(Y), -1)
+    m = Y.mean(axis=0)
+    return Y - m, m

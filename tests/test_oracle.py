@@ -1,0 +1,150 @@
+"""CPU tests: pin the C oracle (oracle/gp_oracle.c) against the reference's own known
+answers, the independent numpy/LAPACK restatement and the mpmath goldens.  No GPU."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests import parity_checks as PC
+from tests.util import golden_files, new_gp, relerr
+
+import ctypes as C
+
+_dp = C.POINTER(C.c_double)
+
+
+def _keval(lib, kind, x1, x2, th):
+    x1 = np.ascontiguousarray(x1, float)
+    x2 = np.ascontiguousarray(x2, float)
+    th = np.ascontiguousarray(th, float)
+    return lib.cdll.orc_kernel_eval(kind, x1.ctypes.data_as(_dp), x2.ctypes.data_as(_dp), x1.size, th.ctypes.data_as(_dp))
+
+
+def _kgrad(lib, kind, x1, x2, th):
+    x1 = np.ascontiguousarray(x1, float)
+    x2 = np.ascontiguousarray(x2, float)
+    th = np.ascontiguousarray(th, float)
+    g = np.zeros(th.size)
+    lib.cdll.orc_kernel_grad(kind, x1.ctypes.data_as(_dp), x2.ctypes.data_as(_dp), x1.size, th.ctypes.data_as(_dp),
+                             g.ctypes.data_as(_dp))
+    return g
+
+
+def test_se_ard_known_answers(oracle_lib):
+    """src/tests/test_kernel.cpp:196-224 (test_kernel_SE_ARD), k = 0 part."""
+    hp = np.zeros(3)
+    v1 = np.array([1.0, 1.0])
+    assert abs(_keval(oracle_lib, O.SE_ARD, v1, v1, hp) - 1) < 1e-6
+    v2 = np.array([0.0, 1.0])
+    s1 = _keval(oracle_lib, O.SE_ARD, v1, v2, hp)
+    assert abs(s1 - np.exp(-0.5 * float(v1 @ v2))) < 1e-5
+    hp[0] = 1
+    s2 = _keval(oracle_lib, O.SE_ARD, v1, v2, hp)
+    assert s1 < s2
+
+
+@pytest.mark.parametrize("kind", [O.SE_ARD, O.MATERN52, O.MATERN32, O.EXP])
+def test_kernel_grad_fd(oracle_lib, kind):
+    """src/tests/test_kernel.cpp:112-194: central FD (e=1e-6) of k wrt every log-hp vs grad(),
+    random hp in [-3,3], x in [-5,5]^D, D = 1..10, error < 1e-5."""
+    rng = np.random.default_rng(kind)
+    e = 1e-6
+    for D in range(1, 11):
+        nt = D + 1 if kind == O.SE_ARD else 2
+        for _ in range(20):
+            th = rng.uniform(-3, 3, size=nt)
+            x1 = rng.uniform(-5, 5, size=D)
+            x2 = rng.uniform(-5, 5, size=D)
+            g = _kgrad(oracle_lib, kind, x1, x2, th)
+            fd = np.zeros(nt)
+            for j in range(nt):
+                tp, tm = th.copy(), th.copy()
+                tp[j] += e
+                tm[j] -= e
+                fd[j] = (_keval(oracle_lib, kind, x1, x2, tp) - _keval(oracle_lib, kind, x1, x2, tm)) / (2 * e)
+            assert np.linalg.norm(g - fd) < 1e-5
+
+
+@pytest.mark.parametrize("kind", [O.SE_ARD, O.MATERN52, O.MATERN32, O.EXP])
+def test_kernel_matrix_vs_numpy(oracle_lib, kind):
+    rng = np.random.default_rng(100 + kind)
+    X = rng.uniform(-2, 2, size=(57, 5))
+    nt = 6 if kind == O.SE_ARD else 2
+    th = rng.uniform(-1, 1, size=nt)
+    h = new_gp(oracle_lib, kind, X, np.zeros((57, 1)), th, 0.03)
+    K = h.get_K()
+    Kn = O.kernel_matrix(kind, X, th, 0.03)
+    assert relerr(K, Kn, floor=1e-30) < 1e-13
+    assert np.array_equal(K, K.T)
+    h.close()
+
+
+@pytest.mark.parametrize("path", golden_files("mp_"), ids=lambda p: p.stem)
+def test_oracle_vs_mpmath_golden(oracle_lib, path):
+    PC.check_against_mp_golden(oracle_lib, path)
+
+
+@pytest.mark.parametrize("path", golden_files("np_"), ids=lambda p: p.stem)
+def test_oracle_vs_lapack_golden(oracle_lib, path):
+    PC.check_against_np_golden(oracle_lib, path)
+
+
+@pytest.mark.parametrize("dup", [False, True])
+def test_oracle_incremental_vs_full(oracle_lib, dup):
+    PC.check_incremental_vs_full(oracle_lib, dup=dup)
+
+
+def test_oracle_add_sample_from_empty(oracle_lib):
+    PC.check_add_sample_from_empty(oracle_lib)
+
+
+@pytest.mark.parametrize("kind,on", [(O.SE_ARD, False), (O.SE_ARD, True), (O.MATERN52, True)])
+def test_oracle_grad_fd(oracle_lib, kind, on):
+    PC.check_grad_fd(oracle_lib, kind, on)
+
+
+def test_oracle_update_alpha_and_clone(oracle_lib):
+    PC.check_update_alpha_and_clone(oracle_lib)
+
+
+def test_oracle_host_K(oracle_lib):
+    PC.check_host_K(oracle_lib)
+
+
+def test_oracle_not_pd(oracle_lib):
+    PC.check_not_pd(oracle_lib)
+
+
+def test_oracle_interpolation_and_prior(oracle_lib):
+    """test_gp.cpp:448-511, :669-758: mu within 1 of y and sigma^2 <= 2(noise+1e-8) at the
+    training points; far away sigma^2 -> sigma_f^2 + noise."""
+    rng = np.random.default_rng(21)
+    X = rng.uniform(0, 1, size=(30, 2))
+    Y = np.sin(6 * X[:, :1])
+    om, mean = O.obs_mean_data(Y)
+    th = np.array([-1.0, -1.0, 0.0])
+    h = new_gp(oracle_lib, O.SE_ARD, X, om, th, 0.01)
+    h.compute()
+    kta, var = h.query_batch(X)
+    mu, s2 = O.finish_query(kta, var, mean, 0.01)
+    assert np.max(np.abs(mu - Y)) < 1.0
+    assert np.all(s2 <= 2 * (0.01 + 1e-8))
+    far = np.full((1, 2), 50.0)
+    kta, var = h.query_batch(far)
+    mu, s2 = O.finish_query(kta, var, mean, 0.01)
+    assert abs(s2[0] - (1.0 + 0.01)) < 0.01
+    h.close()
+
+
+def test_oracle_rprop_improves(oracle_lib):
+    """KernelLFOpt with Rprop (kernel_lf_opt.hpp:60-69, rprop.hpp:84-144): the returned
+    hyper-parameters are the best seen and are no worse than the start."""
+    X, Y = O.make_problem("c1", N=60)
+    om, _ = O.obs_mean_data(Y)
+    h = new_gp(oracle_lib, O.SE_ARD, X, om, np.zeros(3), 0.01)
+    h.compute()
+    ll0 = h.log_lik()
+    th, ll, nev = h.kernel_lf_opt_rprop(optimize_noise=True, iterations=50, eps_stop=1e-2)
+    assert nev <= 50
+    assert ll >= ll0
+    assert abs(h.log_lik() - ll) < 1e-12 * abs(ll)
+    h.close()
