@@ -1,0 +1,104 @@
+// dev.h — internal declarations shared by the HIP translation units of libgpengine.so.
+// gfx950 (MI355X, CDNA4) only: wave = 64 lanes, v_mfma_f64_16x16x4_f64, 160 KiB LDS/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GPE_MAX_THETA 64
+#define GPE_MAX_P 8 // outputs handled per solve launch
+
+// kernel-functor parameters, pre-digested on the host (kernel/kernel.hpp:116-123 and the
+// per-kernel set_params: squared_exp_ard.hpp:96-105, matern_five_halves.hpp:97-102)
+struct KParams {
+    int kind;  // gpe_kernel_kind
+    int D;     // input dimension
+    double sf2;                 // sigma_f^2 = exp(2 p_last)
+    double inv_l;               // 1/l (isotropic kernels)
+    double diag_add;            // noise + 1e-8 (kernel.hpp:83)
+    double noise;               // sigma_n^2
+    double inv_ell[GPE_MAX_THETA]; // 1/ell_d (SE-ARD)
+};
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+static __device__ __forceinline__ d4_t mfma_f64(double a, double b, d4_t c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ---- kernel-matrix build (kbuild.hip) ----------------------------------------------
+// Xt: SoA, D x ldx (sample index contiguous).  Writes the LOWER triangle (incl. diagonal,
+// + diag_add) of K into A (col-major, lda).  gp.hpp:556-558 + kernel.hpp:81-84.
+void launch_build_K(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp,
+                    double* A, int64_t lda);
+// full symmetric K (tests / gpe_get_K)
+void launch_build_K_full(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp,
+                         double* A, int64_t lda);
+// cross kernel Ks[i, m] = k(x_i, q_m), no noise (gp.hpp:626-632); Qt SoA D x ldq; Ks col-major N x M
+void launch_build_Ks(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const double* Qt, int64_t ldq,
+                     int64_t M, const KParams& kp, double* Ks, int64_t ldk);
+// kvv[m] = k(q_m, q_m)
+void launch_kvv(hipStream_t s, const double* Qt, int64_t ldq, int64_t M, const KParams& kp, double* kvv);
+// row-major (n x D) -> SoA (D x ld), writing columns [col0, col0+n)
+void launch_transpose_x(hipStream_t s, const double* Xrm, int64_t n, int D, double* Xt, int64_t ld, int64_t col0);
+
+// ---- Cholesky pieces (potrf.hip) ---------------------------------------------------
+// factor the jb x jb (jb <= 64) diagonal block at A (in place, lower).  info: first bad pivot
+// (1-based, global index = goff + j + 1), written only if *info == 0.
+void launch_potf2(hipStream_t s, double* A, int64_t lda, int jb, int* info, int64_t goff);
+// rows below: X <- X * L11^-T, X is m x jb at A21 (col-major), L11 jb x jb lower
+void launch_trsm_right(hipStream_t s, const double* L11, int64_t ldl, int jb, double* A21, int64_t lda, int64_t m);
+// left solves on a 64-row block for nrhs columns: B <- L11^-1 B (trans=0) or L11^-T B (trans=1)
+void launch_trsm_left(hipStream_t s, const double* L11, int64_t ldl, int jb, double* B, int64_t ldb, int64_t nrhs,
+                      int trans);
+
+// ---- fp64 MFMA GEMM update (gemm.hip) ----------------------------------------------
+// C[m x n] -= opA[m x k] * opB[n x k]^T
+//   a_kmajor = 0: opA(i,kk) = A[i + kk*lda]   (row index contiguous)
+//   a_kmajor = 1: opA(i,kk) = A[kk + i*lda]   (k contiguous)          likewise for B.
+// tri: 0 = all tiles; 1 = skip tiles entirely above the diagonal, where the diagonal is
+//      (global row grow0 + i) == (global col gcol0 + j).
+// ktri: 1 = per-tile k range starts at max(tile row0, tile col0) + koff (LAUUM: X^T X with X lower)
+struct GemmArgs {
+    double* C; int64_t ldc;
+    const double* A; int64_t lda; int a_kmajor;
+    const double* B; int64_t ldb; int b_kmajor;
+    int64_t m, n, k;
+    int tri; int64_t grow0, gcol0;
+    int ktri;
+    int overwrite; // 1: C = +A*B^T (no read of C), 0: C -= A*B^T
+};
+void launch_gemm_sub(hipStream_t s, const GemmArgs& g);
+double gemm_flops(const GemmArgs& g);
+
+// ---- vector solves, reductions (solve.hip) -----------------------------------------
+// one full triangular sweep over P <= GPE_MAX_P right-hand sides (ceil(N/64) launches):
+// trans = 0: out = L^-1 w (top down);  trans = 1: out = L^-T w (bottom up).  w is destroyed.
+void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, double* w, double* out, int64_t ldw,
+                       int P, int trans);
+// out[0] = sum_i log L_ii ; out[1] = sum_{i,p} obs_mean * alpha   (gp.hpp:274-277)
+void launch_loglik_terms(hipStream_t s, const double* L, int64_t ldl, int64_t N, const double* om, const double* alpha,
+                         int64_t ldv, int P, double* out);
+// colsq[m] = sum_i Z[i,m]^2 ; var[m] = kvv[m] - colsq[m]
+void launch_col_var(hipStream_t s, const double* Z, int64_t ldz, int64_t N, int64_t M, const double* kvv, double* var);
+// kta[m, p] = sum_i Ks[i, m] alpha[i, p]
+void launch_kta(hipStream_t s, const double* Ks, int64_t ldk, int64_t N, int64_t M, const double* alpha, int64_t lda,
+                int P, double* kta, int64_t ldo);
+// misc
+void launch_set_identity(hipStream_t s, double* A, int64_t lda, int64_t n);
+void launch_zero_upper(hipStream_t s, double* A, int64_t lda, int64_t n);
+void launch_symmetrize_from_lower(hipStream_t s, double* A, int64_t lda, int64_t n);
+void launch_copy2d(hipStream_t s, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols);
+// add_sample tail: L[n,n] = sqrt(knn - ||row||^2)   (gp.hpp:596-597)
+void launch_append_diag(hipStream_t s, double* Lrow, int64_t ldl, int64_t n, const double* knn, int* info);
+
+// ---- gradient of the log-likelihood (grad.hpp:285-311) (grad.hip) ------------------
+// partial[b, t] per lower-triangle tile b; then a fixed-order final reduction into grad[T]
+void launch_grad_loglik(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, const double* Kinv,
+                        int64_t ldk, const double* alpha, int64_t lda, int P, int n_theta, int optimize_noise,
+                        double* partial, double* grad);
+int64_t grad_partial_size(int64_t N, int T);
+
+// ---- micro-benchmarks (microbench.hip) ---------------------------------------------
+double run_mfma_f64_peak(hipStream_t s);
+double run_hbm_stream_peak(hipStream_t s);

@@ -1,0 +1,1153 @@
+// engine.hip — host side of libgpengine.so: the handle, HBM residency, the blocked algorithms'
+// launch sequences and the C-ABI of include/gpe.h.
+//
+// What lives in HBM per handle (all fp64, column-major, leading dimension `ld`):
+//   Xt    D x ld      samples, SoA (sample index contiguous)          gp.hpp:520 `_samples`
+//   A     ld x cap    K, factored IN PLACE into L (lower)              gp.hpp:528/:530 `_kernel`/`_matrixL`
+//   Om    ld x P      obs_mean = Y - m(X)                              gp.hpp:523 `_obs_mean`
+//   Al    ld x P      alpha                                            gp.hpp:525 `_alpha`
+//   Linv  ld x cap    L^-1   (only once K^-1 is asked for)
+//   Kinv  ld x cap    K^-1 lower triangle                              gp.hpp:528 `_inv_kernel`
+// The reference keeps K, L and K^-1 as three N x N host matrices and deep-copies all of them for
+// every hyper-parameter objective evaluation (kernel_lf_opt.hpp:79); here an evaluation is
+// "same X, new theta" on resident buffers.
+#include "../../include/gpe.h"
+#include "dev.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#define NB 64
+
+namespace {
+
+struct PhaseRec {
+    int phase;
+    hipEvent_t e0, e1;
+    double flops;
+};
+
+} // namespace
+
+struct gpe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    int64_t N = 0, cap = 0, ld = 0;
+    int D = 0, P = 0;
+    int kind = GPE_KERNEL_SE_ARD, n_theta = 0;
+    double theta[GPE_MAX_THETA] = {0};
+    double noise = 0.01; // defaults::kernel::noise (kernel/kernel.hpp:57)
+    KParams kp;
+    double *dXt = nullptr, *dA = nullptr, *dOm = nullptr, *dAl = nullptr, *dW = nullptr, *dY = nullptr;
+    double *dLinv = nullptr, *dKinv = nullptr, *dKhost = nullptr, *dGradPartial = nullptr, *dGrad = nullptr;
+    int64_t grad_partial_cap = 0;
+    int* dInfo = nullptr;
+    double* dScal = nullptr; // [0] sum log L_ii, [1] trace(om^T alpha), [2] knn scratch
+    int* hInfo = nullptr;    // pinned
+    double* hScal = nullptr; // pinned
+    bool have_L = false, inv_ok = false, host_K = false, ll_ok = false;
+    int nbo = 256; // outer panel width of the two-level blocked algorithms
+    // instrumentation
+    bool prof = false;
+    std::vector<PhaseRec> pending;
+    std::vector<hipEvent_t> pool;
+    double ph_ms[GPE_PH_COUNT] = {0}, ph_flops[GPE_PH_COUNT] = {0};
+    int64_t ph_launches[GPE_PH_COUNT] = {0};
+    std::string err;
+};
+
+namespace {
+
+#define HIPCHK(c, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (c)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
+            return GPE_ERR_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+int ld_pad()
+{
+    static int pad = -1;
+    if (pad < 0) {
+        const char* e = getenv("GPE_LD_PAD");
+        pad = e ? atoi(e) : 16; // break power-of-two column strides (HBM channel camping)
+        if (pad < 0 || (pad & 1))
+            pad = 16;
+    }
+    return pad;
+}
+
+hipEvent_t get_event(gpe_ctx* c)
+{
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct PhaseScope {
+    gpe_ctx* c;
+    int phase;
+    double flops;
+    hipEvent_t e0 = nullptr;
+    PhaseScope(gpe_ctx* c_, int ph, double fl = 0.0) : c(c_), phase(ph), flops(fl)
+    {
+        if (c->prof) {
+            e0 = get_event(c);
+            hipEventRecord(e0, c->stream);
+        }
+    }
+    ~PhaseScope()
+    {
+        if (c->prof) {
+            hipEvent_t e1 = get_event(c);
+            hipEventRecord(e1, c->stream);
+            c->pending.push_back(PhaseRec{phase, e0, e1, flops});
+        }
+    }
+};
+
+void drain_phases(gpe_ctx* c)
+{
+    for (auto& r : c->pending) {
+        float ms = 0.f;
+        hipEventSynchronize(r.e1);
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        c->ph_ms[r.phase] += ms;
+        c->ph_flops[r.phase] += r.flops;
+        c->ph_launches[r.phase] += 1;
+        c->pool.push_back(r.e0);
+        c->pool.push_back(r.e1);
+    }
+    c->pending.clear();
+}
+
+void free_dev(gpe_ctx* c)
+{
+    double** ps[] = {&c->dXt, &c->dA, &c->dOm, &c->dAl, &c->dW, &c->dY, &c->dLinv, &c->dKinv, &c->dKhost,
+                     &c->dGradPartial};
+    for (auto p : ps) {
+        if (*p)
+            hipFree(*p);
+        *p = nullptr;
+    }
+    c->grad_partial_cap = 0;
+    c->cap = c->ld = 0;
+}
+
+// (re)allocate for capacity `cap` samples, dimension D, P outputs.  Existing contents are NOT kept.
+int alloc_dev(gpe_ctx* c, int64_t cap, int D, int P)
+{
+    free_dev(c);
+    cap = round_up(std::max<int64_t>(cap, NB), NB);
+    int64_t ld = cap + ld_pad();
+    c->cap = cap;
+    c->ld = ld;
+    HIPCHK(c, hipMalloc(&c->dXt, sizeof(double) * (size_t)(ld * D)));
+    HIPCHK(c, hipMalloc(&c->dA, sizeof(double) * (size_t)(ld * cap)));
+    HIPCHK(c, hipMalloc(&c->dOm, sizeof(double) * (size_t)(ld * P)));
+    HIPCHK(c, hipMalloc(&c->dAl, sizeof(double) * (size_t)(ld * P)));
+    HIPCHK(c, hipMalloc(&c->dW, sizeof(double) * (size_t)(ld * std::max(P, 1))));
+    HIPCHK(c, hipMalloc(&c->dY, sizeof(double) * (size_t)(ld * std::max(P, 1))));
+    HIPCHK(c, hipMemsetAsync(c->dXt, 0, sizeof(double) * (size_t)(ld * D), c->stream));
+    return GPE_OK;
+}
+
+// grow capacity keeping X, L, Om (add_sample path; the reference reallocates K and L on every
+// add_sample — gp.hpp:581,:588 conservativeResize — here capacity doubles)
+int grow_dev(gpe_ctx* c, int64_t need)
+{
+    if (need <= c->cap)
+        return GPE_OK;
+    int64_t ncap = round_up(std::max<int64_t>(need, 2 * c->cap), NB);
+    int64_t nld = ncap + ld_pad();
+    double *nXt = nullptr, *nA = nullptr, *nOm = nullptr, *nAl = nullptr, *nW = nullptr, *nY = nullptr;
+    int D = c->D, P = c->P;
+    HIPCHK(c, hipMalloc(&nXt, sizeof(double) * (size_t)(nld * D)));
+    HIPCHK(c, hipMalloc(&nA, sizeof(double) * (size_t)(nld * ncap)));
+    HIPCHK(c, hipMalloc(&nOm, sizeof(double) * (size_t)(nld * P)));
+    HIPCHK(c, hipMalloc(&nAl, sizeof(double) * (size_t)(nld * P)));
+    HIPCHK(c, hipMalloc(&nW, sizeof(double) * (size_t)(nld * P)));
+    HIPCHK(c, hipMalloc(&nY, sizeof(double) * (size_t)(nld * P)));
+    HIPCHK(c, hipMemsetAsync(nXt, 0, sizeof(double) * (size_t)(nld * D), c->stream));
+    if (c->N > 0) {
+        launch_copy2d(c->stream, c->dXt, c->ld, nXt, nld, c->N, D);
+        launch_copy2d(c->stream, c->dA, c->ld, nA, nld, c->N, c->N);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double* old[] = {c->dXt, c->dA, c->dOm, c->dAl, c->dW, c->dY, c->dLinv, c->dKinv};
+    for (double* p : old)
+        if (p)
+            hipFree(p);
+    c->dXt = nXt;
+    c->dA = nA;
+    c->dOm = nOm;
+    c->dAl = nAl;
+    c->dW = nW;
+    c->dY = nY;
+    c->dLinv = c->dKinv = nullptr;
+    c->inv_ok = false;
+    c->cap = ncap;
+    c->ld = nld;
+    return GPE_OK;
+}
+
+void digest_kernel(gpe_ctx* c)
+{
+    KParams& k = c->kp;
+    memset(&k, 0, sizeof(k));
+    k.kind = c->kind;
+    k.D = c->D;
+    k.noise = c->noise;
+    k.diag_add = c->noise + 1e-8; // kernel.hpp:83
+    if (c->kind == GPE_KERNEL_SE_ARD) {
+        // SquaredExpARD::set_params, squared_exp_ard.hpp:96-105
+        for (int d = 0; d < c->D && d < GPE_MAX_THETA; ++d)
+            k.inv_ell[d] = 1.0 / std::exp(c->theta[d]);
+        k.sf2 = std::exp(2.0 * c->theta[c->D]);
+        k.inv_l = 1.0;
+    }
+    else {
+        // MaternFiveHalves::set_params (matern_five_halves.hpp:97-102), same for Matern3/2, Exp
+        double l = std::exp(c->theta[0]);
+        k.inv_l = 1.0 / l;
+        k.sf2 = std::exp(2.0 * c->theta[1]);
+        for (int d = 0; d < c->D && d < GPE_MAX_THETA; ++d)
+            k.inv_ell[d] = k.inv_l;
+    }
+}
+
+inline double* Aat(gpe_ctx* c, double* base, int64_t i, int64_t j) { return base + i + j * c->ld; }
+
+// ---------------------------------------------------------------------------------------------
+// Blocked right-looking Cholesky, two levels (replaces Eigen::LLT at gp.hpp:565):
+//   outer panels of `nbo` columns: the trailing update runs with k = nbo so that the fp64 MFMA
+//   kernel reads/writes C once per 2*nbo flops per element (k = 64 would be C-traffic bound);
+//   inside a panel: 64-column steps  [potf2 | trsm_right | in-panel update].
+// ---------------------------------------------------------------------------------------------
+void potrf_blocked(gpe_ctx* c, double* A, int64_t N)
+{
+    hipStream_t s = c->stream;
+    const int64_t ld = c->ld;
+    const int64_t nbo = c->nbo;
+    for (int64_t p0 = 0; p0 < N; p0 += nbo) {
+        const int64_t pw = std::min<int64_t>(nbo, N - p0);
+        const int64_t pe = p0 + pw;
+        for (int64_t j0 = p0; j0 < pe; j0 += NB) {
+            const int jb = (int)std::min<int64_t>(NB, pe - j0);
+            const int64_t r0 = j0 + jb;
+            {
+                PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)jb * jb * jb / 3.0 + (double)(N - r0) * jb * jb);
+                launch_potf2(s, A + j0 + j0 * ld, ld, jb, c->dInfo, j0);
+                launch_trsm_right(s, A + j0 + j0 * ld, ld, jb, A + r0 + j0 * ld, ld, N - r0);
+            }
+            if (r0 < pe) { // rest of the panel's columns
+                GemmArgs g{};
+                g.C = A + r0 + r0 * ld;
+                g.ldc = ld;
+                g.A = A + r0 + j0 * ld;
+                g.lda = ld;
+                g.a_kmajor = 0;
+                g.B = A + r0 + j0 * ld;
+                g.ldb = ld;
+                g.b_kmajor = 0;
+                g.m = N - r0;
+                g.n = pe - r0;
+                g.k = jb;
+                g.tri = 1;
+                g.grow0 = r0;
+                g.gcol0 = r0;
+                PhaseScope ps(c, GPE_PH_POTRF_PANEL, gemm_flops(g));
+                launch_gemm_sub(s, g);
+            }
+        }
+        if (pe < N) { // trailing update, k = pw
+            GemmArgs g{};
+            g.C = A + pe + pe * ld;
+            g.ldc = ld;
+            g.A = A + pe + p0 * ld;
+            g.lda = ld;
+            g.B = A + pe + p0 * ld;
+            g.ldb = ld;
+            g.m = N - pe;
+            g.n = N - pe;
+            g.k = pw;
+            g.tri = 1;
+            g.grow0 = pe;
+            g.gcol0 = pe;
+            PhaseScope ps(c, GPE_PH_POTRF_UPDATE, gemm_flops(g));
+            launch_gemm_sub(s, g);
+        }
+    }
+}
+
+// Z <- L^-1 B in place, B is N x M (ldb).  identity_structure: B starts as the identity, so at
+// step j only columns < j + jb are non-zero (L^-1 is lower triangular) — gp.hpp:260 restricted
+// to the triangle.
+void trsm_left_blocked(gpe_ctx* c, const double* L, double* B, int64_t ldb, int64_t N, int64_t M, bool ident, int ph)
+{
+    hipStream_t s = c->stream;
+    const int64_t ld = c->ld;
+    const int64_t nbo = c->nbo;
+    for (int64_t o0 = 0; o0 < N; o0 += nbo) {
+        const int64_t ow = std::min<int64_t>(nbo, N - o0);
+        const int64_t oe = o0 + ow;
+        for (int64_t j0 = o0; j0 < oe; j0 += NB) {
+            const int jb = (int)std::min<int64_t>(NB, oe - j0);
+            const int64_t r0 = j0 + jb;
+            const int64_t ncol = ident ? r0 : M;
+            {
+                PhaseScope ps(c, ph, (double)jb * jb * ncol);
+                launch_trsm_left(s, L + j0 + j0 * ld, ld, jb, B + j0, ldb, ncol, 0);
+            }
+            if (r0 < oe) {
+                GemmArgs g{};
+                g.C = B + r0;
+                g.ldc = ldb;
+                g.A = L + r0 + j0 * ld;
+                g.lda = ld;
+                g.a_kmajor = 0;
+                g.B = B + j0;
+                g.ldb = ldb;
+                g.b_kmajor = 1; // opB(n, kk) = B[j0 + kk, n]
+                g.m = oe - r0;
+                g.n = ncol;
+                g.k = jb;
+                PhaseScope ps(c, ph, gemm_flops(g));
+                launch_gemm_sub(s, g);
+            }
+        }
+        if (oe < N) {
+            GemmArgs g{};
+            g.C = B + oe;
+            g.ldc = ldb;
+            g.A = L + oe + o0 * ld;
+            g.lda = ld;
+            g.B = B + o0;
+            g.ldb = ldb;
+            g.b_kmajor = 1;
+            g.m = N - oe;
+            g.n = ident ? oe : M;
+            g.k = ow;
+            PhaseScope ps(c, ph, gemm_flops(g));
+            launch_gemm_sub(s, g);
+        }
+    }
+}
+
+// GP::_compute_alpha (gp.hpp:605-611): alpha = L^-T (L^-1 obs_mean)
+void solve_alpha(gpe_ctx* c)
+{
+    hipStream_t s = c->stream;
+    PhaseScope ps(c, GPE_PH_SOLVE, 2.0 * (double)c->N * c->N * c->P);
+    for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) {
+        int pc = std::min(GPE_MAX_P, c->P - p0);
+        launch_copy2d(s, c->dOm + (int64_t)p0 * c->ld, c->ld, c->dW, c->ld, c->N, pc);
+        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dW, c->dY, c->ld, pc, 0);
+        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc, 1);
+    }
+}
+
+void enqueue_loglik_terms(gpe_ctx* c)
+{
+    PhaseScope ps(c, GPE_PH_LOGLIK, 0.0);
+    launch_loglik_terms(c->stream, c->dA, c->ld, c->N, c->dOm, c->dAl, c->ld, c->P, c->dScal);
+    hipMemcpyAsync(c->hScal, c->dScal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(c->hInfo, c->dInfo, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+}
+
+int compute_enqueue(gpe_ctx* c)
+{
+    if (c->N <= 0 || !c->dA)
+        return GPE_ERR_STATE;
+    hipStream_t s = c->stream;
+    digest_kernel(c);
+    HIPCHK(c, hipMemsetAsync(c->dInfo, 0, sizeof(int), s));
+    if (c->host_K) {
+        if (!c->dKhost)
+            return GPE_ERR_STATE;
+        PhaseScope ps(c, GPE_PH_KERNEL_BUILD, 0.0);
+        launch_copy2d(s, c->dKhost, c->ld, c->dA, c->ld, c->N, c->N);
+    }
+    else {
+        PhaseScope ps(c, GPE_PH_KERNEL_BUILD, 0.0);
+        launch_build_K(s, c->dXt, c->ld, c->N, c->kp, c->dA, c->ld);
+    }
+    potrf_blocked(c, c->dA, c->N);
+    c->have_L = true;
+    c->inv_ok = false; // gp.hpp:570
+    solve_alpha(c);
+    enqueue_loglik_terms(c);
+    return GPE_OK;
+}
+
+int compute_finish(gpe_ctx* c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    drain_phases(c);
+    c->ll_ok = true;
+    return *c->hInfo; // 0 or 1-based index of the first non-positive pivot
+}
+
+int ensure_inv(gpe_ctx* c)
+{
+    if (c->inv_ok)
+        return GPE_OK;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    hipStream_t s = c->stream;
+    const int64_t N = c->N, ld = c->ld;
+    if (!c->dLinv)
+        HIPCHK(c, hipMalloc(&c->dLinv, sizeof(double) * (size_t)(ld * c->cap)));
+    if (!c->dKinv)
+        HIPCHK(c, hipMalloc(&c->dKinv, sizeof(double) * (size_t)(ld * c->cap)));
+    {
+        PhaseScope ps(c, GPE_PH_INV, 0.0);
+        launch_set_identity(s, c->dLinv, ld, N);
+    }
+    trsm_left_blocked(c, c->dA, c->dLinv, ld, N, N, true, GPE_PH_INV); // L^-1 (gp.hpp:260)
+    {
+        // K^-1 = L^-T L^-1 (gp.hpp:261), lower triangle, k range from the tile diagonal down
+        GemmArgs g{};
+        g.C = c->dKinv;
+        g.ldc = ld;
+        g.A = c->dLinv;
+        g.lda = ld;
+        g.a_kmajor = 1;
+        g.B = c->dLinv;
+        g.ldb = ld;
+        g.b_kmajor = 1;
+        g.m = g.n = g.k = N;
+        g.tri = 1;
+        g.ktri = 1;
+        g.overwrite = 1;
+        PhaseScope ps(c, GPE_PH_INV, gemm_flops(g));
+        launch_gemm_sub(s, g);
+    }
+    c->inv_ok = true; // gp.hpp:263
+    return GPE_OK;
+}
+
+int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise)
+{
+    if (c->host_K)
+        return GPE_ERR_UNSUPPORTED;
+    if (n_grad != c->n_theta + (optimize_noise ? 1 : 0))
+        return GPE_ERR_ARG;
+    int rc = ensure_inv(c);
+    if (rc)
+        return rc;
+    int64_t need = grad_partial_size(c->N, n_grad) + GPE_MAX_THETA + 8;
+    if (need > c->grad_partial_cap) {
+        if (c->dGradPartial)
+            hipFree(c->dGradPartial);
+        HIPCHK(c, hipMalloc(&c->dGradPartial, sizeof(double) * (size_t)need));
+        c->grad_partial_cap = need;
+    }
+    double* dgrad = c->dGradPartial + (need - GPE_MAX_THETA - 8);
+    {
+        PhaseScope ps(c, GPE_PH_GRAD, 0.0);
+        launch_grad_loglik(c->stream, c->dXt, c->ld, c->N, c->kp, c->dKinv, c->ld, c->dAl, c->ld, c->P, c->n_theta,
+                           optimize_noise, c->dGradPartial, dgrad);
+    }
+    c->dGrad = dgrad;
+    return GPE_OK;
+}
+
+struct DevGuard {
+    explicit DevGuard(gpe_ctx* c) { hipSetDevice(c->device); }
+};
+
+} // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+const char* gpe_version(void) { return "limbo_amd-gpe 0.1 (gfx950)"; }
+
+int gpe_create(int device_id, gpe_handle* out)
+{
+    if (!out)
+        return GPE_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev)
+        return GPE_ERR_HIP;
+    gpe_ctx* c = new gpe_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
+        || hipMalloc(&c->dInfo, 64) != hipSuccess || hipMalloc(&c->dScal, 64) != hipSuccess
+        || hipHostMalloc(&c->hInfo, 64) != hipSuccess || hipHostMalloc(&c->hScal, 64) != hipSuccess) {
+        delete c;
+        return GPE_ERR_HIP;
+    }
+    hipMemset(c->dInfo, 0, 64);
+    *c->hInfo = 0;
+    const char* e = getenv("GPE_NBO");
+    if (e) {
+        int v = atoi(e);
+        if (v >= 64 && v % 64 == 0)
+            c->nbo = v;
+    }
+    *out = c;
+    return GPE_OK;
+}
+
+int gpe_destroy(gpe_handle c)
+{
+    if (!c)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    hipStreamSynchronize(c->stream);
+    drain_phases(c);
+    for (auto e : c->pool)
+        hipEventDestroy(e);
+    free_dev(c);
+    hipFree(c->dInfo);
+    hipFree(c->dScal);
+    hipHostFree(c->hInfo);
+    hipHostFree(c->hScal);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return GPE_OK;
+}
+
+const char* gpe_last_error(gpe_handle c) { return c ? c->err.c_str() : "null handle"; }
+
+int gpe_set_data(gpe_handle c, const double* X, int64_t N, int D, const double* obs_mean, int P)
+{
+    if (!c || !X || !obs_mean || N <= 0 || D <= 0 || D > GPE_MAX_THETA - 2 || P <= 0)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (N > c->cap || D != c->D || P != c->P || !c->dA) {
+        int rc = alloc_dev(c, N, D, P);
+        if (rc)
+            return rc;
+    }
+    if (c->dLinv) {
+        hipFree(c->dLinv);
+        c->dLinv = nullptr;
+    }
+    if (c->dKinv) {
+        hipFree(c->dKinv);
+        c->dKinv = nullptr;
+    }
+    c->N = N;
+    c->D = D;
+    c->P = P;
+    c->have_L = c->inv_ok = c->ll_ok = false;
+    c->host_K = (c->kind == GPE_KERNEL_HOST_K);
+    // stage X through the (not yet used) matrix buffer, then transpose to SoA on the device
+    double* tmp = c->dA;
+    HIPCHK(c, hipMemcpyAsync(tmp, X, sizeof(double) * (size_t)(N * D), hipMemcpyHostToDevice, c->stream));
+    launch_transpose_x(c->stream, tmp, N, D, c->dXt, c->ld, 0);
+    HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * c->ld, obs_mean, sizeof(double) * N, sizeof(double) * N, P,
+                               hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GPE_OK;
+}
+
+int gpe_set_data_device(gpe_handle c, const double* dX, int64_t N, int D, const double* dOm, int P)
+{
+    if (!c || !dX || !dOm || N <= 0 || D <= 0 || D > GPE_MAX_THETA - 2 || P <= 0)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (N > c->cap || D != c->D || P != c->P || !c->dA) {
+        int rc = alloc_dev(c, N, D, P);
+        if (rc)
+            return rc;
+    }
+    c->N = N;
+    c->D = D;
+    c->P = P;
+    c->have_L = c->inv_ok = c->ll_ok = false;
+    c->host_K = (c->kind == GPE_KERNEL_HOST_K);
+    launch_transpose_x(c->stream, dX, N, D, c->dXt, c->ld, 0);
+    launch_copy2d(c->stream, dOm, N, c->dOm, c->ld, N, P);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GPE_OK;
+}
+
+int gpe_set_kernel(gpe_handle c, int kind, const double* th, int n_theta, double noise)
+{
+    if (!c || kind < 0 || kind > GPE_KERNEL_HOST_K || n_theta < 0 || n_theta > GPE_MAX_THETA)
+        return GPE_ERR_ARG;
+    if (n_theta > 0 && !th)
+        return GPE_ERR_ARG;
+    c->kind = kind;
+    c->n_theta = n_theta;
+    for (int i = 0; i < n_theta; ++i)
+        c->theta[i] = th[i];
+    c->noise = noise;
+    c->host_K = (kind == GPE_KERNEL_HOST_K);
+    return GPE_OK;
+}
+
+int gpe_set_K_host(gpe_handle c, const double* K, int64_t ldk)
+{
+    if (!c || !K || c->N <= 0 || ldk < c->N)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    if (!c->dKhost)
+        HIPCHK(c, hipMalloc(&c->dKhost, sizeof(double) * (size_t)(c->ld * c->cap)));
+    HIPCHK(c, hipMemcpy2D(c->dKhost, sizeof(double) * c->ld, K, sizeof(double) * ldk, sizeof(double) * c->N, c->N,
+                          hipMemcpyHostToDevice));
+    c->host_K = true;
+    c->kind = GPE_KERNEL_HOST_K;
+    return GPE_OK;
+}
+
+int gpe_compute(gpe_handle c)
+{
+    if (!c)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->host_K) {
+        int need = (c->kind == GPE_KERNEL_SE_ARD) ? c->D + 1 : 2;
+        if (c->n_theta != need) {
+            c->err = "set_kernel: wrong number of hyper-parameters for this kernel/dimension";
+            return GPE_ERR_ARG;
+        }
+    }
+    int rc = compute_enqueue(c);
+    if (rc)
+        return rc;
+    return compute_finish(c);
+}
+
+int gpe_update_alpha(gpe_handle c, const double* obs_mean)
+{
+    if (!c)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (obs_mean)
+        HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * c->ld, obs_mean, sizeof(double) * c->N,
+                                   sizeof(double) * c->N, c->P, hipMemcpyHostToDevice, c->stream));
+    solve_alpha(c);
+    enqueue_loglik_terms(c);
+    int rc = compute_finish(c);
+    return rc < 0 ? rc : GPE_OK;
+}
+
+__global__ void k_vec_to_row(const double* __restrict__ v, double* __restrict__ row, int64_t ld, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        row[i * ld] = v[i];
+}
+__global__ void k_knn(const double* __restrict__ kcol, int64_t n, double diag_add, double* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        out[0] = kcol[n] + diag_add;
+}
+
+int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean, int P)
+{
+    if (!c || !x || !obs_mean || D <= 0 || P <= 0)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->host_K)
+        return GPE_ERR_UNSUPPORTED;
+    hipStream_t s = c->stream;
+    if (c->N == 0) { // gp.hpp:128-137
+        if (D > GPE_MAX_THETA - 2)
+            return GPE_ERR_ARG;
+        int rc = alloc_dev(c, 256, D, P);
+        if (rc)
+            return rc;
+        c->D = D;
+        c->P = P;
+    }
+    else {
+        if (D != c->D || P != c->P) // gp.hpp:139-140
+            return GPE_ERR_ARG;
+        if (!c->have_L)
+            return GPE_ERR_STATE;
+        int rc = grow_dev(c, c->N + 1);
+        if (rc)
+            return rc;
+    }
+    {
+        int need = (c->kind == GPE_KERNEL_SE_ARD) ? c->D + 1 : 2;
+        if (c->n_theta != need) {
+            c->err = "set_kernel: wrong number of hyper-parameters for this kernel/dimension";
+            return GPE_ERR_ARG;
+        }
+    }
+    const int64_t n = c->N; // index of the new sample
+    const int64_t ld = c->ld;
+    digest_kernel(c);
+    // new sample -> column n of Xt (staged through dY)
+    HIPCHK(c, hipMemcpyAsync(c->dY, x, sizeof(double) * D, hipMemcpyHostToDevice, s));
+    launch_transpose_x(s, c->dY, 1, D, c->dXt, ld, n);
+    HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * ld, obs_mean, sizeof(double) * (n + 1),
+                               sizeof(double) * (n + 1), P, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->dInfo, 0, sizeof(int), s));
+    {
+        PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)n * n);
+        // k(x_i, x_new) for i = 0..n (gp.hpp:583-586), no noise yet
+        launch_build_Ks(s, c->dXt, ld, n + 1, c->dXt + n, ld, 1, c->kp, c->dW, ld);
+        hipLaunchKernelGGL(k_knn, dim3(1), dim3(1), 0, s, c->dW, n, c->kp.diag_add, c->dScal + 2);
+        if (n > 0) {
+            // new row of L by forward substitution (gp.hpp:591-594): L[n, 0:n] = (L^-1 k[0:n])^T
+            launch_trsv_sweep(s, c->dA, ld, n, c->dW, c->dY, ld, 1, 0);
+            hipLaunchKernelGGL(k_vec_to_row, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->dY, c->dA + n, ld,
+                               n);
+        }
+        launch_append_diag(s, c->dA + n, ld, n, c->dScal + 2, c->dInfo); // gp.hpp:596-597
+    }
+    c->N = n + 1;
+    c->have_L = true;
+    c->inv_ok = false; // gp.hpp:602
+    solve_alpha(c);    // gp.hpp:599
+    enqueue_loglik_terms(c);
+    return compute_finish(c);
+}
+
+int gpe_log_lik(gpe_handle c, double* out)
+{
+    if (!c || !out)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->ll_ok) {
+        enqueue_loglik_terms(c);
+        int rc = compute_finish(c);
+        if (rc < 0)
+            return rc;
+    }
+    // gp.hpp:274-279 (P-quirk: logdet and n log 2 pi are not multiplied by P)
+    long double logdet = 2 * c->hScal[0];
+    double a = c->hScal[1];
+    *out = (double)(-0.5 * a - 0.5 * logdet - 0.5 * c->N * std::log(2 * M_PI));
+    return GPE_OK;
+}
+
+int gpe_compute_inv_kernel(gpe_handle c)
+{
+    if (!c)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ensure_inv(c);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_phases(c);
+    return GPE_OK;
+}
+
+int gpe_log_lik_grad(gpe_handle c, double* grad, int n_grad, int optimize_noise)
+{
+    if (!c || !grad)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    digest_kernel(c);
+    int rc = grad_enqueue(c, n_grad, optimize_noise);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(grad, c->dGrad, sizeof(double) * n_grad, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_phases(c);
+    return GPE_OK;
+}
+
+int gpe_hp_objective(gpe_handle c, int kind, const double* th, int n_theta, double noise, int optimize_noise,
+                     int want_grad, double* lik, double* grad)
+{
+    if (!c || !lik)
+        return GPE_ERR_ARG;
+    int rc = gpe_set_kernel(c, kind, th, n_theta, noise); // kernel_lf_opt.hpp:80
+    if (rc)
+        return rc;
+    int info = gpe_compute(c); // :82 recompute(false)
+    if (info < 0)
+        return info;
+    rc = gpe_log_lik(c, lik); // :84
+    if (rc)
+        return rc;
+    if (want_grad) { // :89
+        if (!grad)
+            return GPE_ERR_ARG;
+        rc = gpe_log_lik_grad(c, grad, n_theta + (optimize_noise ? 1 : 0), optimize_noise);
+        if (rc)
+            return rc;
+    }
+    return info;
+}
+
+int gpe_query_batch(gpe_handle c, const double* Xq, int64_t M, double* kta, double* var)
+{
+    if (!c || !Xq || M < 0)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    if (c->host_K)
+        return GPE_ERR_UNSUPPORTED;
+    if (M == 0)
+        return GPE_OK;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu); // const queries from several host threads serialise here
+    hipStream_t s = c->stream;
+    digest_kernel(c);
+    const int64_t N = c->N, ld = c->ld;
+    const int D = c->D, P = c->P;
+    // chunk so that the N x mc cross matrix stays under ~2 GiB
+    int64_t mc_max = std::max<int64_t>(64, ((int64_t)1 << 28) / std::max<int64_t>(ld, 1));
+    mc_max = round_up(std::min<int64_t>(mc_max, round_up(M, 64)), 64);
+    const int64_t ldq = mc_max;
+    double *dQrm = nullptr, *dQt = nullptr, *dKs = nullptr, *dKta = nullptr, *dVar = nullptr, *dKvv = nullptr;
+    HIPCHK(c, hipMalloc(&dQrm, sizeof(double) * (size_t)(mc_max * D)));
+    HIPCHK(c, hipMalloc(&dQt, sizeof(double) * (size_t)(ldq * D)));
+    HIPCHK(c, hipMalloc(&dKs, sizeof(double) * (size_t)(ld * mc_max)));
+    HIPCHK(c, hipMalloc(&dKta, sizeof(double) * (size_t)(mc_max * P)));
+    HIPCHK(c, hipMalloc(&dVar, sizeof(double) * (size_t)mc_max));
+    HIPCHK(c, hipMalloc(&dKvv, sizeof(double) * (size_t)mc_max));
+    int rc = GPE_OK;
+    for (int64_t m0 = 0; m0 < M && rc == GPE_OK; m0 += mc_max) {
+        const int64_t mc = std::min<int64_t>(mc_max, M - m0);
+        hipMemcpyAsync(dQrm, Xq + m0 * D, sizeof(double) * (size_t)(mc * D), hipMemcpyHostToDevice, s);
+        launch_transpose_x(s, dQrm, mc, D, dQt, ldq, 0);
+        {
+            PhaseScope ps(c, GPE_PH_QUERY, 0.0);
+            launch_build_Ks(s, c->dXt, ld, N, dQt, ldq, mc, c->kp, dKs, ld); // gp.hpp:626-632
+        }
+        if (kta) {
+            PhaseScope ps(c, GPE_PH_QUERY, 2.0 * N * mc * P);
+            launch_kta(s, dKs, ld, N, mc, c->dAl, ld, P, dKta, mc_max); // gp.hpp:615
+            for (int p = 0; p < P; ++p)
+                hipMemcpyAsync(kta + m0 + (int64_t)p * M, dKta + (int64_t)p * mc_max, sizeof(double) * (size_t)mc,
+                               hipMemcpyDeviceToHost, s);
+        }
+        if (var) {
+            trsm_left_blocked(c, c->dA, dKs, ld, N, mc, false, GPE_PH_QUERY); // gp.hpp:620
+            PhaseScope ps(c, GPE_PH_QUERY, 2.0 * N * mc);
+            launch_kvv(s, dQt, ldq, mc, c->kp, dKvv);
+            launch_col_var(s, dKs, ld, N, mc, dKvv, dVar); // gp.hpp:621
+            hipMemcpyAsync(var + m0, dVar, sizeof(double) * (size_t)mc, hipMemcpyDeviceToHost, s);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) {
+            c->err = "query_batch: stream sync failed";
+            rc = GPE_ERR_HIP;
+        }
+    }
+    drain_phases(c);
+    hipFree(dQrm);
+    hipFree(dQt);
+    hipFree(dKs);
+    hipFree(dKta);
+    hipFree(dVar);
+    hipFree(dKvv);
+    return rc;
+}
+
+int gpe_nb_samples(gpe_handle c, int64_t* N)
+{
+    if (!c || !N)
+        return GPE_ERR_ARG;
+    *N = c->N;
+    return GPE_OK;
+}
+
+int gpe_get_L(gpe_handle c, double* L, int64_t ldh)
+{
+    if (!c || !L || ldh < c->N)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    const int64_t N = c->N;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(L, sizeof(double) * ldh, c->dA, sizeof(double) * c->ld, sizeof(double) * N, N,
+                          hipMemcpyDeviceToHost));
+    for (int64_t j = 1; j < N; ++j) // matrixL(): zero upper triangle (gp.hpp:411)
+        memset(L + j * ldh, 0, sizeof(double) * (size_t)j);
+    return GPE_OK;
+}
+
+int gpe_set_L(gpe_handle c, const double* L, int64_t ldh)
+{
+    if (!c || !L || c->N <= 0 || ldh < c->N)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipMemcpy2D(c->dA, sizeof(double) * c->ld, L, sizeof(double) * ldh, sizeof(double) * c->N, c->N,
+                          hipMemcpyHostToDevice));
+    c->have_L = true;
+    c->inv_ok = false;
+    c->ll_ok = false;
+    return GPE_OK;
+}
+
+int gpe_get_alpha(gpe_handle c, double* a)
+{
+    if (!c || !a)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(a, sizeof(double) * c->N, c->dAl, sizeof(double) * c->ld, sizeof(double) * c->N, c->P,
+                          hipMemcpyDeviceToHost));
+    return GPE_OK;
+}
+
+int gpe_set_alpha(gpe_handle c, const double* a)
+{
+    if (!c || !a || c->N <= 0)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipMemcpy2D(c->dAl, sizeof(double) * c->ld, a, sizeof(double) * c->N, sizeof(double) * c->N, c->P,
+                          hipMemcpyHostToDevice));
+    c->ll_ok = false;
+    return GPE_OK;
+}
+
+int gpe_get_Kinv(gpe_handle c, double* Kinv, int64_t ldh)
+{
+    if (!c || !Kinv || ldh < c->N)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ensure_inv(c);
+    if (rc)
+        return rc;
+    const int64_t N = c->N;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_phases(c);
+    HIPCHK(c, hipMemcpy2D(Kinv, sizeof(double) * ldh, c->dKinv, sizeof(double) * c->ld, sizeof(double) * N, N,
+                          hipMemcpyDeviceToHost));
+    for (int64_t j = 1; j < N; ++j) // mirror the lower triangle
+        for (int64_t i = 0; i < j; ++i)
+            Kinv[i + j * ldh] = Kinv[j + i * ldh];
+    return GPE_OK;
+}
+
+int gpe_get_K(gpe_handle c, double* K, int64_t ldh)
+{
+    if (!c || !K || ldh < c->N || c->N <= 0)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    const int64_t N = c->N;
+    if (c->host_K) {
+        if (!c->dKhost)
+            return GPE_ERR_STATE;
+        HIPCHK(c, hipMemcpy2D(K, sizeof(double) * ldh, c->dKhost, sizeof(double) * c->ld, sizeof(double) * N, N,
+                              hipMemcpyDeviceToHost));
+        return GPE_OK;
+    }
+    digest_kernel(c);
+    double* tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, sizeof(double) * (size_t)(c->ld * N)));
+    launch_build_K_full(c->stream, c->dXt, c->ld, N, c->kp, tmp, c->ld);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2D(K, sizeof(double) * ldh, tmp, sizeof(double) * c->ld, sizeof(double) * N, N,
+                        hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    HIPCHK(c, e);
+    return GPE_OK;
+}
+
+int gpe_clone(gpe_handle src, gpe_handle* out)
+{
+    if (!src || !out)
+        return GPE_ERR_ARG;
+    gpe_handle c = nullptr;
+    int rc = gpe_create(src->device, &c);
+    if (rc)
+        return rc;
+    DevGuard g(src);
+    std::lock_guard<std::mutex> lk(src->mu);
+    hipStreamSynchronize(src->stream);
+    c->kind = src->kind;
+    c->n_theta = src->n_theta;
+    memcpy(c->theta, src->theta, sizeof(c->theta));
+    c->noise = src->noise;
+    c->nbo = src->nbo;
+    c->host_K = src->host_K;
+    if (src->dA) {
+        rc = alloc_dev(c, src->cap, src->D, src->P);
+        if (rc) {
+            gpe_destroy(c);
+            return rc;
+        }
+        // alloc_dev may round differently only if GPE_LD_PAD changed mid-run; same process => same ld
+        c->N = src->N;
+        c->D = src->D;
+        c->P = src->P;
+        const size_t mat = sizeof(double) * (size_t)(c->ld * c->cap);
+        hipMemcpyAsync(c->dXt, src->dXt, sizeof(double) * (size_t)(c->ld * c->D), hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync(c->dA, src->dA, mat, hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync(c->dOm, src->dOm, sizeof(double) * (size_t)(c->ld * c->P), hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync(c->dAl, src->dAl, sizeof(double) * (size_t)(c->ld * c->P), hipMemcpyDeviceToDevice, c->stream);
+        if (src->dKhost) {
+            hipMalloc(&c->dKhost, mat);
+            hipMemcpyAsync(c->dKhost, src->dKhost, mat, hipMemcpyDeviceToDevice, c->stream);
+        }
+        if (src->inv_ok && src->dKinv) {
+            hipMalloc(&c->dKinv, mat);
+            hipMemcpyAsync(c->dKinv, src->dKinv, mat, hipMemcpyDeviceToDevice, c->stream);
+            c->inv_ok = true;
+        }
+        c->have_L = src->have_L;
+        c->ll_ok = src->ll_ok;
+        c->hScal[0] = src->hScal[0];
+        c->hScal[1] = src->hScal[1];
+        *c->hInfo = *src->hInfo;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) {
+            gpe_destroy(c);
+            return GPE_ERR_HIP;
+        }
+    }
+    *out = c;
+    return GPE_OK;
+}
+
+int gpe_batch_compute(gpe_handle* hs, int G, int* status)
+{
+    if (!hs || G < 0)
+        return GPE_ERR_ARG;
+    // enqueue everything first (each GP on its own stream), then collect: kernels of different
+    // GPs overlap on the device — the TBB par::loop of multi_gp.hpp:124-126, on one GPU.
+    std::vector<int> rc(G, 0);
+    for (int g = 0; g < G; ++g) {
+        gpe_ctx* c = hs[g];
+        if (!c) {
+            rc[g] = GPE_ERR_ARG;
+            continue;
+        }
+        hipSetDevice(c->device);
+        c->mu.lock();
+        rc[g] = compute_enqueue(c);
+    }
+    int worst = GPE_OK;
+    for (int g = 0; g < G; ++g) {
+        gpe_ctx* c = hs[g];
+        if (!c)
+            continue;
+        hipSetDevice(c->device);
+        if (rc[g] == GPE_OK)
+            rc[g] = compute_finish(c);
+        c->mu.unlock();
+        if (status)
+            status[g] = rc[g];
+        if (rc[g] < 0)
+            worst = rc[g];
+    }
+    return worst;
+}
+
+int gpe_batch_log_lik(gpe_handle* hs, int G, double* out)
+{
+    if (!hs || !out)
+        return GPE_ERR_ARG;
+    for (int g = 0; g < G; ++g) {
+        int rc = gpe_log_lik(hs[g], out + g);
+        if (rc)
+            return rc;
+    }
+    return GPE_OK;
+}
+
+int gpe_get_stream(gpe_handle c, void** stream)
+{
+    if (!c || !stream)
+        return GPE_ERR_ARG;
+    *stream = (void*)c->stream;
+    return GPE_OK;
+}
+
+int gpe_synchronize(gpe_handle c)
+{
+    if (!c)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GPE_OK;
+}
+
+int gpe_set_profiling(gpe_handle c, int on)
+{
+    if (!c)
+        return GPE_ERR_ARG;
+    c->prof = on != 0;
+    return GPE_OK;
+}
+
+int gpe_get_phase_ms(gpe_handle c, double* ms, int64_t* launches, double* flops, int n)
+{
+    if (!c || n > GPE_PH_COUNT)
+        return GPE_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (ms)
+            ms[i] = c->ph_ms[i];
+        if (launches)
+            launches[i] = c->ph_launches[i];
+        if (flops)
+            flops[i] = c->ph_flops[i];
+    }
+    return GPE_OK;
+}
+
+int gpe_reset_phase_ms(gpe_handle c)
+{
+    if (!c)
+        return GPE_ERR_ARG;
+    for (int i = 0; i < GPE_PH_COUNT; ++i) {
+        c->ph_ms[i] = c->ph_flops[i] = 0.0;
+        c->ph_launches[i] = 0;
+    }
+    return GPE_OK;
+}
+
+int gpe_mfma_f64_peak(int device_id, double* tflops)
+{
+    if (!tflops || hipSetDevice(device_id) != hipSuccess)
+        return GPE_ERR_HIP;
+    *tflops = run_mfma_f64_peak(nullptr);
+    return *tflops > 0 ? GPE_OK : GPE_ERR_HIP;
+}
+
+int gpe_hbm_stream_peak(int device_id, double* gbs)
+{
+    if (!gbs || hipSetDevice(device_id) != hipSuccess)
+        return GPE_ERR_HIP;
+    *gbs = run_hbm_stream_peak(nullptr);
+    return *gbs > 0 ? GPE_OK : GPE_ERR_HIP;
+}
+
+} // extern "C"

@@ -1,0 +1,193 @@
+// grad.hip — gradient of the log marginal likelihood wrt the kernel hyper-parameters (gfx950).
+//
+// Replaces GP::compute_kernel_grad_log_lik (src/limbo/model/gp.hpp:285-311), which walks the
+// N(N+1)/2 pairs calling Kernel::grad (kernel.hpp:86-96; squared_exp_ard.hpp:127-135,
+// matern_five_halves.hpp:115-133, matern_three_halves.hpp:109-121, exp.hpp:104-113) and
+// allocating a VectorXd per pair:
+//     grad_t = sum_{i>j} w_ij g_ij,t + 1/2 sum_i w_ii g_ii,t ,   w = alpha alpha^T - K^-1.
+// Here dK/dtheta is never materialised: each 64x64 lower-triangle tile recomputes the pair
+// distances from the two sample panels (LDS), reads K^-1 once (coalesced, HBM-read bound:
+// N(N+1)/2 * 8 B), and keeps T partial sums in registers.  Partials are written per tile and
+// summed in a fixed order by a second kernel, so the result is run-to-run deterministic.
+#include "dev.h"
+
+#define TILE 64
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp,
+                                                    const double* __restrict__ Kinv, int64_t ldk,
+                                                    const double* __restrict__ alpha, int64_t lda, int P, int n_theta,
+                                                    int optimize_noise, double* __restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[]; // xj[D][64] | aj[P][64] | red[4][T]
+    const int D = kp.D;
+    const int T = n_theta + (optimize_noise ? 1 : 0);
+    double* xj = smem;
+    double* aj = smem + D * TILE;
+    double* red = aj + GPE_MAX_P * TILE;
+
+    long long b = blockIdx.x;
+    long long t = (long long)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((t + 1) * (t + 2) / 2 <= b)
+        ++t;
+    while (t * (t + 1) / 2 > b)
+        --t;
+    const int ti = (int)t, tj = (int)(b - t * (t + 1) / 2);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t i = (int64_t)ti * TILE + tx;
+    const int64_t j0 = (int64_t)tj * TILE;
+
+    for (int e = threadIdx.x; e < D * TILE; e += 256) {
+        const int d = e >> 6, c = e & 63;
+        xj[e] = (j0 + c < N) ? Xt[(int64_t)d * ldx + j0 + c] : 0.0;
+    }
+    for (int e = threadIdx.x; e < P * TILE; e += 256) {
+        const int p = e >> 6, c = e & 63;
+        aj[e] = (j0 + c < N) ? alpha[(int64_t)p * lda + j0 + c] : 0.0;
+    }
+    double xi[DMAX], ai[GPE_MAX_P];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+        xi[d] = (d < D && i < N) ? Xt[(int64_t)d * ldx + i] : 0.0;
+#pragma unroll
+    for (int p = 0; p < GPE_MAX_P; ++p)
+        ai[p] = (p < P && i < N) ? alpha[(int64_t)p * lda + i] : 0.0;
+    double acc[DMAX + 2];
+#pragma unroll
+    for (int q = 0; q < DMAX + 2; ++q)
+        acc[q] = 0.0;
+    __syncthreads();
+
+    if (i < N) {
+        for (int c = 0; c < 16; ++c) {
+            const int cc = ty * 16 + c;
+            const int64_t j = j0 + cc;
+            if (j >= N || j > i)
+                break;
+            double w = 0.0; // gp.hpp:293-296
+#pragma unroll
+            for (int p = 0; p < GPE_MAX_P; ++p)
+                if (p < P)
+                    w = fma(ai[p], aj[p * TILE + cc], w);
+            w -= Kinv[i + j * ldk];
+            if (i == j)
+                w *= 0.5; // gp.hpp:303-304
+            double z[DMAX];
+            double zs = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                double q = (d < D) ? (xi[d] - xj[d * TILE + cc]) * kp.inv_ell[d] : 0.0;
+                z[d] = q * q;
+                zs += z[d];
+            }
+            if (kp.kind == 0) { // squared_exp_ard.hpp:127-135 (k = 0 branch)
+                const double k = kp.sf2 * exp(-0.5 * zs);
+                const double wk = w * k;
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d)
+                    acc[d] = fma(wk, z[d], acc[d]);
+                acc[DMAX] = fma(wk, 2.0, acc[DMAX]);
+            }
+            else if (kp.kind == 1) { // matern_five_halves.hpp:115-133
+                const double r_ = sqrt(zs);
+                const double term1 = 2.23606797749978969641 * r_;
+                const double term2 = (5.0 / 3.0) * zs;
+                const double r = exp(-term1);
+                const double g0 = kp.sf2 * (r * term1 * (1 + term1 + term2) + (-term1 - 2. * term2) * r);
+                const double g1 = 2 * kp.sf2 * (1 + term1 + term2) * r;
+                acc[0] = fma(w, g0, acc[0]);
+                acc[1] = fma(w, g1, acc[1]);
+            }
+            else if (kp.kind == 2) { // matern_three_halves.hpp:109-121
+                const double term = 1.73205080756887729353 * sqrt(zs);
+                const double r = exp(-term);
+                const double g0 = kp.sf2 * (-term * r + (1 + term) * term * r);
+                const double g1 = 2 * kp.sf2 * (1 + term) * r;
+                acc[0] = fma(w, g0, acc[0]);
+                acc[1] = fma(w, g1, acc[1]);
+            }
+            else { // exp.hpp:104-113
+                const double k = kp.sf2 * exp(-0.5 * zs);
+                acc[0] = fma(w * k, zs, acc[0]);
+                acc[1] = fma(w * k, 2.0, acc[1]);
+            }
+            if (i == j) // kernel.hpp:90-93: 2 * noise on the diagonal
+                acc[DMAX + 1] = fma(w, 2.0 * kp.noise, acc[DMAX + 1]);
+        }
+    }
+    // block reduction of the T sums: wave shuffles, then 4 waves through LDS in fixed order
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < DMAX + 2; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            v += __shfl_down(v, o);
+        if (lane == 0)
+            red[wv * (DMAX + 2) + q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < T) {
+        // map output slot -> accumulator slot
+        int q;
+        if (optimize_noise && (int)threadIdx.x == T - 1)
+            q = DMAX + 1;
+        else if (kp.kind == 0)
+            q = ((int)threadIdx.x == n_theta - 1) ? DMAX : (int)threadIdx.x;
+        else
+            q = (int)threadIdx.x;
+        partial[(int64_t)blockIdx.x * T + threadIdx.x] = red[0 * (DMAX + 2) + q] + red[1 * (DMAX + 2) + q]
+            + red[2 * (DMAX + 2) + q] + red[3 * (DMAX + 2) + q];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grad_final(const double* __restrict__ partial, int64_t nblk, int T,
+                                                    double* __restrict__ grad)
+{
+    __shared__ double sh[4];
+    const int t = blockIdx.x;
+    double s = 0.0;
+    for (int64_t b = threadIdx.x; b < nblk; b += 256)
+        s += partial[b * T + t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0)
+        sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        grad[t] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+int64_t grad_partial_size(int64_t N, int T)
+{
+    int64_t nt = (N + TILE - 1) / TILE;
+    return nt * (nt + 1) / 2 * T;
+}
+
+void launch_grad_loglik(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, const double* Kinv,
+                        int64_t ldk, const double* alpha, int64_t lda, int P, int n_theta, int optimize_noise,
+                        double* partial, double* grad)
+{
+    const int T = n_theta + (optimize_noise ? 1 : 0);
+    const int64_t nt = (N + TILE - 1) / TILE;
+    const int64_t nblk = nt * (nt + 1) / 2;
+    const int D = kp.D;
+    dim3 grid((unsigned)nblk), block(256);
+#define LG(DM)                                                                                                   \
+    hipLaunchKernelGGL((k_grad_tiles<DM>), grid, block,                                                          \
+                       (size_t)(D * TILE + GPE_MAX_P * TILE + 4 * (DM + 2)) * sizeof(double), s, Xt, ldx, N, kp, \
+                       Kinv, ldk, alpha, lda, P, n_theta, optimize_noise, partial)
+    if (D <= 4)
+        LG(4);
+    else if (D <= 8)
+        LG(8);
+    else if (D <= 16)
+        LG(16);
+    else if (D <= 32)
+        LG(32);
+    else
+        LG(64);
+#undef LG
+    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)T), dim3(256), 0, s, partial, nblk, T, grad);
+}

@@ -1,0 +1,378 @@
+// solve.hip — vector triangular sweeps, reductions and small utilities (gfx950).
+//
+// k_trsv_fwd_step / k_trsv_bwd_step: one 64-unknown block step of L y = b / L^T a = y
+// (GP::_compute_alpha, src/limbo/model/gp.hpp:605-611).  Every workgroup of a step first
+// solves the 64x64 diagonal system redundantly (one wave, lane = row, pivot broadcast by
+// v_readlane) — redundancy costs no time and saves a kernel boundary per step — and then
+// applies the rank-64 update to its own slab of the remaining right-hand side.  The solution
+// goes to a separate `out` vector so no workgroup reads what another one overwrites.
+#include "dev.h"
+
+#define NB 64
+#define LSTR 65
+
+__device__ __forceinline__ void stage_diag(const double* __restrict__ L11, int64_t ldl, int jb, double* Ls,
+                                           double* invd)
+{
+    // Ls[r*65 + c] = L[r][c] (lower), identity padding for short blocks
+    for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+        const int r = e & 63, c = e >> 6;
+        double v = 0.0;
+        if (r < jb && c < jb)
+            v = (c <= r) ? L11[r + (int64_t)c * ldl] : 0.0;
+        else if (r == c)
+            v = 1.0;
+        Ls[r * LSTR + c] = v;
+        if (r == c)
+            invd[r] = 1.0 / v;
+    }
+}
+
+// forward: lane r holds b[r]; for j = 0..63: x_j = b_j / L_jj ; b_r -= L[r][j] x_j (r > j)
+template <int J>
+struct WaveFwd {
+    static __device__ __forceinline__ void run(double& b, const double* Ls, const double* invd, int lane)
+    {
+        WaveFwd<J - 1>::run(b, Ls, invd, lane);
+        const double xj = __shfl(b, J) * invd[J];
+        if (lane == J)
+            b = xj;
+        else if (lane > J)
+            b = fma(-Ls[lane * LSTR + J], xj, b);
+    }
+};
+template <>
+struct WaveFwd<-1> {
+    static __device__ __forceinline__ void run(double&, const double*, const double*, int) {}
+};
+// backward (L^T x = b): for j = 63..0: x_j = b_j / L_jj ; b_c -= L[j][c] x_j (c < j)
+template <int J>
+struct WaveBwd {
+    static __device__ __forceinline__ void run(double& b, const double* Ls, const double* invd, int lane)
+    {
+        WaveBwd<J + 1>::run(b, Ls, invd, lane);
+        const double xj = __shfl(b, J) * invd[J];
+        if (lane == J)
+            b = xj;
+        else if (lane < J)
+            b = fma(-Ls[J * LSTR + lane], xj, b);
+    }
+};
+template <>
+struct WaveBwd<NB> {
+    static __device__ __forceinline__ void run(double&, const double*, const double*, int) {}
+};
+
+// L: full matrix (col-major, ld); block at j0 of size jb; N = order.
+// w: running right-hand side (N x P, ldw); out: solution (N x P, ldw)
+__global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, int64_t ld, int64_t N,
+                                                       int64_t j0, int jb, double* __restrict__ w,
+                                                       double* __restrict__ out, int64_t ldw, int P)
+{
+    __shared__ double Ls[NB * LSTR];
+    __shared__ double invd[NB];
+    __shared__ double xs[GPE_MAX_P][NB];
+    stage_diag(L + j0 + j0 * ld, ld, jb, Ls, invd);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        for (int p = 0; p < P; ++p) {
+            double b = (lane < jb) ? w[j0 + lane + (int64_t)p * ldw] : 0.0;
+            WaveFwd<NB - 1>::run(b, Ls, invd, lane);
+            xs[p][lane] = b;
+            if (blockIdx.x == 0 && lane < jb)
+                out[j0 + lane + (int64_t)p * ldw] = b;
+        }
+    }
+    __syncthreads();
+    // update rows below: w[r] -= sum_k L[r][j0+k] x[k]
+    const int64_t r = j0 + jb + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < N) {
+        double acc[GPE_MAX_P];
+#pragma unroll
+        for (int p = 0; p < GPE_MAX_P; ++p)
+            acc[p] = 0.0;
+        const double* Lr = L + r + j0 * ld;
+        for (int k = 0; k < jb; ++k) {
+            const double l = Lr[(int64_t)k * ld];
+#pragma unroll
+            for (int p = 0; p < GPE_MAX_P; ++p)
+                if (p < P)
+                    acc[p] = fma(l, xs[p][k], acc[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < GPE_MAX_P; ++p)
+            if (p < P)
+                w[r + (int64_t)p * ldw] -= acc[p];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, int64_t ld, int64_t N,
+                                                       int64_t j0, int jb, double* __restrict__ w,
+                                                       double* __restrict__ out, int64_t ldw, int P)
+{
+    __shared__ double Ls[NB * LSTR];
+    __shared__ double invd[NB];
+    __shared__ double xs[GPE_MAX_P][NB];
+    __shared__ double Ts[NB * LSTR];
+    (void)N;
+    stage_diag(L + j0 + j0 * ld, ld, jb, Ls, invd);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {
+        for (int p = 0; p < P; ++p) {
+            double b = (lane < jb) ? w[j0 + lane + (int64_t)p * ldw] : 0.0;
+            WaveBwd<0>::run(b, Ls, invd, lane);
+            xs[p][lane] = b;
+            if (blockIdx.x == 0 && lane < jb)
+                out[j0 + lane + (int64_t)p * ldw] = b;
+        }
+    }
+    // this workgroup's 64 earlier unknowns c0..c0+63:  w[c] -= sum_k L[j0+k][c] x[k]
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    if (c0 < j0) {
+        // tile T[k][c] = L[j0+k][c0+c], read coalesced along k, stored Ts[c][k]
+        for (int c = wv; c < NB; c += 4) {
+            const int64_t col = c0 + c;
+            Ts[c * LSTR + lane] = (col < j0 && lane < jb) ? L[j0 + lane + col * ld] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (c0 < j0) {
+        const int c = lane;
+        const int64_t col = c0 + c;
+        for (int p = wv; p < P; p += 4) {
+            double acc = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < NB; ++k)
+                acc = fma(Ts[c * LSTR + k], xs[p][k], acc);
+            if (col < j0)
+                w[col + (int64_t)p * ldw] -= acc;
+        }
+    }
+}
+
+// one full sweep = ceil(N/64) launches.  trans = 0: L y = b (top down); 1: L^T a = y (bottom up)
+void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, double* w, double* out, int64_t ldw,
+                       int P, int trans)
+{
+    if (N <= 0)
+        return;
+    const int64_t nblk = (N + NB - 1) / NB;
+    if (!trans) {
+        for (int64_t b = 0; b < nblk; ++b) {
+            int64_t j0 = b * NB;
+            int jb = (int)((N - j0 < NB) ? N - j0 : NB);
+            int64_t rest = N - j0 - jb;
+            unsigned grid = (unsigned)((rest + 255) / 256);
+            if (grid == 0)
+                grid = 1;
+            hipLaunchKernelGGL(k_trsv_fwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, w, out, ldw, P);
+        }
+    }
+    else {
+        for (int64_t b = nblk - 1; b >= 0; --b) {
+            int64_t j0 = b * NB;
+            int jb = (int)((N - j0 < NB) ? N - j0 : NB);
+            unsigned grid = (unsigned)((j0 + 63) / 64);
+            if (grid == 0)
+                grid = 1;
+            hipLaunchKernelGGL(k_trsv_bwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, w, out, ldw, P);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_256(double v, double* sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0)
+        sh[wv] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3]; // fixed order: deterministic
+}
+
+// out[0] = sum_i log L_ii (gp.hpp:274) ; out[1] = trace(obs_mean^T alpha) (gp.hpp:276-277)
+__global__ __launch_bounds__(256) void k_loglik_terms(const double* __restrict__ L, int64_t ldl, int64_t N,
+                                                      const double* __restrict__ om, const double* __restrict__ al,
+                                                      int64_t ldv, int P, double* __restrict__ out)
+{
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 256)
+        s += log(L[i + i * ldl]);
+    s = block_sum_256(s, sh);
+    double a = 0.0;
+    for (int p = 0; p < P; ++p)
+        for (int64_t i = threadIdx.x; i < N; i += 256)
+            a = fma(om[i + (int64_t)p * ldv], al[i + (int64_t)p * ldv], a);
+    a = block_sum_256(a, sh);
+    if (threadIdx.x == 0) {
+        out[0] = s;
+        out[1] = a;
+    }
+}
+void launch_loglik_terms(hipStream_t s, const double* L, int64_t ldl, int64_t N, const double* om, const double* alpha,
+                         int64_t ldv, int P, double* out)
+{
+    hipLaunchKernelGGL(k_loglik_terms, dim3(1), dim3(256), 0, s, L, ldl, N, om, alpha, ldv, P, out);
+}
+
+// var[m] = kvv[m] - sum_i Z[i,m]^2   (gp.hpp:621)
+__global__ __launch_bounds__(256) void k_col_var(const double* __restrict__ Z, int64_t ldz, int64_t N, int64_t M,
+                                                 const double* __restrict__ kvv, double* __restrict__ var)
+{
+    __shared__ double sh[4];
+    for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+        const double* z = Z + m * ldz;
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < N; i += 256) {
+            const double v = z[i];
+            s = fma(v, v, s);
+        }
+        s = block_sum_256(s, sh);
+        if (threadIdx.x == 0)
+            var[m] = kvv[m] - s;
+    }
+}
+void launch_col_var(hipStream_t s, const double* Z, int64_t ldz, int64_t N, int64_t M, const double* kvv, double* var)
+{
+    if (M <= 0)
+        return;
+    unsigned grid = (unsigned)(M < 4096 ? M : 4096);
+    hipLaunchKernelGGL(k_col_var, dim3(grid), dim3(256), 0, s, Z, ldz, N, M, kvv, var);
+}
+
+// kta[m, p] = sum_i Ks[i, m] alpha[i, p]   (gp.hpp:615)
+__global__ __launch_bounds__(256) void k_kta(const double* __restrict__ Ks, int64_t ldk, int64_t N, int64_t M,
+                                             const double* __restrict__ alpha, int64_t lda, int P,
+                                             double* __restrict__ kta, int64_t ldo)
+{
+    __shared__ double sh[4];
+    for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+        const double* k = Ks + m * ldk;
+        for (int p = 0; p < P; ++p) {
+            const double* a = alpha + (int64_t)p * lda;
+            double s = 0.0;
+            for (int64_t i = threadIdx.x; i < N; i += 256)
+                s = fma(k[i], a[i], s);
+            s = block_sum_256(s, sh);
+            if (threadIdx.x == 0)
+                kta[m + (int64_t)p * ldo] = s;
+        }
+    }
+}
+void launch_kta(hipStream_t s, const double* Ks, int64_t ldk, int64_t N, int64_t M, const double* alpha, int64_t lda,
+                int P, double* kta, int64_t ldo)
+{
+    if (M <= 0)
+        return;
+    unsigned grid = (unsigned)(M < 4096 ? M : 4096);
+    hipLaunchKernelGGL(k_kta, dim3(grid), dim3(256), 0, s, Ks, ldk, N, M, alpha, lda, P, kta, ldo);
+}
+
+// ---------------------------------------------------------------------------------------
+// small utilities
+// ---------------------------------------------------------------------------------------
+__global__ void k_set_identity(double* __restrict__ A, int64_t lda, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = blockIdx.y;
+    if (i < n)
+        A[i + j * lda] = (i == j) ? 1.0 : 0.0;
+}
+void launch_set_identity(hipStream_t s, double* A, int64_t lda, int64_t n)
+{
+    if (n <= 0)
+        return;
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, A, lda, n);
+}
+
+__global__ void k_zero_upper(double* __restrict__ A, int64_t lda, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = blockIdx.y;
+    if (i < n && i < j)
+        A[i + j * lda] = 0.0;
+}
+void launch_zero_upper(hipStream_t s, double* A, int64_t lda, int64_t n)
+{
+    if (n <= 0)
+        return;
+    hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, A, lda, n);
+}
+
+// A[i][j] = A[j][i] for i < j (32x32 LDS-transposed tiles so both sides are coalesced)
+__global__ __launch_bounds__(256) void k_symmetrize(double* __restrict__ A, int64_t lda, int64_t n)
+{
+    __shared__ double T[32][33];
+    const int bi = blockIdx.x, bj = blockIdx.y; // source tile (rows bi, cols bj) with bi >= bj
+    if (bi < bj)
+        return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = (int64_t)bi * 32 + tx, j = (int64_t)bj * 32 + ty + 8 * q;
+        T[ty + 8 * q][tx] = (i < n && j < n) ? A[i + j * lda] : 0.0;
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        // destination element (row = bj*32 + tx, col = bi*32 + ty+8q) = source (col, row)
+        const int64_t r = (int64_t)bj * 32 + tx, c = (int64_t)bi * 32 + ty + 8 * q;
+        if (r < n && c < n && r < c)
+            A[r + c * lda] = T[tx][ty + 8 * q];
+    }
+}
+void launch_symmetrize_from_lower(hipStream_t s, double* A, int64_t lda, int64_t n)
+{
+    if (n <= 0)
+        return;
+    unsigned t = (unsigned)((n + 31) / 32);
+    hipLaunchKernelGGL(k_symmetrize, dim3(t, t), dim3(256), 0, s, A, lda, n);
+}
+
+__global__ void k_copy2d(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd,
+                         int64_t rows, int64_t cols)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows)
+        return;
+    for (int64_t j = blockIdx.y; j < cols; j += gridDim.y)
+        dst[i + j * ldd] = src[i + j * lds_];
+}
+void launch_copy2d(hipStream_t s, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols)
+{
+    if (rows <= 0 || cols <= 0)
+        return;
+    unsigned gy = (unsigned)(cols < 65535 ? cols : 65535);
+    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((rows + 255) / 256), gy), dim3(256), 0, s, src, lds_, dst, ldd, rows,
+                       cols);
+}
+
+// add_sample tail (gp.hpp:596-597): L[n][n] = sqrt(K_nn - ||L[n][0:n]||^2); Lrow points at L[n][0]
+__global__ __launch_bounds__(256) void k_append_diag(double* __restrict__ Lrow, int64_t ldl, int64_t n,
+                                                     const double* __restrict__ knn, int* __restrict__ info)
+{
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int64_t k = threadIdx.x; k < n; k += 256) {
+        const double v = Lrow[k * ldl];
+        s = fma(v, v, s);
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) {
+        const double d = knn[0] - s;
+        if (!(d > 0.0) && *info == 0)
+            *info = (int)(n + 1);
+        Lrow[n * ldl] = sqrt(d);
+    }
+}
+void launch_append_diag(hipStream_t s, double* Lrow, int64_t ldl, int64_t n, const double* knn, int* info)
+{
+    hipLaunchKernelGGL(k_append_diag, dim3(1), dim3(256), 0, s, Lrow, ldl, n, knn, info);
+}

@@ -1,0 +1,67 @@
+"""CPU tests of the boundary: libgpengine.so loads and exports every symbol include/gpe.h
+declares; the oracle mirrors the same set under orc_.  No compute calls (no GPU here)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    txt = (ROOT / "include" / "gpe.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpe_[a-z0-9_A-Z]+)\s*\(", txt)))
+
+
+def test_header_declares_the_path():
+    syms = declared_symbols()
+    for must in ("gpe_compute", "gpe_add_sample", "gpe_query_batch", "gpe_log_lik", "gpe_log_lik_grad",
+                 "gpe_hp_objective", "gpe_clone", "gpe_set_data"):
+        assert must in syms
+
+
+def test_engine_exports_every_declared_symbol():
+    from limbo_amd import _capi
+
+    assert _capi.ENGINE_SO.exists(), "libgpengine.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(str(_capi.ENGINE_SO))
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+    lib.gpe_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.gpe_version()
+
+
+def test_engine_contains_gfx950_code_object():
+    from limbo_amd import _capi
+
+    blob = _capi.ENGINE_SO.read_bytes()
+    assert b"gfx950" in blob
+    assert b"k_gemm_sub" in blob and b"k_potf2" in blob
+
+
+def test_engine_is_independent_of_the_oracle():
+    """The product must not link or reference the oracle."""
+    from limbo_amd import _capi
+
+    blob = _capi.ENGINE_SO.read_bytes()
+    assert b"liboracle" not in blob and b"orc_compute" not in blob
+    src = "".join(p.read_text() for p in (ROOT / "limbo_amd").rglob("*") if p.suffix in (".hip", ".h", ".hpp"))
+    assert "oracle" not in src.lower().replace("oracle/", "")  or "orc_" not in src
+
+
+def test_oracle_mirrors_the_abi(oracle_lib):
+    skip = {"gpe_get_stream", "gpe_set_profiling", "gpe_get_phase_ms", "gpe_reset_phase_ms", "gpe_mfma_f64_peak",
+            "gpe_hbm_stream_peak"}
+    for s in declared_symbols():
+        if s in skip:
+            continue
+        assert hasattr(oracle_lib.cdll, "orc_" + s[4:]), s
+
+
+def test_binding_loads_engine_without_gpu():
+    from limbo_amd import _capi
+
+    lib = _capi.load_engine()  # declares argtypes for every symbol: AttributeError if one is missing
+    assert lib.prefix == "gpe_"

@@ -1,0 +1,179 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, through the C-ABI, against
+(1) the committed mpmath / LAPACK goldens, (2) the CPU oracle on the same seeded inputs at
+sizes the oracle finishes in seconds, (3) size-independent properties at BASELINE sizes.
+Tolerances: mu, sigma^2 <= 1e-8 rel; log-lik <= 1e-10 rel; grad <= 1e-6 rel."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests import parity_checks as PC
+from tests.util import golden_files, new_gp, relerr, relerr_norm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("path", golden_files("mp_"), ids=lambda p: p.stem)
+def test_gpu_vs_mpmath_golden(engine_lib, path):
+    PC.check_against_mp_golden(engine_lib, path)
+
+
+@pytest.mark.parametrize("path", golden_files("np_"), ids=lambda p: p.stem)
+def test_gpu_vs_lapack_golden(engine_lib, path):
+    PC.check_against_np_golden(engine_lib, path)
+
+
+@pytest.mark.parametrize("kind", [O.SE_ARD, O.MATERN52, O.MATERN32, O.EXP])
+def test_gpu_kernel_matrix_vs_oracle(engine_lib, oracle_lib, kind):
+    """kernel build (gp.hpp:556-562): elementwise vs the oracle, ragged N, exact symmetry."""
+    rng = np.random.default_rng(200 + kind)
+    N, D = 333, 6
+    X = rng.uniform(-2, 2, size=(N, D))
+    nt = D + 1 if kind == O.SE_ARD else 2
+    th = rng.uniform(-1, 1, size=nt)
+    g = new_gp(engine_lib, kind, X, np.zeros((N, 1)), th, 0.03)
+    o = new_gp(oracle_lib, kind, X, np.zeros((N, 1)), th, 0.03)
+    Kg, Ko = g.get_K(), o.get_K()
+    assert relerr(Kg, Ko, floor=1e-30) < 5e-14
+    assert np.array_equal(Kg, Kg.T)
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("N,D,P,kind", [(1, 2, 1, O.SE_ARD), (63, 3, 1, O.SE_ARD), (64, 3, 2, O.MATERN52),
+                                        (65, 1, 1, O.SE_ARD), (257, 6, 3, O.SE_ARD), (700, 12, 1, O.MATERN52),
+                                        (1100, 6, 2, O.SE_ARD)])
+def test_gpu_vs_oracle_full_path(engine_lib, oracle_lib, N, D, P, kind):
+    """compute / log-lik / grad / query against the oracle on identical inputs, including
+    block-edge sizes (63, 64, 65, 257: the 64-column and 256-column panel boundaries)."""
+    rng = np.random.default_rng(N * 7 + D)
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) + 0.05 * rng.normal(size=N) for p in range(P)], axis=1)
+    om, mean = O.obs_mean_data(Y)
+    nt = D + 1 if kind == O.SE_ARD else 2
+    th = rng.uniform(-0.5, 0.3, size=nt)
+    noise = 0.01
+    g = new_gp(engine_lib, kind, X, om, th, noise)
+    o = new_gp(oracle_lib, kind, X, om, th, noise)
+    assert g.compute() == 0 and o.compute() == 0
+    Lg, Lo = g.get_L(), o.get_L()
+    assert np.max(np.abs(Lg - Lo)) < 1e-10 * np.max(np.abs(Lo))
+    assert np.all(np.triu(Lg, 1) == 0.0)
+    assert relerr_norm(g.get_alpha(), o.get_alpha()) < 1e-7
+    llg, llo = g.log_lik(), o.log_lik()
+    assert abs(llg - llo) <= PC.TOL_LL * max(1.0, abs(llo))
+    gg, go = g.log_lik_grad(True), o.log_lik_grad(True)
+    assert relerr_norm(gg, go) < PC.TOL_GRAD
+    Xq = rng.uniform(0, 1, size=(130, D))
+    Xq[:3] = X[:3] if N >= 3 else Xq[:3]
+    kg, vg = g.query_batch(Xq)
+    ko, vo = o.query_batch(Xq)
+    mug, s2g = O.finish_query(kg, vg, mean, noise)
+    muo, s2o = O.finish_query(ko, vo, mean, noise)
+    assert relerr(mug, muo, floor=1e-3) < PC.TOL_MU
+    assert relerr(s2g, s2o) < PC.TOL_VAR
+    assert relerr_norm(g.get_Kinv(), o.get_Kinv()) < 1e-8
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("dup", [False, True])
+def test_gpu_incremental_vs_full(engine_lib, dup):
+    PC.check_incremental_vs_full(engine_lib, dup=dup)
+
+
+def test_gpu_incremental_across_capacity_growth(engine_lib):
+    """add_sample past the initial capacity (reallocation keeps X and L)."""
+    PC.check_incremental_vs_full(engine_lib, kind=O.MATERN52, n0=250, n1=270, D=2, P=1, seed=17)
+
+
+def test_gpu_add_sample_from_empty(engine_lib):
+    PC.check_add_sample_from_empty(engine_lib)
+
+
+@pytest.mark.parametrize("kind,on", [(O.SE_ARD, False), (O.SE_ARD, True), (O.MATERN52, True)])
+def test_gpu_grad_fd(engine_lib, kind, on):
+    PC.check_grad_fd(engine_lib, kind, on)
+
+
+def test_gpu_update_alpha_and_clone(engine_lib):
+    PC.check_update_alpha_and_clone(engine_lib)
+
+
+def test_gpu_host_K(engine_lib):
+    PC.check_host_K(engine_lib)
+
+
+def test_gpu_not_pd(engine_lib):
+    PC.check_not_pd(engine_lib)
+
+
+def test_gpu_batch_compute_matches_single(engine_lib):
+    """independent GPs (multi_gp.hpp:124-126) enqueued together == one at a time."""
+    from limbo_amd import _capi
+
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 1, size=(300, 6))
+    hs, ref = [], []
+    for gidx in range(6):
+        Y = rng.normal(size=(300, 1))
+        om, _ = O.obs_mean_data(Y)
+        th = rng.uniform(-0.3, 0.3, size=7)
+        hs.append(new_gp(engine_lib, O.SE_ARD, X, om, th, 0.01))
+        r = new_gp(engine_lib, O.SE_ARD, X, om, th, 0.01)
+        r.compute()
+        ref.append(r.log_lik())
+        r.close()
+    st = _capi.batch_compute(hs)
+    assert st == [0] * 6
+    ll = _capi.batch_log_lik(hs)
+    assert np.array_equal(ll, np.array(ref))  # same kernels, same order: bitwise
+    for h in hs:
+        h.close()
+
+
+def test_gpu_deterministic(engine_lib):
+    """two runs on the same inputs are bitwise identical (fixed-order reductions, no atomics)."""
+    X, Y = O.make_problem("c2", N=900)
+    om, _ = O.obs_mean_data(Y)
+    out = []
+    for _ in range(2):
+        h = new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(7), 0.01)
+        h.compute()
+        out.append((h.log_lik(), h.log_lik_grad(True), h.get_alpha()))
+        h.close()
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])
+
+
+def test_gpu_c2_full_size_properties(engine_lib):
+    """BASELINE config C2 (N=4096, D=6, SE-ARD, fp64) — size-independent properties:
+    L L^T reproduces K, K alpha = obs_mean, K^-1 K = I on sampled columns, and the
+    log-likelihood matches LAPACK (scipy) to 1e-10."""
+    import scipy.linalg as sla
+
+    X, Y = O.make_problem("c2")
+    om, mean = O.obs_mean_data(Y)
+    th = np.zeros(7)
+    h = new_gp(engine_lib, O.SE_ARD, X, om, th, 0.01)
+    assert h.compute() == 0
+    L = h.get_L()
+    K = O.kernel_matrix(O.SE_ARD, X, th, 0.01)
+    rng = np.random.default_rng(0)
+    cols = rng.integers(0, 4096, size=32)
+    LLt = L @ L[cols].T
+    assert np.max(np.abs(LLt - K[:, cols])) < 1e-12 * np.max(np.abs(K))
+    a = h.get_alpha()
+    assert np.linalg.norm(K @ a - om) < 1e-9 * np.linalg.norm(om)
+    Ln = sla.cholesky(K, lower=True)
+    ll_ref = O.log_lik(Ln, om, sla.cho_solve((Ln, True), om))
+    assert abs(h.log_lik() - ll_ref) <= 1e-10 * abs(ll_ref)
+    # mu / sigma^2 on 256 test points vs LAPACK
+    Xq = rng.uniform(0, 1, size=(256, 6))
+    kta, var = h.query_batch(Xq)
+    kr, vr = O.query(O.SE_ARD, X, th, Ln, sla.cho_solve((Ln, True), om), Xq)
+    mu, s2 = O.finish_query(kta, var, mean, 0.01)
+    mur, s2r = O.finish_query(kr, vr, mean, 0.01)
+    assert relerr(mu, mur, floor=1e-3) < PC.TOL_MU
+    assert relerr(s2, s2r) < PC.TOL_VAR
+    h.close()
