@@ -1,54 +1,73 @@
-// gemm.hip — fp64 MFMA (v_mfma_f64_16x16x4_f64) rank-k update for gfx950.
+// gemm.hip — fp64 matrix-core rank-k update for gfx950, built on v_mfma_f64_4x4x4_4b.
 //
 //   C[m x n] -= opA[m x k] * opB[n x k]^T          (or C = opA opB^T when `overwrite`)
 //
 // This one kernel is the contraction engine of the whole path:
-//   * Cholesky trailing update A22 -= L21 L21^T  (replaces the rankUpdate inside Eigen::LLT,
-//     call-site src/limbo/model/gp.hpp:565),
+//   * Cholesky trailing / in-panel updates A22 -= L21 L21^T  (replaces the rankUpdate inside
+//     Eigen::LLT, call-site src/limbo/model/gp.hpp:565),
 //   * the block forward substitution for L^-1 and for batched query variances
 //     (gp.hpp:260-261, :620),
 //   * K^-1 = L^-T L^-1 as X^T X with a triangular k range (gp.hpp:254-264).
 //
-// Tile: 128 x 128 x 16 per 256-thread workgroup (4 waves as 2 x 2, each wave a 64 x 64
-// sub-tile = 4 x 4 MFMA tiles of 16x16, 128 accumulator VGPRs).  Operands are staged through
-// LDS (double-buffered, register prefetch of the next k-tile).  The MFMA is issued
-// "transposed" (A-operand <- B panel, B-operand <- A panel) so that the fp64 C/D layout
-// (col = lane&15, row = (lane>>4) + 4*reg — NOT the f32 map) puts 16 consecutive lanes on 16
-// consecutive ROWS of column-major C: every C access is a 128-byte segment.
+// Why the 4x4x4 "4 blocks" instruction and not v_mfma_f64_16x16x4: measured on MI355X
+// (tools/ubench2.hip, profiles/r01_ubench.log) the 16x16x4 form tops out at 48 TFLOP/s
+// (one instruction per ~100-140 cycles per SIMD), the 4x4x4_4b form issues every 20 cycles and
+// reaches 76-77 TFLOP/s = 97 % of the 78.6 TFLOP/s fp64 peak.  It computes four independent
+// 4x4x4 products per instruction:
+//     A operand lane l : block (l>>2)&3, row i = l&3,  k = l>>4
+//     B operand lane l : block (l>>2)&3, col j = l&3,  k = l>>4
+//     D result  lane l : block (l>>2)&3, col j = l&3,  row i = l>>4          (probed: tools/probe4.hip)
+// Here the four blocks are four 4-row groups of a 16-row slab of opA, and the B operand is ONE
+// 4(k) x 4(col) block of opB replicated over the blocks (the replication is free: the lanes of
+// the four blocks read the same LDS address).  One instruction therefore produces a 16 x 4
+// piece of C with k = 4; a wave holds RA x RB such pieces (RA 16-row slabs x RB 4-column
+// groups) in RA*RB accumulator registers and needs RA + RB ds_read_b64 per RA*RB MFMAs.
+// D rows for a fixed column are 16 consecutive rows of column-major C (scrambled lane order):
+// every C access instruction touches four 128-byte segments.
+//
+// Workgroup tile TM x TN x 16 (256 threads, 4 waves as 2 x 2), operands staged through LDS
+// (double-buffered, register prefetch of the next k-tile).  Three tile shapes are instantiated;
+// launch_gemm_sub picks the largest one that still yields enough workgroups to cover the 256 CUs
+// (the latency-critical in-panel updates of the blocked Cholesky are tiny).
 //
 // LDS layouts (conflict-free ds_read_b64 per 32-lane half):
-//   row-contiguous operand : S[kk][i], row stride 144 doubles  (144 = 16 mod 32)
-//   k-contiguous operand   : S[i][kk], row stride 18 doubles   (18*i + h covers 32 banks)
+//   row-contiguous operand : S[kk][i], row stride = ROWS + 16 doubles  (== 16 mod 32)
+//   k-contiguous operand   : S[i][kk], row stride 18 doubles
 #include "dev.h"
+#include <cstdlib>
 
-#define BM 128
-#define BN 128
 #define BKT 16
-#define LDS_M 144 // stride of S[kk][i]
-#define LDS_K 18  // stride of S[i][kk]
-#define OPER_ELEMS 2304 // 16*144 == 128*18
+#define LDS_K 18 // stride of S[i][kk]
 
-template <bool KMAJOR>
+static __device__ __forceinline__ double mfma4(double a, double b, double c)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+template <bool KMAJOR, int ROWS>
 struct Stager {
-    // each thread moves 8 elements of a 128 x 16 operand tile
-    double r[8];
+    static constexpr int PER = ROWS * BKT / 256;              // elements per thread
+    static constexpr int STRIDE = ROWS + 16;                  // S[kk][i] row stride
+    static constexpr int ELEMS = KMAJOR ? ROWS * LDS_K : BKT * STRIDE;
+    double r[PER];
     // global -> registers (guarded: rows < rows_left, kk < k_left; zero fill)
     __device__ __forceinline__ void load(const double* __restrict__ P, int64_t ld, int64_t rows_left, int64_t k_left)
     {
         const int t = threadIdx.x;
         if (!KMAJOR) {
-            const int i = t & 127, kk0 = t >> 7;
+            const int i = t % ROWS, kk0 = t / ROWS;
+            constexpr int KS = 256 / ROWS;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                int kk = kk0 + 2 * q;
+            for (int q = 0; q < PER; ++q) {
+                const int kk = kk0 + KS * q;
                 r[q] = (i < rows_left && kk < k_left) ? P[i + (int64_t)kk * ld] : 0.0;
             }
         }
         else {
             const int kk = t & 15, j0 = t >> 4;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                int j = j0 + 16 * q;
+            for (int q = 0; q < PER; ++q) {
+                const int j = j0 + 16 * q;
                 r[q] = (j < rows_left && kk < k_left) ? P[kk + (int64_t)j * ld] : 0.0;
             }
         }
@@ -57,36 +76,41 @@ struct Stager {
     {
         const int t = threadIdx.x;
         if (!KMAJOR) {
-            const int i = t & 127, kk0 = t >> 7;
+            const int i = t % ROWS, kk0 = t / ROWS;
+            constexpr int KS = 256 / ROWS;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                S[(kk0 + 2 * q) * LDS_M + i] = r[q];
+            for (int q = 0; q < PER; ++q)
+                S[(kk0 + KS * q) * STRIDE + i] = r[q];
         }
         else {
             const int kk = t & 15, j0 = t >> 4;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < PER; ++q)
                 S[(j0 + 16 * q) * LDS_K + kk] = r[q];
         }
     }
-    // fragment element for MFMA lane l: operand row (off + (l&15)), k index (k0 + (l>>4))
-    static __device__ __forceinline__ double frag(const double* __restrict__ S, int off, int k0, int lane)
+    // operand element: row `row` of the tile, k index kq
+    static __device__ __forceinline__ double at(const double* __restrict__ S, int row, int kq)
     {
         if (!KMAJOR)
-            return S[(k0 + (lane >> 4)) * LDS_M + off + (lane & 15)];
+            return S[kq * STRIDE + row];
         else
-            return S[(off + (lane & 15)) * LDS_K + k0 + (lane >> 4)];
+            return S[row * LDS_K + kq];
     }
 };
 
-template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void k_gemm_sub(GemmArgs g)
+template <int TM, int TN, bool AK, bool BK>
+__global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
 {
-    __shared__ __attribute__((aligned(16))) double lds[2][2][OPER_ELEMS];
+    using SA = Stager<AK, TM>;
+    using SB = Stager<BK, TN>;
+    constexpr int RA = TM / 2 / 16; // 16-row slabs per wave
+    constexpr int RB = TN / 2 / 4;  // 4-column groups per wave
+    __shared__ __attribute__((aligned(16))) double lds[2][SA::ELEMS + SB::ELEMS];
     // XCD-aware tile order: workgroups b, b+8, b+16.. land on the same XCD (private L2), so give
-    // each XCD a contiguous band of tile rows: they share the same A row-panel.
-    const int tiles_m = (int)((g.m + BM - 1) / BM);
-    const int tiles_n = (int)((g.n + BN - 1) / BN);
+    // each XCD a contiguous band of tiles: neighbours share operand panels in that L2.
+    const int tiles_m = (int)((g.m + TM - 1) / TM);
+    const int tiles_n = (int)((g.n + TN - 1) / TN);
     const int nwg = tiles_m * tiles_n;
     int wg = blockIdx.x;
     {
@@ -95,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sub(GemmArgs g)
     }
     const int ti = wg % tiles_m; // row tile fastest: neighbours share the B (column) panel
     const int tj = wg / tiles_m;
-    const int64_t row0 = (int64_t)ti * BM, col0 = (int64_t)tj * BN;
-    if (g.tri && (g.grow0 + row0 + BM - 1 < g.gcol0 + col0))
+    const int64_t row0 = (int64_t)ti * TM, col0 = (int64_t)tj * TN;
+    if (g.tri && (g.grow0 + row0 + TM - 1 < g.gcol0 + col0))
         return; // tile entirely above the diagonal
     int64_t kbeg = 0;
     if (g.ktri) { // X^T X with X lower triangular: rows of X below max(row0, col0) only
@@ -107,7 +131,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sub(GemmArgs g)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int wm = (wave & 1) * (TM / 2), wn = (wave >> 1) * (TN / 2);
+    const int arow = wm + (lane & 15); // + 16 m
+    const int bcol = wn + (lane & 3);  // + 4 n
+    const int kq = lane >> 4;
 
     const double* Ap = AK ? g.A + kbeg + row0 * g.lda : g.A + row0 + kbeg * g.lda;
     const double* Bp = BK ? g.B + kbeg + col0 * g.ldb : g.B + col0 + kbeg * g.ldb;
@@ -115,21 +142,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sub(GemmArgs g)
     const int64_t b_kstep = BK ? (int64_t)BKT : (int64_t)BKT * g.ldb;
     const int64_t mrows = g.m - row0, ncols = g.n - col0;
 
-    d4_t acc[4][4]; // [nt][mt]
+    double acc[RA][RB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < RA; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-            acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < RB; ++b)
+            acc[a][b] = 0.0;
 
-    Stager<AK> sa;
-    Stager<BK> sb;
+    SA sa;
+    SB sb;
     int64_t kleft = kend - kbeg;
     if (kleft > 0) {
         sa.load(Ap, g.lda, mrows, kleft);
         sb.load(Bp, g.ldb, ncols, kleft);
-        sa.store(lds[0][0]);
-        sb.store(lds[0][1]);
+        sa.store(lds[0]);
+        sb.store(lds[0] + SA::ELEMS);
     }
     __syncthreads();
     int buf = 0;
@@ -141,52 +168,83 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sub(GemmArgs g)
             sa.load(Ap, g.lda, mrows, kend - k0 - BKT);
             sb.load(Bp, g.ldb, ncols, kend - k0 - BKT);
         }
-        const double* As = lds[buf][0];
-        const double* Bs = lds[buf][1];
+        const double* As = lds[buf];
+        const double* Bs = lds[buf] + SA::ELEMS;
 #pragma unroll
         for (int ks = 0; ks < BKT; ks += 4) {
-            double af[4], bf[4];
+            double af[RA], bf[RB];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                af[x] = Stager<AK>::frag(As, wm + 16 * x, ks, lane);
-                bf[x] = Stager<BK>::frag(Bs, wn + 16 * x, ks, lane);
-            }
+            for (int x = 0; x < RA; ++x)
+                af[x] = SA::at(As, arow + 16 * x, ks + kq);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int x = 0; x < RB; ++x)
+                bf[x] = SB::at(Bs, bcol + 4 * x, ks + kq);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = mfma_f64(bf[nt], af[mt], acc[nt][mt]);
+            for (int n = 0; n < RB; ++n)
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
         }
         if (more) {
-            sa.store(lds[buf ^ 1][0]);
-            sb.store(lds[buf ^ 1][1]);
+            sa.store(lds[buf ^ 1]);
+            sb.store(lds[buf ^ 1] + SA::ELEMS);
         }
         __syncthreads();
         buf ^= 1;
     }
 
-    // epilogue.  D layout (fp64): lane l, reg v -> (n = (l>>4) + 4v, m = l&15) of the 16x16 tile
-    const int lm = lane & 15, ln = lane >> 4;
+    // epilogue.  D lane l -> row 4*((l>>2)&3) + (l>>4) of the 16-row slab, column l&3 of the group
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);
+    const int dcol = lane & 3;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int n = 0; n < RB; ++n) {
+        const int64_t cn = col0 + wn + 4 * n + dcol;
+        if (cn >= g.n)
+            continue;
+        double* Cc = g.C + cn * g.ldc;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int64_t n = col0 + wn + nt * 16 + ln + 4 * v;
-            if (n >= g.n)
-                continue;
-            double* Cc = g.C + n * g.ldc;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int64_t mrow = row0 + wm + mt * 16 + lm;
-                if (mrow < g.m) {
-                    if (g.overwrite)
-                        Cc[mrow] = acc[nt][mt][v];
-                    else
-                        Cc[mrow] -= acc[nt][mt][v];
-                }
+        for (int m = 0; m < RA; ++m) {
+            const int64_t rm = row0 + wm + 16 * m + drow;
+            if (rm < g.m) {
+                if (g.overwrite)
+                    Cc[rm] = acc[m][n];
+                else
+                    Cc[rm] -= acc[m][n];
             }
         }
     }
+}
+
+template <int TM, int TN>
+static void launch_tile(hipStream_t s, const GemmArgs& g)
+{
+    int64_t tiles = ((g.m + TM - 1) / TM) * ((g.n + TN - 1) / TN);
+    dim3 grid((unsigned)tiles), block(256);
+    if (!g.a_kmajor && !g.b_kmajor)
+        hipLaunchKernelGGL((k_gemm4<TM, TN, false, false>), grid, block, 0, s, g);
+    else if (!g.a_kmajor && g.b_kmajor)
+        hipLaunchKernelGGL((k_gemm4<TM, TN, false, true>), grid, block, 0, s, g);
+    else if (g.a_kmajor && !g.b_kmajor)
+        hipLaunchKernelGGL((k_gemm4<TM, TN, true, false>), grid, block, 0, s, g);
+    else
+        hipLaunchKernelGGL((k_gemm4<TM, TN, true, true>), grid, block, 0, s, g);
+}
+
+// number of TM x TN tiles that do work (triangular skipping accounted for)
+static int64_t live_tiles(const GemmArgs& g, int TM, int TN)
+{
+    const int64_t tm = (g.m + TM - 1) / TM, tn = (g.n + TN - 1) / TN;
+    if (!g.tri)
+        return tm * tn;
+    int64_t cnt = 0;
+    for (int64_t tj = 0; tj < tn; ++tj) {
+        // tile (ti, tj) is live iff grow0 + ti*TM + TM - 1 >= gcol0 + tj*TN
+        int64_t need = g.gcol0 + tj * TN - g.grow0 - (TM - 1); // ti*TM >= need
+        int64_t ti0 = need <= 0 ? 0 : (need + TM - 1) / TM;
+        if (ti0 < tm)
+            cnt += tm - ti0;
+    }
+    return cnt;
 }
 
 void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
@@ -195,16 +253,28 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         return;
     if (g.k <= 0 && !g.overwrite)
         return;
-    int64_t tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
-    dim3 grid((unsigned)tiles), block(256);
-    if (!g.a_kmajor && !g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm_sub<false, false>), grid, block, 0, s, g);
-    else if (!g.a_kmajor && g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm_sub<false, true>), grid, block, 0, s, g);
-    else if (g.a_kmajor && !g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm_sub<true, false>), grid, block, 0, s, g);
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("GPE_GEMM_TILE"); // debug/tuning: 128, 64 or 32
+        force = e ? atoi(e) : 0;
+    }
+    int tile = force;
+    if (tile != 128 && tile != 64 && tile != 32) {
+        // 256 CUs, 2 workgroups resident per CU at the 128 tile: want >= ~2 full rounds before
+        // paying for the larger tile's longer per-workgroup latency
+        if (live_tiles(g, 128, 128) >= 1024)
+            tile = 128;
+        else if (live_tiles(g, 64, 64) >= 512)
+            tile = 64;
+        else
+            tile = 32;
+    }
+    if (tile == 128)
+        launch_tile<128, 128>(s, g);
+    else if (tile == 64)
+        launch_tile<64, 64>(s, g);
     else
-        hipLaunchKernelGGL((k_gemm_sub<true, true>), grid, block, 0, s, g);
+        launch_tile<32, 64>(s, g);
 }
 
 // algorithmic flops of one launch (2 m n k, lower-triangular tile skipping accounted for at
