@@ -42,15 +42,15 @@ void launch_kvv(hipStream_t s, const double* Qt, int64_t ldq, int64_t M, const K
 // row-major (n x D) -> SoA (D x ld), writing columns [col0, col0+n)
 void launch_transpose_x(hipStream_t s, const double* Xrm, int64_t n, int D, double* Xt, int64_t ld, int64_t col0);
 
-// ---- Cholesky pieces (potrf.hip) ---------------------------------------------------
-// factor the jb x jb (jb <= 64) diagonal block at A (in place, lower).  info: first bad pivot
-// (1-based, global index = goff + j + 1), written only if *info == 0.
-void launch_potf2(hipStream_t s, double* A, int64_t lda, int jb, int* info, int64_t goff);
-// rows below: X <- X * L11^-T, X is m x jb at A21 (col-major), L11 jb x jb lower
-void launch_trsm_right(hipStream_t s, const double* L11, int64_t ldl, int jb, double* A21, int64_t lda, int64_t m);
-// left solves on a 64-row block for nrhs columns: B <- L11^-1 B (trans=0) or L11^-T B (trans=1)
-void launch_trsm_left(hipStream_t s, const double* L11, int64_t ldl, int jb, double* B, int64_t ldb, int64_t nrhs,
-                      int trans);
+// ---- Cholesky diagonal block (potrf.hip) --------------------------------------------
+// factor the jb x jb (jb <= 64) diagonal block at A (in place, lower) and write the transposed
+// inverse Xt[k + 64 c] = (L11^-1)[c][k] (64 x 64, identity-padded for jb < 64).  info: first bad
+// pivot (1-based, global index = goff + j + 1), written only if *info == 0.
+void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff);
+// inverses of diagonal blocks b0 .. b0+nblocks-1 of an existing factor L (order N) into
+// Xt_all + 4096 b
+void launch_diag_inv(hipStream_t s, const double* L, int64_t ldl, int64_t N, int64_t b0, int64_t nblocks,
+                     double* Xt_all);
 
 // ---- fp64 MFMA GEMM update (gemm.hip) ----------------------------------------------
 // C[m x n] -= opA[m x k] * opB[n x k]^T
@@ -67,6 +67,7 @@ struct GemmArgs {
     int tri; int64_t grow0, gcol0;
     int ktri;
     int overwrite; // 1: C = +A*B^T (no read of C), 0: C -= A*B^T
+    int tile;      // 0: pick by problem size; 128 / 64 / 32: force the 128x128 / 64x64 / 32x64 tile
 };
 void launch_gemm_sub(hipStream_t s, const GemmArgs& g);
 double gemm_flops(const GemmArgs& g);
@@ -74,8 +75,12 @@ double gemm_flops(const GemmArgs& g);
 // ---- vector solves, reductions (solve.hip) -----------------------------------------
 // one full triangular sweep over P <= GPE_MAX_P right-hand sides (ceil(N/64) launches):
 // trans = 0: out = L^-1 w (top down);  trans = 1: out = L^-T w (bottom up).  w is destroyed.
-void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, double* w, double* out, int64_t ldw,
-                       int P, int trans);
+// Xt_all: inverses of the 64 x 64 diagonal blocks (launch_diag / launch_diag_inv).
+void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, double* w,
+                       double* out, int64_t ldw, int P, int trans);
+// Arows[p + i*lda] = V[i + p*ldv] (P rows appended under the matrix) and back
+void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N, int P, double* Arows, int64_t lda);
+void launch_rows_to_cols(hipStream_t s, const double* Arows, int64_t lda, int64_t N, int P, double* V, int64_t ldv);
 // out[0] = sum_i log L_ii ; out[1] = sum_{i,p} obs_mean * alpha   (gp.hpp:274-277)
 void launch_loglik_terms(hipStream_t s, const double* L, int64_t ldl, int64_t N, const double* om, const double* alpha,
                          int64_t ldv, int P, double* out);

@@ -6,6 +6,9 @@
 //   A     ld x cap    K, factored IN PLACE into L (lower)              gp.hpp:528/:530 `_kernel`/`_matrixL`
 //   Om    ld x P      obs_mean = Y - m(X)                              gp.hpp:523 `_obs_mean`
 //   Al    ld x P      alpha                                            gp.hpp:525 `_alpha`
+//   Xinv  cap/64 x 64 x 64   L_bb^-T of every diagonal block (by-product of the factorisation)
+// Rows N..N+P-1 of A carry obs_mean^T during the factorisation: the forward substitution
+// z = L^-1 obs_mean (gp.hpp:608) rides along as P extra rows of every panel and update.
 //   Linv  ld x cap    L^-1   (only once K^-1 is asked for)
 //   Kinv  ld x cap    K^-1 lower triangle                              gp.hpp:528 `_inv_kernel`
 // The reference keeps K, L and K^-1 as three N x N host matrices and deep-copies all of them for
@@ -47,6 +50,7 @@ struct gpe_ctx {
     KParams kp;
     double *dXt = nullptr, *dA = nullptr, *dOm = nullptr, *dAl = nullptr, *dW = nullptr, *dY = nullptr;
     double *dLinv = nullptr, *dKinv = nullptr, *dKhost = nullptr, *dGradPartial = nullptr, *dGrad = nullptr;
+    double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     int64_t grad_partial_cap = 0;
     int* dInfo = nullptr;
     double* dScal = nullptr; // [0] sum log L_ii, [1] trace(om^T alpha), [2] knn scratch
@@ -87,6 +91,10 @@ int ld_pad()
     }
     return pad;
 }
+
+// leading dimension: cap rows + room for the P right-hand-side rows + a pad that breaks
+// power-of-two column strides
+int64_t ld_for(int64_t cap, int P) { return cap + round_up((int64_t)P + ld_pad(), 16); }
 
 hipEvent_t get_event(gpe_ctx* c)
 {
@@ -140,7 +148,7 @@ void drain_phases(gpe_ctx* c)
 void free_dev(gpe_ctx* c)
 {
     double** ps[] = {&c->dXt, &c->dA, &c->dOm, &c->dAl, &c->dW, &c->dY, &c->dLinv, &c->dKinv, &c->dKhost,
-                     &c->dGradPartial};
+                     &c->dGradPartial, &c->dXinv};
     for (auto p : ps) {
         if (*p)
             hipFree(*p);
@@ -155,7 +163,7 @@ int alloc_dev(gpe_ctx* c, int64_t cap, int D, int P)
 {
     free_dev(c);
     cap = round_up(std::max<int64_t>(cap, NB), NB);
-    int64_t ld = cap + ld_pad();
+    int64_t ld = ld_for(cap, P);
     c->cap = cap;
     c->ld = ld;
     HIPCHK(c, hipMalloc(&c->dXt, sizeof(double) * (size_t)(ld * D)));
@@ -164,6 +172,7 @@ int alloc_dev(gpe_ctx* c, int64_t cap, int D, int P)
     HIPCHK(c, hipMalloc(&c->dAl, sizeof(double) * (size_t)(ld * P)));
     HIPCHK(c, hipMalloc(&c->dW, sizeof(double) * (size_t)(ld * std::max(P, 1))));
     HIPCHK(c, hipMalloc(&c->dY, sizeof(double) * (size_t)(ld * std::max(P, 1))));
+    HIPCHK(c, hipMalloc(&c->dXinv, sizeof(double) * (size_t)(cap / NB) * NB * NB));
     HIPCHK(c, hipMemsetAsync(c->dXt, 0, sizeof(double) * (size_t)(ld * D), c->stream));
     return GPE_OK;
 }
@@ -175,22 +184,25 @@ int grow_dev(gpe_ctx* c, int64_t need)
     if (need <= c->cap)
         return GPE_OK;
     int64_t ncap = round_up(std::max<int64_t>(need, 2 * c->cap), NB);
-    int64_t nld = ncap + ld_pad();
-    double *nXt = nullptr, *nA = nullptr, *nOm = nullptr, *nAl = nullptr, *nW = nullptr, *nY = nullptr;
     int D = c->D, P = c->P;
+    int64_t nld = ld_for(ncap, P);
+    double *nXt = nullptr, *nA = nullptr, *nOm = nullptr, *nAl = nullptr, *nW = nullptr, *nY = nullptr, *nXi = nullptr;
     HIPCHK(c, hipMalloc(&nXt, sizeof(double) * (size_t)(nld * D)));
     HIPCHK(c, hipMalloc(&nA, sizeof(double) * (size_t)(nld * ncap)));
     HIPCHK(c, hipMalloc(&nOm, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nAl, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nW, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nY, sizeof(double) * (size_t)(nld * P)));
+    HIPCHK(c, hipMalloc(&nXi, sizeof(double) * (size_t)(ncap / NB) * NB * NB));
     HIPCHK(c, hipMemsetAsync(nXt, 0, sizeof(double) * (size_t)(nld * D), c->stream));
     if (c->N > 0) {
         launch_copy2d(c->stream, c->dXt, c->ld, nXt, nld, c->N, D);
         launch_copy2d(c->stream, c->dA, c->ld, nA, nld, c->N, c->N);
+        hipMemcpyAsync(nXi, c->dXinv, sizeof(double) * (size_t)(c->cap / NB) * NB * NB, hipMemcpyDeviceToDevice,
+                       c->stream);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    double* old[] = {c->dXt, c->dA, c->dOm, c->dAl, c->dW, c->dY, c->dLinv, c->dKinv};
+    double* old[] = {c->dXt, c->dA, c->dOm, c->dAl, c->dW, c->dY, c->dLinv, c->dKinv, c->dXinv};
     for (double* p : old)
         if (p)
             hipFree(p);
@@ -200,6 +212,7 @@ int grow_dev(gpe_ctx* c, int64_t need)
     c->dAl = nAl;
     c->dW = nW;
     c->dY = nY;
+    c->dXinv = nXi;
     c->dLinv = c->dKinv = nullptr;
     c->inv_ok = false;
     c->cap = ncap;
@@ -236,11 +249,13 @@ inline double* Aat(gpe_ctx* c, double* base, int64_t i, int64_t j) { return base
 
 // ---------------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky, two levels (replaces Eigen::LLT at gp.hpp:565):
-//   outer panels of `nbo` columns: the trailing update runs with k = nbo so that the fp64 MFMA
+//   outer panels of `nbo` columns: the trailing update runs with k = nbo so that the matrix-core
 //   kernel reads/writes C once per 2*nbo flops per element (k = 64 would be C-traffic bound);
-//   inside a panel: 64-column steps  [potf2 | trsm_right | in-panel update].
+//   inside a panel: 64-column steps  [k_diag: factor + invert | L21 = A21 X^T | in-panel update],
+//   the last two being calls of the same matrix-core kernel.
+// M >= N rows take part (rows N..M-1 = right-hand sides: they come out as (L^-1 b)^T).
 // ---------------------------------------------------------------------------------------------
-void potrf_blocked(gpe_ctx* c, double* A, int64_t N)
+void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
 {
     hipStream_t s = c->stream;
     const int64_t ld = c->ld;
@@ -251,10 +266,28 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N)
         for (int64_t j0 = p0; j0 < pe; j0 += NB) {
             const int jb = (int)std::min<int64_t>(NB, pe - j0);
             const int64_t r0 = j0 + jb;
+            double* Xt = c->dXinv + (j0 / NB) * (NB * NB);
             {
-                PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)jb * jb * jb / 3.0 + (double)(N - r0) * jb * jb);
-                launch_potf2(s, A + j0 + j0 * ld, ld, jb, c->dInfo, j0);
-                launch_trsm_right(s, A + j0 + j0 * ld, ld, jb, A + r0 + j0 * ld, ld, N - r0);
+                PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)jb * jb * jb);
+                launch_diag(s, A + j0 + j0 * ld, ld, jb, Xt, c->dInfo, j0);
+            }
+            if (r0 < M) { // L21 = A21 L11^-T, in place (each 32-row workgroup reads only its own rows)
+                GemmArgs g{};
+                g.C = A + r0 + j0 * ld;
+                g.ldc = ld;
+                g.A = A + r0 + j0 * ld;
+                g.lda = ld;
+                g.a_kmajor = 0;
+                g.B = Xt;
+                g.ldb = NB;
+                g.b_kmajor = 1; // opB(col, kk) = X[col][kk] = Xt[kk + 64 col]
+                g.m = M - r0;
+                g.n = jb;
+                g.k = jb;
+                g.overwrite = 1;
+                g.tile = 32;
+                PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - r0) * jb * jb);
+                launch_gemm_sub(s, g);
             }
             if (r0 < pe) { // rest of the panel's columns
                 GemmArgs g{};
@@ -266,7 +299,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N)
                 g.B = A + r0 + j0 * ld;
                 g.ldb = ld;
                 g.b_kmajor = 0;
-                g.m = N - r0;
+                g.m = M - r0;
                 g.n = pe - r0;
                 g.k = jb;
                 g.tri = 1;
@@ -284,7 +317,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N)
             g.lda = ld;
             g.B = A + pe + p0 * ld;
             g.ldb = ld;
-            g.m = N - pe;
+            g.m = M - pe;
             g.n = N - pe;
             g.k = pw;
             g.tri = 1;
@@ -298,7 +331,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N)
 
 // Z <- L^-1 B in place, B is N x M (ldb).  identity_structure: B starts as the identity, so at
 // step j only columns < j + jb are non-zero (L^-1 is lower triangular) — gp.hpp:260 restricted
-// to the triangle.
+// to the triangle.  The 64-row diagonal solves are products with the stored block inverses.
 void trsm_left_blocked(gpe_ctx* c, const double* L, double* B, int64_t ldb, int64_t N, int64_t M, bool ident, int ph)
 {
     hipStream_t s = c->stream;
@@ -312,8 +345,23 @@ void trsm_left_blocked(gpe_ctx* c, const double* L, double* B, int64_t ldb, int6
             const int64_t r0 = j0 + jb;
             const int64_t ncol = ident ? r0 : M;
             {
+                // B_j <- X_j B_j, in place: one 64-row tile, every workgroup owns its columns
+                GemmArgs g{};
+                g.C = B + j0;
+                g.ldc = ldb;
+                g.A = c->dXinv + (j0 / NB) * (NB * NB);
+                g.lda = NB;
+                g.a_kmajor = 1; // opA(i, kk) = X[i][kk] = Xt[kk + 64 i]
+                g.B = B + j0;
+                g.ldb = ldb;
+                g.b_kmajor = 1; // opB(n, kk) = B[j0 + kk, n]
+                g.m = jb;
+                g.n = ncol;
+                g.k = jb;
+                g.overwrite = 1;
+                g.tile = 64;
                 PhaseScope ps(c, ph, (double)jb * jb * ncol);
-                launch_trsm_left(s, L + j0 + j0 * ld, ld, jb, B + j0, ldb, ncol, 0);
+                launch_gemm_sub(s, g);
             }
             if (r0 < oe) {
                 GemmArgs g{};
@@ -358,8 +406,20 @@ void solve_alpha(gpe_ctx* c)
     for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) {
         int pc = std::min(GPE_MAX_P, c->P - p0);
         launch_copy2d(s, c->dOm + (int64_t)p0 * c->ld, c->ld, c->dW, c->ld, c->N, pc);
-        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dW, c->dY, c->ld, pc, 0);
-        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc, 1);
+        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dW, c->dY, c->ld, pc, 0);
+        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc, 1);
+    }
+}
+
+// second half of gp.hpp:605-611 when z = L^-1 obs_mean already sits in rows N.. of A
+void solve_alpha_from_z(gpe_ctx* c)
+{
+    hipStream_t s = c->stream;
+    PhaseScope ps(c, GPE_PH_SOLVE, (double)c->N * c->N * c->P);
+    for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) {
+        int pc = std::min(GPE_MAX_P, c->P - p0);
+        launch_rows_to_cols(s, c->dA + c->N + p0, c->ld, c->N, pc, c->dY, c->ld);
+        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc, 1);
     }
 }
 
@@ -388,10 +448,11 @@ int compute_enqueue(gpe_ctx* c)
         PhaseScope ps(c, GPE_PH_KERNEL_BUILD, 0.0);
         launch_build_K(s, c->dXt, c->ld, c->N, c->kp, c->dA, c->ld);
     }
-    potrf_blocked(c, c->dA, c->N);
+    launch_cols_to_rows(s, c->dOm, c->ld, c->N, c->P, c->dA + c->N, c->ld);
+    potrf_blocked(c, c->dA, c->N, c->N + c->P);
     c->have_L = true;
     c->inv_ok = false; // gp.hpp:570
-    solve_alpha(c);
+    solve_alpha_from_z(c);
     enqueue_loglik_terms(c);
     return GPE_OK;
 }
@@ -714,11 +775,12 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         hipLaunchKernelGGL(k_knn, dim3(1), dim3(1), 0, s, c->dW, n, c->kp.diag_add, c->dScal + 2);
         if (n > 0) {
             // new row of L by forward substitution (gp.hpp:591-594): L[n, 0:n] = (L^-1 k[0:n])^T
-            launch_trsv_sweep(s, c->dA, ld, n, c->dW, c->dY, ld, 1, 0);
+            launch_trsv_sweep(s, c->dA, ld, n, c->dXinv, c->dW, c->dY, ld, 1, 0);
             hipLaunchKernelGGL(k_vec_to_row, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->dY, c->dA + n, ld,
                                n);
         }
         launch_append_diag(s, c->dA + n, ld, n, c->dScal + 2, c->dInfo); // gp.hpp:596-597
+        launch_diag_inv(s, c->dA, ld, n + 1, n / NB, 1, c->dXinv); // the last block gained a row
     }
     c->N = n + 1;
     c->have_L = true;
@@ -903,6 +965,8 @@ int gpe_set_L(gpe_handle c, const double* L, int64_t ldh)
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipMemcpy2D(c->dA, sizeof(double) * c->ld, L, sizeof(double) * ldh, sizeof(double) * c->N, c->N,
                           hipMemcpyHostToDevice));
+    launch_diag_inv(c->stream, c->dA, c->ld, c->N, 0, (c->N + NB - 1) / NB, c->dXinv);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_L = true;
     c->inv_ok = false;
     c->ll_ok = false;
@@ -1014,6 +1078,8 @@ int gpe_clone(gpe_handle src, gpe_handle* out)
         hipMemcpyAsync(c->dA, src->dA, mat, hipMemcpyDeviceToDevice, c->stream);
         hipMemcpyAsync(c->dOm, src->dOm, sizeof(double) * (size_t)(c->ld * c->P), hipMemcpyDeviceToDevice, c->stream);
         hipMemcpyAsync(c->dAl, src->dAl, sizeof(double) * (size_t)(c->ld * c->P), hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync(c->dXinv, src->dXinv, sizeof(double) * (size_t)(c->cap / NB) * NB * NB, hipMemcpyDeviceToDevice,
+                       c->stream);
         if (src->dKhost) {
             hipMalloc(&c->dKhost, mat);
             hipMemcpyAsync(c->dKhost, src->dKhost, mat, hipMemcpyDeviceToDevice, c->stream);

@@ -258,7 +258,7 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         const char* e = getenv("GPE_GEMM_TILE"); // debug/tuning: 128, 64 or 32
         force = e ? atoi(e) : 0;
     }
-    int tile = force;
+    int tile = g.tile ? g.tile : force;
     if (tile != 128 && tile != 64 && tile != 32) {
         // 256 CUs, 2 workgroups resident per CU at the 128 tile: want >= ~2 full rounds before
         // paying for the larger tile's longer per-workgroup latency

@@ -1,230 +1,334 @@
-// potrf.hip — the serial pieces of the blocked Cholesky and of the triangular solves (gfx950).
+// potrf.hip — the serial piece of the blocked Cholesky (gfx950): the 64 x 64 diagonal block.
 //
-// Together with gemm.hip these replace Eigen::LLT<MatrixXd>(K).matrixL()
+// Together with gemm.hip this replaces Eigen::LLT<MatrixXd>(K).matrixL()
 // (src/limbo/model/gp.hpp:565) and the TriangularView solves (gp.hpp:260-261, :608-610, :620).
 //
-//   k_potf2       64x64 diagonal block, one 256-thread workgroup, block kept in registers
-//                 (thread = (row, column class mod 4)), one LDS column broadcast + one barrier
-//                 per column step.
-//   k_trsm_right  rows below the diagonal block: X <- X L11^-T, one row per lane, the row's 64
-//                 entries in registers, L11 read as LDS broadcasts.
-//   k_trsm_left   64-row block times many columns: B <- L11^-1 B or L11^-T B, one column per lane.
+//   k_diag      one 256-thread workgroup: factor the diagonal block D = L11 L11^T in registers
+//               and then invert L11 with the fp64 matrix cores; writes L11 in place and
+//               X^T = L11^-T (as Xt[k + 64 c] = X[c][k]) to a side buffer.
+//   k_diag_inv  the inversion alone, batched over blocks (load(..., recompute = false) and
+//               add_sample need the inverses of blocks they did not factor).
+//
+// Everything below the diagonal block then is a matrix-core product with X (gemm.hip):
+// L21 = A21 X^T, and the triangular sweeps become 64 x 64 mat-vecs with X / X^T (solve.hip).
+//
+// Factorisation.  The critical path of a Cholesky is the chain of N pivots
+// (pivot -> rsqrt -> scale -> update of the next column), ~170 cycles each on this chip
+// (tools/ubench.hip); everything here is arranged around it.  Thread (r, w): lane r = row,
+// wave w owns the four-column groups g = 4q + w (columns 4g .. 4g+3), 16 doubles per thread.
+// Round g: the owner wave first applies round g-1's rank-4 update to its four columns, then
+// factors the 64 x 4 panel entirely inside the wave (pivot and multipliers broadcast with
+// v_readlane, 1/sqrt by v_rsq_f64 + two Newton steps — no IEEE sqrt/div sequence on the chain),
+// and publishes the four scaled columns through LDS; ONE barrier per four columns.  The other
+// three waves meanwhile apply the previous rank-4 update to all their later columns; the owner's
+// own non-critical columns are caught up one round later (4 LDS buffers keep that legal).
 #include "dev.h"
 
 #define NB 64
+#define XS 66 // LDS row stride (doubles) of the 64 x 64 work matrices: conflict-free MFMA operand reads
 
-// ---------------------------------------------------------------------------------------
-// diagonal block
-// ---------------------------------------------------------------------------------------
-template <int J>
-struct Potf2Steps {
-    static __device__ __forceinline__ void run(double (&a)[16], double (*colbuf)[NB], int r, int cg, int& bad)
-    {
-        Potf2Steps<J - 1>::run(a, colbuf, r, cg, bad);
-        constexpr int own = J & 3, mj = J >> 2, pb = J & 1;
-        if (cg == own)
-            colbuf[pb][r] = a[mj];
-        __syncthreads();
-        const double d = colbuf[pb][J];
-        if (!(d > 0.0) && bad == 0)
-            bad = J + 1;
-        const double ljj = sqrt(d);
-        const double inv = 1.0 / ljj;
-        const double lr = colbuf[pb][r] * inv; // L[r, J] for r > J
-        if (cg == own)
-            a[mj] = (r == J) ? ljj : lr;
-        // trailing columns c = cg + 4m > J
-        if (cg > own) {
-            const double lc = colbuf[pb][cg + 4 * mj] * inv;
-            a[mj] = fma(-lr, lc, a[mj]);
-        }
+static __device__ __forceinline__ double mfma4(double a, double b, double c)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+static __device__ __forceinline__ double bcast_lane(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(p) to full double precision: v_rsq_f64 seed + two Newton steps
+static __device__ __forceinline__ double rsqrt_full(double p)
+{
+    double y = __builtin_amdgcn_rsq(p);
+    double t = p * y;
+    double e = fma(-t, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    t = p * y;
+    e = fma(-t, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+
+// a[qq][*] -= sum_e Lt[r][e] * Lt[c][e] for this thread's column groups qq with 4 qq + w >= gmin
+// (Lt: one round's four scaled columns, Lt[row * 4 + e])
+static __device__ __forceinline__ void rank4_update(double (&a)[4][4], const double* __restrict__ Lt, int r, int w,
+                                                    int gmin, int qlo)
+{
+    const double m0 = Lt[r * 4 + 0], m1 = Lt[r * 4 + 1], m2 = Lt[r * 4 + 2], m3 = Lt[r * 4 + 3];
 #pragma unroll
-        for (int m = mj + 1; m < 16; ++m) {
-            const double lc = colbuf[pb][cg + 4 * m] * inv;
-            a[m] = fma(-lr, lc, a[m]);
+    for (int qq = 0; qq < 4; ++qq) {
+        if (qq < qlo || 4 * qq + w < gmin)
+            continue; // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double* lc = Lt + (16 * qq + 4 * w + e) * 4; // wave-uniform address: LDS broadcast
+            double v = a[qq][e];
+            v = fma(-m0, lc[0], v);
+            v = fma(-m1, lc[1], v);
+            v = fma(-m2, lc[2], v);
+            v = fma(-m3, lc[3], v);
+            a[qq][e] = v;
         }
+    }
+}
+
+template <int G>
+struct DiagRound {
+    static __device__ __forceinline__ void run(double (&a)[4][4], double* __restrict__ Ltb, double* __restrict__ invd,
+                                               int* __restrict__ sbad, int r, int w)
+    {
+        DiagRound<G - 1>::run(a, Ltb, invd, sbad, r, w);
+        constexpr int q = G >> 2, own = G & 3, c0 = 4 * G;
+        double* Lt = Ltb + (G & 3) * (NB * 4);
+        const double* Lp = Ltb + ((G + 3) & 3) * (NB * 4); // round G-1
+        const double* Lpp = Ltb + ((G + 2) & 3) * (NB * 4); // round G-2
+        if (w == own) {
+            if (G > 0) {
+                // critical: round G-1's update on this group's four columns only
+                const double m0 = Lp[r * 4 + 0], m1 = Lp[r * 4 + 1], m2 = Lp[r * 4 + 2], m3 = Lp[r * 4 + 3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double* lc = Lp + (c0 + e) * 4;
+                    double v = a[q][e];
+                    v = fma(-m0, lc[0], v);
+                    v = fma(-m1, lc[1], v);
+                    v = fma(-m2, lc[2], v);
+                    v = fma(-m3, lc[3], v);
+                    a[q][e] = v;
+                }
+            }
+            double a0 = a[q][0], a1 = a[q][1], a2 = a[q][2], a3 = a[q][3];
+            // column c0
+            const double p0 = bcast_lane(a0, c0);
+            const double y0 = rsqrt_full(p0);
+            const double l0 = a0 * y0;
+            a1 = fma(-l0, bcast_lane(l0, c0 + 1), a1);
+            // column c0+1
+            const double p1 = bcast_lane(a1, c0 + 1);
+            const double y1 = rsqrt_full(p1);
+            a2 = fma(-l0, bcast_lane(l0, c0 + 2), a2);
+            a3 = fma(-l0, bcast_lane(l0, c0 + 3), a3);
+            const double l1 = a1 * y1;
+            a2 = fma(-l1, bcast_lane(l1, c0 + 2), a2);
+            // column c0+2
+            const double p2 = bcast_lane(a2, c0 + 2);
+            const double y2 = rsqrt_full(p2);
+            a3 = fma(-l1, bcast_lane(l1, c0 + 3), a3);
+            const double l2 = a2 * y2;
+            a3 = fma(-l2, bcast_lane(l2, c0 + 3), a3);
+            // column c0+3
+            const double p3 = bcast_lane(a3, c0 + 3);
+            const double y3 = rsqrt_full(p3);
+            const double l3 = a3 * y3;
+            a[q][0] = l0;
+            a[q][1] = l1;
+            a[q][2] = l2;
+            a[q][3] = l3;
+            Lt[r * 4 + 0] = l0;
+            Lt[r * 4 + 1] = l1;
+            Lt[r * 4 + 2] = l2;
+            Lt[r * 4 + 3] = l3;
+            if (r == 0) {
+                invd[c0 + 0] = y0;
+                invd[c0 + 1] = y1;
+                invd[c0 + 2] = y2;
+                invd[c0 + 3] = y3;
+                // first non-positive pivot (the reference never checks LLT::info(), gp.hpp:565)
+                int bad = 0;
+                if (!(p3 > 0.0))
+                    bad = c0 + 4;
+                if (!(p2 > 0.0))
+                    bad = c0 + 3;
+                if (!(p1 > 0.0))
+                    bad = c0 + 2;
+                if (!(p0 > 0.0))
+                    bad = c0 + 1;
+                if (bad != 0 && *sbad == 0)
+                    *sbad = bad;
+            }
+        }
+        else {
+            if (G > 1 && w == ((G - 1) & 3)) // last round's owner catches up on round G-2
+                rank4_update(a, Lpp, r, w, G, 0);
+            if (G > 0)
+                rank4_update(a, Lp, r, w, G, 0);
+        }
+        __syncthreads();
     }
 };
 template <>
-struct Potf2Steps<-1> {
-    static __device__ __forceinline__ void run(double (&)[16], double (*)[NB], int, int, int&) {}
+struct DiagRound<-1> {
+    static __device__ __forceinline__ void run(double (&)[4][4], double*, double*, int*, int, int) {}
 };
 
-__global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t lda, int jb, int* __restrict__ info,
-                                               int64_t goff)
+// ---- inversion of the 64 x 64 lower-triangular L (in LDS, Ls[row * XS + col]) --------------------
+// acc[n] += sum_{k < 16} P[i0 + i][pk0 + k] * Q[qk0 + k][j0 + 4 n + j]   (16 x 16 x 16, n in [n0, n1))
+static __device__ __forceinline__ void mm16(const double* __restrict__ P, int i0, int pk0, const double* __restrict__ Q,
+                                            int qk0, int j0, double (&acc)[4], int n0, int n1, int lane)
 {
-    __shared__ double colbuf[2][NB];
-    const int r = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    double a[16];
+    const int ai = i0 + (lane & 15), kq = lane >> 4, bj = j0 + (lane & 3);
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int c = cg + 4 * m;
-        // only the lower triangle of A is meaningful; pad a short block with the identity
-        a[m] = (r < jb && c < jb) ? ((c <= r) ? A[r + (int64_t)c * lda] : 0.0) : ((r == c) ? 1.0 : 0.0);
-    }
-    int bad = 0;
-    Potf2Steps<NB - 1>::run(a, colbuf, r, cg, bad);
+    for (int ks = 0; ks < 16; ks += 4) {
+        const double av = P[ai * XS + pk0 + ks + kq];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int c = cg + 4 * m;
-        if (r < jb && c <= r)
-            A[r + (int64_t)c * lda] = a[m];
+        for (int n = 0; n < 4; ++n)
+            if (n >= n0 && n < n1)
+                acc[n] = mfma4(av, Q[(qk0 + ks + kq) * XS + bj + 4 * n], acc[n]);
     }
-    if (threadIdx.x == 0 && bad != 0 && bad <= jb && *info == 0)
-        *info = (int)(goff + bad);
+}
+// D[i0 + row][j0 + col] = sign * acc   (result layout of v_mfma_f64_4x4x4_4b, see gemm.hip)
+static __device__ __forceinline__ void st16(double* __restrict__ D, int i0, int j0, const double (&acc)[4], int n0,
+                                            int n1, double sign, int lane)
+{
+    const int row = i0 + 4 * ((lane >> 2) & 3) + (lane >> 4), col = j0 + (lane & 3);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        if (n >= n0 && n < n1)
+            D[row * XS + col + 4 * n] = sign * acc[n];
 }
 
-void launch_potf2(hipStream_t s, double* A, int64_t lda, int jb, int* info, int64_t goff)
+// Ls: L (lower, zeros above).  invd[j] = 1 / L[j][j].  Xs <- L^-1 (zeros above).  Ts: scratch.
+// All 256 threads; ends with a barrier.
+static __device__ __forceinline__ void invert_L64(const double* __restrict__ Ls, const double* __restrict__ invd,
+                                                  double* __restrict__ Xs, double* __restrict__ Ts)
 {
-    hipLaunchKernelGGL(k_potf2, dim3(1), dim3(256), 0, s, A, lda, jb, info, goff);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < NB * XS; e += 256)
+        Xs[e] = 0.0;
+    __syncthreads();
+    { // level 0: the four 16 x 16 diagonal blocks, wave w -> block w, lane (mod 16) = column of X
+        const int b0 = 16 * w, c = lane & 15;
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            x[j] = (j == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            x[j] *= invd[b0 + j];
+#pragma unroll
+            for (int i = j + 1; i < 16; ++i)
+                x[i] = fma(-Ls[(b0 + i) * XS + b0 + j], x[j], x[i]);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                Xs[(b0 + j) * XS + b0 + c] = x[j];
+        }
+    }
+    __syncthreads();
+    { // level 1: blocks (1,0) and (3,2):  X_ib,jb = -X_ib,ib (L_ib,jb X_jb,jb); two waves per block
+        const int t = w >> 1, h = w & 1, ib = 2 * t + 1, jb = 2 * t;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        mm16(Ls, 16 * ib, 16 * jb, Xs, 16 * jb, 16 * jb, acc, 2 * h, 2 * h + 2, lane);
+        st16(Ts, 16 * ib, 16 * jb, acc, 2 * h, 2 * h + 2, 1.0, lane);
+        __syncthreads();
+        double acc2[4] = {0.0, 0.0, 0.0, 0.0};
+        mm16(Xs, 16 * ib, 16 * ib, Ts, 16 * ib, 16 * jb, acc2, 2 * h, 2 * h + 2, lane);
+        st16(Xs, 16 * ib, 16 * jb, acc2, 2 * h, 2 * h + 2, -1.0, lane);
+    }
+    __syncthreads();
+    { // level 2: rows 32..63 x cols 0..31, one 16 x 16 block per wave
+        const int ib = 2 + (w >> 1), jb = w & 1;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int kb = jb; kb < 2; ++kb) // T = L_21 X_11, X_11 lower
+            mm16(Ls, 16 * ib, 16 * kb, Xs, 16 * kb, 16 * jb, acc, 0, 4, lane);
+        st16(Ts, 16 * ib, 16 * jb, acc, 0, 4, 1.0, lane);
+        __syncthreads();
+        double acc2[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int kb = 2; kb <= ib; ++kb) // X_21 = -X_22 T, X_22 lower
+            mm16(Xs, 16 * ib, 16 * kb, Ts, 16 * kb, 16 * jb, acc2, 0, 4, lane);
+        st16(Xs, 16 * ib, 16 * jb, acc2, 0, 4, -1.0, lane);
+    }
+    __syncthreads();
 }
 
-// ---------------------------------------------------------------------------------------
-// shared: stage the 64x64 diagonal block into LDS as Ls[j][k] (row j contiguous) with the
-// reciprocal diagonal; TRANS stores U = L^T (U[j][k] = L[k][j]).  Short blocks padded with I.
-// ---------------------------------------------------------------------------------------
-template <bool TRANS>
-__device__ __forceinline__ void stage_L11(const double* __restrict__ L11, int64_t ldl, int jb, double* Ls,
-                                          double* invd, int nthreads)
+// Xt[k + 64 c] = X[c][k]
+static __device__ __forceinline__ void store_Xt(const double* __restrict__ Xs, double* __restrict__ Xt)
 {
-    for (int e = threadIdx.x; e < NB * NB; e += nthreads) {
-        const int r = e & 63, c = e >> 6; // coalesced along rows of the column-major block
+    for (int e = threadIdx.x; e < NB * NB; e += 256)
+        Xt[e] = Xs[(e >> 6) * XS + (e & 63)];
+}
+
+__global__ __launch_bounds__(256) void k_diag(double* __restrict__ A, int64_t lda, int jb, double* __restrict__ Xt,
+                                              int* __restrict__ info, int64_t goff)
+{
+    __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Xs[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Ts[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Ltb[4 * NB * 4];
+    __shared__ double invd[NB];
+    __shared__ int sbad;
+    const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        sbad = 0;
+    double a[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 16 * q + 4 * w + e;
+            // only the lower triangle of A is meaningful; a short block is padded with the identity
+            a[q][e] = (r < jb && c < jb) ? ((c <= r) ? A[r + (int64_t)c * lda] : 0.0) : ((r == c) ? 1.0 : 0.0);
+        }
+    __syncthreads();
+    DiagRound<15>::run(a, Ltb, invd, &sbad, r, w);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 16 * q + 4 * w + e;
+            const double v = (c <= r) ? a[q][e] : 0.0;
+            Ls[r * XS + c] = v;
+            if (r < jb && c <= r)
+                A[r + (int64_t)c * lda] = v;
+        }
+    if (threadIdx.x == 0 && sbad != 0 && sbad <= jb && *info == 0)
+        *info = (int)(goff + sbad);
+    __syncthreads();
+    invert_L64(Ls, invd, Xs, Ts);
+    store_Xt(Xs, Xt);
+}
+
+void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff)
+{
+    hipLaunchKernelGGL(k_diag, dim3(1), dim3(256), 0, s, A, lda, jb, Xt, info, goff);
+}
+
+// inverses of the diagonal blocks of an existing factor: block b at L[64 b, 64 b]
+__global__ __launch_bounds__(256) void k_diag_inv(const double* __restrict__ L, int64_t ldl, int64_t N, int64_t b0,
+                                                  double* __restrict__ Xt_all)
+{
+    __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Xs[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Ts[NB * XS];
+    __shared__ double invd[NB];
+    const int64_t b = b0 + blockIdx.x;
+    const int64_t j0 = b * NB;
+    const int jb = (int)((N - j0 < NB) ? N - j0 : NB);
+    const double* L11 = L + j0 + j0 * ldl;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e & 63, c = e >> 6;
         double v = 0.0;
         if (r < jb && c < jb)
             v = (c <= r) ? L11[r + (int64_t)c * ldl] : 0.0;
         else if (r == c)
             v = 1.0;
-        if (!TRANS)
-            Ls[r * NB + c] = v; // Ls[j=r][k=c] = L[r][c]
-        else
-            Ls[c * NB + r] = v; // Us[j=c][k=r] = L[r][c]
+        Ls[r * XS + c] = v;
         if (r == c)
             invd[r] = 1.0 / v;
     }
-}
-
-// x[j] = (x[j] - sum_{k<j} Ls[j][k] x[k]) * invd[j]   (forward;  lower L)
-template <int J>
-struct FwdSub {
-    static __device__ __forceinline__ void run(double (&x)[NB], const double* __restrict__ Ls,
-                                               const double* __restrict__ invd)
-    {
-        FwdSub<J - 1>::run(x, Ls, invd);
-        asm volatile("" ::: "memory"); // keep hipcc from hoisting all 2016 LDS reads (15 KB/lane of scratch)
-        double s = x[J];
-#pragma unroll
-        for (int k = 0; k < J; ++k)
-            s = fma(-Ls[J * NB + k], x[k], s);
-        x[J] = s * invd[J];
-    }
-};
-template <>
-struct FwdSub<-1> {
-    static __device__ __forceinline__ void run(double (&)[NB], const double*, const double*) {}
-};
-// x[j] = (x[j] - sum_{k>j} Us[j][k] x[k]) * invd[j]   (backward; U = L^T)
-template <int J>
-struct BwdSub {
-    static __device__ __forceinline__ void run(double (&x)[NB], const double* __restrict__ Us,
-                                               const double* __restrict__ invd)
-    {
-        BwdSub<J + 1>::run(x, Us, invd);
-        asm volatile("" ::: "memory");
-        double s = x[J];
-#pragma unroll
-        for (int k = J + 1; k < NB; ++k)
-            s = fma(-Us[J * NB + k], x[k], s);
-        x[J] = s * invd[J];
-    }
-};
-template <>
-struct BwdSub<NB> {
-    static __device__ __forceinline__ void run(double (&)[NB], const double*, const double*) {}
-};
-
-// ---------------------------------------------------------------------------------------
-// rows below the diagonal block:  X <- X * L11^-T   (row r: solve L11 x^T = a_r^T, forward)
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_trsm_right(const double* __restrict__ L11, int64_t ldl, int jb,
-                                                   double* __restrict__ A21, int64_t lda, int64_t m)
-{
-    __shared__ double Ls[NB * NB];
-    __shared__ double invd[NB];
-    __shared__ double Xs[NB * NB]; // Xs[j][lane]: the row panel, staged so the global loop stays rolled
-    stage_L11<false>(L11, ldl, jb, Ls, invd, 64);
-    const int lane = threadIdx.x;
-    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
-    for (int j = 0; j < NB; ++j)
-        Xs[j * NB + lane] = (r < m && j < jb) ? A21[r + (int64_t)j * lda] : 0.0;
     __syncthreads();
-    double x[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-        x[j] = Xs[j * NB + lane];
-    FwdSub<NB - 1>::run(x, Ls, invd);
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-        Xs[j * NB + lane] = x[j];
-    if (r < m) {
-        for (int j = 0; j < jb; ++j)
-            A21[r + (int64_t)j * lda] = Xs[j * NB + lane];
-    }
+    invert_L64(Ls, invd, Xs, Ts);
+    store_Xt(Xs, Xt_all + b * (NB * NB));
 }
 
-void launch_trsm_right(hipStream_t s, const double* L11, int64_t ldl, int jb, double* A21, int64_t lda, int64_t m)
+void launch_diag_inv(hipStream_t s, const double* L, int64_t ldl, int64_t N, int64_t b0, int64_t nblocks,
+                     double* Xt_all)
 {
-    if (m <= 0)
+    if (nblocks <= 0)
         return;
-    hipLaunchKernelGGL(k_trsm_right, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, L11, ldl, jb, A21, lda, m);
-}
-
-// ---------------------------------------------------------------------------------------
-// 64-row block, many right-hand sides:  B <- L11^-1 B   or   B <- L11^-T B
-// one column per lane; the 64x64 tile of B goes through LDS so that global access is
-// coalesced along the rows (column-major B).
-// ---------------------------------------------------------------------------------------
-template <bool TRANS>
-__global__ __launch_bounds__(64) void k_trsm_left(const double* __restrict__ L11, int64_t ldl, int jb,
-                                                  double* __restrict__ B, int64_t ldb, int64_t nrhs)
-{
-    __shared__ double Ls[NB * NB];
-    __shared__ double invd[NB];
-    __shared__ double Bs[NB * (NB + 1)];
-    stage_L11<TRANS>(L11, ldl, jb, Ls, invd, 64);
-    const int64_t c0 = (int64_t)blockIdx.x * 64;
-    const int lane = threadIdx.x;
-    for (int c = 0; c < NB; ++c) { // lane = row k: coalesced
-        const int64_t col = c0 + c;
-        Bs[c * (NB + 1) + lane] = (col < nrhs && lane < jb) ? B[lane + col * ldb] : 0.0;
-    }
-    __syncthreads();
-    double x[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
-        x[k] = Bs[lane * (NB + 1) + k];
-    if (!TRANS)
-        FwdSub<NB - 1>::run(x, Ls, invd);
-    else
-        BwdSub<0>::run(x, Ls, invd);
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
-        Bs[lane * (NB + 1) + k] = x[k];
-    __syncthreads();
-    for (int c = 0; c < NB; ++c) {
-        const int64_t col = c0 + c;
-        if (col < nrhs && lane < jb)
-            B[lane + col * ldb] = Bs[c * (NB + 1) + lane];
-    }
-}
-
-void launch_trsm_left(hipStream_t s, const double* L11, int64_t ldl, int jb, double* B, int64_t ldb, int64_t nrhs,
-                      int trans)
-{
-    if (nrhs <= 0)
-        return;
-    dim3 grid((unsigned)((nrhs + 63) / 64));
-    if (trans)
-        hipLaunchKernelGGL((k_trsm_left<true>), grid, dim3(64), 0, s, L11, ldl, jb, B, ldb, nrhs);
-    else
-        hipLaunchKernelGGL((k_trsm_left<false>), grid, dim3(64), 0, s, L11, ldl, jb, B, ldb, nrhs);
+    hipLaunchKernelGGL(k_diag_inv, dim3((unsigned)nblocks), dim3(256), 0, s, L, ldl, N, b0, Xt_all);
 }

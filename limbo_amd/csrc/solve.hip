@@ -1,90 +1,69 @@
 // solve.hip — vector triangular sweeps, reductions and small utilities (gfx950).
 //
 // k_trsv_fwd_step / k_trsv_bwd_step: one 64-unknown block step of L y = b / L^T a = y
-// (GP::_compute_alpha, src/limbo/model/gp.hpp:605-611).  Every workgroup of a step first
-// solves the 64x64 diagonal system redundantly (one wave, lane = row, pivot broadcast by
-// v_readlane) — redundancy costs no time and saves a kernel boundary per step — and then
-// applies the rank-64 update to its own slab of the remaining right-hand side.  The solution
-// goes to a separate `out` vector so no workgroup reads what another one overwrites.
+// (GP::_compute_alpha, src/limbo/model/gp.hpp:605-611), using the inverses of the 64 x 64
+// diagonal blocks that the factorisation leaves behind (potrf.hip).
 #include "dev.h"
 
 #define NB 64
 #define LSTR 65
 
-__device__ __forceinline__ void stage_diag(const double* __restrict__ L11, int64_t ldl, int jb, double* Ls,
-                                           double* invd)
+// xs[p][c] = sum_k M[c][k] v_p[k] with M = X (forward, TRANS = 0: M[c][k] = Xt[k + 64 c]) or
+// M = X^T (backward, TRANS = 1: M[c][k] = Xt[c + 64 k]).  256 threads; v_p = w[j0 .. j0+jb) of
+// right-hand side p (zero beyond jb).  Stg: NB*LSTR doubles of LDS scratch.  Ends with a barrier.
+template <int TRANS>
+__device__ __forceinline__ void diag_matvec(const double* __restrict__ Xt, const double* __restrict__ w, int64_t ldw,
+                                            int64_t j0, int jb, int P, double* __restrict__ Stg,
+                                            double (*__restrict__ xs)[NB], double (*__restrict__ part)[4][NB])
 {
-    // Ls[r*65 + c] = L[r][c] (lower), identity padding for short blocks
-    for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
-        const int r = e & 63, c = e >> 6;
-        double v = 0.0;
-        if (r < jb && c < jb)
-            v = (c <= r) ? L11[r + (int64_t)c * ldl] : 0.0;
-        else if (r == c)
-            v = 1.0;
-        Ls[r * LSTR + c] = v;
-        if (r == c)
-            invd[r] = 1.0 / v;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // Stg[c][k] = M[c][k]; global reads are coalesced along the fast index of Xt
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int f = e & 63, s = e >> 6; // Xt[f + 64 s]
+        if (!TRANS)
+            Stg[s * LSTR + f] = Xt[e]; // c = s, k = f
+        else
+            Stg[f * LSTR + s] = Xt[e]; // c = f, k = s
     }
+    __syncthreads();
+    for (int p = 0; p < P; ++p) {
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = 16 * wv + kk;
+            const double v = (k < jb) ? w[j0 + k + (int64_t)p * ldw] : 0.0;
+            acc = fma(Stg[lane * LSTR + k], v, acc);
+        }
+        part[p][wv][lane] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64)
+        for (int p = 0; p < P; ++p)
+            xs[p][lane] = (part[p][0][lane] + part[p][1][lane]) + (part[p][2][lane] + part[p][3][lane]);
+    __syncthreads();
 }
 
-// forward: lane r holds b[r]; for j = 0..63: x_j = b_j / L_jj ; b_r -= L[r][j] x_j (r > j)
-template <int J>
-struct WaveFwd {
-    static __device__ __forceinline__ void run(double& b, const double* Ls, const double* invd, int lane)
-    {
-        WaveFwd<J - 1>::run(b, Ls, invd, lane);
-        const double xj = __shfl(b, J) * invd[J];
-        if (lane == J)
-            b = xj;
-        else if (lane > J)
-            b = fma(-Ls[lane * LSTR + J], xj, b);
-    }
-};
-template <>
-struct WaveFwd<-1> {
-    static __device__ __forceinline__ void run(double&, const double*, const double*, int) {}
-};
-// backward (L^T x = b): for j = 63..0: x_j = b_j / L_jj ; b_c -= L[j][c] x_j (c < j)
-template <int J>
-struct WaveBwd {
-    static __device__ __forceinline__ void run(double& b, const double* Ls, const double* invd, int lane)
-    {
-        WaveBwd<J + 1>::run(b, Ls, invd, lane);
-        const double xj = __shfl(b, J) * invd[J];
-        if (lane == J)
-            b = xj;
-        else if (lane < J)
-            b = fma(-Ls[J * LSTR + lane], xj, b);
-    }
-};
-template <>
-struct WaveBwd<NB> {
-    static __device__ __forceinline__ void run(double&, const double*, const double*, int) {}
-};
-
-// L: full matrix (col-major, ld); block at j0 of size jb; N = order.
+// One 64-unknown block step of L y = b / L^T a = y (GP::_compute_alpha, gp.hpp:605-611).  Every
+// workgroup of a step first forms the block's solution redundantly as a 64 x 64 mat-vec with the
+// inverse of the diagonal block (computed by k_diag during the factorisation) — redundancy costs
+// no time and saves a kernel boundary per step — and then applies the rank-64 update to its own
+// slab of the remaining right-hand side.  The solution goes to a separate `out` vector so no
+// workgroup reads what another one overwrites.
+// L: full matrix (col-major, ld); block at j0 of size jb; N = order; Xt: this block's inverse.
 // w: running right-hand side (N x P, ldw); out: solution (N x P, ldw)
 __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, int64_t ld, int64_t N,
-                                                       int64_t j0, int jb, double* __restrict__ w,
-                                                       double* __restrict__ out, int64_t ldw, int P)
+                                                       int64_t j0, int jb, const double* __restrict__ Xt,
+                                                       double* __restrict__ w, double* __restrict__ out, int64_t ldw,
+                                                       int P)
 {
-    __shared__ double Ls[NB * LSTR];
-    __shared__ double invd[NB];
+    __shared__ double Stg[NB * LSTR];
     __shared__ double xs[GPE_MAX_P][NB];
-    stage_diag(L + j0 + j0 * ld, ld, jb, Ls, invd);
-    __syncthreads();
+    __shared__ double part[GPE_MAX_P][4][NB];
+    diag_matvec<0>(Xt, w, ldw, j0, jb, P, Stg, xs, part);
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x < 64) {
-        for (int p = 0; p < P; ++p) {
-            double b = (lane < jb) ? w[j0 + lane + (int64_t)p * ldw] : 0.0;
-            WaveFwd<NB - 1>::run(b, Ls, invd, lane);
-            xs[p][lane] = b;
-            if (blockIdx.x == 0 && lane < jb)
-                out[j0 + lane + (int64_t)p * ldw] = b;
-        }
-    }
-    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 64 && lane < jb)
+        for (int p = 0; p < P; ++p)
+            out[j0 + lane + (int64_t)p * ldw] = xs[p][lane];
     // update rows below: w[r] -= sum_k L[r][j0+k] x[k]
     const int64_t r = j0 + jb + (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r < N) {
@@ -108,53 +87,55 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict_
 }
 
 __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, int64_t ld, int64_t N,
-                                                       int64_t j0, int jb, double* __restrict__ w,
-                                                       double* __restrict__ out, int64_t ldw, int P)
+                                                       int64_t j0, int jb, const double* __restrict__ Xt,
+                                                       double* __restrict__ w, double* __restrict__ out, int64_t ldw,
+                                                       int P)
 {
-    __shared__ double Ls[NB * LSTR];
-    __shared__ double invd[NB];
+    __shared__ double Stg[NB * LSTR];
     __shared__ double xs[GPE_MAX_P][NB];
-    __shared__ double Ts[NB * LSTR];
+    __shared__ double part[GPE_MAX_P][4][NB];
     (void)N;
-    stage_diag(L + j0 + j0 * ld, ld, jb, Ls, invd);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x < 64) {
-        for (int p = 0; p < P; ++p) {
-            double b = (lane < jb) ? w[j0 + lane + (int64_t)p * ldw] : 0.0;
-            WaveBwd<0>::run(b, Ls, invd, lane);
-            xs[p][lane] = b;
-            if (blockIdx.x == 0 && lane < jb)
-                out[j0 + lane + (int64_t)p * ldw] = b;
-        }
-    }
-    // this workgroup's 64 earlier unknowns c0..c0+63:  w[c] -= sum_k L[j0+k][c] x[k]
+    // this workgroup's 64 earlier unknowns c0..c0+63: prefetch its slab of L into registers first
+    // (independent of the mat-vec):  T[k][c] = L[j0+k][c0+c], read coalesced along k
     const int64_t c0 = (int64_t)blockIdx.x * 64;
-    if (c0 < j0) {
-        // tile T[k][c] = L[j0+k][c0+c], read coalesced along k, stored Ts[c][k]
-        for (int c = wv; c < NB; c += 4) {
-            const int64_t col = c0 + c;
-            Ts[c * LSTR + lane] = (col < j0 && lane < jb) ? L[j0 + lane + col * ld] : 0.0;
-        }
+    double tl[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int64_t col = c0 + wv + 4 * q;
+        tl[q] = (c0 < j0 && col < j0 && lane < jb) ? L[j0 + lane + col * ld] : 0.0;
     }
-    __syncthreads();
-    if (c0 < j0) {
+    diag_matvec<1>(Xt, w, ldw, j0, jb, P, Stg, xs, part);
+    if (blockIdx.x == 0 && threadIdx.x < 64 && lane < jb)
+        for (int p = 0; p < P; ++p)
+            out[j0 + lane + (int64_t)p * ldw] = xs[p][lane];
+    if (c0 < j0) { // w[c] -= sum_k L[j0+k][c] x[k]
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            Stg[(wv + 4 * q) * LSTR + lane] = tl[q]; // Stg[c][k]
+        __syncthreads();
         const int c = lane;
         const int64_t col = c0 + c;
-        for (int p = wv; p < P; p += 4) {
+        for (int p = 0; p < P; ++p) {
             double acc = 0.0;
-#pragma unroll 8
-            for (int k = 0; k < NB; ++k)
-                acc = fma(Ts[c * LSTR + k], xs[p][k], acc);
-            if (col < j0)
-                w[col + (int64_t)p * ldw] -= acc;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = 16 * wv + kk;
+                acc = fma(Stg[c * LSTR + k], xs[p][k], acc);
+            }
+            part[p][wv][c] = acc;
         }
+        __syncthreads();
+        if (threadIdx.x < 64 && col < j0)
+            for (int p = 0; p < P; ++p)
+                w[col + (int64_t)p * ldw] -= (part[p][0][c] + part[p][1][c]) + (part[p][2][c] + part[p][3][c]);
     }
 }
 
 // one full sweep = ceil(N/64) launches.  trans = 0: L y = b (top down); 1: L^T a = y (bottom up)
-void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, double* w, double* out, int64_t ldw,
-                       int P, int trans)
+// Xt_all: inverses of the diagonal blocks (block b at Xt_all + 4096 b)
+void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, double* w,
+                       double* out, int64_t ldw, int P, int trans)
 {
     if (N <= 0)
         return;
@@ -167,7 +148,8 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, do
             unsigned grid = (unsigned)((rest + 255) / 256);
             if (grid == 0)
                 grid = 1;
-            hipLaunchKernelGGL(k_trsv_fwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, w, out, ldw, P);
+            hipLaunchKernelGGL(k_trsv_fwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, Xt_all + b * NB * NB, w,
+                               out, ldw, P);
         }
     }
     else {
@@ -177,9 +159,39 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, do
             unsigned grid = (unsigned)((j0 + 63) / 64);
             if (grid == 0)
                 grid = 1;
-            hipLaunchKernelGGL(k_trsv_bwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, w, out, ldw, P);
+            hipLaunchKernelGGL(k_trsv_bwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, Xt_all + b * NB * NB, w,
+                               out, ldw, P);
         }
     }
+}
+
+// rows N..N+P-1 of the matrix <- obs_mean^T (before the factorisation) and back (z = L^-1 obs_mean
+// after it): the forward substitution rides along the Cholesky as P extra rows of the panel.
+__global__ void k_cols_to_rows(const double* __restrict__ V, int64_t ldv, int64_t N, int P, double* __restrict__ Arows,
+                               int64_t lda)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N)
+        for (int p = 0; p < P; ++p)
+            Arows[p + i * lda] = V[i + (int64_t)p * ldv];
+}
+__global__ void k_rows_to_cols(const double* __restrict__ Arows, int64_t lda, int64_t N, int P, double* __restrict__ V,
+                               int64_t ldv)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N)
+        for (int p = 0; p < P; ++p)
+            V[i + (int64_t)p * ldv] = Arows[p + i * lda];
+}
+void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N, int P, double* Arows, int64_t lda)
+{
+    if (N > 0 && P > 0)
+        hipLaunchKernelGGL(k_cols_to_rows, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, V, ldv, N, P, Arows, lda);
+}
+void launch_rows_to_cols(hipStream_t s, const double* Arows, int64_t lda, int64_t N, int P, double* V, int64_t ldv)
+{
+    if (N > 0 && P > 0)
+        hipLaunchKernelGGL(k_rows_to_cols, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Arows, lda, N, P, V, ldv);
 }
 
 // ---------------------------------------------------------------------------------------
