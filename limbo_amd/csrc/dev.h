@@ -67,6 +67,7 @@ struct GemmArgs {
     int tri; int64_t grow0, gcol0;
     int ktri;
     int overwrite; // 1: C = +A*B^T (no read of C), 0: C -= A*B^T
+    int fold_len;  // set by launch_gemm_sub (tri): live tiles per folded tile-column pair
     int tile;      // 0: pick by problem size; 128 / 64 / 32: force the 128x128 / 64x64 / 32x64 tile
 };
 void launch_gemm_sub(hipStream_t s, const GemmArgs& g);

@@ -36,39 +36,54 @@
 #include "dev.h"
 #include <cstdlib>
 
-#define BKT 16
-#define LDS_K 18 // stride of S[i][kk]
+#ifndef GEMM_ABL
+#define GEMM_ABL 0 // debug ablations (tools/kbench): 1 = no global loads / LDS stores in the k loop, 2 = no MFMA
+#endif
 
 static __device__ __forceinline__ double mfma4(double a, double b, double c)
 {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
-template <bool KMAJOR, int ROWS>
+template <bool KMAJOR, int ROWS, int BK>
 struct Stager {
-    static constexpr int PER = ROWS * BKT / 256;              // elements per thread
-    static constexpr int STRIDE = ROWS + 16;                  // S[kk][i] row stride
-    static constexpr int ELEMS = KMAJOR ? ROWS * LDS_K : BKT * STRIDE;
+    static constexpr int PER = ROWS * BK / 256;               // elements per thread
+    static constexpr int STRIDE = ROWS + 16;                  // S[kk][i] row stride (== 16 mod 32)
+    static constexpr int KSTR = BK + 2;                       // S[i][kk] row stride
+    static constexpr int ELEMS = KMAJOR ? ROWS * KSTR : BK * STRIDE;
     double r[PER];
-    // global -> registers (guarded: rows < rows_left, kk < k_left; zero fill)
-    __device__ __forceinline__ void load(const double* __restrict__ P, int64_t ld, int64_t rows_left, int64_t k_left)
+    // global -> registers.  No conditional loads: hipcc turns `cond ? P[..] : 0` into a branch
+    // around every load with its own wait (dependent L2 round trips).  Instead the addresses are
+    // clamped into the valid range; rows >= rl then carry a copy of row rl-1 and only feed output
+    // rows/columns the epilogue never stores, and k >= kl is cancelled by multiplying the A
+    // operand (MASKK) with an exact 0/1 factor.
+    template <bool MASKK>
+    __device__ __forceinline__ void load(const double* __restrict__ P, int64_t ld, int rl, int kl)
     {
         const int t = threadIdx.x;
         if (!KMAJOR) {
             const int i = t % ROWS, kk0 = t / ROWS;
             constexpr int KS = 256 / ROWS;
+            const int ic = i < rl ? i : rl - 1;
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
                 const int kk = kk0 + KS * q;
-                r[q] = (i < rows_left && kk < k_left) ? P[i + (int64_t)kk * ld] : 0.0;
+                const int kc = kk < kl ? kk : kl - 1;
+                const double v = P[ic + (int64_t)kc * ld];
+                r[q] = MASKK ? v * (kk < kl ? 1.0 : 0.0) : v;
             }
         }
         else {
-            const int kk = t & 15, j0 = t >> 4;
+            const int kk = t % BK, j0 = t / BK;
+            constexpr int JS = 256 / BK;
+            const int kc = kk < kl ? kk : kl - 1;
+            const double km = kk < kl ? 1.0 : 0.0;
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
-                const int j = j0 + 16 * q;
-                r[q] = (j < rows_left && kk < k_left) ? P[kk + (int64_t)j * ld] : 0.0;
+                const int j = j0 + JS * q;
+                const int jc = j < rl ? j : rl - 1;
+                const double v = P[kc + (int64_t)jc * ld];
+                r[q] = MASKK ? v * km : v;
             }
         }
     }
@@ -83,10 +98,11 @@ struct Stager {
                 S[(kk0 + KS * q) * STRIDE + i] = r[q];
         }
         else {
-            const int kk = t & 15, j0 = t >> 4;
+            const int kk = t % BK, j0 = t / BK;
+            constexpr int JS = 256 / BK;
 #pragma unroll
             for (int q = 0; q < PER; ++q)
-                S[(j0 + 16 * q) * LDS_K + kk] = r[q];
+                S[(j0 + JS * q) * KSTR + kk] = r[q];
         }
     }
     // operand element: row `row` of the tile, k index kq
@@ -95,33 +111,67 @@ struct Stager {
         if (!KMAJOR)
             return S[kq * STRIDE + row];
         else
-            return S[row * LDS_K + kq];
+            return S[row * KSTR + kq];
     }
 };
 
-template <int TM, int TN, bool AK, bool BK>
+// first row tile of tile column tj that touches the lower triangle (global row >= global col),
+// clamped to tiles_m
+template <int TM, int TN>
+static __host__ __device__ __forceinline__ int first_live_tile(const GemmArgs& g, int tj)
+{
+    const int tiles_m = (int)((g.m + TM - 1) / TM);
+    const int64_t need = g.gcol0 + (int64_t)tj * TN - g.grow0 - (TM - 1); // ti*TM >= need
+    int64_t t = need <= 0 ? 0 : (need + TM - 1) / TM;
+    return (int)(t < tiles_m ? t : tiles_m);
+}
+
+template <int TM, int TN, int BKT, bool AK, bool BK>
 __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
 {
-    using SA = Stager<AK, TM>;
-    using SB = Stager<BK, TN>;
+    using SA = Stager<AK, TM, BKT>;
+    using SB = Stager<BK, TN, BKT>;
     constexpr int RA = TM / 2 / 16; // 16-row slabs per wave
     constexpr int RB = TN / 2 / 4;  // 4-column groups per wave
     __shared__ __attribute__((aligned(16))) double lds[2][SA::ELEMS + SB::ELEMS];
-    // XCD-aware tile order: workgroups b, b+8, b+16.. land on the same XCD (private L2), so give
-    // each XCD a contiguous band of tiles: neighbours share operand panels in that L2.
+    // Workgroup -> tile.  Two concerns:
+    //  * triangular problems: only tiles touching the lower triangle are enumerated, and column
+    //    tj is folded with column tiles_n-1-tj so that every "super column" has the same number of
+    //    live tiles — a plain 2-D grid with early exits leaves the XCDs that draw the right-hand
+    //    columns idle while XCD 0 works through three rounds;
+    //  * XCD-aware order: workgroups b, b+8, b+16.. land on the same XCD (private L2), so each XCD
+    //    gets a contiguous band of the enumeration: neighbours share operand panels in that L2.
     const int tiles_m = (int)((g.m + TM - 1) / TM);
     const int tiles_n = (int)((g.n + TN - 1) / TN);
-    const int nwg = tiles_m * tiles_n;
     int wg = blockIdx.x;
     {
+        const int nwg = gridDim.x;
         const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int ti = wg % tiles_m; // row tile fastest: neighbours share the B (column) panel
-    const int tj = wg / tiles_m;
+    int ti, tj;
+    if (g.tri) {
+        const int sc = wg / g.fold_len;
+        int rr = wg % g.fold_len;
+        const int t0 = first_live_tile<TM, TN>(g, sc), c0 = tiles_m - t0;
+        if (rr < c0) {
+            tj = sc;
+            ti = t0 + rr;
+        }
+        else {
+            tj = tiles_n - 1 - sc;
+            const int t1 = first_live_tile<TM, TN>(g, tj);
+            rr -= c0;
+            if (tj == sc || rr >= tiles_m - t1)
+                return;
+            ti = t1 + rr;
+        }
+    }
+    else {
+        ti = wg % tiles_m; // row tile fastest: neighbours share the B (column) panel
+        tj = wg / tiles_m;
+    }
     const int64_t row0 = (int64_t)ti * TM, col0 = (int64_t)tj * TN;
-    if (g.tri && (g.grow0 + row0 + TM - 1 < g.gcol0 + col0))
-        return; // tile entirely above the diagonal
     int64_t kbeg = 0;
     if (g.ktri) { // X^T X with X lower triangular: rows of X below max(row0, col0) only
         kbeg = (row0 > col0 ? row0 : col0);
@@ -141,6 +191,7 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
     const int64_t a_kstep = AK ? (int64_t)BKT : (int64_t)BKT * g.lda;
     const int64_t b_kstep = BK ? (int64_t)BKT : (int64_t)BKT * g.ldb;
     const int64_t mrows = g.m - row0, ncols = g.n - col0;
+    const int mr = (int)(mrows < TM ? mrows : TM), nc = (int)(ncols < TN ? ncols : TN);
 
     double acc[RA][RB];
 #pragma unroll
@@ -153,20 +204,28 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
     SB sb;
     int64_t kleft = kend - kbeg;
     if (kleft > 0) {
-        sa.load(Ap, g.lda, mrows, kleft);
-        sb.load(Bp, g.ldb, ncols, kleft);
+        const int kl = (int)(kleft < BKT ? kleft : BKT);
+        sa.template load<true>(Ap, g.lda, mr, kl);
+        sb.template load<false>(Bp, g.ldb, nc, kl);
         sa.store(lds[0]);
         sb.store(lds[0] + SA::ELEMS);
     }
     __syncthreads();
     int buf = 0;
     for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
+#if GEMM_ABL != 1
         const bool more = (k0 + BKT < kend);
+#endif
+#if GEMM_ABL == 1
+        const bool more = false;
+#endif
         if (more) { // prefetch next k-tile into registers while this one is consumed
             Ap += a_kstep;
             Bp += b_kstep;
-            sa.load(Ap, g.lda, mrows, kend - k0 - BKT);
-            sb.load(Bp, g.ldb, ncols, kend - k0 - BKT);
+            const int64_t kleft2 = kend - k0 - BKT;
+            const int kl = (int)(kleft2 < BKT ? kleft2 : BKT);
+            sa.template load<true>(Ap, g.lda, mr, kl);
+            sb.template load<false>(Bp, g.ldb, nc, kl);
         }
         const double* As = lds[buf];
         const double* Bs = lds[buf] + SA::ELEMS;
@@ -183,7 +242,11 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
             for (int n = 0; n < RB; ++n)
 #pragma unroll
                 for (int m = 0; m < RA; ++m)
+#if GEMM_ABL == 2
+                    acc[m][n] += af[m] * bf[n] * (ks == 0 && m == 0 && n == 0 ? 1.0 : 0.0);
+#else
                     acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+#endif
         }
         if (more) {
             sa.store(lds[buf ^ 1]);
@@ -196,38 +259,74 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
     // epilogue.  D lane l -> row 4*((l>>2)&3) + (l>>4) of the 16-row slab, column l&3 of the group
     const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);
     const int dcol = lane & 3;
+    double* Cb = g.C + (col0 + wn + dcol) * g.ldc + row0 + wm + drow;
+    if (mr == TM && nc == TN) { // interior tile: no guards
+        if (g.overwrite) {
 #pragma unroll
-    for (int n = 0; n < RB; ++n) {
-        const int64_t cn = col0 + wn + 4 * n + dcol;
-        if (cn >= g.n)
-            continue;
-        double* Cc = g.C + cn * g.ldc;
+            for (int n = 0; n < RB; ++n)
 #pragma unroll
-        for (int m = 0; m < RA; ++m) {
-            const int64_t rm = row0 + wm + 16 * m + drow;
-            if (rm < g.m) {
-                if (g.overwrite)
-                    Cc[rm] = acc[m][n];
-                else
-                    Cc[rm] -= acc[m][n];
+                for (int m = 0; m < RA; ++m)
+                    Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = acc[m][n];
+        }
+        else {
+#pragma unroll
+            for (int n = 0; n < RB; ++n) {
+                double cv[RA];
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    cv[m] = Cb[(int64_t)(4 * n) * g.ldc + 16 * m];
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = cv[m] - acc[m][n];
+            }
+        }
+    }
+    else {
+#pragma unroll
+        for (int n = 0; n < RB; ++n) {
+            const bool cok = wn + 4 * n + dcol < nc;
+#pragma unroll
+            for (int m = 0; m < RA; ++m) {
+                if (cok && wm + 16 * m + drow < mr) {
+                    double* cp = Cb + (int64_t)(4 * n) * g.ldc + 16 * m;
+                    if (g.overwrite)
+                        *cp = acc[m][n];
+                    else
+                        *cp -= acc[m][n];
+                }
             }
         }
     }
 }
 
-template <int TM, int TN>
-static void launch_tile(hipStream_t s, const GemmArgs& g)
+template <int TM, int TN, int BKT>
+static void launch_tile(hipStream_t s, const GemmArgs& g0)
 {
-    int64_t tiles = ((g.m + TM - 1) / TM) * ((g.n + TN - 1) / TN);
+    GemmArgs g = g0;
+    const int tiles_m = (int)((g.m + TM - 1) / TM), tiles_n = (int)((g.n + TN - 1) / TN);
+    int64_t tiles = (int64_t)tiles_m * tiles_n;
+    if (g.tri) { // folded enumeration of the live tiles (see k_gemm4)
+        int fold = 1;
+        const int nsup = (tiles_n + 1) / 2;
+        for (int sc = 0; sc < nsup; ++sc) {
+            const int t2 = tiles_n - 1 - sc;
+            int len = tiles_m - first_live_tile<TM, TN>(g, sc);
+            if (t2 != sc)
+                len += tiles_m - first_live_tile<TM, TN>(g, t2);
+            fold = len > fold ? len : fold;
+        }
+        g.fold_len = fold;
+        tiles = (int64_t)nsup * fold;
+    }
     dim3 grid((unsigned)tiles), block(256);
     if (!g.a_kmajor && !g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm4<TM, TN, false, false>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, false, false>), grid, block, 0, s, g);
     else if (!g.a_kmajor && g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm4<TM, TN, false, true>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, false, true>), grid, block, 0, s, g);
     else if (g.a_kmajor && !g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm4<TM, TN, true, false>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, true, false>), grid, block, 0, s, g);
     else
-        hipLaunchKernelGGL((k_gemm4<TM, TN, true, true>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, true, true>), grid, block, 0, s, g);
 }
 
 // number of TM x TN tiles that do work (triangular skipping accounted for)
@@ -270,11 +369,11 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
             tile = 32;
     }
     if (tile == 128)
-        launch_tile<128, 128>(s, g);
+        launch_tile<128, 128, 32>(s, g);
     else if (tile == 64)
-        launch_tile<64, 64>(s, g);
+        launch_tile<64, 64, 32>(s, g);
     else
-        launch_tile<32, 64>(s, g);
+        launch_tile<32, 64, 32>(s, g);
 }
 
 // algorithmic flops of one launch (2 m n k, lower-triangular tile skipping accounted for at

@@ -23,8 +23,18 @@
 // three waves meanwhile apply the previous rank-4 update to all their later columns; the owner's
 // own non-critical columns are caught up one round later (4 LDS buffers keep that legal).
 #include "dev.h"
+#include <cstdio>
 
 #define NB 64
+#ifndef DIAG_ABL
+#define DIAG_ABL 0 // debug ablations (tools/kbench): 1 = no factorisation rounds, 2 = no inversion
+#endif
+#ifdef DIAG_TIMING
+__device__ long long g_diag_ts[32];
+#define TS(i) do { if (threadIdx.x == 0) g_diag_ts[i] = clock64(); } while (0)
+#else
+#define TS(i) do { } while (0)
+#endif
 #define XS 66 // LDS row stride (doubles) of the 64 x 64 work matrices: conflict-free MFMA operand reads
 
 static __device__ __forceinline__ double mfma4(double a, double b, double c)
@@ -157,6 +167,8 @@ struct DiagRound {
                 rank4_update(a, Lp, r, w, G, 0);
         }
         __syncthreads();
+        if (G < 16)
+            TS(10 + G);
     }
 };
 template <>
@@ -199,6 +211,7 @@ static __device__ __forceinline__ void invert_L64(const double* __restrict__ Ls,
     for (int e = threadIdx.x; e < NB * XS; e += 256)
         Xs[e] = 0.0;
     __syncthreads();
+    TS(4);
     { // level 0: the four 16 x 16 diagonal blocks, wave w -> block w, lane (mod 16) = column of X
         const int b0 = 16 * w, c = lane & 15;
         double x[16];
@@ -219,6 +232,7 @@ static __device__ __forceinline__ void invert_L64(const double* __restrict__ Ls,
         }
     }
     __syncthreads();
+    TS(5);
     { // level 1: blocks (1,0) and (3,2):  X_ib,jb = -X_ib,ib (L_ib,jb X_jb,jb); two waves per block
         const int t = w >> 1, h = w & 1, ib = 2 * t + 1, jb = 2 * t;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -230,6 +244,7 @@ static __device__ __forceinline__ void invert_L64(const double* __restrict__ Ls,
         st16(Xs, 16 * ib, 16 * jb, acc2, 2 * h, 2 * h + 2, -1.0, lane);
     }
     __syncthreads();
+    TS(6);
     { // level 2: rows 32..63 x cols 0..31, one 16 x 16 block per wave
         const int ib = 2 + (w >> 1), jb = w & 1;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -243,6 +258,7 @@ static __device__ __forceinline__ void invert_L64(const double* __restrict__ Ls,
         st16(Xs, 16 * ib, 16 * jb, acc2, 0, 4, -1.0, lane);
     }
     __syncthreads();
+    TS(7);
 }
 
 // Xt[k + 64 c] = X[c][k]
@@ -273,8 +289,13 @@ __global__ __launch_bounds__(256) void k_diag(double* __restrict__ A, int64_t ld
             // only the lower triangle of A is meaningful; a short block is padded with the identity
             a[q][e] = (r < jb && c < jb) ? ((c <= r) ? A[r + (int64_t)c * lda] : 0.0) : ((r == c) ? 1.0 : 0.0);
         }
+    TS(0);
     __syncthreads();
+    TS(1);
+#if DIAG_ABL != 1
     DiagRound<15>::run(a, Ltb, invd, &sbad, r, w);
+#endif
+    TS(2);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -288,10 +309,27 @@ __global__ __launch_bounds__(256) void k_diag(double* __restrict__ A, int64_t ld
     if (threadIdx.x == 0 && sbad != 0 && sbad <= jb && *info == 0)
         *info = (int)(goff + sbad);
     __syncthreads();
+    TS(3);
+#if DIAG_ABL != 2
     invert_L64(Ls, invd, Xs, Ts);
+#endif
     store_Xt(Xs, Xt);
+    TS(8);
 }
 
+#ifdef DIAG_TIMING
+void dump_diag_timing()
+{
+    long long h[32];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag_ts), sizeof(h));
+    printf("k_diag cycles: load %lld | rounds %lld | writeL %lld | zeroX %lld | inv0 %lld | inv1 %lld | inv2 %lld | storeXt %lld | total %lld\n",
+           h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[8] - h[0]);
+    printf("rounds:");
+    for (int g = 0; g < 16; ++g)
+        printf(" %lld", h[10 + g] - (g ? h[9 + g] : h[1]));
+    printf("\n");
+}
+#endif
 void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff)
 {
     hipLaunchKernelGGL(k_diag, dim3(1), dim3(256), 0, s, A, lda, jb, Xt, info, goff);

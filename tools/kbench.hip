@@ -1,0 +1,81 @@
+// kbench.hip — isolated launches of the engine's kernels at the N = 4096 shapes; run under
+// `rocprofv3 --kernel-trace` and read the per-(kernel, grid) durations with tools/kstats.py.
+// build: make -C tools kbench   (links the engine's object files)
+#include "../limbo_amd/csrc/dev.h"
+#include "../include/gpe.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+int main(int argc, char** argv)
+{
+    const int64_t N = 4096, ld = N + 32;
+    const int D = 6, reps = argc > 1 ? atoi(argv[1]) : 10;
+    hipStream_t s;
+    CHK(hipStreamCreate(&s));
+    std::mt19937_64 rng(1);
+    std::uniform_real_distribution<double> U(0, 1);
+    std::vector<double> hXt((size_t)ld * D);
+    for (auto& v : hXt) v = U(rng);
+    double *dXt, *A0, *A, *Xi, *w, *out;
+    int* info;
+    CHK(hipMalloc(&dXt, sizeof(double) * ld * D));
+    CHK(hipMalloc(&A0, sizeof(double) * ld * N));
+    CHK(hipMalloc(&A, sizeof(double) * ld * N));
+    CHK(hipMalloc(&Xi, sizeof(double) * 64 * 4096));
+    CHK(hipMalloc(&w, sizeof(double) * ld));
+    CHK(hipMalloc(&out, sizeof(double) * ld));
+    CHK(hipMalloc(&info, 64));
+    CHK(hipMemset(info, 0, 64));
+    CHK(hipMemcpy(dXt, hXt.data(), sizeof(double) * ld * D, hipMemcpyHostToDevice));
+    KParams kp{};
+    kp.kind = GPE_KERNEL_SE_ARD;
+    kp.D = D;
+    kp.sf2 = 1.0;
+    kp.inv_l = 1.0;
+    kp.noise = 0.01;
+    kp.diag_add = 0.01 + 1e-8;
+    for (int d = 0; d < D; ++d) kp.inv_ell[d] = 1.0;
+    launch_build_K(s, dXt, ld, N, kp, A0, ld);
+    CHK(hipMemcpyAsync(A, A0, sizeof(double) * ld * N, hipMemcpyDeviceToDevice, s));
+    CHK(hipMemsetAsync(w, 0, sizeof(double) * ld, s));
+    for (int r = 0; r < reps; ++r) {
+        // diagonal block
+        launch_copy2d(s, A0, ld, A, ld, 64, 64);
+        launch_diag(s, A, ld, 64, Xi, info, 0);
+        // trsm shape: (4032 x 64) x (64 x 64), in place
+        {
+            GemmArgs g{};
+            g.C = A + 64; g.ldc = ld; g.A = A + 64; g.lda = ld; g.B = Xi; g.ldb = 64; g.b_kmajor = 1;
+            g.m = 4032; g.n = 64; g.k = 64; g.overwrite = 1; g.tile = 32;
+            launch_gemm_sub(s, g);
+        }
+        // in-panel update: (4032 x 192), k = 64
+        {
+            GemmArgs g{};
+            g.C = A + 64 + 64 * ld; g.ldc = ld; g.A = A + 64; g.lda = ld; g.B = A + 64; g.ldb = ld;
+            g.m = 4032; g.n = 192; g.k = 64; g.tri = 1; g.grow0 = 64; g.gcol0 = 64;
+            for (int t : {32, 64}) { g.tile = t; launch_gemm_sub(s, g); }
+        }
+        // outer updates, k = 256
+        for (int64_t m : {3840, 2816, 1792, 768}) {
+            GemmArgs g{};
+            int64_t pe = N - m;
+            g.C = A + pe + pe * ld; g.ldc = ld; g.A = A + pe; g.lda = ld; g.B = A + pe; g.ldb = ld;
+            g.m = m; g.n = m; g.k = 256; g.tri = 1; g.grow0 = pe; g.gcol0 = pe;
+            for (int t : {32, 64, 128}) { g.tile = t; launch_gemm_sub(s, g); }
+        }
+        // backward step at the last block and in the middle
+        launch_trsv_sweep(s, A, ld, N, Xi, w, out, ld, 1, 1);
+    }
+    CHK(hipStreamSynchronize(s));
+#ifdef DIAG_TIMING
+    extern void dump_diag_timing();
+    dump_diag_timing();
+#endif
+    printf("kbench done\n");
+    return 0;
+}
