@@ -34,6 +34,7 @@
 //   row-contiguous operand : S[kk][i], row stride = ROWS + 16 doubles  (== 16 mod 32)
 //   k-contiguous operand   : S[i][kk], row stride 18 doubles
 #include "dev.h"
+#include <cstdint>
 #include <cstdlib>
 
 #ifndef GEMM_ABL
@@ -126,14 +127,17 @@ static __host__ __device__ __forceinline__ int first_live_tile(const GemmArgs& g
     return (int)(t < tiles_m ? t : tiles_m);
 }
 
-template <int TM, int TN, int BKT, bool AK, bool BK>
+// NBUF = 2: double-buffered k loop.  NBUF = 1: the whole k range (<= BKT) is staged at once — the
+// latency-critical one-shot form used by the panel steps of the Cholesky (k = 64): every global
+// load of the workgroup, including its C tile, is in flight before the first wait.
+template <int TM, int TN, int BKT, int NBUF, bool AK, bool BK>
 __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
 {
     using SA = Stager<AK, TM, BKT>;
     using SB = Stager<BK, TN, BKT>;
     constexpr int RA = TM / 2 / 16; // 16-row slabs per wave
     constexpr int RB = TN / 2 / 4;  // 4-column groups per wave
-    __shared__ __attribute__((aligned(16))) double lds[2][SA::ELEMS + SB::ELEMS];
+    __shared__ __attribute__((aligned(16))) double lds[NBUF][SA::ELEMS + SB::ELEMS];
     // Workgroup -> tile.  Two concerns:
     //  * triangular problems: only tiles touching the lower triangle are enumerated, and column
     //    tj is folded with column tiles_n-1-tj so that every "super column" has the same number of
@@ -200,6 +204,21 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
         for (int b = 0; b < RB; ++b)
             acc[a][b] = 0.0;
 
+    // epilogue addressing.  D lane l -> row 4*((l>>2)&3) + (l>>4) of the 16-row slab, column l&3
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);
+    const int dcol = lane & 3;
+    double* Cb = g.C + (col0 + wn + dcol) * g.ldc + row0 + wm + drow;
+    const bool interior = (mr == TM && nc == TN);
+    constexpr bool CPRE = (NBUF == 1); // small one-shot tiles: fetch C together with the operands
+    double cpre[CPRE ? RA : 1][CPRE ? RB : 1];
+    if (CPRE && interior && !g.overwrite) {
+#pragma unroll
+        for (int n = 0; n < RB; ++n)
+#pragma unroll
+            for (int m = 0; m < RA; ++m)
+                cpre[CPRE ? m : 0][CPRE ? n : 0] = Cb[(int64_t)(4 * n) * g.ldc + 16 * m];
+    }
+
     SA sa;
     SB sb;
     int64_t kleft = kend - kbeg;
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
     int buf = 0;
     for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
 #if GEMM_ABL != 1
-        const bool more = (k0 + BKT < kend);
+        const bool more = (NBUF == 2) && (k0 + BKT < kend);
 #endif
 #if GEMM_ABL == 1
         const bool more = false;
@@ -248,25 +267,30 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
                     acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
 #endif
         }
-        if (more) {
-            sa.store(lds[buf ^ 1]);
-            sb.store(lds[buf ^ 1] + SA::ELEMS);
+        if (NBUF == 2) {
+            if (more) {
+                sa.store(lds[buf ^ 1]);
+                sb.store(lds[buf ^ 1] + SA::ELEMS);
+            }
+            __syncthreads();
+            buf ^= 1;
         }
-        __syncthreads();
-        buf ^= 1;
     }
 
-    // epilogue.  D lane l -> row 4*((l>>2)&3) + (l>>4) of the 16-row slab, column l&3 of the group
-    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);
-    const int dcol = lane & 3;
-    double* Cb = g.C + (col0 + wn + dcol) * g.ldc + row0 + wm + drow;
-    if (mr == TM && nc == TN) { // interior tile: no guards
+    if (interior) { // no guards
         if (g.overwrite) {
 #pragma unroll
             for (int n = 0; n < RB; ++n)
 #pragma unroll
                 for (int m = 0; m < RA; ++m)
                     Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = acc[m][n];
+        }
+        else if (CPRE) {
+#pragma unroll
+            for (int n = 0; n < RB; ++n)
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = cpre[CPRE ? m : 0][CPRE ? n : 0] - acc[m][n];
         }
         else {
 #pragma unroll
@@ -299,7 +323,7 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
     }
 }
 
-template <int TM, int TN, int BKT>
+template <int TM, int TN, int BKT, int NBUF>
 static void launch_tile(hipStream_t s, const GemmArgs& g0)
 {
     GemmArgs g = g0;
@@ -320,13 +344,197 @@ static void launch_tile(hipStream_t s, const GemmArgs& g0)
     }
     dim3 grid((unsigned)tiles), block(256);
     if (!g.a_kmajor && !g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, false, false>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, NBUF, false, false>), grid, block, 0, s, g);
     else if (!g.a_kmajor && g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, false, true>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, NBUF, false, true>), grid, block, 0, s, g);
     else if (g.a_kmajor && !g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, true, false>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, NBUF, true, false>), grid, block, 0, s, g);
     else
-        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, true, true>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, NBUF, true, true>), grid, block, 0, s, g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: both operands row-contiguous (the Cholesky updates), k a multiple of BKT.
+// Operand k-rows go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
+// instruction = one k-row of a 128-row operand tile), no staging VGPRs, no ds_write pass and no
+// per-load address arithmetic; NST LDS stages, counted vmcnt and raw s_barrier so that the next
+// stage's loads stay in flight across the barriers; NWV waves (2 per SIMD at 8) so that one wave's
+// LDS reads and waits sit under the other's MFMAs.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int TM, int TN, int WM, int WN, int BKT, int NST>
+__global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
+{
+    static_assert(TM == 128 && TN == 128, "one k-row of an operand tile = one 1 KiB glds instruction");
+    constexpr int NWV = WM * WN;
+    constexpr int SA = TM + 16, SB = TN + 16; // k-row strides (doubles), == 16 mod 32
+    constexpr int STAGE = BKT * (SA + SB);
+    constexpr int RA = TM / WM / 16, RB = TN / WN / 4;
+    constexpr int LPW = 2 * BKT / NWV; // glds instructions per wave per stage
+    __shared__ __attribute__((aligned(16))) double lds[NST * STAGE];
+
+    const int tiles_m = (int)((g.m + TM - 1) / TM);
+    const int tiles_n = (int)((g.n + TN - 1) / TN);
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int ti, tj;
+    if (g.tri) {
+        const int sc = wg / g.fold_len;
+        int rr = wg % g.fold_len;
+        const int t0 = first_live_tile<TM, TN>(g, sc), c0 = tiles_m - t0;
+        if (rr < c0) {
+            tj = sc;
+            ti = t0 + rr;
+        }
+        else {
+            tj = tiles_n - 1 - sc;
+            const int t1 = first_live_tile<TM, TN>(g, tj);
+            rr -= c0;
+            if (tj == sc || rr >= tiles_m - t1)
+                return;
+            ti = t1 + rr;
+        }
+    }
+    else {
+        ti = wg % tiles_m;
+        tj = wg / tiles_m;
+    }
+    const int64_t row0 = (int64_t)ti * TM, col0 = (int64_t)tj * TN;
+    const int64_t mrows = g.m - row0, ncols = g.n - col0;
+    const int mr = (int)(mrows < TM ? mrows : TM), nc = (int)(ncols < TN ? ncols : TN);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave % WM) * (TM / WM), wn = (wave / WM) * (TN / WN);
+    const int arow = wm + (lane & 15), bcol = wn + (lane & 3), kq = lane >> 4;
+
+    // this lane's 16-byte piece of every k-row: rows (2 lane, 2 lane + 1), clamped into the tile's
+    // valid rows (copies of valid rows only feed outputs the epilogue does not store)
+    int ra = 2 * lane, rb = 2 * lane;
+    {
+        const int ma = (mr - 1) & ~1, mb = (nc - 1) & ~1;
+        ra = ra < ma ? ra : ma;
+        rb = rb < mb ? rb : mb;
+    }
+    const double* pa = g.A + row0 + ra + (int64_t)wave * g.lda;
+    const double* pb = g.B + col0 + rb + (int64_t)wave * g.ldb;
+    const int64_t astep = (int64_t)NWV * g.lda, bstep = (int64_t)NWV * g.ldb;
+
+    auto issue = [&](int stage) {
+        double* sa = lds + stage * STAGE + wave * SA;
+        double* sb = lds + stage * STAGE + BKT * SA + wave * SB;
+#pragma unroll
+        for (int q = 0; q < BKT / NWV; ++q) {
+            __builtin_amdgcn_global_load_lds(pa, (lds_void_t*)(sa + q * NWV * SA), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(pb, (lds_void_t*)(sb + q * NWV * SB), 16, 0, 0);
+            pa += astep;
+            pb += bstep;
+        }
+    };
+
+    double acc[RA][RB];
+#pragma unroll
+    for (int a = 0; a < RA; ++a)
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+            acc[a][b] = 0.0;
+
+    const int nk = (int)(g.k / BKT);
+    issue(0);
+    for (int t = 0; t < nk; ++t) {
+        const int st = t % NST;
+        if (t + 1 < nk) {
+            issue((t + 1) % NST);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        }
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // every wave's pieces of stage st have landed
+        const double* As = lds + st * STAGE;
+        const double* Bs = As + BKT * SA;
+#pragma unroll
+        for (int ks = 0; ks < BKT; ks += 4) {
+            double af[RA], bf[RB];
+#pragma unroll
+            for (int x = 0; x < RA; ++x)
+                af[x] = As[(ks + kq) * SA + arow + 16 * x];
+#pragma unroll
+            for (int x = 0; x < RB; ++x)
+                bf[x] = Bs[(ks + kq) * SB + bcol + 4 * x];
+#pragma unroll
+            for (int n = 0; n < RB; ++n)
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // stage st may be refilled
+    }
+
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);
+    const int dcol = lane & 3;
+    double* Cb = g.C + (col0 + wn + dcol) * g.ldc + row0 + wm + drow;
+    if (mr == TM && nc == TN) {
+#pragma unroll
+        for (int n = 0; n < RB; ++n) {
+            double cv[RA];
+#pragma unroll
+            for (int m = 0; m < RA; ++m)
+                cv[m] = g.overwrite ? 0.0 : Cb[(int64_t)(4 * n) * g.ldc + 16 * m];
+#pragma unroll
+            for (int m = 0; m < RA; ++m)
+                Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = g.overwrite ? acc[m][n] : cv[m] - acc[m][n];
+        }
+    }
+    else {
+#pragma unroll
+        for (int n = 0; n < RB; ++n) {
+            const bool cok = wn + 4 * n + dcol < nc;
+#pragma unroll
+            for (int m = 0; m < RA; ++m) {
+                if (cok && wm + 16 * m + drow < mr) {
+                    double* cp = Cb + (int64_t)(4 * n) * g.ldc + 16 * m;
+                    if (g.overwrite)
+                        *cp = acc[m][n];
+                    else
+                        *cp -= acc[m][n];
+                }
+            }
+        }
+    }
+}
+
+static bool glds_ok(const GemmArgs& g)
+{
+    return !g.a_kmajor && !g.b_kmajor && !g.ktri && g.k >= 32 && g.k % 32 == 0 && (g.lda % 2) == 0 && (g.ldb % 2) == 0
+        && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0;
+}
+
+static void launch_glds128(hipStream_t s, const GemmArgs& g0)
+{
+    constexpr int TM = 128, TN = 128;
+    GemmArgs g = g0;
+    const int tiles_m = (int)((g.m + TM - 1) / TM), tiles_n = (int)((g.n + TN - 1) / TN);
+    int64_t tiles = (int64_t)tiles_m * tiles_n;
+    if (g.tri) {
+        int fold = 1;
+        const int nsup = (tiles_n + 1) / 2;
+        for (int sc = 0; sc < nsup; ++sc) {
+            const int t2 = tiles_n - 1 - sc;
+            int len = tiles_m - first_live_tile<TM, TN>(g, sc);
+            if (t2 != sc)
+                len += tiles_m - first_live_tile<TM, TN>(g, t2);
+            fold = len > fold ? len : fold;
+        }
+        g.fold_len = fold;
+        tiles = (int64_t)nsup * fold;
+    }
+    hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 32, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
 }
 
 // number of TM x TN tiles that do work (triangular skipping accounted for)
@@ -359,21 +567,26 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
     }
     int tile = g.tile ? g.tile : force;
     if (tile != 128 && tile != 64 && tile != 32) {
-        // 256 CUs, 2 workgroups resident per CU at the 128 tile: want >= ~2 full rounds before
-        // paying for the larger tile's longer per-workgroup latency
-        if (live_tiles(g, 128, 128) >= 1024)
+        // measured at k = 256 (tools/kbench): one 128 x 128 glds workgroup per CU runs at the
+        // LDS-fed MFMA rate (~48 us per tile); below ~200 live tiles too many CUs idle and the
+        // 64 x 64 tile (4x the workgroups) wins; the 32 x 64 tile serves the tiny panel steps
+        if (glds_ok(g) && live_tiles(g, 128, 128) >= 200)
             tile = 128;
         else if (live_tiles(g, 64, 64) >= 512)
             tile = 64;
         else
             tile = 32;
     }
-    if (tile == 128)
-        launch_tile<128, 128, 32>(s, g);
+    if (tile == 128 && glds_ok(g))
+        launch_glds128(s, g);
+    else if (tile == 128)
+        launch_tile<128, 128, 32, 2>(s, g);
     else if (tile == 64)
-        launch_tile<64, 64, 32>(s, g);
+        launch_tile<64, 64, 32, 2>(s, g);
+    else if (g.k <= 64 && !g.ktri)
+        launch_tile<32, 64, 64, 1>(s, g); // one-shot panel-step form
     else
-        launch_tile<32, 64, 32>(s, g);
+        launch_tile<32, 64, 32, 2>(s, g);
 }
 
 // algorithmic flops of one launch (2 m n k, lower-triangular tile skipping accounted for at
