@@ -79,6 +79,8 @@ int gpe_set_data(gpe_handle h, const double* X_rowmajor, int64_t N, int D,
 /* same, from device memory already resident on the handle's device */
 int gpe_set_data_device(gpe_handle h, const double* dX_rowmajor, int64_t N, int D,
                         const double* d_obs_mean, int P);
+/* gp.hpp:537-548 result again, X unchanged (recompute(true, .)): replaces obs_mean only */
+int gpe_set_obs_mean(gpe_handle h, const double* obs_mean);
 /* kernel.hpp:116-123 set_h_params + the per-kernel set_params.  log_theta has
  * n_theta entries (without the optional noise parameter); noise is sigma_n^2
  * (Params::kernel::noise(), or exp(2 p_noise) when optimize_noise). */
@@ -117,6 +119,10 @@ int gpe_hp_objective(gpe_handle h, int kind, const double* log_theta, int n_thet
  * either output may be NULL. */
 int gpe_query_batch(gpe_handle h, const double* Xq_rowmajor, int64_t M,
                     double* kta, double* var);
+
+/* the same for kernels without device code: the caller supplies the cross kernel
+ * Ks[i + N*m] = k(x_i, v_m) (N x M column-major, gp.hpp:626-632); zz[m] = ||L^-1 k*_m||^2 */
+int gpe_query_batch_cross(gpe_handle h, const double* Ks, int64_t M, double* kta, double* zz);
 
 /* ---- accessors (host mirrors for matrixL()/alpha()/save/load) ------------ */
 int gpe_nb_samples(gpe_handle h, int64_t* N);

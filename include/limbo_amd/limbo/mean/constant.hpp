@@ -1,0 +1,34 @@
+// limbo/mean/constant.hpp — a fixed constant mean (src/limbo/mean/constant.hpp:52-83)
+#ifndef LIMBO_MEAN_CONSTANT_HPP
+#define LIMBO_MEAN_CONSTANT_HPP
+#include <limbo/mean/mean.hpp>
+namespace limbo {
+    namespace defaults {
+        struct mean_constant {
+            BO_PARAM(double, constant, 1);
+        };
+    } // namespace defaults
+    namespace mean {
+        template <typename Params>
+        struct Constant : public BaseMean<Params> {
+            Constant(size_t dim_out = 1) : _dim_out(dim_out), _constant(Params::mean_constant::constant()) {}
+            template <typename GP>
+            Eigen::VectorXd operator()(const Eigen::VectorXd&, const GP&) const { return Eigen::VectorXd::Constant(_dim_out, _constant); }
+            template <typename GP>
+            Eigen::MatrixXd grad(const Eigen::VectorXd&, const GP&) const { return Eigen::MatrixXd::Ones(_dim_out, 1); }
+            size_t h_params_size() const { return 1; }
+            Eigen::VectorXd h_params() const
+            {
+                Eigen::VectorXd p(1);
+                p(0) = _constant;
+                return p;
+            }
+            void set_h_params(const Eigen::VectorXd& p) { _constant = p(0); }
+
+        protected:
+            size_t _dim_out;
+            double _constant;
+        };
+    } // namespace mean
+} // namespace limbo
+#endif

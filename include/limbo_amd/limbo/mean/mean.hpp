@@ -1,0 +1,26 @@
+// limbo/mean/mean.hpp — base of the mean functors (contract: src/limbo/mean/mean.hpp:61-77).
+// Mean functors receive the GP itself and are evaluated on the HOST (gp.hpp:537-548): only
+// obs_mean = Y - m(X) crosses to the device.
+#ifndef LIMBO_MEAN_MEAN_HPP
+#define LIMBO_MEAN_MEAN_HPP
+#include <Eigen/Core>
+#include <cassert>
+#include <limbo/tools/macros.hpp>
+namespace limbo {
+    namespace mean {
+        template <typename Params>
+        struct BaseMean {
+            BaseMean(size_t /*dim_out*/ = 1) {}
+            size_t h_params_size() const { return 0; }
+            Eigen::VectorXd h_params() const { return Eigen::VectorXd(); }
+            void set_h_params(const Eigen::VectorXd&) {}
+            template <typename GP>
+            Eigen::MatrixXd grad(const Eigen::VectorXd&, const GP&) const
+            {
+                assert(false && "this mean function has no hyper-parameters");
+                return Eigen::MatrixXd();
+            }
+        };
+    } // namespace mean
+} // namespace limbo
+#endif

@@ -1,0 +1,711 @@
+// limbo/model/gp.hpp — drop-in limbo::model::GP<Params, Kernel, Mean, HPOpt> whose linear algebra
+// lives on an MI355X behind the C-ABI of include/gpe.h (libgpengine.so).
+//
+// Interface contract: src/limbo/model/gp.hpp:77-642 of resibots/limbo — same template
+// parameters and defaults, same public members with the same meaning, same protected member
+// names (subclasses and the reference's white-box tests touch _samples, _observations, _matrixL,
+// _alpha ...: sparsified_gp.hpp:109-116, test_gp.cpp:1128-1155), same quirks:
+//   * training K gets +noise+1e-8 on the diagonal (kernel.hpp:83); query()/sigma() add `noise` only
+//   * sigma^2 is clamped to 0 when <= DBL_EPSILON before the noise is added (gp.hpp:621-623)
+//   * log-lik: logdet and n log 2pi are NOT multiplied by dim_out (gp.hpp:274-279)
+//   * no exception on a non-positive-definite K: NaNs propagate (gp.hpp:565); the pivot index the
+//     device reports is kept in last_status()
+// What is different is where the state lives: X, K/L, alpha, K^-1 are resident in HBM (one
+// gpe_handle per GP, deep-copied by the copy constructor like the reference's value semantics);
+// _matrixL/_alpha/_inv_kernel on the host are lazily filled mirrors.  The mean functor receives the
+// GP itself and is evaluated on the host (gp.hpp:537-548); kernels without device code
+// (limbo_amd::device_kernel<K>::kind == KIND_HOST_K) have their K and k* built by the functor on
+// the host while factorisation and solves stay on the device.  There is no CPU fallback for the
+// linear algebra: without libgpengine.so / a GPU, construction throws.
+//
+// Additions (not in the reference): query_batch() — the batched acquisition path of SURVEY.md
+// §8 row a13/N1 — and last_status().
+#ifndef LIMBO_MODEL_GP_HPP
+#define LIMBO_MODEL_GP_HPP
+
+#include <cassert>
+#include <cfloat>
+#include <cmath>
+#include <iostream>
+#include <limits>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include <Eigen/Core>
+
+#include <limbo/kernel/matern_five_halves.hpp>
+#include <limbo/kernel/squared_exp_ard.hpp>
+#include <limbo/mean/constant.hpp>
+#include <limbo/mean/data.hpp>
+#include <limbo/model/gp/kernel_lf_opt.hpp>
+#include <limbo/model/gp/no_lf_opt.hpp>
+#include <limbo/tools/math.hpp>
+
+#include "../../../gpe.h"
+
+namespace limbo_amd {
+    /// RAII owner of one engine handle (one GP resident on the device)
+    class Engine {
+    public:
+        explicit Engine(int device) : _h(nullptr), _device(device) {}
+        Engine(const Engine& o) : _h(nullptr), _device(o._device)
+        {
+            if (o._h)
+                check(gpe_clone(o._h, &_h), "gpe_clone");
+        }
+        Engine& operator=(const Engine& o)
+        {
+            if (this != &o) {
+                reset();
+                _device = o._device;
+                if (o._h)
+                    check(gpe_clone(o._h, &_h), "gpe_clone");
+            }
+            return *this;
+        }
+        ~Engine() { reset(); }
+        void reset()
+        {
+            if (_h)
+                gpe_destroy(_h);
+            _h = nullptr;
+        }
+        gpe_handle get()
+        {
+            if (!_h)
+                check(gpe_create(_device, &_h), "gpe_create");
+            return _h;
+        }
+        gpe_handle peek() const { return _h; }
+        /// negative status = API/HIP error: loud; positive = non-positive pivot: returned
+        int check(int rc, const char* what) const
+        {
+            if (rc < 0)
+                throw std::runtime_error(std::string("limbo_amd engine: ") + what + " failed (" + std::to_string(rc) + "): "
+                    + (_h ? gpe_last_error(_h) : "no MI355X / libgpengine.so not usable"));
+            return rc;
+        }
+
+    private:
+        gpe_handle _h;
+        int _device;
+    };
+} // namespace limbo_amd
+
+namespace limbo {
+    namespace model {
+        template <typename Params, typename KernelFunction = kernel::MaternFiveHalves<Params>, typename MeanFunction = mean::Data<Params>, typename HyperParamsOptimizer = gp::NoLFOpt<Params>>
+        class GP {
+        public:
+            GP() : _dim_in(-1), _dim_out(-1), _log_lik(0), _log_loo_cv(0), _inv_kernel_updated(false), _eng(0) {}
+
+            GP(int dim_in, int dim_out)
+                : _dim_in(dim_in), _dim_out(dim_out), _kernel_function(dim_in), _mean_function(dim_out), _log_lik(0), _log_loo_cv(0), _inv_kernel_updated(false), _eng(0) {}
+
+            /// value semantics as in the reference: the device state is deep-copied (gpe_clone)
+            GP(const GP& o)
+                : _dim_in(o._dim_in), _dim_out(o._dim_out), _kernel_function(o._kernel_function), _mean_function(o._mean_function), _samples(o._samples), _observations(o._observations), _mean_vector(o._mean_vector), _obs_mean(o._obs_mean), _alpha(o._alpha), _mean_observation(o._mean_observation), _kernel(o._kernel), _inv_kernel(o._inv_kernel), _matrixL(o._matrixL), _log_lik(o._log_lik), _log_loo_cv(o._log_loo_cv), _inv_kernel_updated(o._inv_kernel_updated), _hp_optimize(o._hp_optimize), _eng(o._eng), _status(o._status), _L_stale(o._L_stale), _alpha_stale(o._alpha_stale), _Kinv_stale(o._Kinv_stale), _dev_theta(o._dev_theta), _dev_noise(o._dev_noise), _dev_kernel_ok(o._dev_kernel_ok) {}
+
+            GP& operator=(const GP& o)
+            {
+                if (this != &o) {
+                    GP tmp(o);
+                    _swap(tmp);
+                }
+                return *this;
+            }
+
+            /// gp.hpp:88-116
+            void compute(const std::vector<Eigen::VectorXd>& samples, const std::vector<Eigen::VectorXd>& observations, bool compute_kernel = true)
+            {
+                assert(samples.size() != 0);
+                assert(observations.size() != 0);
+                assert(samples.size() == observations.size());
+
+                if (_dim_in != (int)samples[0].size()) {
+                    _dim_in = samples[0].size();
+                    _kernel_function = KernelFunction(_dim_in);
+                }
+                if (_dim_out != (int)observations[0].size()) {
+                    _dim_out = observations[0].size();
+                    _mean_function = MeanFunction(_dim_out);
+                }
+                _samples = samples;
+                _observations.resize(observations.size(), _dim_out);
+                for (int i = 0; i < (int)_observations.rows(); ++i)
+                    for (int p = 0; p < _dim_out; ++p)
+                        _observations(i, p) = observations[i](p);
+                _update_mean_observation();
+                this->_compute_obs_mean();
+                _data_on_device = false;
+                if (compute_kernel)
+                    this->_compute_full_kernel();
+            }
+
+            /// gp.hpp:119-122
+            void optimize_hyperparams() { _hp_optimize(*this); }
+
+            /// gp.hpp:126-152 — one row appended to L on the device (capacity-doubling buffers, no
+            /// O(n^2) reallocation per sample)
+            void add_sample(const Eigen::VectorXd& sample, const Eigen::VectorXd& observation)
+            {
+                if (_samples.empty()) {
+                    if (_dim_in != (int)sample.size()) {
+                        _dim_in = sample.size();
+                        _kernel_function = KernelFunction(_dim_in);
+                    }
+                    if (_dim_out != (int)observation.size()) {
+                        _dim_out = observation.size();
+                        _mean_function = MeanFunction(_dim_out);
+                    }
+                }
+                else {
+                    assert((int)sample.size() == _dim_in);
+                    assert((int)observation.size() == _dim_out);
+                }
+                _samples.push_back(sample);
+                _observations.conservativeResize(_observations.rows() + 1, _dim_out);
+                for (int p = 0; p < _dim_out; ++p)
+                    _observations(_observations.rows() - 1, p) = observation(p);
+                _update_mean_observation();
+                this->_compute_obs_mean();
+                this->_compute_incremental_kernel();
+            }
+
+            /// gp.hpp:159-167
+            std::tuple<Eigen::VectorXd, double> query(const Eigen::VectorXd& v) const
+            {
+                if (_samples.size() == 0)
+                    return std::make_tuple(_mean_function(v, *this), _kernel_function(v, v) + _kernel_function.noise());
+                Eigen::VectorXd kta;
+                double var;
+                _query_one(v, &kta, &var);
+                return std::make_tuple(_finish_mu(v, kta), _finish_sigma(var) + _kernel_function.noise());
+            }
+
+            /// gp.hpp:174-179
+            Eigen::VectorXd mu(const Eigen::VectorXd& v) const
+            {
+                if (_samples.size() == 0)
+                    return _mean_function(v, *this);
+                Eigen::VectorXd kta;
+                _query_one(v, &kta, nullptr);
+                return _finish_mu(v, kta);
+            }
+
+            /// gp.hpp:186-191
+            double sigma(const Eigen::VectorXd& v) const
+            {
+                if (_samples.size() == 0)
+                    return _kernel_function(v, v) + _kernel_function.noise();
+                double var;
+                _query_one(v, nullptr, &var);
+                return _finish_sigma(var) + _kernel_function.noise();
+            }
+
+            /// Batched query (not in the reference, which loops over query()):
+            /// mu is M x dim_out, sigma_sq has M entries; row m equals query(points[m]).
+            void query_batch(const std::vector<Eigen::VectorXd>& points, Eigen::MatrixXd& mu_out, Eigen::VectorXd& sigma_sq) const
+            {
+                const int64_t M = points.size();
+                mu_out.resize(M, _dim_out);
+                sigma_sq.resize(M);
+                if (M == 0)
+                    return;
+                if (_samples.size() == 0) {
+                    for (int64_t m = 0; m < M; ++m) {
+                        Eigen::VectorXd mv = _mean_function(points[m], *this);
+                        for (int p = 0; p < _dim_out; ++p)
+                            mu_out(m, p) = mv(p);
+                        sigma_sq(m) = _kernel_function(points[m], points[m]) + _kernel_function.noise();
+                    }
+                    return;
+                }
+                std::vector<double> kta((size_t)(M * _dim_out)), var((size_t)M);
+                _query_many(points, kta.data(), var.data());
+                for (int64_t m = 0; m < M; ++m) {
+                    Eigen::VectorXd mv = _mean_function(points[m], *this);
+                    for (int p = 0; p < _dim_out; ++p)
+                        mu_out(m, p) = kta[(size_t)(m + M * p)] + mv(p);
+                    sigma_sq(m) = _finish_sigma(var[(size_t)m]) + _kernel_function.noise();
+                }
+            }
+
+            int dim_in() const
+            {
+                assert(_dim_in != -1);
+                return _dim_in;
+            }
+            int dim_out() const
+            {
+                assert(_dim_out != -1);
+                return _dim_out;
+            }
+            const KernelFunction& kernel_function() const { return _kernel_function; }
+            KernelFunction& kernel_function() { return _kernel_function; }
+            const MeanFunction& mean_function() const { return _mean_function; }
+            MeanFunction& mean_function() { return _mean_function; }
+
+            Eigen::VectorXd max_observation() const
+            {
+                if (_observations.cols() > 1)
+                    std::cout << "WARNING max_observation with multi dimensional observations doesn't make sense" << std::endl;
+                return tools::make_vector(_observations.maxCoeff());
+            }
+            Eigen::VectorXd mean_observation() const
+            {
+                assert(_dim_out > 0);
+                return _samples.size() > 0 ? _mean_observation : Eigen::VectorXd::Zero(_dim_out);
+            }
+            const Eigen::MatrixXd& mean_vector() const { return _mean_vector; }
+            const Eigen::MatrixXd& obs_mean() const { return _obs_mean; }
+            int nb_samples() const { return _samples.size(); }
+
+            /// gp.hpp:241-252
+            void recompute(bool update_obs_mean = true, bool update_full_kernel = true)
+            {
+                assert(!_samples.empty());
+                if (update_obs_mean)
+                    this->_compute_obs_mean();
+                if (update_full_kernel)
+                    this->_compute_full_kernel(); // re-sends obs_mean, X stays resident
+                else
+                    this->_compute_alpha();
+            }
+
+            /// gp.hpp:254-264: K^-1 from L, cached until K changes
+            void compute_inv_kernel()
+            {
+                _status_or(_eng.check(gpe_compute_inv_kernel(_eng.get()), "gpe_compute_inv_kernel"));
+                _Kinv_stale = true;
+                _inv_kernel_updated = true;
+            }
+
+            /// gp.hpp:267-282
+            double compute_log_lik()
+            {
+                double ll = 0.0;
+                _eng.check(gpe_log_lik(_eng.get(), &ll), "gpe_log_lik");
+                _log_lik = ll;
+                return _log_lik;
+            }
+
+            /// gp.hpp:285-311
+            Eigen::VectorXd compute_kernel_grad_log_lik()
+            {
+                const int T = _kernel_function.h_params_size();
+                Eigen::VectorXd grad = Eigen::VectorXd::Zero(T);
+                if (limbo_amd::device_kernel<KernelFunction>::kind != limbo_amd::KIND_HOST_K) {
+                    _push_kernel();
+                    _eng.check(gpe_log_lik_grad(_eng.get(), grad.data(), T, Params::kernel::optimize_noise() ? 1 : 0), "gpe_log_lik_grad");
+                    _inv_kernel_updated = true; // the device computed and cached K^-1 (gp.hpp:289-291)
+                    _Kinv_stale = true;
+                    return grad;
+                }
+                // kernels without device code: w = alpha alpha^T - K^-1 from the device, d k / d theta from the functor
+                if (!_inv_kernel_updated)
+                    compute_inv_kernel();
+                const Eigen::MatrixXd& Ki = _host_Kinv();
+                const Eigen::MatrixXd& al = alpha();
+                const size_t n = _samples.size();
+                for (size_t i = 0; i < n; ++i)
+                    for (size_t j = 0; j <= i; ++j) {
+                        double w = -Ki(i, j);
+                        for (int p = 0; p < _dim_out; ++p)
+                            w += al(i, p) * al(j, p);
+                        Eigen::VectorXd g = _kernel_function.grad(_samples[i], _samples[j], i, j);
+                        const double f = (i == j) ? 0.5 * w : w;
+                        for (int t = 0; t < T; ++t)
+                            grad(t) += f * g(t);
+                    }
+                return grad;
+            }
+
+            /// gp.hpp:314-330 (host: O(N^2 P) with K^-1 from the device)
+            Eigen::VectorXd compute_mean_grad_log_lik()
+            {
+                if (!_inv_kernel_updated)
+                    compute_inv_kernel();
+                const Eigen::MatrixXd& Ki = _host_Kinv();
+                const size_t n = _samples.size();
+                const int T = _mean_function.h_params_size();
+                Eigen::VectorXd grad = Eigen::VectorXd::Zero(T);
+                for (int p = 0; p < _dim_out; ++p)
+                    for (size_t m = 0; m < n; ++m) {
+                        double c = 0.0; // obs_mean(:, p)^T K^-1(:, m)
+                        for (size_t i = 0; i < n; ++i)
+                            c += _obs_mean(i, p) * Ki(i, m);
+                        Eigen::MatrixXd gm = _mean_function.grad(_samples[m], *this);
+                        for (int t = 0; t < T; ++t)
+                            grad(t) += c * gm(p, t);
+                    }
+                return grad;
+            }
+
+            double get_log_lik() const { return _log_lik; }
+            void set_log_lik(double log_lik) { _log_lik = log_lik; }
+
+            /// gp.hpp:339-351 (host, from the device's K^-1 diagonal and alpha)
+            double compute_log_loo_cv()
+            {
+                if (!_inv_kernel_updated)
+                    compute_inv_kernel();
+                const Eigen::MatrixXd& Ki = _host_Kinv();
+                const Eigen::MatrixXd& al = alpha();
+                const size_t n = _samples.size();
+                double s = 0.0;
+                for (int p = 0; p < _dim_out; ++p)
+                    for (size_t i = 0; i < n; ++i) {
+                        const double inv_d = 1.0 / Ki(i, i);
+                        s += -0.5 * al(i, p) * al(i, p) * inv_d - 0.5 * std::log(inv_d) - 0.5 * std::log(2 * M_PI);
+                    }
+                _log_loo_cv = s;
+                return _log_loo_cv;
+            }
+            double get_log_loo_cv() const { return _log_loo_cv; }
+            void set_log_loo_cv(double v) { _log_loo_cv = v; }
+
+            const Eigen::MatrixXd& matrixL() const
+            {
+                std::lock_guard<std::mutex> lk(_mirror_mu);
+                if (_L_stale) {
+                    const int64_t n = _samples.size();
+                    _matrixL.resize(n, n);
+                    _eng.check(gpe_get_L(_eng.get(), _matrixL.data(), n), "gpe_get_L");
+                    _L_stale = false;
+                }
+                return _matrixL;
+            }
+            const Eigen::MatrixXd& alpha() const
+            {
+                std::lock_guard<std::mutex> lk(_mirror_mu);
+                if (_alpha_stale) {
+                    _alpha.resize(_samples.size(), _dim_out);
+                    _eng.check(gpe_get_alpha(_eng.get(), _alpha.data()), "gpe_get_alpha");
+                    _alpha_stale = false;
+                }
+                return _alpha;
+            }
+            const std::vector<Eigen::VectorXd>& samples() const { return _samples; }
+            std::vector<Eigen::VectorXd> observations() const
+            {
+                std::vector<Eigen::VectorXd> obs;
+                for (int i = 0; i < (int)_observations.rows(); ++i) {
+                    Eigen::VectorXd o(_dim_out);
+                    for (int p = 0; p < _dim_out; ++p)
+                        o(p) = _observations(i, p);
+                    obs.push_back(o);
+                }
+                return obs;
+            }
+            const Eigen::MatrixXd& observations_matrix() const { return _observations; }
+            bool inv_kernel_computed() { return _inv_kernel_updated; }
+
+            /// 0, or the 1-based index of the first non-positive Cholesky pivot of the last factorisation
+            int last_status() const { return _status; }
+
+            /// gp.hpp:439-460: any archive with save(vector / matrix / vector-of-vectors, name)
+            template <typename A>
+            void save(const std::string& directory) const
+            {
+                A archive(directory);
+                save(archive);
+            }
+            template <typename A>
+            void save(const A& archive) const
+            {
+                if (_kernel_function.h_params_size() > 0)
+                    archive.save(_kernel_function.h_params(), "kernel_params");
+                if (_mean_function.h_params_size() > 0)
+                    archive.save(_mean_function.h_params(), "mean_params");
+                archive.save(_samples, "samples");
+                archive.save(_observations, "observations");
+                archive.save(matrixL(), "matrixL");
+                archive.save(alpha(), "alpha");
+            }
+            /// gp.hpp:462-511
+            template <typename A>
+            void load(const std::string& directory, bool recompute = true)
+            {
+                A archive(directory);
+                load(archive, recompute);
+            }
+            template <typename A>
+            void load(const A& archive, bool recompute = true)
+            {
+                _samples.clear();
+                archive.load(_samples, "samples");
+                archive.load(_observations, "observations");
+                _dim_in = _samples[0].size();
+                _kernel_function = KernelFunction(_dim_in);
+                if (_kernel_function.h_params_size() > 0) {
+                    Eigen::VectorXd h_params;
+                    archive.load(h_params, "kernel_params");
+                    assert(h_params.size() == (int)_kernel_function.h_params_size());
+                    _kernel_function.set_h_params(h_params);
+                }
+                _dim_out = _observations.cols();
+                _mean_function = MeanFunction(_dim_out);
+                if (_mean_function.h_params_size() > 0) {
+                    Eigen::VectorXd h_params;
+                    archive.load(h_params, "mean_params");
+                    assert(h_params.size() == (int)_mean_function.h_params_size());
+                    _mean_function.set_h_params(h_params);
+                }
+                _update_mean_observation();
+                _data_on_device = false;
+                if (recompute)
+                    this->recompute(true, true);
+                else { // trust the stored factor: upload L and alpha (the block inverses are rebuilt on the device)
+                    this->_compute_obs_mean();
+                    archive.load(_matrixL, "matrixL");
+                    archive.load(_alpha, "alpha");
+                    _push_data();
+                    _push_kernel();
+                    _eng.check(gpe_set_L(_eng.get(), _matrixL.data(), _matrixL.rows()), "gpe_set_L");
+                    _eng.check(gpe_set_alpha(_eng.get(), _alpha.data()), "gpe_set_alpha");
+                    _L_stale = _alpha_stale = false;
+                    _inv_kernel_updated = false;
+                }
+            }
+
+        protected:
+            int _dim_in;
+            int _dim_out;
+
+            KernelFunction _kernel_function;
+            MeanFunction _mean_function;
+
+            std::vector<Eigen::VectorXd> _samples;
+            Eigen::MatrixXd _observations;
+            Eigen::MatrixXd _mean_vector;
+            Eigen::MatrixXd _obs_mean;
+
+            mutable Eigen::MatrixXd _alpha; // host mirror of the device's alpha
+            Eigen::VectorXd _mean_observation;
+
+            mutable Eigen::MatrixXd _kernel, _inv_kernel; // _kernel: host K (HOST_K kernels only); _inv_kernel: mirror
+
+            mutable Eigen::MatrixXd _matrixL; // host mirror of the device's L
+
+            double _log_lik, _log_loo_cv;
+            bool _inv_kernel_updated;
+
+            HyperParamsOptimizer _hp_optimize;
+
+            // ---- device side -------------------------------------------------------------------
+            mutable limbo_amd::Engine _eng;
+            int _status = 0;
+            mutable bool _L_stale = true, _alpha_stale = true, _Kinv_stale = true;
+            bool _data_on_device = false;
+            Eigen::VectorXd _dev_theta; // hyper-parameters last sent to the device
+            double _dev_noise = -1.0;
+            bool _dev_kernel_ok = false;
+            mutable std::mutex _mirror_mu;
+
+            void _swap(GP& o)
+            {
+                std::swap(_dim_in, o._dim_in);
+                std::swap(_dim_out, o._dim_out);
+                std::swap(_kernel_function, o._kernel_function);
+                std::swap(_mean_function, o._mean_function);
+                std::swap(_samples, o._samples);
+                std::swap(_observations, o._observations);
+                std::swap(_mean_vector, o._mean_vector);
+                std::swap(_obs_mean, o._obs_mean);
+                std::swap(_alpha, o._alpha);
+                std::swap(_mean_observation, o._mean_observation);
+                std::swap(_kernel, o._kernel);
+                std::swap(_inv_kernel, o._inv_kernel);
+                std::swap(_matrixL, o._matrixL);
+                std::swap(_log_lik, o._log_lik);
+                std::swap(_log_loo_cv, o._log_loo_cv);
+                std::swap(_inv_kernel_updated, o._inv_kernel_updated);
+                std::swap(_eng, o._eng);
+                std::swap(_status, o._status);
+                std::swap(_L_stale, o._L_stale);
+                std::swap(_alpha_stale, o._alpha_stale);
+                std::swap(_Kinv_stale, o._Kinv_stale);
+                std::swap(_data_on_device, o._data_on_device);
+                std::swap(_dev_theta, o._dev_theta);
+                std::swap(_dev_noise, o._dev_noise);
+                std::swap(_dev_kernel_ok, o._dev_kernel_ok);
+            }
+
+            void _status_or(int rc)
+            {
+                if (rc > 0)
+                    _status = rc;
+            }
+
+            void _update_mean_observation()
+            {
+                _mean_observation = Eigen::VectorXd::Zero(_dim_out);
+                const int n = _observations.rows();
+                for (int p = 0; p < _dim_out; ++p) {
+                    double s = 0.0;
+                    for (int i = 0; i < n; ++i)
+                        s += _observations(i, p);
+                    _mean_observation(p) = n > 0 ? s / n : 0.0;
+                }
+            }
+
+            /// gp.hpp:537-548 — host, by design
+            void _compute_obs_mean()
+            {
+                assert(!_samples.empty());
+                _mean_vector.resize(_samples.size(), _dim_out);
+                _obs_mean.resize(_samples.size(), _dim_out);
+                for (int i = 0; i < (int)_mean_vector.rows(); i++) {
+                    assert((int)_samples[i].size() == _dim_in);
+                    Eigen::VectorXd m = _mean_function(_samples[i], *this);
+                    for (int p = 0; p < _dim_out; ++p) {
+                        _mean_vector(i, p) = m(p);
+                        _obs_mean(i, p) = _observations(i, p) - m(p);
+                    }
+                }
+            }
+
+            void _push_data()
+            {
+                const int64_t n = _samples.size();
+                std::vector<double> X((size_t)(n * _dim_in));
+                for (int64_t i = 0; i < n; ++i)
+                    for (int d = 0; d < _dim_in; ++d)
+                        X[(size_t)(i * _dim_in + d)] = _samples[i](d);
+                _eng.check(gpe_set_data(_eng.get(), X.data(), n, _dim_in, _obs_mean.data(), _dim_out), "gpe_set_data");
+                _data_on_device = true;
+                _dev_kernel_ok = false;
+            }
+
+            /// kernel.hpp:116-123 on the device: log-space parameters (without the noise entry) + sigma_n^2
+            void _push_kernel()
+            {
+                constexpr int kind = limbo_amd::device_kernel<KernelFunction>::kind;
+                if (kind == limbo_amd::KIND_HOST_K) {
+                    _eng.check(gpe_set_kernel(_eng.get(), kind, nullptr, 0, _kernel_function.noise()), "gpe_set_kernel");
+                    return;
+                }
+                Eigen::VectorXd hp = _kernel_function.h_params();
+                const int nk = (int)hp.size() - (Params::kernel::optimize_noise() ? 1 : 0);
+                _eng.check(gpe_set_kernel(_eng.get(), kind, hp.data(), nk, _kernel_function.noise()), "gpe_set_kernel");
+            }
+
+            /// gp.hpp:550-571: K -> L -> alpha, all on the device
+            void _compute_full_kernel()
+            {
+                if (!_data_on_device)
+                    _push_data();
+                else
+                    _eng.check(gpe_set_obs_mean(_eng.get(), _obs_mean.data()), "gpe_set_obs_mean");
+                _push_kernel();
+                if (limbo_amd::device_kernel<KernelFunction>::kind == limbo_amd::KIND_HOST_K) {
+                    const size_t n = _samples.size();
+                    _kernel.resize(n, n);
+                    for (size_t i = 0; i < n; i++)
+                        for (size_t j = 0; j <= i; ++j) {
+                            _kernel(i, j) = _kernel_function(_samples[i], _samples[j], i, j);
+                            _kernel(j, i) = _kernel(i, j);
+                        }
+                    _eng.check(gpe_set_K_host(_eng.get(), _kernel.data(), n), "gpe_set_K_host");
+                }
+                _status = _eng.check(gpe_compute(_eng.get()), "gpe_compute");
+                _L_stale = _alpha_stale = _Kinv_stale = true;
+                _inv_kernel_updated = false; // gp.hpp:570
+            }
+
+            /// gp.hpp:573-603
+            void _compute_incremental_kernel()
+            {
+                if (limbo_amd::device_kernel<KernelFunction>::kind == limbo_amd::KIND_HOST_K || !_data_on_device || _samples.size() == 1) {
+                    _data_on_device = false;
+                    _compute_full_kernel(); // first sample / functor-built K: full path
+                    return;
+                }
+                _push_kernel();
+                _status_or(_eng.check(gpe_add_sample(_eng.get(), _samples.back().data(), _dim_in, _obs_mean.data(), _dim_out), "gpe_add_sample"));
+                _L_stale = _alpha_stale = _Kinv_stale = true;
+                _inv_kernel_updated = false; // gp.hpp:602
+            }
+
+            /// gp.hpp:605-611 with the existing factor
+            void _compute_alpha()
+            {
+                _eng.check(gpe_update_alpha(_eng.get(), _obs_mean.data()), "gpe_update_alpha");
+                _alpha_stale = true;
+            }
+
+            const Eigen::MatrixXd& _host_Kinv() const
+            {
+                std::lock_guard<std::mutex> lk(_mirror_mu);
+                if (_Kinv_stale) {
+                    const int64_t n = _samples.size();
+                    _inv_kernel.resize(n, n);
+                    _eng.check(gpe_get_Kinv(_eng.get(), _inv_kernel.data(), n), "gpe_get_Kinv");
+                    _Kinv_stale = false;
+                }
+                return _inv_kernel;
+            }
+
+            // kta[m + M p] = k*^T alpha_p ; var[m] = k(v,v) - |L^-1 k*|^2  (before mean / clamp / noise)
+            void _query_many(const std::vector<Eigen::VectorXd>& pts, double* kta, double* var) const
+            {
+                const int64_t M = pts.size(), n = _samples.size();
+                if (limbo_amd::device_kernel<KernelFunction>::kind != limbo_amd::KIND_HOST_K) {
+                    std::vector<double> Xq((size_t)(M * _dim_in));
+                    for (int64_t m = 0; m < M; ++m) {
+                        assert((int)pts[m].size() == _dim_in);
+                        for (int d = 0; d < _dim_in; ++d)
+                            Xq[(size_t)(m * _dim_in + d)] = pts[m](d);
+                    }
+                    _eng.check(gpe_query_batch(_eng.get(), Xq.data(), M, kta, var), "gpe_query_batch");
+                    return;
+                }
+                // functor-built cross kernel (gp.hpp:626-632), solves on the device
+                std::vector<double> Ks((size_t)(n * M)), zz((size_t)M);
+                for (int64_t m = 0; m < M; ++m)
+                    for (int64_t i = 0; i < n; ++i)
+                        Ks[(size_t)(i + n * m)] = _kernel_function(_samples[i], pts[m]);
+                _eng.check(gpe_query_batch_cross(_eng.get(), Ks.data(), M, kta, var ? zz.data() : nullptr), "gpe_query_batch_cross");
+                if (var)
+                    for (int64_t m = 0; m < M; ++m)
+                        var[m] = _kernel_function(pts[m], pts[m]) - zz[(size_t)m];
+            }
+            void _query_one(const Eigen::VectorXd& v, Eigen::VectorXd* kta, double* var) const
+            {
+                std::vector<Eigen::VectorXd> one(1, v);
+                std::vector<double> k((size_t)_dim_out);
+                double vv = 0.0;
+                _query_many(one, kta ? k.data() : nullptr, var ? &vv : nullptr);
+                if (kta) {
+                    kta->resize(_dim_out);
+                    for (int p = 0; p < _dim_out; ++p)
+                        (*kta)(p) = k[(size_t)p];
+                }
+                if (var)
+                    *var = vv;
+            }
+            /// gp.hpp:613-616
+            Eigen::VectorXd _finish_mu(const Eigen::VectorXd& v, const Eigen::VectorXd& kta) const
+            {
+                Eigen::VectorXd m = _mean_function(v, *this);
+                for (int p = 0; p < _dim_out; ++p)
+                    m(p) += kta(p);
+                return m;
+            }
+            /// gp.hpp:621-623
+            static double _finish_sigma(double res) { return (res <= std::numeric_limits<double>::epsilon()) ? 0 : res; }
+        };
+
+        template <typename Params>
+        using GPBasic = GP<Params, kernel::MaternFiveHalves<Params>, mean::Data<Params>, gp::NoLFOpt<Params>>;
+
+        template <typename Params>
+        using GPOpt = GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>, gp::KernelLFOpt<Params>>;
+    } // namespace model
+} // namespace limbo
+
+#endif

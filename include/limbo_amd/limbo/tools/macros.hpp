@@ -1,0 +1,62 @@
+// limbo/tools/macros.hpp — the compile-time parameter system of limbo's policy API.
+// These macro NAMES and their expansion contract are the configuration interface every user
+// `Params` struct is written against (reference: src/limbo/tools/macros.hpp:53-110), so they are
+// kept verbatim-compatible: BO_PARAM(T, name, v) yields `static constexpr T name()`, BO_DYN_PARAM
+// a runtime-settable static, and so on.  New MI355X knobs live in limbo::defaults::gpu below.
+#ifndef LIMBO_TOOLS_MACROS_HPP
+#define LIMBO_TOOLS_MACROS_HPP
+
+#include <Eigen/Core>
+#include <cassert>
+#include <cstddef>
+#include <initializer_list>
+
+#define BO_PARAM(Type, Name, Value) \
+    static constexpr Type Name() { return Value; }
+
+#define BO_DYN_PARAM(Type, Name)                 \
+    static Type _##Name;                         \
+    static Type Name() { return _##Name; }       \
+    static void set_##Name(const Type& v) { _##Name = v; }
+
+#define BO_DECLARE_DYN_PARAM(Type, Namespace, Name) Type Namespace::_##Name;
+
+#define BO_PARAM_STRING(Name, Value) \
+    static constexpr const char* Name() { return Value; }
+
+// BO_PARAM_ARRAY(double, name, 1., 2., 3.) -> name(i), name_size(), name_t
+#define BO_PARAM_ARRAY(Type, Name, ...)                                   \
+    static Type Name(size_t i)                                            \
+    {                                                                     \
+        static constexpr Type _##Name[] = {__VA_ARGS__};                  \
+        assert(i < sizeof(_##Name) / sizeof(_##Name[0]));                 \
+        return _##Name[i];                                                \
+    }                                                                     \
+    static constexpr size_t Name##_size()                                 \
+    {                                                                     \
+        return std::initializer_list<Type>{__VA_ARGS__}.size();           \
+    }                                                                     \
+    using Name##_t = Type;
+
+// BO_PARAM_VECTOR(double, name, 1., 2.) -> Eigen::VectorXd name()
+#define BO_PARAM_VECTOR(Type, Name, ...)                                  \
+    static const Eigen::VectorXd Name()                                   \
+    {                                                                     \
+        static constexpr Type _##Name[] = {__VA_ARGS__};                  \
+        constexpr size_t n_ = sizeof(_##Name) / sizeof(_##Name[0]);       \
+        Eigen::VectorXd v_(n_);                                           \
+        for (size_t i_ = 0; i_ < n_; ++i_)                                \
+            v_(i_) = _##Name[i_];                                         \
+        return v_;                                                        \
+    }
+
+namespace limbo {
+    namespace defaults {
+        /// device selection for the MI355X engine (not in the reference)
+        struct gpu {
+            BO_PARAM(int, device, 0);
+        };
+    } // namespace defaults
+} // namespace limbo
+
+#endif

@@ -59,6 +59,8 @@ def _sig(lib, prefix):
         "log_lik_grad": [_vp, _dp, C.c_int, C.c_int],
         "hp_objective": [_vp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _dp, _dp],
         "query_batch": [_vp, _dp, _i64, _dp, _dp],
+        "query_batch_cross": [_vp, _dp, _i64, _dp, _dp],
+        "set_obs_mean": [_vp, _dp],
         "nb_samples": [_vp, C.POINTER(_i64)],
         "get_L": [_vp, _dp, _i64],
         "set_L": [_vp, _dp, _i64],

@@ -867,18 +867,10 @@ int gpe_hp_objective(gpe_handle c, int kind, const double* th, int n_theta, doub
     return info;
 }
 
-int gpe_query_batch(gpe_handle c, const double* Xq, int64_t M, double* kta, double* var)
+// shared by gpe_query_batch (cross kernel built on the device from Xq) and gpe_query_batch_cross
+// (cross kernel handed over by the caller): kta = Ks^T alpha, var = kvv - colsum((L^-1 Ks)^2)
+static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_t M, double* kta, double* var)
 {
-    if (!c || !Xq || M < 0)
-        return GPE_ERR_ARG;
-    if (!c->have_L)
-        return GPE_ERR_STATE;
-    if (c->host_K)
-        return GPE_ERR_UNSUPPORTED;
-    if (M == 0)
-        return GPE_OK;
-    DevGuard g(c);
-    std::lock_guard<std::mutex> lk(c->mu); // const queries from several host threads serialise here
     hipStream_t s = c->stream;
     digest_kernel(c);
     const int64_t N = c->N, ld = c->ld;
@@ -888,8 +880,8 @@ int gpe_query_batch(gpe_handle c, const double* Xq, int64_t M, double* kta, doub
     mc_max = round_up(std::min<int64_t>(mc_max, round_up(M, 64)), 64);
     const int64_t ldq = mc_max;
     double *dQrm = nullptr, *dQt = nullptr, *dKs = nullptr, *dKta = nullptr, *dVar = nullptr, *dKvv = nullptr;
-    HIPCHK(c, hipMalloc(&dQrm, sizeof(double) * (size_t)(mc_max * D)));
-    HIPCHK(c, hipMalloc(&dQt, sizeof(double) * (size_t)(ldq * D)));
+    HIPCHK(c, hipMalloc(&dQrm, sizeof(double) * (size_t)(mc_max * std::max(D, 1))));
+    HIPCHK(c, hipMalloc(&dQt, sizeof(double) * (size_t)(ldq * std::max(D, 1))));
     HIPCHK(c, hipMalloc(&dKs, sizeof(double) * (size_t)(ld * mc_max)));
     HIPCHK(c, hipMalloc(&dKta, sizeof(double) * (size_t)(mc_max * P)));
     HIPCHK(c, hipMalloc(&dVar, sizeof(double) * (size_t)mc_max));
@@ -897,11 +889,15 @@ int gpe_query_batch(gpe_handle c, const double* Xq, int64_t M, double* kta, doub
     int rc = GPE_OK;
     for (int64_t m0 = 0; m0 < M && rc == GPE_OK; m0 += mc_max) {
         const int64_t mc = std::min<int64_t>(mc_max, M - m0);
-        hipMemcpyAsync(dQrm, Xq + m0 * D, sizeof(double) * (size_t)(mc * D), hipMemcpyHostToDevice, s);
-        launch_transpose_x(s, dQrm, mc, D, dQt, ldq, 0);
-        {
+        if (Xq) {
+            hipMemcpyAsync(dQrm, Xq + m0 * D, sizeof(double) * (size_t)(mc * D), hipMemcpyHostToDevice, s);
+            launch_transpose_x(s, dQrm, mc, D, dQt, ldq, 0);
             PhaseScope ps(c, GPE_PH_QUERY, 0.0);
             launch_build_Ks(s, c->dXt, ld, N, dQt, ldq, mc, c->kp, dKs, ld); // gp.hpp:626-632
+        }
+        else {
+            hipMemcpy2DAsync(dKs, sizeof(double) * ld, KsHost + m0 * N, sizeof(double) * N, sizeof(double) * N, mc,
+                             hipMemcpyHostToDevice, s);
         }
         if (kta) {
             PhaseScope ps(c, GPE_PH_QUERY, 2.0 * N * mc * P);
@@ -913,7 +909,10 @@ int gpe_query_batch(gpe_handle c, const double* Xq, int64_t M, double* kta, doub
         if (var) {
             trsm_left_blocked(c, c->dA, dKs, ld, N, mc, false, GPE_PH_QUERY); // gp.hpp:620
             PhaseScope ps(c, GPE_PH_QUERY, 2.0 * N * mc);
-            launch_kvv(s, dQt, ldq, mc, c->kp, dKvv);
+            if (Xq)
+                launch_kvv(s, dQt, ldq, mc, c->kp, dKvv);
+            else
+                hipMemsetAsync(dKvv, 0, sizeof(double) * (size_t)mc, s);
             launch_col_var(s, dKs, ld, N, mc, dKvv, dVar); // gp.hpp:621
             hipMemcpyAsync(var + m0, dVar, sizeof(double) * (size_t)mc, hipMemcpyDeviceToHost, s);
         }
@@ -930,6 +929,51 @@ int gpe_query_batch(gpe_handle c, const double* Xq, int64_t M, double* kta, doub
     hipFree(dVar);
     hipFree(dKvv);
     return rc;
+}
+
+int gpe_query_batch(gpe_handle c, const double* Xq, int64_t M, double* kta, double* var)
+{
+    if (!c || !Xq || M < 0)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    if (c->host_K)
+        return GPE_ERR_UNSUPPORTED;
+    if (M == 0)
+        return GPE_OK;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu); // const queries from several host threads serialise here
+    return query_impl(c, Xq, nullptr, M, kta, var);
+}
+
+int gpe_query_batch_cross(gpe_handle c, const double* Ks, int64_t M, double* kta, double* zz)
+{
+    if (!c || !Ks || M < 0)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    if (M == 0)
+        return GPE_OK;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = query_impl(c, nullptr, Ks, M, kta, zz);
+    if (rc == GPE_OK && zz)
+        for (int64_t m = 0; m < M; ++m)
+            zz[m] = -zz[m]; // query_impl returned 0 - |L^-1 k*|^2
+    return rc;
+}
+
+int gpe_set_obs_mean(gpe_handle c, const double* obs_mean)
+{
+    if (!c || !obs_mean || c->N <= 0 || !c->dOm)
+        return GPE_ERR_ARG;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * c->ld, obs_mean, sizeof(double) * c->N, sizeof(double) * c->N,
+                               c->P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->ll_ok = false;
+    return GPE_OK;
 }
 
 int gpe_nb_samples(gpe_handle c, int64_t* N)

@@ -49,18 +49,33 @@ static __device__ __forceinline__ double bcast_lane(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(p) to full double precision: v_rsq_f64 seed + two Newton steps
-static __device__ __forceinline__ double rsqrt_full(double p)
-{
-    double y = __builtin_amdgcn_rsq(p);
-    double t = p * y;
-    double e = fma(-t, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    t = p * y;
-    e = fma(-t, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    return y;
-}
+// Scaling a column by 1/sqrt(p) with the shortest dependent chain (every fp64 op costs ~32 cycles
+// of latency on the pivot chain): y0 = v_rsq_f64(p) is a ~1e-8-accurate seed; with
+// eh = 1/2 - (p/2) y0^2 (= half the relative residual) the Newton-corrected factor is
+// y = y0 (1 + eh) and a * y = fma(a*y0, eh, a*y0).  Chain: rsq -> mul -> fma -> fma.
+// A second correction step is applied off the chain only to the stored inverse pivot `y`.
+struct RsqScale {
+    double y0, eh;
+    __device__ __forceinline__ explicit RsqScale(double p)
+    {
+        y0 = __builtin_amdgcn_rsq(p);
+        const double t = (0.5 * p) * y0;
+        eh = fma(-t, y0, 0.5);
+    }
+    __device__ __forceinline__ double scale(double a) const
+    {
+        const double l = a * y0;
+        return fma(l, eh, l);
+    }
+    // 1/sqrt(p) itself, one more Newton step (not on the critical path)
+    __device__ __forceinline__ double inv(double p) const
+    {
+        double y = fma(y0, eh, y0);
+        const double t = p * y;
+        const double e = fma(-t, y, 1.0);
+        return fma(0.5 * y, e, y);
+    }
+};
 
 // a[qq][*] -= sum_e Lt[r][e] * Lt[c][e] for this thread's column groups qq with 4 qq + w >= gmin
 // (Lt: one round's four scaled columns, Lt[row * 4 + e])
@@ -113,26 +128,27 @@ struct DiagRound {
             double a0 = a[q][0], a1 = a[q][1], a2 = a[q][2], a3 = a[q][3];
             // column c0
             const double p0 = bcast_lane(a0, c0);
-            const double y0 = rsqrt_full(p0);
-            const double l0 = a0 * y0;
+            const RsqScale s0(p0);
+            const double l0 = s0.scale(a0);
             a1 = fma(-l0, bcast_lane(l0, c0 + 1), a1);
             // column c0+1
             const double p1 = bcast_lane(a1, c0 + 1);
-            const double y1 = rsqrt_full(p1);
+            const RsqScale s1(p1);
             a2 = fma(-l0, bcast_lane(l0, c0 + 2), a2);
             a3 = fma(-l0, bcast_lane(l0, c0 + 3), a3);
-            const double l1 = a1 * y1;
+            const double l1 = s1.scale(a1);
             a2 = fma(-l1, bcast_lane(l1, c0 + 2), a2);
             // column c0+2
             const double p2 = bcast_lane(a2, c0 + 2);
-            const double y2 = rsqrt_full(p2);
+            const RsqScale s2(p2);
             a3 = fma(-l1, bcast_lane(l1, c0 + 3), a3);
-            const double l2 = a2 * y2;
+            const double l2 = s2.scale(a2);
             a3 = fma(-l2, bcast_lane(l2, c0 + 3), a3);
             // column c0+3
             const double p3 = bcast_lane(a3, c0 + 3);
-            const double y3 = rsqrt_full(p3);
-            const double l3 = a3 * y3;
+            const RsqScale s3(p3);
+            const double l3 = s3.scale(a3);
+            const double y0 = s0.inv(p0), y1 = s1.inv(p1), y2 = s2.inv(p2), y3 = s3.inv(p3);
             a[q][0] = l0;
             a[q][1] = l1;
             a[q][2] = l2;
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(256) void k_diag(double* __restrict__ A, int64_t ld
     __shared__ __attribute__((aligned(16))) double Ltb[4 * NB * 4];
     __shared__ double invd[NB];
     __shared__ int sbad;
-    const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0)
         sbad = 0;
     double a[4][4];

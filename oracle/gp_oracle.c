@@ -628,6 +628,44 @@ int orc_query_batch(orc_handle c, const double* Xq, int64_t M, double* kta, doub
     return 0;
 }
 
+/* gp.hpp:537-548 result handed over again without touching X, K or L (recompute(true, .)) */
+int orc_set_obs_mean(orc_handle c, const double* obs_mean)
+{
+    if (!c || !obs_mean || c->N <= 0)
+        return -1;
+    memcpy(c->obs_mean, obs_mean, sizeof(double) * (size_t)(c->N * c->P));
+    return 0;
+}
+
+/* gp.hpp:613-624 with the cross kernel k* supplied by the caller (kernels without device code):
+ * kta[m + M p] = k*_m^T alpha_p (:615), zz[m] = |L^-1 k*_m|^2 (:620-621) */
+int orc_query_batch_cross(orc_handle c, const double* Ks, int64_t M, double* kta, double* zz)
+{
+    if (!c || !c->have_L || !Ks)
+        return -2;
+    int64_t n = c->N;
+    double* k = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int64_t m = 0; m < M; ++m) {
+        memcpy(k, Ks + m * n, sizeof(double) * (size_t)n);
+        if (kta)
+            for (int p = 0; p < c->P; ++p) {
+                double s = 0.0;
+                for (int64_t i = 0; i < n; ++i)
+                    s += k[i] * c->alpha[i + p * n];
+                kta[m + M * p] = s;
+            }
+        if (zz) {
+            trsv_lower(c->L, n, n, k);
+            double q = 0.0;
+            for (int64_t i = 0; i < n; ++i)
+                q += k[i] * k[i];
+            zz[m] = q;
+        }
+    }
+    free(k);
+    return 0;
+}
+
 int orc_nb_samples(orc_handle c, int64_t* N)
 {
     *N = c->N;

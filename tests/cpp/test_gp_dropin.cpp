@@ -1,0 +1,423 @@
+// test_gp_dropin.cpp — the reference's own GP unit tests (src/tests/test_gp.cpp, Boost.Test)
+// re-expressed without Boost against the MI355X drop-in limbo::model::GP, plus a comparison with a
+// naive host Cholesky GP written here (test infrastructure).  Case names follow test_gp.cpp.
+// Run on a GPU box:  ./test_gp_dropin   (exit code = number of failed cases)
+#include <chrono>
+#include <cstdio>
+#include <functional>
+#include <random>
+#include <string>
+
+#include <limbo/kernel/exp.hpp>
+#include <limbo/kernel/matern_three_halves.hpp>
+#include <limbo/mean/null_function.hpp>
+#include <limbo/model/gp.hpp>
+#include <limbo/opt/parallel_repeater.hpp>
+
+using namespace limbo;
+using Eigen::MatrixXd;
+using Eigen::VectorXd;
+
+static int g_failed = 0, g_checks = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        ++g_checks;                                                                  \
+        if (!(cond)) {                                                               \
+            ++g_failed_here;                                                         \
+            std::printf("    CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond);  \
+        }                                                                            \
+    } while (0)
+#define CASE(name)                                         \
+    static void name(int& g_failed_here);                  \
+    static void name##_run()                               \
+    {                                                      \
+        int f = 0;                                         \
+        name(f);                                           \
+        std::printf("%s %s\n", f ? "FAIL" : "ok  ", #name); \
+        g_failed += f ? 1 : 0;                             \
+    }                                                      \
+    static void name(int& g_failed_here)
+
+struct Params {
+    struct kernel : public defaults::kernel {
+        BO_PARAM(double, noise, 0.01);
+    };
+    struct kernel_squared_exp_ard : public defaults::kernel_squared_exp_ard {};
+    struct kernel_maternfivehalves : public defaults::kernel_maternfivehalves {};
+    struct kernel_maternthreehalves : public defaults::kernel_maternthreehalves {};
+    struct kernel_exp : public defaults::kernel_exp {};
+    struct mean_constant : public defaults::mean_constant {};
+    struct opt_rprop : public defaults::opt_rprop {
+        BO_PARAM(int, iterations, 30);
+    };
+    struct opt_parallelrepeater : public defaults::opt_parallelrepeater {
+        BO_PARAM(int, repeats, 4);
+    };
+};
+struct ParamsNoiseOpt : public Params {
+    struct kernel : public defaults::kernel {
+        BO_PARAM(double, noise, 0.01);
+        BO_PARAM(bool, optimize_noise, true);
+    };
+};
+struct ParamsLambda : public Params { // SE-ARD with a Lambda column: no device code -> host-built K
+    struct kernel_squared_exp_ard : public defaults::kernel_squared_exp_ard {
+        BO_PARAM(int, k, 1);
+    };
+};
+
+static std::mt19937_64 g_rng(20260926);
+static VectorXd rand_vec(int d, double lo, double hi)
+{
+    std::uniform_real_distribution<double> u(lo, hi);
+    VectorXd v(d);
+    for (int i = 0; i < d; ++i)
+        v(i) = u(g_rng);
+    return v;
+}
+static VectorXd make_v1(double x) { return tools::make_vector(x); }
+
+// ---- naive host GP (test infrastructure): textbook Cholesky, forward/back substitution -------
+template <typename K>
+struct HostGP {
+    std::vector<VectorXd> X;
+    MatrixXd om, L, alpha;
+    VectorXd mean;
+    const K& k;
+    // `mean_`: the (constant) value of the GP's mean functor
+    HostGP(const K& k_, const std::vector<VectorXd>& X_, const std::vector<VectorXd>& Y, const VectorXd& mean_) : X(X_), k(k_)
+    {
+        const int n = X.size(), P = Y[0].size();
+        mean = mean_;
+        om.resize(n, P);
+        for (int i = 0; i < n; ++i)
+            for (int p = 0; p < P; ++p)
+                om(i, p) = Y[i](p) - mean(p);
+        L = MatrixXd::Zero(n, n);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j <= i; ++j)
+                L(i, j) = k(X[i], X[j], i, j);
+        for (int j = 0; j < n; ++j) {
+            double d = L(j, j);
+            for (int q = 0; q < j; ++q)
+                d -= L(j, q) * L(j, q);
+            L(j, j) = std::sqrt(d);
+            for (int i = j + 1; i < n; ++i) {
+                double s = L(i, j);
+                for (int q = 0; q < j; ++q)
+                    s -= L(i, q) * L(j, q);
+                L(i, j) = s / L(j, j);
+            }
+        }
+        alpha = om;
+        for (int p = 0; p < P; ++p) {
+            for (int i = 0; i < n; ++i) {
+                double s = alpha(i, p);
+                for (int q = 0; q < i; ++q)
+                    s -= L(i, q) * alpha(q, p);
+                alpha(i, p) = s / L(i, i);
+            }
+            for (int i = n - 1; i >= 0; --i) {
+                double s = alpha(i, p);
+                for (int q = i + 1; q < n; ++q)
+                    s -= L(q, i) * alpha(q, p);
+                alpha(i, p) = s / L(i, i);
+            }
+        }
+    }
+    double log_lik() const
+    {
+        const int n = X.size();
+        double logdet = 0, a = 0;
+        for (int i = 0; i < n; ++i)
+            logdet += 2 * std::log(L(i, i));
+        for (int p = 0; p < (int)om.cols(); ++p)
+            for (int i = 0; i < n; ++i)
+                a += om(i, p) * alpha(i, p);
+        return -0.5 * a - 0.5 * logdet - 0.5 * n * std::log(2 * M_PI);
+    }
+    void query(const VectorXd& v, VectorXd& mu, double& s2) const
+    {
+        const int n = X.size();
+        VectorXd kk(n);
+        for (int i = 0; i < n; ++i)
+            kk(i) = k(X[i], v);
+        mu = mean;
+        for (int p = 0; p < (int)om.cols(); ++p)
+            for (int i = 0; i < n; ++i)
+                mu(p) += kk(i) * alpha(i, p);
+        for (int i = 0; i < n; ++i) {
+            double s = kk(i);
+            for (int q = 0; q < i; ++q)
+                s -= L(i, q) * kk(q);
+            kk(i) = s / L(i, i);
+        }
+        double r = k(v, v) - kk.dot(kk);
+        s2 = (r <= std::numeric_limits<double>::epsilon() ? 0 : r) + k.noise();
+    }
+};
+
+static void make_problem(int n, int D, int P, std::vector<VectorXd>& X, std::vector<VectorXd>& Y)
+{
+    X.clear();
+    Y.clear();
+    std::normal_distribution<double> g(0, 0.05);
+    for (int i = 0; i < n; ++i) {
+        VectorXd x = rand_vec(D, 0, 1), y(P);
+        double s = 0;
+        for (int d = 0; d < D; ++d)
+            s += x(d);
+        for (int p = 0; p < P; ++p)
+            y(p) = std::cos((p + 1) * s) + g(g_rng);
+        X.push_back(x);
+        Y.push_back(y);
+    }
+}
+
+template <typename GP_t>
+static void compare_with_host(int n, int D, int P, int& g_failed_here, double tol = 1e-8)
+{
+    std::vector<VectorXd> X, Y;
+    make_problem(n, D, P, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    gp.kernel_function().set_h_params(rand_vec(gp.kernel_function().h_params_size(), -0.5, 0.3));
+    gp.recompute(false);
+    HostGP<typename std::decay<decltype(gp.kernel_function())>::type> ref(gp.kernel_function(), X, Y, gp.mean_function()(X[0], gp));
+    CHECK(gp.last_status() == 0);
+    const double ll = gp.compute_log_lik(), llr = ref.log_lik();
+    CHECK(std::abs(ll - llr) <= 1e-10 * std::max(1.0, std::abs(llr)));
+    const MatrixXd& L = gp.matrixL();
+    double dl = 0, nl = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            dl = std::max(dl, std::abs(L(i, j) - ref.L(i, j)));
+            nl = std::max(nl, std::abs(ref.L(i, j)));
+        }
+    CHECK(dl <= 1e-10 * nl);
+    std::vector<VectorXd> pts;
+    for (int m = 0; m < 37; ++m)
+        pts.push_back(m < 3 ? X[m] : rand_vec(D, 0, 1));
+    MatrixXd mub;
+    VectorXd s2b;
+    gp.query_batch(pts, mub, s2b);
+    for (int m = 0; m < (int)pts.size(); ++m) {
+        VectorXd mu, mur;
+        double s2, s2r;
+        std::tie(mu, s2) = gp.query(pts[m]);
+        ref.query(pts[m], mur, s2r);
+        for (int p = 0; p < P; ++p) {
+            CHECK(std::abs(mu(p) - mur(p)) <= tol * std::max(std::abs(mur(p)), 1e-3));
+            CHECK(mub(m, p) == mu(p)); // batched path == single-point path
+        }
+        CHECK(std::abs(s2 - s2r) <= tol * s2r);
+        CHECK(s2b(m) == s2);
+        // mu()/sigma() bitwise equal to query()  (test_gp.cpp:502-510)
+        VectorXd mu2 = gp.mu(pts[m]);
+        for (int p = 0; p < P; ++p)
+            CHECK(mu2(p) == mu(p));
+        CHECK(gp.sigma(pts[m]) == s2);
+    }
+}
+
+CASE(test_gp_vs_host_se_ard) { compare_with_host<model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>>(150, 4, 2, g_failed_here); }
+CASE(test_gp_vs_host_matern52) { compare_with_host<model::GP<Params, kernel::MaternFiveHalves<Params>, mean::Data<Params>>>(97, 3, 1, g_failed_here); }
+CASE(test_gp_vs_host_matern32) { compare_with_host<model::GP<Params, kernel::MaternThreeHalves<Params>, mean::Constant<Params>>>(64, 2, 1, g_failed_here); }
+CASE(test_gp_vs_host_exp) { compare_with_host<model::GP<Params, kernel::Exp<Params>, mean::NullFunction<Params>>>(65, 5, 3, g_failed_here); }
+CASE(test_gp_vs_host_functor_kernel) { compare_with_host<model::GP<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>, mean::Data<ParamsLambda>>>(80, 3, 2, g_failed_here); }
+
+// test_gp.cpp:131-271 — analytic gradient of the log-likelihood vs central finite differences,
+// through the same calls the optimiser objective makes (set_h_params, recompute(false), compute_log_lik)
+template <typename GP_t>
+static void check_grad(int& g_failed_here)
+{
+    const int n = 40, D = 4, P = 2, M = 20;
+    std::vector<VectorXd> X, Y;
+    make_problem(n, D, P, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    const int T = gp.kernel_function().h_params_size();
+    double cumul = 0;
+    for (int t = 0; t < M; ++t) {
+        VectorXd th = rand_vec(T, -1.5, 1.0);
+        auto f = [&](const VectorXd& p) {
+            gp.kernel_function().set_h_params(p);
+            gp.recompute(false);
+            return gp.compute_log_lik();
+        };
+        f(th);
+        VectorXd g = gp.compute_kernel_grad_log_lik();
+        VectorXd fd(T);
+        const double e = 1e-5;
+        for (int j = 0; j < T; ++j) {
+            VectorXd a = th, b = th;
+            a(j) += e;
+            b(j) -= e;
+            fd(j) = (f(a) - f(b)) / (2 * e);
+        }
+        cumul += (g - fd).norm() / std::max(1.0, fd.norm());
+    }
+    CHECK(cumul < M * 1e-4);
+}
+CASE(test_gp_check_lf_grad) { check_grad<model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>>(g_failed_here); }
+CASE(test_gp_check_lf_grad_noise) { check_grad<model::GP<ParamsNoiseOpt, kernel::SquaredExpARD<ParamsNoiseOpt>, mean::Data<ParamsNoiseOpt>>>(g_failed_here); }
+CASE(test_gp_check_lf_grad_matern) { check_grad<model::GP<ParamsNoiseOpt, kernel::MaternFiveHalves<ParamsNoiseOpt>, mean::Data<ParamsNoiseOpt>>>(g_failed_here); }
+CASE(test_gp_check_lf_grad_functor_kernel) { check_grad<model::GP<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>, mean::Data<ParamsLambda>>>(g_failed_here); }
+
+// test_gp.cpp:382-446 — _inv_kernel_updated state machine
+CASE(test_gp_check_inv_kernel_computation)
+{
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(30, 3, 1, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    CHECK(!gp.inv_kernel_computed());
+    gp.compute_inv_kernel();
+    CHECK(gp.inv_kernel_computed());
+    gp.recompute(false, true);
+    CHECK(!gp.inv_kernel_computed());
+    gp.compute_kernel_grad_log_lik();
+    CHECK(gp.inv_kernel_computed());
+    gp.recompute(true, false); // alpha only: K unchanged
+    CHECK(gp.inv_kernel_computed());
+    gp.add_sample(rand_vec(3, 0, 1), make_v1(0.3));
+    CHECK(!gp.inv_kernel_computed());
+}
+
+// test_gp.cpp:448-511 — interpolation sanity
+CASE(test_gp)
+{
+    using GP_t = model::GP<Params, kernel::MaternFiveHalves<Params>, mean::Constant<Params>>;
+    GP_t gp;
+    std::vector<VectorXd> obs = {make_v1(5), make_v1(10), make_v1(5)};
+    std::vector<VectorXd> smp = {make_v1(1), make_v1(2), make_v1(3)};
+    gp.compute(smp, obs);
+    VectorXd mu;
+    double sigma;
+    std::tie(mu, sigma) = gp.query(make_v1(1));
+    CHECK(std::abs(mu(0) - 5) < 1);
+    CHECK(sigma <= 2. * (Params::kernel::noise() + 1e-8));
+    std::tie(mu, sigma) = gp.query(make_v1(2));
+    CHECK(std::abs(mu(0) - 10) < 1);
+    CHECK(sigma <= 2. * (Params::kernel::noise() + 1e-8));
+    for (double x = 0; x < 4; x += 0.5) {
+        VectorXd m2 = gp.mu(make_v1(x));
+        double s2 = gp.sigma(make_v1(x));
+        std::tie(mu, sigma) = gp.query(make_v1(x));
+        CHECK(m2(0) == mu(0));
+        CHECK(s2 == sigma);
+    }
+}
+
+// test_gp.cpp:697-758 — prior variance with no sample
+CASE(test_gp_no_samples_acqui_opt)
+{
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    GP_t gp(2, 1);
+    VectorXd mu;
+    double s2;
+    std::tie(mu, s2) = gp.query(rand_vec(2, 0, 1));
+    CHECK(std::abs(s2 - (1.0 + Params::kernel::noise())) < 1e-12);
+    CHECK(mu(0) == 0.0);
+}
+
+// test_gp.cpp:513-635 — incremental Cholesky (add_sample) vs full compute, incl. duplicated points
+CASE(test_gp_bw_inversion)
+{
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    for (int dup = 0; dup < 2; ++dup) {
+        std::vector<VectorXd> X, Y;
+        make_problem(90, 2, 1, X, Y);
+        if (dup)
+            for (int i = 10; i < 20; ++i)
+                X[i] = X[3]; // ten copies of one point: K only regular through the noise term
+        GP_t inc, full;
+        inc.compute(std::vector<VectorXd>(X.begin(), X.begin() + 5), std::vector<VectorXd>(Y.begin(), Y.begin() + 5));
+        for (size_t i = 5; i < X.size(); ++i)
+            inc.add_sample(X[i], Y[i]);
+        full.compute(X, Y);
+        CHECK(inc.matrixL().isApprox(full.matrixL(), 1e-5));
+        MatrixXd LLt = MatrixXd::Zero(90, 90);
+        const MatrixXd& L = inc.matrixL();
+        for (int i = 0; i < 90; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double s = 0;
+                for (int q = 0; q <= j; ++q)
+                    s += L(i, q) * L(j, q);
+                LLt(i, j) = s;
+                LLt(j, i) = s;
+            }
+        MatrixXd K(90, 90);
+        for (int i = 0; i < 90; ++i)
+            for (int j = 0; j < 90; ++j)
+                K(i, j) = inc.kernel_function()(X[i], X[j], i, j);
+        CHECK(LLt.isApprox(K, 1e-5));
+        VectorXd q = rand_vec(2, 0, 1);
+        CHECK((inc.mu(q) - full.mu(q)).norm() < 1e-5);
+        CHECK(std::abs(inc.sigma(q) - full.sigma(q)) < 1e-5);
+    }
+}
+
+// value semantics (kernel_lf_opt.hpp:79, multi_gp.hpp:73-76): a copy owns its own device state
+CASE(test_gp_copy_semantics)
+{
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(70, 3, 1, X, Y);
+    GP_t a;
+    a.compute(X, Y);
+    VectorXd q = rand_vec(3, 0, 1);
+    const double s0 = a.sigma(q), m0 = a.mu(q)(0);
+    GP_t b(a);
+    CHECK(b.sigma(q) == s0 && b.mu(q)(0) == m0);
+    b.kernel_function().set_h_params(rand_vec(4, -1, 0));
+    b.recompute(false);
+    CHECK(b.sigma(q) != s0);
+    CHECK(a.sigma(q) == s0 && a.mu(q)(0) == m0);
+    GP_t c;
+    c = b;
+    CHECK(c.sigma(q) == b.sigma(q));
+}
+
+// model/gp/kernel_lf_opt.hpp:59-69 — the fit must not decrease the likelihood; restarts in parallel
+CASE(test_gp_auto)
+{
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>, model::gp::KernelLFOpt<Params>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(120, 2, 1, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    const double ll0 = gp.compute_log_lik();
+    gp.optimize_hyperparams();
+    CHECK(gp.get_log_lik() >= ll0);
+    CHECK(gp.get_log_lik() == gp.compute_log_lik());
+    using GPr_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>, model::gp::KernelLFOpt<Params, opt::ParallelRepeater<Params, opt::Rprop<Params>>>>;
+    GPr_t gpr;
+    gpr.compute(X, Y);
+    gpr.optimize_hyperparams();
+    CHECK(gpr.get_log_lik() >= ll0);
+}
+
+int main()
+{
+    auto t0 = std::chrono::steady_clock::now();
+    test_gp_vs_host_se_ard_run();
+    test_gp_vs_host_matern52_run();
+    test_gp_vs_host_matern32_run();
+    test_gp_vs_host_exp_run();
+    test_gp_vs_host_functor_kernel_run();
+    test_gp_check_lf_grad_run();
+    test_gp_check_lf_grad_noise_run();
+    test_gp_check_lf_grad_matern_run();
+    test_gp_check_lf_grad_functor_kernel_run();
+    test_gp_check_inv_kernel_computation_run();
+    test_gp_run();
+    test_gp_no_samples_acqui_opt_run();
+    test_gp_bw_inversion_run();
+    test_gp_copy_semantics_run();
+    test_gp_auto_run();
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("%d checks, %d failed cases, %.1f s\n", g_checks, g_failed, s);
+    return g_failed;
+}

@@ -38,7 +38,7 @@ def test_engine_contains_gfx950_code_object():
 
     blob = _capi.ENGINE_SO.read_bytes()
     assert b"gfx950" in blob
-    assert b"k_gemm_sub" in blob and b"k_potf2" in blob
+    assert b"k_gemm4" in blob and b"k_gemm_glds" in blob and b"k_diag" in blob
 
 
 def test_engine_is_independent_of_the_oracle():
