@@ -26,7 +26,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-FP64_MFMA_PEAK_TF = 78.6  # 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz; re-measured below
+FP64_MFMA_PEAK_TF = 78.6  # 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz; v_mfma_f64_4x4x4_4b measures 76-77 (tools/ubench3)
 N_C2, D_C2 = 4096, 6
 
 
@@ -88,15 +88,10 @@ def main():
     ll = 0.0
     for _ in range(args.steps):
         info, ll = step()
-    best_theta = theta
-    if dist is not None:
-        # arg-max over the restarts: all-gather (log_lik, theta) -- the only collective
-        rec = torch.tensor([ll] + list(theta), dtype=torch.float64, device=f"cuda:{local_rank}")
-        allrec = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        allrec = torch.stack(allrec).cpu().numpy()
-        best = int(np.argmax(allrec[:, 0]))
-        best_theta = allrec[best, 1:]
+    # arg-max over the restarts: all-gather of (log_lik, theta) -- the only collective
+    from limbo_amd import parallel as PAR
+
+    best_ll, best_theta, best_rank = PAR.argmax_over_ranks([ll], [theta], dist, device=f"cuda:{local_rank}")
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -142,15 +137,62 @@ def main():
 
         pk = C.c_double()
         eng.fn("mfma_f64_peak")(local_rank, C.byref(pk))
+        # HBM traffic of the dominant launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md): profiles/, not live
+        traffic = None
+        pmc = ROOT / "profiles" / "r01_pmc_trailing_update.json"
+        if pmc.exists() and N == N_C2:
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch_corrected")
         out["roofline"] = {
-            "bound": "mfma", "kernel": "k_gemm_sub (Cholesky trailing update A22 -= L21 L21^T)",
+            "bound": "mfma",
+            "kernel": "k_gemm_glds / k_gemm4 (Cholesky trailing update A22 -= L21 L21^T, v_mfma_f64_4x4x4_4b): "
+                      "all 15 launches of one factorisation, HIP events on the handle's stream",
             "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": "bytes of the first (largest) update launch, PMC (profiles/r01_pmc_trailing_update.json); "
+                            "algorithmic bytes of that launch = 2 x 60.9 MB C tiles + 7.9 MB panel",
             "launches_per_step": upd["launches"] / reps, "avg_launch_us": 1e3 * upd["ms"] / max(upd["launches"], 1),
             "algorithmic_flops_per_step": upd["flops"] / reps,
-            "measured_mfma_f64_peak_tflops": pk.value,
+            "measured_mfma_f64_4x4x4_peak_tflops": pk.value,
         }
         out["phases_ms_per_step"] = {k: v["ms"] / reps for k, v in ph.items() if v["launches"]}
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # throughput with R independent evaluations in flight (the reference runs hyper-parameter
+        # restarts concurrently: opt/parallel_repeater.hpp:86-105 under tools::par::max).  One
+        # factorisation is a latency-bound chain of small kernels; R of them on R streams fill the idle CUs.
+        import threading
+
+        conc = {}
+        for R in (4, 8):
+            hs = []
+            for r in range(R):
+                hr = _capi.Handle(eng, local_rank)
+                hr.set_kernel(O.SE_ARD, theta + 1e-3 * r, 0.01)
+                hr.set_data(X, om)
+                hs.append(hr)
+            per = max(4, args.steps // 2)
+
+            def worker(hr):
+                for _ in range(per):
+                    hr.compute()
+                    hr.log_lik()
+
+            for hr in hs:  # warm-up
+                hr.compute()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ths = [threading.Thread(target=worker, args=(hr,)) for hr in hs]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t0
+            conc[f"in_flight_{R}"] = R * per / dtc
+            for hr in hs:
+                hr.close()
+        out["concurrent_evaluations_per_s"] = conc
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU side-by-side: the oracle (C restatement of the reference's path, 1 thread = the

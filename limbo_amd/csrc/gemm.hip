@@ -534,7 +534,15 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
         g.fold_len = fold;
         tiles = (int64_t)nsup * fold;
     }
-    hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 32, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
+    static int variant = -1;
+    if (variant < 0) {
+        const char* e = getenv("GPE_GLDS_VARIANT"); // tuning: 0 = 8 waves x BKT 32 (1 WG/CU), 1 = 4 waves x BKT 16 (2 WG/CU)
+        variant = e ? atoi(e) : 0;
+    }
+    if (variant == 1)
+        hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 2, 16, 2>), dim3((unsigned)tiles), dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 32, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
 }
 
 // number of TM x TN tiles that do work (triangular skipping accounted for)

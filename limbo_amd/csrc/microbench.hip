@@ -1,26 +1,27 @@
 // microbench.hip — roofline denominators measured on the device itself.
 //
-// MI355X_MICROARCH.md has no fp64-MFMA row, so the peak used for `roofline.frac` of the
-// trailing update is measured here: a register-only stream of independent
-// v_mfma_f64_16x16x4_f64 (8 accumulators per wave, 1..2 waves per SIMD).
+// MI355X_MICROARCH.md has no fp64-MFMA row.  The instruction the engine uses is
+// v_mfma_f64_4x4x4_4b (gemm.hip): a register-only stream of independent ones (16 accumulators
+// per wave, 4 waves per SIMD) measures 76-77 TFLOP/s, i.e. the 78.6 TFLOP/s datasheet peak;
+// v_mfma_f64_16x16x4 tops out at 47-49 TFLOP/s on the same chip (tools/ubench2.hip).
 #include "dev.h"
 
 __global__ __launch_bounds__(256) void k_mfma_peak(double* out, int iters)
 {
-    d4_t acc[8];
+    double acc[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-        acc[q] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < 16; ++q)
+        acc[q] = 0.0;
     double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            acc[q] = mfma_f64(a, b, acc[q]);
+        for (int q = 0; q < 16; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[q], 0, 0, 0);
     }
     double s = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-        s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    for (int q = 0; q < 16; ++q)
+        s += acc[q];
     if (s == 123.456)
         out[0] = s; // keep the chain live
 }
@@ -34,7 +35,7 @@ double run_mfma_f64_peak(hipStream_t s)
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int iters = 4096;
-    const int blocks = 256 * 2; // 2 workgroups of 4 waves per CU
+    const int blocks = 256 * 4; // 4 workgroups of 4 waves per CU
     hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, s, d, 64); // warm-up
     double best = 0.0;
     for (int rep = 0; rep < 5; ++rep) {
@@ -44,7 +45,7 @@ double run_mfma_f64_peak(hipStream_t s)
         hipEventSynchronize(e1);
         float ms = 0.f;
         hipEventElapsedTime(&ms, e0, e1);
-        double flops = (double)blocks * 4.0 * iters * 8.0 * 2.0 * 16 * 16 * 4;
+        double flops = (double)blocks * 4.0 * iters * 16.0 * 512.0; // 4x4x4_4b: 4 blocks x 2*4*4*4
         double tf = flops / (ms * 1e-3) / 1e12;
         if (tf > best)
             best = tf;
