@@ -47,6 +47,14 @@ void launch_transpose_x(hipStream_t s, const double* Xrm, int64_t n, int D, doub
 // inverse Xt[k + 64 c] = (L11^-1)[c][k] (64 x 64, identity-padded for jb < 64).  info: first bad
 // pivot (1-based, global index = goff + j + 1), written only if *info == 0.
 void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff);
+// one fused 64-column step below the factored diagonal block at (j0, j0): L21 = A21 X^T for rows
+// j0+64 .. M-1, the updates of the next `nt` 64-column blocks of the outer panel, and (do_next) the
+// factorisation + inversion of the next diagonal block (-> Xt_next).  Full 64-blocks only.
+// Hs: nt scratch tiles (64 x 64 each) for the L of the first nt row blocks; launch_head_copy moves
+// the tiles of the nf fused steps of the panel at p0 (nt0 = tiles of its first step) into A.
+void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
+                       double* Xt_next, int do_next, int* info, double* Hs);
+void launch_head_copy(hipStream_t s, double* A, int64_t lda, int64_t p0, int nt0, int nf, const double* H);
 // inverses of diagonal blocks b0 .. b0+nblocks-1 of an existing factor L (order N) into
 // Xt_all + 4096 b
 void launch_diag_inv(hipStream_t s, const double* L, int64_t ldl, int64_t N, int64_t b0, int64_t nblocks,

@@ -50,6 +50,7 @@ struct gpe_ctx {
     KParams kp;
     double *dXt = nullptr, *dA = nullptr, *dOm = nullptr, *dAl = nullptr, *dW = nullptr, *dY = nullptr;
     double *dLinv = nullptr, *dKinv = nullptr, *dKhost = nullptr, *dGradPartial = nullptr, *dGrad = nullptr;
+    double* dHead = nullptr; // scratch tiles of the fused panel steps (k_panel_step)
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     int64_t grad_partial_cap = 0;
     int* dInfo = nullptr;
@@ -58,6 +59,7 @@ struct gpe_ctx {
     double* hScal = nullptr; // pinned
     bool have_L = false, inv_ok = false, host_K = false, ll_ok = false;
     int nbo = 256; // outer panel width of the two-level blocked algorithms
+    bool fuse_panel = true; // k_panel_step instead of the three-launch panel step (GPE_FUSE_PANEL=0 disables)
     // instrumentation
     bool prof = false;
     std::vector<PhaseRec> pending;
@@ -263,13 +265,36 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     for (int64_t p0 = 0; p0 < N; p0 += nbo) {
         const int64_t pw = std::min<int64_t>(nbo, N - p0);
         const int64_t pe = p0 + pw;
+        bool diag_done = false; // the previous fused step already factored this diagonal block
+        int nf = 0, nt0 = 0;    // fused steps of this panel and head tiles of the first one
+        int64_t htile = 0;
         for (int64_t j0 = p0; j0 < pe; j0 += NB) {
             const int jb = (int)std::min<int64_t>(NB, pe - j0);
             const int64_t r0 = j0 + jb;
             double* Xt = c->dXinv + (j0 / NB) * (NB * NB);
-            {
+            if (!diag_done) {
                 PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)jb * jb * jb);
                 launch_diag(s, A + j0 + j0 * ld, ld, jb, Xt, c->dInfo, j0);
+            }
+            diag_done = false;
+            // fused step: needs full 64-column blocks up to the end of the panel and rows for block s+1
+            if (c->fuse_panel && jb == NB && r0 < pe && (pe - r0) % NB == 0 && r0 + NB <= M
+                && htile + (pe - r0) / NB <= 64) {
+                const int nt = (int)((pe - r0) / NB);
+                PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - r0) * NB * NB * (1 + nt));
+                if (nf == 0)
+                    nt0 = nt;
+                launch_panel_step(s, A, ld, j0, M, nt, Xt, Xt + NB * NB, 1, c->dInfo, c->dHead + htile * NB * NB);
+                htile += nt;
+                ++nf;
+                diag_done = true;
+                continue;
+            }
+            if (nf > 0) { // the head tiles of the fused steps go to their place before anything reads them
+                PhaseScope ps(c, GPE_PH_POTRF_PANEL, 0.0);
+                launch_head_copy(s, A, ld, p0, nt0, nf, c->dHead);
+                nf = 0;
+                htile = 0;
             }
             if (r0 < M) { // L21 = A21 L11^-T, in place (each 32-row workgroup reads only its own rows)
                 GemmArgs g{};
@@ -308,6 +333,10 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 PhaseScope ps(c, GPE_PH_POTRF_PANEL, gemm_flops(g));
                 launch_gemm_sub(s, g);
             }
+        }
+        if (nf > 0) {
+            launch_head_copy(s, A, ld, p0, nt0, nf, c->dHead);
+            nf = 0;
         }
         if (pe < N) { // trailing update, k = pw
             GemmArgs g{};
@@ -555,12 +584,15 @@ int gpe_create(int device_id, gpe_handle* out)
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
         || hipMalloc(&c->dInfo, 64) != hipSuccess || hipMalloc(&c->dScal, 64) != hipSuccess
+        || hipMalloc(&c->dHead, sizeof(double) * 64 * NB * NB) != hipSuccess
         || hipHostMalloc(&c->hInfo, 64) != hipSuccess || hipHostMalloc(&c->hScal, 64) != hipSuccess) {
         delete c;
         return GPE_ERR_HIP;
     }
     hipMemset(c->dInfo, 0, 64);
     *c->hInfo = 0;
+    if (const char* f = getenv("GPE_FUSE_PANEL"))
+        c->fuse_panel = atoi(f) != 0;
     const char* e = getenv("GPE_NBO");
     if (e) {
         int v = atoi(e);
@@ -583,6 +615,7 @@ int gpe_destroy(gpe_handle c)
     free_dev(c);
     hipFree(c->dInfo);
     hipFree(c->dScal);
+    hipFree(c->dHead);
     hipHostFree(c->hInfo);
     hipHostFree(c->hScal);
     hipStreamDestroy(c->stream);
@@ -1106,6 +1139,7 @@ int gpe_clone(gpe_handle src, gpe_handle* out)
     memcpy(c->theta, src->theta, sizeof(c->theta));
     c->noise = src->noise;
     c->nbo = src->nbo;
+    c->fuse_panel = src->fuse_panel;
     c->host_K = src->host_K;
     if (src->dA) {
         rc = alloc_dev(c, src->cap, src->D, src->P);

@@ -351,6 +351,281 @@ void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int*
     hipLaunchKernelGGL(k_diag, dim3(1), dim3(256), 0, s, A, lda, jb, Xt, info, goff);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_panel_step — one 64-column step of the blocked factorisation below an already factored
+// diagonal block, fused into ONE launch (a dependent launch costs ~3.4 us here, so the
+// three-launch form [L21 = A21 X^T | in-panel update | next k_diag] pays 10 us of floor per step):
+//   workgroup b owns rows R_b = [r0 + 64 b, +64) of the panel (r0 = j0 + 64):
+//     1. L_b = A[R_b, j0:j0+64] X^T                                    (matrix cores, X = L11^-1)
+//     2. for every remaining 64-column block t of the outer panel with t <= b:
+//          A[R_b, block t] -= L_b L_t^T,  L_t = rows of block t of the same product.
+//        L_t belongs to another workgroup; instead of an inter-workgroup hand-off it is recomputed
+//        here (256 MFMAs per wave, hidden behind workgroup 0's serial diagonal factorisation).
+//     3. workgroup 0 then holds the fully updated next diagonal block and factors + inverts it
+//        (same code as k_diag), so the next step needs no separate diagonal launch.
+// Requires full 64-column blocks (host falls back to the three-launch form otherwise).
+// ---------------------------------------------------------------------------------------------
+#define PS 80 // stride (doubles) of the [kk][i] operand tiles: == 16 mod 32
+
+// acc[m][n] += sum_k Aop[k][wm + 16 m + ..] * Bop(...)   for a 32 x 16 wave tile (8 waves), k = 64
+// BKM = true : B operand stored k-contiguous, Bk[c * XS + k]      (X as L11^-1 rows)
+// BKM = false: B operand stored [kk][n],      Bn[k * PS + n]
+template <bool BKM>
+static __device__ __forceinline__ void mm64(const double* __restrict__ Aop, const double* __restrict__ Bop, int wm, int wn,
+                                            int lane, double (&acc)[2][4])
+{
+    const int ar = wm + (lane & 15), bc = wn + (lane & 3), kq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < NB; ks += 4) {
+        double af[2], bf[4];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+            af[x] = Aop[(ks + kq) * PS + ar + 16 * x];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            bf[x] = BKM ? Bop[(bc + 4 * x) * XS + ks + kq] : Bop[(ks + kq) * PS + bc + 4 * x];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+    }
+}
+
+// 64 x 64 tile of column-major G (rows clamped to nrows) <-> registers <-> T[kk * PS + i]; 512 threads
+struct TileRegs {
+    double v[8];
+    __device__ __forceinline__ void load(const double* __restrict__ G, int64_t ld, int nrows)
+    {
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+        const int ic = i < nrows ? i : nrows - 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            v[q] = G[ic + (int64_t)(kk0 + 8 * q) * ld];
+    }
+    __device__ __forceinline__ void store(double* __restrict__ T) const
+    {
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            T[(kk0 + 8 * q) * PS + i] = v[q];
+    }
+};
+
+#define PANEL_PRE 3 // head tiles prefetched into registers at kernel start (nbo = 256 needs 3)
+
+__global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
+                                                    const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
+                                                    int do_next, int* __restrict__ info, double* __restrict__ Hs)
+{
+    // one LDS array, carved: [Bx | T0 | T1]; workgroup 0 re-carves it as [Ls | Xs | Ts | Ltb | invd]
+    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS];
+    __shared__ int sbad;
+    double* Bx = lds;
+    double* T0 = lds + NB * XS;
+    double* T1 = T0 + NB * PS;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+    const int b = blockIdx.x;
+    const int64_t r0 = j0 + NB, R0 = r0 + (int64_t)NB * b;
+    const int nrows = (int)((M - R0 < NB) ? M - R0 : NB);
+    const int tmax = (b < nt - 1) ? b : nt - 1;
+    if (threadIdx.x == 0)
+        sbad = 0;
+
+    // every global load this workgroup needs before its first product goes out now: X, its own
+    // tile, and the head tiles it will re-derive (one exposed memory latency instead of one per tile)
+    TileRegs own, head[PANEL_PRE];
+    own.load(A + R0 + j0 * lda, lda, nrows);
+    double xv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        xv[q] = Xt_cur[threadIdx.x + 512 * q];
+#pragma unroll
+    for (int t = 0; t < PANEL_PRE; ++t)
+        if (t <= tmax && t != b)
+            head[t].load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = threadIdx.x + 512 * q;
+        Bx[(e >> 6) * XS + (e & 63)] = xv[q]; // Bx[c][k] = X[c][k]
+    }
+    own.store(T0);
+    __syncthreads();
+
+    // 1. L_b = A_b X^T
+    double acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            acc[m][n] = 0.0;
+    mm64<true>(T0, Bx, wm, wn, lane, acc);
+    __syncthreads(); // every wave is done reading the A tile
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int row = wm + 16 * m + drow, col = wn + 4 * n + dcol;
+            T0[col * PS + row] = acc[m][n]; // own L as [kk = col][i = row]
+            // Row blocks b < nt are the "head" tiles other workgroups re-derive from A while this
+            // one runs: they must not be overwritten in place here.  Their L goes to the scratch
+            // tile Hs[b] and k_head_copy moves it into A after the panel's fused steps.
+            if (b < nt)
+                Hs[(int64_t)b * (NB * NB) + row + NB * col] = acc[m][n];
+            else if (row < nrows)
+                A[R0 + row + (j0 + col) * lda] = acc[m][n];
+        }
+    __syncthreads();
+
+    // 2. in-panel updates of this row block
+    double cres[2][4]; // workgroup 0: the updated next diagonal block
+#pragma unroll 1
+    for (int t = 0; t <= tmax; ++t) {
+        double* Cg = A + R0 + (r0 + (int64_t)NB * t) * lda;
+        double cv[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int row = wm + 16 * m + drow, col = wn + 4 * n + dcol;
+                const int rc = row < nrows ? row : nrows - 1;
+                cv[m][n] = Cg[rc + (int64_t)col * lda];
+            }
+        const double* Bop = T0;
+        if (t != b) { // head tile of another row block: recompute L_t = A_t X^T
+            if (t == 0)
+                head[0].store(T1);
+            else if (t == 1)
+                head[1].store(T1);
+            else if (t == 2)
+                head[2].store(T1);
+            else {
+                TileRegs late;
+                late.load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
+                late.store(T1);
+            }
+            __syncthreads();
+            double ah[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    ah[m][n] = 0.0;
+            mm64<true>(T1, Bx, wm, wn, lane, ah);
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    T1[(wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = ah[m][n];
+            __syncthreads();
+            Bop = T1;
+        }
+        double a2[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                a2[m][n] = 0.0;
+        mm64<false>(T0, Bop, wm, wn, lane, a2);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int row = wm + 16 * m + drow, col = wn + 4 * n + dcol;
+                const double v = cv[m][n] - a2[m][n];
+                if (t == 0)
+                    cres[m][n] = v;
+                if (row < nrows)
+                    Cg[row + (int64_t)col * lda] = v;
+            }
+        __syncthreads(); // T1 is free again
+    }
+
+    // 3. workgroup 0: factor + invert the next diagonal block (it is block t = 0 of its own rows)
+    if (b != 0 || !do_next)
+        return;
+    double* Ls = lds;
+    double* Xs = Ls + NB * XS;
+    double* Ts = Xs + NB * XS;
+    double* Ltb = Ts + NB * XS;
+    double* invd = Ltb + 4 * NB * 4;
+    static_assert(3 * NB * XS + 4 * NB * 4 + NB <= NB * XS + 2 * NB * PS, "diag scratch must fit the panel-step LDS");
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            Ls[(wm + 16 * m + drow) * XS + wn + 4 * n + dcol] = cres[m][n];
+    __syncthreads();
+    // the serial part runs on 4 waves (k_diag's code); waves 4..7 end here — s_barrier only counts
+    // the waves of the workgroup that are still alive
+    if (wave >= 4)
+        return;
+    const int r = lane, w = wave;
+    double a[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 16 * q + 4 * w + e;
+            a[q][e] = (c <= r) ? Ls[r * XS + c] : 0.0;
+        }
+    __syncthreads();
+    DiagRound<15>::run(a, Ltb, invd, &sbad, r, w);
+    double* Ad = A + r0 + r0 * lda;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 16 * q + 4 * w + e;
+            const double v = (c <= r) ? a[q][e] : 0.0;
+            Ls[r * XS + c] = v;
+            if (c <= r)
+                Ad[r + (int64_t)c * lda] = v;
+        }
+    if (threadIdx.x == 0 && sbad != 0 && *info == 0)
+        *info = (int)(r0 + sbad);
+    __syncthreads();
+    invert_L64(Ls, invd, Xs, Ts);
+    store_Xt(Xs, Xt_next);
+}
+
+void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
+                       double* Xt_next, int do_next, int* info, double* Hs)
+{
+    const int64_t rows = M - (j0 + NB);
+    if (rows <= 0)
+        return;
+    hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, j0, M, nt, Xt_cur,
+                       Xt_next, do_next, info, Hs);
+}
+
+// head tiles of the fused steps of one outer panel -> their place in A.  Step f (f = 0..nf-1) of the
+// panel starting at column p0 left nt0 - f tiles: tile t = rows p0 + 64 (f + 1 + t), columns p0 + 64 f.
+__global__ __launch_bounds__(256) void k_head_copy(double* __restrict__ A, int64_t lda, int64_t p0, int nt0,
+                                                   const double* __restrict__ H)
+{
+    int f = 0, t = blockIdx.x;
+    while (t >= nt0 - f) {
+        t -= nt0 - f;
+        ++f;
+    }
+    const double* src = H + (int64_t)blockIdx.x * (NB * NB);
+    double* dst = A + (p0 + NB * (int64_t)(f + 1 + t)) + (p0 + NB * (int64_t)f) * lda;
+    for (int e = threadIdx.x; e < NB * NB; e += 256)
+        dst[(e & 63) + (int64_t)(e >> 6) * lda] = src[e];
+}
+void launch_head_copy(hipStream_t s, double* A, int64_t lda, int64_t p0, int nt0, int nf, const double* H)
+{
+    int tiles = 0;
+    for (int f = 0; f < nf; ++f)
+        tiles += nt0 - f;
+    if (tiles > 0)
+        hipLaunchKernelGGL(k_head_copy, dim3((unsigned)tiles), dim3(256), 0, s, A, lda, p0, nt0, H);
+}
+
 // inverses of the diagonal blocks of an existing factor: block b at L[64 b, 64 b]
 __global__ __launch_bounds__(256) void k_diag_inv(const double* __restrict__ L, int64_t ldl, int64_t N, int64_t b0,
                                                   double* __restrict__ Xt_all)
