@@ -87,6 +87,9 @@ double gemm_flops(const GemmArgs& g);
 // Xt_all: inverses of the 64 x 64 diagonal blocks (launch_diag / launch_diag_inv).
 void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, double* w,
                        double* out, int64_t ldw, int P, int trans);
+// the whole backward sweep a = L^-T y in one data-flow launch (err: set to 1 if a hand-off timed out)
+void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, double* y,
+                          double* a, int64_t ldw, int P, int* err);
 // Arows[p + i*lda] = V[i + p*ldv] (P rows appended under the matrix) and back
 void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N, int P, double* Arows, int64_t lda);
 void launch_rows_to_cols(hipStream_t s, const double* Arows, int64_t lda, int64_t N, int P, double* V, int64_t ldv);

@@ -59,6 +59,7 @@ struct gpe_ctx {
     double* hScal = nullptr; // pinned
     bool have_L = false, inv_ok = false, host_K = false, ll_ok = false;
     int nbo = 256; // outer panel width of the two-level blocked algorithms
+    bool flow_solve = true; // one data-flow launch for the backward sweep (GPE_FLOW_SOLVE=0: per-block launches)
     bool fuse_panel = true; // k_panel_step instead of the three-launch panel step (GPE_FUSE_PANEL=0 disables)
     // instrumentation
     bool prof = false;
@@ -448,7 +449,11 @@ void solve_alpha_from_z(gpe_ctx* c)
     for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) {
         int pc = std::min(GPE_MAX_P, c->P - p0);
         launch_rows_to_cols(s, c->dA + c->N + p0, c->ld, c->N, pc, c->dY, c->ld);
-        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc, 1);
+        if (c->flow_solve)
+            launch_trsv_bwd_flow(s, c->dA, c->ld, c->N, c->dXinv, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc,
+                                 c->dInfo + 1);
+        else
+            launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc, 1);
     }
 }
 
@@ -457,7 +462,7 @@ void enqueue_loglik_terms(gpe_ctx* c)
     PhaseScope ps(c, GPE_PH_LOGLIK, 0.0);
     launch_loglik_terms(c->stream, c->dA, c->ld, c->N, c->dOm, c->dAl, c->ld, c->P, c->dScal);
     hipMemcpyAsync(c->hScal, c->dScal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    hipMemcpyAsync(c->hInfo, c->dInfo, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(c->hInfo, c->dInfo, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
 }
 
 int compute_enqueue(gpe_ctx* c)
@@ -466,7 +471,7 @@ int compute_enqueue(gpe_ctx* c)
         return GPE_ERR_STATE;
     hipStream_t s = c->stream;
     digest_kernel(c);
-    HIPCHK(c, hipMemsetAsync(c->dInfo, 0, sizeof(int), s));
+    HIPCHK(c, hipMemsetAsync(c->dInfo, 0, 2 * sizeof(int), s));
     if (c->host_K) {
         if (!c->dKhost)
             return GPE_ERR_STATE;
@@ -492,6 +497,11 @@ int compute_finish(gpe_ctx* c)
     HIPCHK(c, hipGetLastError());
     drain_phases(c);
     c->ll_ok = true;
+    if (c->hInfo[1] != 0) { // the data-flow solve gave up waiting for a producer (never legal)
+        c->err = "backward sweep: inter-workgroup hand-off timed out";
+        c->hInfo[1] = 0;
+        return GPE_ERR_HIP;
+    }
     return *c->hInfo; // 0 or 1-based index of the first non-positive pivot
 }
 
@@ -590,7 +600,9 @@ int gpe_create(int device_id, gpe_handle* out)
         return GPE_ERR_HIP;
     }
     hipMemset(c->dInfo, 0, 64);
-    *c->hInfo = 0;
+    c->hInfo[0] = c->hInfo[1] = 0;
+    if (const char* f = getenv("GPE_FLOW_SOLVE"))
+        c->flow_solve = atoi(f) != 0;
     if (const char* f = getenv("GPE_FUSE_PANEL"))
         c->fuse_panel = atoi(f) != 0;
     const char* e = getenv("GPE_NBO");
@@ -800,7 +812,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     launch_transpose_x(s, c->dY, 1, D, c->dXt, ld, n);
     HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * ld, obs_mean, sizeof(double) * (n + 1),
                                sizeof(double) * (n + 1), P, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(c->dInfo, 0, sizeof(int), s));
+    HIPCHK(c, hipMemsetAsync(c->dInfo, 0, 2 * sizeof(int), s));
     {
         PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)n * n);
         // k(x_i, x_new) for i = 0..n (gp.hpp:583-586), no noise yet
@@ -1140,6 +1152,7 @@ int gpe_clone(gpe_handle src, gpe_handle* out)
     c->noise = src->noise;
     c->nbo = src->nbo;
     c->fuse_panel = src->fuse_panel;
+    c->flow_solve = src->flow_solve;
     c->host_K = src->host_K;
     if (src->dA) {
         rc = alloc_dev(c, src->cap, src->D, src->P);

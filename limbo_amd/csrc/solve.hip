@@ -165,6 +165,131 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_trsv_bwd_flow — the whole backward sweep L^T a = y in ONE launch (a dependent launch costs
+// ~3.4 us here; the 64-launch sweep spent 0.5 ms at N = 4096, almost all of it launch floor).
+// Workgroup j owns unknown block j.  It folds in the contributions L[t, j]^T a_t of the later
+// blocks t = nblk-1 .. j+1 as those a_t appear in global memory, then forms a_j = X_j^T w_j with the
+// stored block inverse and publishes it.  Hand-off without flags or fences: the output vector is
+// pre-filled with an all-ones bit pattern (a NaN no arithmetic produces); every value is published
+// by ONE naturally aligned 8-byte agent-scope store and consumed by agent-scope loads that poll the
+// value itself (MI355X_MICROARCH.md, "granule" hand-off: an 8-byte store is never torn and needs no
+// ordering with anything else).  All nblk <= 256 workgroups are resident (1 per CU), so the
+// pipeline cannot deadlock; the poll is bounded anyway and raises *err instead of hanging.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict__ L, int64_t ld, int64_t N,
+                                                       const double* __restrict__ Xt_all, const double* __restrict__ y,
+                                                       double* a, int64_t ldw, int P, int* __restrict__ err)
+{
+    __shared__ double Stg[NB * LSTR];
+    __shared__ double xs[NB];
+    __shared__ double wj[NB];
+    __shared__ double part[4][NB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t nblk = (N + NB - 1) / NB;
+    const int64_t j = blockIdx.x, j0 = j * NB;
+    const int jb = (int)((N - j0 < NB) ? N - j0 : NB);
+    const unsigned long long SENT = ~0ull;
+    for (int p = 0; p < P; ++p) {
+        const double* yp = y + (int64_t)p * ldw;
+        double* ap = a + (int64_t)p * ldw;
+        if (threadIdx.x < NB)
+            wj[lane] = (lane < jb) ? yp[j0 + lane] : 0.0;
+        // tile of the first contributor, prefetched: T[k][c] = L[t0 + k][j0 + c], lane = k
+        double tl[16];
+        int64_t t = nblk - 1;
+        auto fetch = [&](int64_t tt) {
+            const int64_t t0 = tt * NB;
+            const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
+            const int kc = lane < tb ? lane : tb - 1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int c = wv + 4 * q;
+                const int cc = c < jb ? c : jb - 1;
+                const double v = L[t0 + kc + (j0 + cc) * ld];
+                tl[q] = (lane < tb && c < jb) ? v : 0.0;
+            }
+        };
+        if (t > j)
+            fetch(t);
+        for (; t > j; --t) {
+            __syncthreads(); // Stg / xs of the previous contributor are consumed
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                Stg[(wv + 4 * q) * LSTR + lane] = tl[q]; // Stg[c][k]
+            if (t - 1 > j)
+                fetch(t - 1); // in flight while we wait for a_t
+            if (threadIdx.x < NB) {
+                const int64_t t0 = t * NB;
+                const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
+                double v = 0.0;
+                if (lane < tb) {
+                    unsigned long long bits = SENT;
+                    int spins = 0;
+                    while (true) {
+                        bits = __hip_atomic_load((const unsigned long long*)(ap + t0 + lane), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                        if (bits != SENT)
+                            break;
+                        if (++spins > (1 << 24)) { // ~seconds: a lost producer, never a legal state
+                            *err = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    v = __longlong_as_double((long long)bits);
+                }
+                xs[lane] = v;
+            }
+            __syncthreads();
+            double acc = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = 16 * wv + kk;
+                acc = fma(Stg[lane * LSTR + k], xs[k], acc);
+            }
+            part[wv][lane] = acc;
+            __syncthreads();
+            if (threadIdx.x < NB)
+                wj[lane] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        }
+        __syncthreads();
+        // a_j = X_j^T w_j :  a[c] = sum_r Xt[c + 64 r] w[r]   (coalesced along c)
+        const double* Xt = Xt_all + j * (NB * NB);
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int r = 16 * wv + kk;
+            acc = fma(Xt[lane + NB * r], wj[r], acc);
+        }
+        part[wv][lane] = acc;
+        __syncthreads();
+        if (threadIdx.x < NB && lane < jb) {
+            const double v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            __hip_atomic_store((unsigned long long*)(ap + j0 + lane), (unsigned long long)__double_as_longlong(v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+}
+
+// a <- L^-T y in one launch; `a` must not alias y.  Falls back to the per-block sweep when the
+// blocks cannot all be resident.
+void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, double* y,
+                          double* a, int64_t ldw, int P, int* err)
+{
+    if (N <= 0)
+        return;
+    const int64_t nblk = (N + NB - 1) / NB;
+    if (nblk > 256) {
+        launch_trsv_sweep(s, L, ld, N, Xt_all, y, a, ldw, P, 1);
+        return;
+    }
+    for (int p = 0; p < P; ++p)
+        hipMemsetAsync(a + (int64_t)p * ldw, 0xFF, sizeof(double) * (size_t)N, s);
+    hipLaunchKernelGGL(k_trsv_bwd_flow, dim3((unsigned)nblk), dim3(256), 0, s, L, ld, N, Xt_all, y, a, ldw, P, err);
+}
+
 // rows N..N+P-1 of the matrix <- obs_mean^T (before the factorisation) and back (z = L^-1 obs_mean
 // after it): the forward substitution rides along the Cholesky as P extra rows of the panel.
 __global__ void k_cols_to_rows(const double* __restrict__ V, int64_t ldv, int64_t N, int P, double* __restrict__ Arows,
