@@ -76,6 +76,8 @@ struct GemmArgs {
     int ktri;
     int overwrite; // 1: C = +A*B^T (no read of C), 0: C -= A*B^T
     int fold_len;  // set by launch_gemm_sub (tri): live tiles per folded tile-column pair
+    int total;     // set by launch_gemm_sub: logical workgroups (glds kernel)
+    int grid_limit; // > 0: at most this many physical workgroups (they loop) — leaves CUs to another stream
     int tile;      // 0: pick by problem size; 128 / 64 / 32: force the 128x128 / 64x64 / 32x64 tile
 };
 void launch_gemm_sub(hipStream_t s, const GemmArgs& g);

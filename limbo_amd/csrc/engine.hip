@@ -41,6 +41,10 @@ struct PhaseRec {
 struct gpe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // look-ahead: bulk of a trailing update runs here, behind the next panel
+    std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
+    bool lookahead = true;             // GPE_LOOKAHEAD=0 disables
+    int bulk_wgs = 192;                // physical workgroups of a look-ahead bulk update (GPE_BULK_WGS)
     std::mutex mu;
     int64_t N = 0, cap = 0, ld = 0;
     int D = 0, P = 0;
@@ -263,6 +267,8 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     hipStream_t s = c->stream;
     const int64_t ld = c->ld;
     const int64_t nbo = c->nbo;
+    bool la_pending = false; // a bulk update is (possibly) still running on stream2
+    size_t la_last = 0;
     for (int64_t p0 = 0; p0 < N; p0 += nbo) {
         const int64_t pw = std::min<int64_t>(nbo, N - p0);
         const int64_t pe = p0 + pw;
@@ -340,23 +346,62 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
             nf = 0;
         }
         if (pe < N) { // trailing update, k = pw
-            GemmArgs g{};
-            g.C = A + pe + pe * ld;
-            g.ldc = ld;
-            g.A = A + pe + p0 * ld;
-            g.lda = ld;
-            g.B = A + pe + p0 * ld;
-            g.ldb = ld;
-            g.m = M - pe;
-            g.n = N - pe;
-            g.k = pw;
-            g.tri = 1;
-            g.grow0 = pe;
-            g.gcol0 = pe;
-            PhaseScope ps(c, GPE_PH_POTRF_UPDATE, gemm_flops(g));
-            launch_gemm_sub(s, g);
+            auto upd = [&](hipStream_t st, int64_t c0, int64_t c1, int64_t rlo, int grid_limit = 0) {
+                // C[rlo:M, c0:c1] -= L[rlo:M, p0:pe] L[c0:c1, p0:pe]^T   (elements on/below the diagonal)
+                GemmArgs g{};
+                g.C = A + rlo + c0 * ld;
+                g.ldc = ld;
+                g.A = A + rlo + p0 * ld;
+                g.lda = ld;
+                g.B = A + c0 + p0 * ld;
+                g.ldb = ld;
+                g.m = M - rlo;
+                g.n = c1 - c0;
+                g.k = pw;
+                g.tri = 1;
+                g.grow0 = rlo;
+                g.gcol0 = c0;
+                g.grid_limit = grid_limit;
+                if (grid_limit > 0)
+                    g.tile = 128; // the glds kernel is the one that honours grid_limit
+                PhaseScope ps(c, GPE_PH_POTRF_UPDATE, gemm_flops(g));
+                launch_gemm_sub(st, g);
+            };
+            const int64_t pe2 = std::min<int64_t>(pe + nbo, N);
+            if (c->lookahead && !c->prof && pe2 < N) {
+                // look-ahead: the next panel's columns are updated on the main stream, the rest of the
+                // trailing matrix on the second stream while the next panel is factored
+                auto ev = [&](size_t i) {
+                    while (c->la_events.size() <= i) {
+                        hipEvent_t e;
+                        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                        c->la_events.push_back(e);
+                    }
+                    return c->la_events[i];
+                };
+                const size_t kp = (size_t)(p0 / nbo);
+                if (la_pending)
+                    hipStreamWaitEvent(s, ev(2 * (kp - 1) + 1), 0); // the previous bulk update also wrote these columns
+                upd(s, pe, pe2, pe);
+                hipEventRecord(ev(2 * kp), s); // panel kp factored and the next panel's columns updated:
+                                               // the bulk update starts now and shares the chip with panel kp+1 only
+                hipStreamWaitEvent(c->stream2, ev(2 * kp), 0);
+                upd(c->stream2, pe2, N, pe2, c->bulk_wgs); // 1 workgroup per CU: leaves 256 - bulk_wgs CUs to the panel
+                hipEventRecord(ev(2 * kp + 1), c->stream2);
+                la_pending = true;
+                la_last = 2 * kp + 1;
+            }
+            else {
+                if (la_pending) {
+                    hipStreamWaitEvent(s, c->la_events[la_last], 0);
+                    la_pending = false;
+                }
+                upd(s, pe, N, pe);
+            }
         }
     }
+    if (la_pending)
+        hipStreamWaitEvent(s, c->la_events[la_last], 0);
 }
 
 // Z <- L^-1 B in place, B is N x M (ldb).  identity_structure: B starts as the identity, so at
@@ -570,6 +615,28 @@ int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise)
     return GPE_OK;
 }
 
+// The look-ahead stream runs the bulk of a trailing update while the main stream factors the next
+// panel.  A GEMM workgroup (147 KB LDS) and a panel-step workgroup (115 KB) cannot share a CU, so a
+// bulk update that owns all 256 CUs would simply delay the panel: the bulk update is launched with
+// `bulk_wgs` < 256 looping workgroups (gemm.hip, GemmArgs::grid_limit), the other CUs stay free for
+// the critical path.  (A CU mask on the stream was tried first and had no effect.)
+hipError_t create_bulk_stream(hipStream_t* st)
+{
+    int keep = 4; // of every 4 CUs (GPE_BULK_CU_MASK=1..3 enables a mask; it had no measurable effect on MI355X/ROCm 7.2)
+    if (const char* e = getenv("GPE_BULK_CU_MASK"))
+        keep = atoi(e);
+    if (keep >= 4 || keep <= 0)
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    uint32_t mask[8];
+    for (int w = 0; w < 8; ++w) {
+        mask[w] = 0;
+        for (int b = 0; b < 32; ++b)
+            if (((w * 32 + b) & 3) < keep)
+                mask[w] |= 1u << b;
+    }
+    return hipExtStreamCreateWithCUMask(st, 8, mask);
+}
+
 struct DevGuard {
     explicit DevGuard(gpe_ctx* c) { hipSetDevice(c->device); }
 };
@@ -593,6 +660,7 @@ int gpe_create(int device_id, gpe_handle* out)
     gpe_ctx* c = new gpe_ctx();
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
+        || create_bulk_stream(&c->stream2) != hipSuccess
         || hipMalloc(&c->dInfo, 64) != hipSuccess || hipMalloc(&c->dScal, 64) != hipSuccess
         || hipMalloc(&c->dHead, sizeof(double) * 64 * NB * NB) != hipSuccess
         || hipHostMalloc(&c->hInfo, 64) != hipSuccess || hipHostMalloc(&c->hScal, 64) != hipSuccess) {
@@ -601,6 +669,10 @@ int gpe_create(int device_id, gpe_handle* out)
     }
     hipMemset(c->dInfo, 0, 64);
     c->hInfo[0] = c->hInfo[1] = 0;
+    if (const char* f = getenv("GPE_BULK_WGS"))
+        c->bulk_wgs = atoi(f);
+    if (const char* f = getenv("GPE_LOOKAHEAD"))
+        c->lookahead = atoi(f) != 0;
     if (const char* f = getenv("GPE_FLOW_SOLVE"))
         c->flow_solve = atoi(f) != 0;
     if (const char* f = getenv("GPE_FUSE_PANEL"))
@@ -630,6 +702,10 @@ int gpe_destroy(gpe_handle c)
     hipFree(c->dHead);
     hipHostFree(c->hInfo);
     hipHostFree(c->hScal);
+    for (auto e : c->la_events)
+        hipEventDestroy(e);
+    hipStreamSynchronize(c->stream2);
+    hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->stream);
     delete c;
     return GPE_OK;
@@ -1153,6 +1229,8 @@ int gpe_clone(gpe_handle src, gpe_handle* out)
     c->nbo = src->nbo;
     c->fuse_panel = src->fuse_panel;
     c->flow_solve = src->flow_solve;
+    c->lookahead = src->lookahead;
+    c->bulk_wgs = src->bulk_wgs;
     c->host_K = src->host_K;
     if (src->dA) {
         rc = alloc_dev(c, src->cap, src->D, src->P);

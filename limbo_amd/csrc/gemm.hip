@@ -376,9 +376,12 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
 
     const int tiles_m = (int)((g.m + TM - 1) / TM);
     const int tiles_n = (int)((g.n + TN - 1) / TN);
-    int wg = blockIdx.x;
+    // g.total logical workgroups; a launch with fewer physical ones (gridDim.x < g.total: the
+    // look-ahead update, which must leave CUs free for the panel on the other stream) loops.
+    for (int lwg = blockIdx.x; lwg < g.total; lwg += gridDim.x) {
+    int wg = lwg;
     {
-        const int nwg = gridDim.x;
+        const int nwg = g.total;
         const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
             const int t1 = first_live_tile<TM, TN>(g, tj);
             rr -= c0;
             if (tj == sc || rr >= tiles_m - t1)
-                return;
+                continue;
             ti = t1 + rr;
         }
     }
@@ -507,6 +510,8 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
             }
         }
     }
+    __syncthreads(); // the next tile's prologue overwrites the LDS stages
+    } // logical workgroups
 }
 
 static bool glds_ok(const GemmArgs& g)
@@ -534,6 +539,9 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
         g.fold_len = fold;
         tiles = (int64_t)nsup * fold;
     }
+    g.total = (int)tiles;
+    if (g.grid_limit > 0 && tiles > g.grid_limit)
+        tiles = g.grid_limit;
     static int variant = -1;
     if (variant < 0) {
         const char* e = getenv("GPE_GLDS_VARIANT"); // tuning: 0 = 8 waves x BKT 32 (1 WG/CU), 1 = 4 waves x BKT 16 (2 WG/CU)
