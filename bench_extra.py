@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Secondary measurements of SURVEY.md §8(d) on one MI355X (not the driver's bench.py contract):
+HP-objective evaluations/s with gradient (config 2), batched queries/s (config 3), add_sample/s
+(config 5), G independent GPs (config 4 on one GPU).  Prints one JSON object."""
+import argparse, json, sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    import torch
+    assert torch.cuda.is_available()
+    from limbo_amd import _capi
+    from oracle import np_oracle as O
+    eng = _capi.load_engine()
+    out = {}
+
+    # config 2: HP objective with gradient at N=4096, D=6
+    X, Y = O.make_problem("c2", N=4096)
+    om, mean = O.obs_mean_data(Y)
+    h = _capi.Handle(eng, 0)
+    h.set_data(X, om)
+    th = np.zeros(7)
+    h.set_kernel(O.SE_ARD, th, 0.01)
+    h.compute(); h.log_lik_grad(False)
+    n = 3 if args.quick else 10
+    t0 = time.perf_counter()
+    for i in range(n):
+        h.set_kernel(O.SE_ARD, th + 1e-3 * i, 0.01)
+        h.compute(); h.log_lik(); g = h.log_lik_grad(False)
+    dt = time.perf_counter() - t0
+    out["c2_hp_objective_with_grad_per_s"] = n / dt
+    out["c2_hp_objective_ms"] = 1e3 * dt / n
+    # batched query at N=4096 (M = 20000)
+    M = 5000 if args.quick else 20000
+    Xq = np.random.default_rng(1).uniform(0, 1, size=(M, 6))
+    h.query_batch(Xq[:256])
+    t0 = time.perf_counter(); kta, var = h.query_batch(Xq); dt = time.perf_counter() - t0
+    out["c2_query_batch_points_per_s_N4096"] = M / dt
+    h.close()
+
+    # config 3: N=16384, D=12, Matern5/2: compute + batched query
+    N3 = 8192 if args.quick else 16384
+    rng = np.random.default_rng(3)
+    X3 = rng.uniform(0, 1, size=(N3, 12))
+    Y3 = (np.cos(2 * X3).sum(axis=1) + 0.05 * rng.normal(size=N3))[:, None]
+    om3, mean3 = O.obs_mean_data(Y3)
+    h = _capi.Handle(eng, 0)
+    h.set_data(X3, om3)
+    h.set_kernel(O.MATERN52, np.zeros(2), 0.01)
+    t0 = time.perf_counter(); info = h.compute(); ll = h.log_lik(); dt = time.perf_counter() - t0
+    out["c3_N"] = N3
+    out["c3_compute_loglik_s"] = dt
+    out["c3_info"] = int(info)
+    M3 = 10000 if args.quick else 100000
+    Xq3 = rng.uniform(0, 1, size=(M3, 12))
+    h.query_batch(Xq3[:256])
+    t0 = time.perf_counter(); kta, var = h.query_batch(Xq3); dt = time.perf_counter() - t0
+    out["c3_query_points"] = M3
+    out["c3_query_batch_s"] = dt
+    out["c3_query_points_per_s"] = M3 / dt
+    out["c3_query_tflops"] = 1.0 * M3 * N3 * N3 / dt / 1e12
+    h.close()
+
+    # config 4 on one GPU: 8 independent GPs N=2048 via batch_compute
+    X4, Y4 = O.make_problem("c2", N=2048)
+    om4, _ = O.obs_mean_data(Y4)
+    hs = []
+    for g_ in range(8):
+        hh = _capi.Handle(eng, 0)
+        hh.set_data(X4, om4)
+        hh.set_kernel(O.SE_ARD, np.zeros(7) + 1e-2 * g_, 0.01)
+        hs.append(hh)
+    _capi.batch_compute(hs) if hasattr(_capi, "batch_compute") else [x.compute() for x in hs]
+    reps = 2 if args.quick else 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        if hasattr(_capi, "batch_compute"):
+            _capi.batch_compute(hs)
+        else:
+            [x.compute() for x in hs]
+        [x.log_lik() for x in hs]
+    dt = time.perf_counter() - t0
+    out["c4_8gps_N2048_evals_per_s"] = 8 * reps / dt
+    for hh in hs:
+        hh.close()
+
+    # config 5: incremental add_sample, n = 10 -> 200, D = 6
+    X5, Y5 = O.make_problem("c2", N=200)
+    h = _capi.Handle(eng, 0)
+    h.set_kernel(O.SE_ARD, np.zeros(7), 0.01)
+    om5, _ = O.obs_mean_data(Y5[:10])
+    h.set_data(X5[:10], om5)
+    h.compute()
+    t0 = time.perf_counter()
+    for i in range(10, 200):
+        omi, _ = O.obs_mean_data(Y5[: i + 1])
+        h.add_sample(X5[i], omi)
+    dt = time.perf_counter() - t0
+    out["c5_add_sample_per_s"] = 190 / dt
+    h.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

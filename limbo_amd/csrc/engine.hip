@@ -275,6 +275,10 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
         bool diag_done = false; // the previous fused step already factored this diagonal block
         int nf = 0, nt0 = 0;    // fused steps of this panel and head tiles of the first one
         int64_t htile = 0;
+        // head-tile scratch, two halves by panel parity: the copy into A is off the critical path
+        // (nothing before the end of the factorisation reads those tiles of A) and may still be
+        // pending on the second stream while the next panel is factored
+        double* const Hbase = c->dHead + ((p0 / nbo) & 1) * (32 * NB * NB);
         for (int64_t j0 = p0; j0 < pe; j0 += NB) {
             const int jb = (int)std::min<int64_t>(NB, pe - j0);
             const int64_t r0 = j0 + jb;
@@ -286,22 +290,16 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
             diag_done = false;
             // fused step: needs full 64-column blocks up to the end of the panel and rows for block s+1
             if (c->fuse_panel && jb == NB && r0 < pe && (pe - r0) % NB == 0 && r0 + NB <= M
-                && htile + (pe - r0) / NB <= 64) {
+                && htile + (pe - r0) / NB <= 32) {
                 const int nt = (int)((pe - r0) / NB);
                 PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - r0) * NB * NB * (1 + nt));
                 if (nf == 0)
                     nt0 = nt;
-                launch_panel_step(s, A, ld, j0, M, nt, Xt, Xt + NB * NB, 1, c->dInfo, c->dHead + htile * NB * NB);
+                launch_panel_step(s, A, ld, j0, M, nt, Xt, Xt + NB * NB, 1, c->dInfo, Hbase + htile * NB * NB);
                 htile += nt;
                 ++nf;
                 diag_done = true;
                 continue;
-            }
-            if (nf > 0) { // the head tiles of the fused steps go to their place before anything reads them
-                PhaseScope ps(c, GPE_PH_POTRF_PANEL, 0.0);
-                launch_head_copy(s, A, ld, p0, nt0, nf, c->dHead);
-                nf = 0;
-                htile = 0;
             }
             if (r0 < M) { // L21 = A21 L11^-T, in place (each 32-row workgroup reads only its own rows)
                 GemmArgs g{};
@@ -340,10 +338,6 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 PhaseScope ps(c, GPE_PH_POTRF_PANEL, gemm_flops(g));
                 launch_gemm_sub(s, g);
             }
-        }
-        if (nf > 0) {
-            launch_head_copy(s, A, ld, p0, nt0, nf, c->dHead);
-            nf = 0;
         }
         if (pe < N) { // trailing update, k = pw
             auto upd = [&](hipStream_t st, int64_t c0, int64_t c1, int64_t rlo, int grid_limit = 0) {
@@ -386,6 +380,9 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 hipEventRecord(ev(2 * kp), s); // panel kp factored and the next panel's columns updated:
                                                // the bulk update starts now and shares the chip with panel kp+1 only
                 hipStreamWaitEvent(c->stream2, ev(2 * kp), 0);
+                if (nf > 0)
+                    launch_head_copy(c->stream2, A, ld, p0, nt0, nf, Hbase);
+                nf = 0;
                 upd(c->stream2, pe2, N, pe2, c->bulk_wgs); // 1 workgroup per CU: leaves 256 - bulk_wgs CUs to the panel
                 hipEventRecord(ev(2 * kp + 1), c->stream2);
                 la_pending = true;
@@ -396,8 +393,16 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                     hipStreamWaitEvent(s, c->la_events[la_last], 0);
                     la_pending = false;
                 }
+                if (nf > 0)
+                    launch_head_copy(s, A, ld, p0, nt0, nf, Hbase);
+                nf = 0;
                 upd(s, pe, N, pe);
             }
+        }
+        if (nf > 0) { // last panel: no trailing update
+            PhaseScope ps(c, GPE_PH_POTRF_PANEL, 0.0);
+            launch_head_copy(s, A, ld, p0, nt0, nf, Hbase);
+            nf = 0;
         }
     }
     if (la_pending)

@@ -581,6 +581,11 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         const char* e = getenv("GPE_GEMM_TILE"); // debug/tuning: 128, 64 or 32
         force = e ? atoi(e) : 0;
     }
+    static int deep32 = -1;
+    if (deep32 < 0) {
+        const char* e = getenv("GPE_GEMM_DEEP32");
+        deep32 = e ? atoi(e) : 1;
+    }
     int tile = g.tile ? g.tile : force;
     if (tile != 128 && tile != 64 && tile != 32) {
         // measured at k = 256 (tools/kbench): one 128 x 128 glds workgroup per CU runs at the
@@ -601,6 +606,8 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         launch_tile<64, 64, 32, 2>(s, g);
     else if (g.k <= 64 && !g.ktri)
         launch_tile<32, 64, 64, 1>(s, g); // one-shot panel-step form
+    else if (deep32)
+        launch_tile<32, 64, 64, 2>(s, g); // latency-bound small updates: half the k iterations
     else
         launch_tile<32, 64, 32, 2>(s, g);
 }

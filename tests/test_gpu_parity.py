@@ -177,3 +177,37 @@ def test_gpu_c2_full_size_properties(engine_lib):
     assert relerr(mu, mur, floor=1e-3) < PC.TOL_MU
     assert relerr(s2, s2r) < PC.TOL_VAR
     h.close()
+
+
+def test_gpu_c3_full_size_properties(engine_lib):
+    """BASELINE config C3 (N=16384, D=12, Matern-5/2, fp64; 4096 of the 100k queries here) —
+    size-independent properties: K alpha = obs_mean on sampled rows, at training points
+    mu ~ y and sigma^2 <= 2 (noise + 1e-8) (src/tests/test_gp.cpp:448-511), batched == chunked."""
+    rng = np.random.default_rng(3)
+    N, D = 16384, 12
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = (np.cos(2 * X).sum(axis=1) + 0.05 * rng.normal(size=N))[:, None]
+    om, mean = O.obs_mean_data(Y)
+    th = np.zeros(2)
+    noise = 0.01
+    h = new_gp(engine_lib, O.MATERN52, X, om, th, noise)
+    assert h.compute() == 0
+    a = h.get_alpha()
+    rows = rng.integers(0, N, size=48)
+    # K[rows, :] on the host (Matern 5/2, l = 1, sigma_f = 1), + (noise + 1e-8) on the diagonal
+    d = np.sqrt(((X[rows, None, :] - X[None, :, :]) ** 2).sum(-1))
+    t1 = np.sqrt(5.0) * d
+    Kr = (1 + t1 + 5.0 * d * d / 3.0) * np.exp(-t1)
+    Kr[np.arange(len(rows)), rows] += noise + 1e-8
+    assert np.max(np.abs(Kr @ a[:, 0] - om[rows, 0])) < 1e-8 * np.max(np.abs(om))
+    assert np.isfinite(h.log_lik())
+    kta, var = h.query_batch(X[rows])
+    mu, s2 = O.finish_query(kta, var, mean, noise)
+    assert np.max(np.abs(mu[:, 0] - Y[rows, 0])) < 1.0
+    assert np.all(s2 <= 2.0 * (noise + 1e-8))
+    Xq = rng.uniform(0, 1, size=(4096, D))
+    k1, v1 = h.query_batch(Xq)
+    k2, v2 = h.query_batch(Xq[:1000])
+    assert np.array_equal(k1[:1000], k2) and np.array_equal(v1[:1000], v2)
+    assert np.all(np.isfinite(v1)) and np.all(v1 > -1e-9)
+    h.close()
