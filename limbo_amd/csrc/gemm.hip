@@ -584,7 +584,7 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
     static int deep32 = -1;
     if (deep32 < 0) {
         const char* e = getenv("GPE_GEMM_DEEP32");
-        deep32 = e ? atoi(e) : 1;
+        deep32 = e ? atoi(e) : 0;
     }
     int tile = g.tile ? g.tile : force;
     if (tile != 128 && tile != 64 && tile != 32) {
