@@ -1,0 +1,27 @@
+// limbo/model/multi_gp/parallel_lf_opt.hpp — fit the hyper-parameters of every output GP of a
+// MultiGP, all at once (contract: src/limbo/model/multi_gp/parallel_lf_opt.hpp:56-70).  Each output
+// GP is an independent device GP on its own stream: the fits overlap on the MI355X.
+#ifndef LIMBO_MODEL_MULTI_GP_PARALLEL_LF_OPT_HPP
+#define LIMBO_MODEL_MULTI_GP_PARALLEL_LF_OPT_HPP
+#include <limbo/model/gp/hp_opt.hpp>
+#include <limbo/tools/parallel.hpp>
+namespace limbo {
+    namespace model {
+        namespace multi_gp {
+            template <typename Params, typename HyperParamsOptimizer = limbo::model::gp::NoLFOpt<Params>>
+            struct ParallelLFOpt : public limbo::model::gp::HPOpt<Params> {
+                template <typename GP>
+                void operator()(GP& gp)
+                {
+                    this->_called = true;
+                    auto& gps = gp.gp_models();
+                    limbo::tools::par::loop(0, gps.size(), [&](size_t i) {
+                        HyperParamsOptimizer hp_optimize;
+                        hp_optimize(gps[i]);
+                    });
+                }
+            };
+        } // namespace multi_gp
+    } // namespace model
+} // namespace limbo
+#endif

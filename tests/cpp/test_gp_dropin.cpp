@@ -12,6 +12,10 @@
 #include <limbo/kernel/matern_three_halves.hpp>
 #include <limbo/mean/null_function.hpp>
 #include <limbo/model/gp.hpp>
+#include <limbo/model/multi_gp.hpp>
+#include <limbo/model/multi_gp/parallel_lf_opt.hpp>
+#include <limbo/serialize/binary_archive.hpp>
+#include <limbo/serialize/text_archive.hpp>
 #include <limbo/opt/parallel_repeater.hpp>
 
 using namespace limbo;
@@ -399,6 +403,129 @@ CASE(test_gp_auto)
     CHECK(gpr.get_log_lik() >= ll0);
 }
 
+// test_gp.cpp:912-953 — MultiGP == one GP per output dimension
+CASE(test_multi_gp_dim)
+{
+    using Mean_t = mean::Constant<Params>;
+    using Multi_t = model::MultiGP<Params, model::GP, kernel::SquaredExpARD<Params>, Mean_t>;
+    using Single_t = model::GP<Params, kernel::SquaredExpARD<Params>, Mean_t>;
+    std::vector<VectorXd> X, Y;
+    make_problem(60, 3, 2, X, Y);
+    Multi_t mgp;
+    mgp.compute(X, Y);
+    std::vector<Single_t> gps(2);
+    for (int p = 0; p < 2; ++p) {
+        std::vector<VectorXd> yp;
+        for (auto& y : Y)
+            yp.push_back(make_v1(y(p)));
+        gps[p].compute(X, yp);
+    }
+    for (int t = 0; t < 50; ++t) {
+        VectorXd q = rand_vec(3, 0, 1), mu, sig;
+        std::tie(mu, sig) = mgp.query(q);
+        for (int p = 0; p < 2; ++p) {
+            VectorXd m1;
+            double s1;
+            std::tie(m1, s1) = gps[p].query(q);
+            CHECK(std::abs(mu(p) - m1(0)) < 1e-6);
+            CHECK(std::abs(sig(p) - s1) < 1e-6);
+        }
+        VectorXd mu2 = mgp.mu(q), s2 = mgp.sigma(q);
+        CHECK(mu2(0) == mu(0) && mu2(1) == mu(1) && s2(0) == sig(0) && s2(1) == sig(1));
+    }
+    CHECK(mgp.nb_samples() == 60 && mgp.dim_in() == 3 && mgp.dim_out() == 2);
+    // add_sample keeps the members in step (test_gp.cpp:1128-1155 reads _observations)
+    mgp.add_sample(rand_vec(3, 0, 1), rand_vec(2, -1, 1));
+    CHECK(mgp.nb_samples() == 61 && mgp.gp_models()[0].nb_samples() == 61);
+}
+
+// multi_gp/parallel_lf_opt.hpp:59-68 — per-output hyper-parameter fits, all outputs at once
+CASE(test_multi_gp_auto)
+{
+    using Multi_t = model::MultiGP<Params, model::GP, kernel::SquaredExpARD<Params>, mean::Data<Params>, model::multi_gp::ParallelLFOpt<Params, model::gp::KernelLFOpt<Params>>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(80, 2, 3, X, Y);
+    Multi_t mgp;
+    mgp.compute(X, Y);
+    std::vector<double> ll0;
+    for (auto& g : mgp.gp_models())
+        ll0.push_back(g.compute_log_lik());
+    mgp.optimize_hyperparams();
+    for (size_t i = 0; i < ll0.size(); ++i)
+        CHECK(mgp.gp_models()[i].compute_log_lik() >= ll0[i]);
+}
+
+// test_serialize.cpp:120-205 — save -> load (with and without recompute) -> same predictions
+template <typename Archive, typename GP_t>
+static void check_serialize(const std::string& dir, int P, int& g_failed_here)
+{
+    std::vector<VectorXd> X, Y;
+    make_problem(50, 2, P, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    gp.template save<Archive>(dir);
+    GP_t a, b;
+    a.template load<Archive>(dir);         // recompute from data + params
+    b.template load<Archive>(dir, false);  // trust the stored L and alpha
+    CHECK(a.nb_samples() == gp.nb_samples() && b.nb_samples() == gp.nb_samples());
+    for (int t = 0; t < 200; ++t) {
+        VectorXd q = rand_vec(2, 0, 1);
+        auto r0 = gp.query(q);
+        auto r1 = a.query(q);
+        auto r2 = b.query(q);
+        for (int p = 0; p < P; ++p) {
+            CHECK(std::abs(std::get<0>(r0)(p) - std::get<0>(r1)(p)) < 1e-10);
+            CHECK(std::abs(std::get<0>(r0)(p) - std::get<0>(r2)(p)) < 1e-10);
+        }
+    }
+}
+template <typename Archive>
+static void check_serialize_sigma(const std::string& dir, int& g_failed_here)
+{
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(50, 2, 1, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    gp.template save<Archive>(dir);
+    GP_t b;
+    b.template load<Archive>(dir, false);
+    for (int t = 0; t < 100; ++t) {
+        VectorXd q = rand_vec(2, 0, 1);
+        CHECK(std::abs(gp.sigma(q) - b.sigma(q)) < 1e-10);
+    }
+    CHECK(std::abs(gp.compute_log_lik() - b.compute_log_lik()) < 1e-9);
+}
+CASE(test_text_archive)
+{
+    check_serialize<serialize::TextArchive, model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>>("/tmp/limbo_amd_gp_text", 2, g_failed_here);
+    check_serialize_sigma<serialize::TextArchive>("/tmp/limbo_amd_gp_text_s", g_failed_here);
+}
+CASE(test_bin_archive)
+{
+    check_serialize<serialize::BinaryArchive, model::GP<Params, kernel::MaternFiveHalves<Params>, mean::Constant<Params>>>("/tmp/limbo_amd_gp_bin", 1, g_failed_here);
+    check_serialize_sigma<serialize::BinaryArchive>("/tmp/limbo_amd_gp_bin_s", g_failed_here);
+}
+CASE(test_multi_gp_archive)
+{
+    using Multi_t = model::MultiGP<Params, model::GP, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(40, 2, 2, X, Y);
+    Multi_t m;
+    m.compute(X, Y);
+    m.save<serialize::TextArchive>("/tmp/limbo_amd_mgp_text");
+    m.save<serialize::BinaryArchive>("/tmp/limbo_amd_mgp_bin");
+    Multi_t a, b;
+    a.load<serialize::TextArchive>("/tmp/limbo_amd_mgp_text");
+    b.load<serialize::BinaryArchive>("/tmp/limbo_amd_mgp_bin");
+    for (int t = 0; t < 100; ++t) {
+        VectorXd q = rand_vec(2, 0, 1);
+        VectorXd m0 = m.mu(q), m1 = a.mu(q), m2 = b.mu(q);
+        CHECK((m0 - m1).norm() < 1e-10 && (m0 - m2).norm() < 1e-10);
+        CHECK((m.sigma(q) - a.sigma(q)).norm() < 1e-10);
+    }
+}
+
 int main()
 {
     auto t0 = std::chrono::steady_clock::now();
@@ -417,6 +544,11 @@ int main()
     test_gp_bw_inversion_run();
     test_gp_copy_semantics_run();
     test_gp_auto_run();
+    test_multi_gp_dim_run();
+    test_multi_gp_auto_run();
+    test_text_archive_run();
+    test_bin_archive_run();
+    test_multi_gp_archive_run();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%d checks, %d failed cases, %.1f s\n", g_checks, g_failed, s);
     return g_failed;
