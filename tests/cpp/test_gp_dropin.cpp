@@ -8,6 +8,9 @@
 #include <random>
 #include <string>
 
+#include <limbo/acqui/ei.hpp>
+#include <limbo/acqui/gp_ucb.hpp>
+#include <limbo/acqui/ucb.hpp>
 #include <limbo/kernel/exp.hpp>
 #include <limbo/kernel/matern_three_halves.hpp>
 #include <limbo/mean/null_function.hpp>
@@ -54,6 +57,9 @@ struct Params {
     struct opt_rprop : public defaults::opt_rprop {
         BO_PARAM(int, iterations, 30);
     };
+    struct acqui_ucb : public defaults::acqui_ucb {};
+    struct acqui_gpucb : public defaults::acqui_gpucb {};
+    struct acqui_ei : public defaults::acqui_ei {};
     struct opt_parallelrepeater : public defaults::opt_parallelrepeater {
         BO_PARAM(int, repeats, 4);
     };
@@ -526,6 +532,35 @@ CASE(test_multi_gp_archive)
     }
 }
 
+// acqui/{ucb,gp_ucb,ei}.hpp — the batched acquisition path equals the per-point functor
+CASE(test_acqui_batch)
+{
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(100, 3, 1, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    auto first = [](const VectorXd& v) { return v(0); };
+    std::vector<VectorXd> pts;
+    for (int m = 0; m < 300; ++m)
+        pts.push_back(rand_vec(3, 0, 1));
+    acqui::UCB<Params, GP_t> ucb(gp);
+    acqui::GP_UCB<Params, GP_t> gpucb(gp, 7);
+    acqui::EI<Params, GP_t> ei(gp);
+    auto bu = ucb.batch(pts, first);
+    auto bg = gpucb.batch(pts, first);
+    auto be = ei.batch(pts, first);
+    double ei_max = 0;
+    for (size_t m = 0; m < pts.size(); ++m) {
+        CHECK(bu[m] == opt::fun(ucb(pts[m], first, false)));
+        CHECK(bg[m] == opt::fun(gpucb(pts[m], first, false)));
+        CHECK(be[m] == opt::fun(ei(pts[m], first, false)));
+        CHECK(be[m] >= 0.0);
+        ei_max = std::max(ei_max, be[m]);
+    }
+    CHECK(ei_max > 0.0);
+}
+
 int main()
 {
     auto t0 = std::chrono::steady_clock::now();
@@ -549,6 +584,7 @@ int main()
     test_text_archive_run();
     test_bin_archive_run();
     test_multi_gp_archive_run();
+    test_acqui_batch_run();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%d checks, %d failed cases, %.1f s\n", g_checks, g_failed, s);
     return g_failed;
