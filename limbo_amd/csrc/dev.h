@@ -46,7 +46,10 @@ void launch_transpose_x(hipStream_t s, const double* Xrm, int64_t n, int D, doub
 // factor the jb x jb (jb <= 64) diagonal block at A (in place, lower) and write the transposed
 // inverse Xt[k + 64 c] = (L11^-1)[c][k] (64 x 64, identity-padded for jb < 64).  info: first bad
 // pivot (1-based, global index = goff + j + 1), written only if *info == 0.
-void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff);
+// half_form (jb == 64 only): only the inverses of the two 32 x 32 diagonal half-blocks are produced
+// (what k_panel_step consumes); launch_xinv_complete fills in the off-diagonal quarter afterwards.
+void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff, int half_form);
+void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b0, int64_t nblocks, double* Xt_all);
 // one fused 64-column step below the factored diagonal block at (j0, j0): L21 = A21 X^T for rows
 // j0+64 .. M-1, the updates of the next `nt` 64-column blocks of the outer panel, and (do_next) the
 // factorisation + inversion of the next diagonal block (-> Xt_next).  Full 64-blocks only.

@@ -180,6 +180,7 @@ int alloc_dev(gpe_ctx* c, int64_t cap, int D, int P)
     HIPCHK(c, hipMalloc(&c->dW, sizeof(double) * (size_t)(ld * std::max(P, 1))));
     HIPCHK(c, hipMalloc(&c->dY, sizeof(double) * (size_t)(ld * std::max(P, 1))));
     HIPCHK(c, hipMalloc(&c->dXinv, sizeof(double) * (size_t)(cap / NB) * NB * NB));
+    HIPCHK(c, hipMemsetAsync(c->dXinv, 0, sizeof(double) * (size_t)(cap / NB) * NB * NB, c->stream));
     HIPCHK(c, hipMemsetAsync(c->dXt, 0, sizeof(double) * (size_t)(ld * D), c->stream));
     return GPE_OK;
 }
@@ -201,6 +202,7 @@ int grow_dev(gpe_ctx* c, int64_t need)
     HIPCHK(c, hipMalloc(&nW, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nY, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nXi, sizeof(double) * (size_t)(ncap / NB) * NB * NB));
+    HIPCHK(c, hipMemsetAsync(nXi, 0, sizeof(double) * (size_t)(ncap / NB) * NB * NB, c->stream));
     HIPCHK(c, hipMemsetAsync(nXt, 0, sizeof(double) * (size_t)(nld * D), c->stream));
     if (c->N > 0) {
         launch_copy2d(c->stream, c->dXt, c->ld, nXt, nld, c->N, D);
@@ -283,22 +285,23 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
             const int jb = (int)std::min<int64_t>(NB, pe - j0);
             const int64_t r0 = j0 + jb;
             double* Xt = c->dXinv + (j0 / NB) * (NB * NB);
+            // fused step (k_panel_step): full 64-column blocks up to the end of the panel
+            const int nt = (int)((pe - r0) / NB);
+            const bool fuse = c->fuse_panel && jb == NB && (pe - r0) % NB == 0 && r0 < M && htile + nt <= 32;
             if (!diag_done) {
                 PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)jb * jb * jb);
-                launch_diag(s, A + j0 + j0 * ld, ld, jb, Xt, c->dInfo, j0);
+                launch_diag(s, A + j0 + j0 * ld, ld, jb, Xt, c->dInfo, j0, fuse ? 1 : 0);
             }
             diag_done = false;
-            // fused step: needs full 64-column blocks up to the end of the panel and rows for block s+1
-            if (c->fuse_panel && jb == NB && r0 < pe && (pe - r0) % NB == 0 && r0 + NB <= M
-                && htile + (pe - r0) / NB <= 32) {
-                const int nt = (int)((pe - r0) / NB);
+            if (fuse) {
                 PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - r0) * NB * NB * (1 + nt));
                 if (nf == 0)
                     nt0 = nt;
-                launch_panel_step(s, A, ld, j0, M, nt, Xt, Xt + NB * NB, 1, c->dInfo, Hbase + htile * NB * NB);
+                launch_panel_step(s, A, ld, j0, M, nt, Xt, Xt + NB * NB, nt > 0 ? 1 : 0, c->dInfo, Hbase + htile * NB * NB);
                 htile += nt;
-                ++nf;
-                diag_done = true;
+                if (nt > 0)
+                    ++nf;
+                diag_done = nt > 0;
                 continue;
             }
             if (r0 < M) { // L21 = A21 L11^-T, in place (each 32-row workgroup reads only its own rows)
@@ -407,6 +410,10 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     }
     if (la_pending)
         hipStreamWaitEvent(s, c->la_events[la_last], 0);
+    if (c->fuse_panel && N >= NB) { // off-diagonal quarters of the block inverses (half-form steps)
+        PhaseScope ps(c, GPE_PH_POTRF_PANEL, 0.0);
+        launch_xinv_complete(s, A, ld, 0, N / NB, c->dXinv);
+    }
 }
 
 // Z <- L^-1 B in place, B is N x M (ldb).  identity_structure: B starts as the identity, so at

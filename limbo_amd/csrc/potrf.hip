@@ -103,9 +103,9 @@ static __device__ __forceinline__ void rank4_update(double (&a)[4][4], const dou
 template <int G>
 struct DiagRound {
     static __device__ __forceinline__ void run(double (&a)[4][4], double* __restrict__ Ltb, double* __restrict__ invd,
-                                               int* __restrict__ sbad, int r, int w)
+                                               int* __restrict__ sbad, int r, int w, double* __restrict__ Ls)
     {
-        DiagRound<G - 1>::run(a, Ltb, invd, sbad, r, w);
+        DiagRound<G - 1>::run(a, Ltb, invd, sbad, r, w, Ls);
         constexpr int q = G >> 2, own = G & 3, c0 = 4 * G;
         double* Lt = Ltb + (G & 3) * (NB * 4);
         const double* Lp = Ltb + ((G + 3) & 3) * (NB * 4); // round G-1
@@ -157,6 +157,12 @@ struct DiagRound {
             Lt[r * 4 + 1] = l1;
             Lt[r * 4 + 2] = l2;
             Lt[r * 4 + 3] = l3;
+            if (Ls) { // the finished columns, for the inversion pipeline (XPipe32)
+                Ls[r * XS + c0 + 0] = l0;
+                Ls[r * XS + c0 + 1] = l1;
+                Ls[r * XS + c0 + 2] = l2;
+                Ls[r * XS + c0 + 3] = l3;
+            }
             if (r == 0) {
                 invd[c0 + 0] = y0;
                 invd[c0 + 1] = y1;
@@ -189,8 +195,67 @@ struct DiagRound {
 };
 template <>
 struct DiagRound<-1> {
-    static __device__ __forceinline__ void run(double (&)[4][4], double*, double*, int*, int, int) {}
+    static __device__ __forceinline__ void run(double (&)[4][4], double*, double*, int*, int, int, double*) {}
 };
+
+// ---- inversion pipelined behind the factorisation ------------------------------------------------
+// The panel steps only need the inverses of the two 32 x 32 diagonal half-blocks of L11 (the
+// triangular solve against L11 is then three small products: Y1 = A1 X11^T,
+// Y2 = (A2 - Y1 L21^T) X22^T); the off-diagonal block X21 = -X22 L21 X11 is filled in for all blocks
+// by k_xinv_complete after the factorisation, off the critical path.  The two half inverses cost a
+// quarter of the full inverse and are computed by ONE extra wave, row block by row block, one
+// round behind the factorisation: lane c = column c of X (lanes 0-31: X11 during rounds 0-7, lanes
+// 32-63: X22 during rounds 8-15), right-looking forward substitution on the identity with the 32
+// running right-hand sides in registers.  The wave executes the factor waves' barriers.
+template <int G>
+struct XPipe32 {
+    static __device__ __forceinline__ void run(double (&S)[32], const double* __restrict__ Ls,
+                                               const double* __restrict__ invd, double* __restrict__ Xt, int c)
+    {
+        XPipe32<G - 1>::run(S, Ls, invd, Xt, c);
+        __syncthreads(); // = the barrier that ends round G: columns 4G..4G+3 of L and their pivots are final
+        constexpr int hb = G >> 3, i0 = 4 * (G & 7), base = 32 * hb;
+        if ((c >> 5) == hb) {
+            const double* Lb = Ls + base * XS + base; // this half-block of L
+            const double x0 = S[i0] * invd[base + i0];
+            const double x1 = fma(-Lb[(i0 + 1) * XS + i0], x0, S[i0 + 1]) * invd[base + i0 + 1];
+            double t2 = fma(-Lb[(i0 + 2) * XS + i0], x0, S[i0 + 2]);
+            t2 = fma(-Lb[(i0 + 2) * XS + i0 + 1], x1, t2);
+            const double x2 = t2 * invd[base + i0 + 2];
+            double t3 = fma(-Lb[(i0 + 3) * XS + i0], x0, S[i0 + 3]);
+            t3 = fma(-Lb[(i0 + 3) * XS + i0 + 1], x1, t3);
+            t3 = fma(-Lb[(i0 + 3) * XS + i0 + 2], x2, t3);
+            const double x3 = t3 * invd[base + i0 + 3];
+            // rows base+i0 .. +3 of X are final: Xt[col + 64 row] = X[row][col]
+            Xt[c + NB * (base + i0 + 0)] = x0;
+            Xt[c + NB * (base + i0 + 1)] = x1;
+            Xt[c + NB * (base + i0 + 2)] = x2;
+            Xt[c + NB * (base + i0 + 3)] = x3;
+#pragma unroll
+            for (int i = i0 + 4; i < 32; ++i) { // fold the four new rows into every later row of the half-block
+                double v = S[i];
+                v = fma(-Lb[i * XS + i0 + 0], x0, v);
+                v = fma(-Lb[i * XS + i0 + 1], x1, v);
+                v = fma(-Lb[i * XS + i0 + 2], x2, v);
+                v = fma(-Lb[i * XS + i0 + 3], x3, v);
+                S[i] = v;
+            }
+        }
+    }
+};
+template <>
+struct XPipe32<-1> {
+    static __device__ __forceinline__ void run(double (&)[32], const double*, const double*, double*, int) {}
+};
+static __device__ __forceinline__ void xpipe32_wave(const double* __restrict__ Ls, const double* __restrict__ invd,
+                                                    double* __restrict__ Xt, int c)
+{
+    double S[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        S[k] = (k == (c & 31)) ? 1.0 : 0.0;
+    XPipe32<15>::run(S, Ls, invd, Xt, c);
+}
 
 // ---- inversion of the 64 x 64 lower-triangular L (in LDS, Ls[row * XS + col]) --------------------
 // acc[n] += sum_{k < 16} P[i0 + i][pk0 + k] * Q[qk0 + k][j0 + 4 n + j]   (16 x 16 x 16, n in [n0, n1))
@@ -218,6 +283,8 @@ static __device__ __forceinline__ void st16(double* __restrict__ D, int i0, int 
             D[row * XS + col + 4 * n] = sign * acc[n];
 }
 
+static __device__ __forceinline__ void invert_level2(const double* __restrict__ Ls, double* __restrict__ Xs,
+                                                     double* __restrict__ Ts);
 // Ls: L (lower, zeros above).  invd[j] = 1 / L[j][j].  Xs <- L^-1 (zeros above).  Ts: scratch.
 // All 256 threads; ends with a barrier.
 static __device__ __forceinline__ void invert_L64(const double* __restrict__ Ls, const double* __restrict__ invd,
@@ -261,20 +328,27 @@ static __device__ __forceinline__ void invert_L64(const double* __restrict__ Ls,
     }
     __syncthreads();
     TS(6);
-    { // level 2: rows 32..63 x cols 0..31, one 16 x 16 block per wave
-        const int ib = 2 + (w >> 1), jb = w & 1;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int kb = jb; kb < 2; ++kb) // T = L_21 X_11, X_11 lower
-            mm16(Ls, 16 * ib, 16 * kb, Xs, 16 * kb, 16 * jb, acc, 0, 4, lane);
-        st16(Ts, 16 * ib, 16 * jb, acc, 0, 4, 1.0, lane);
-        __syncthreads();
-        double acc2[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int kb = 2; kb <= ib; ++kb) // X_21 = -X_22 T, X_22 lower
-            mm16(Xs, 16 * ib, 16 * kb, Ts, 16 * kb, 16 * jb, acc2, 0, 4, lane);
-        st16(Xs, 16 * ib, 16 * jb, acc2, 0, 4, -1.0, lane);
-    }
-    __syncthreads();
+    invert_level2(Ls, Xs, Ts);
     TS(7);
+}
+
+// level 2: X[32:64, 0:32] = -X22 (L21 X11) given the two 32 x 32 diagonal inverses in Xs, one
+// 16 x 16 block per wave; 256 threads, ends with a barrier
+static __device__ __forceinline__ void invert_level2(const double* __restrict__ Ls, double* __restrict__ Xs,
+                                                     double* __restrict__ Ts)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ib = 2 + (w >> 1), jb = w & 1;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int kb = jb; kb < 2; ++kb) // T = L_21 X_11, X_11 lower
+        mm16(Ls, 16 * ib, 16 * kb, Xs, 16 * kb, 16 * jb, acc, 0, 4, lane);
+    st16(Ts, 16 * ib, 16 * jb, acc, 0, 4, 1.0, lane);
+    __syncthreads();
+    double acc2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int kb = 2; kb <= ib; ++kb) // X_21 = -X_22 T, X_22 lower
+        mm16(Xs, 16 * ib, 16 * kb, Ts, 16 * kb, 16 * jb, acc2, 0, 4, lane);
+    st16(Xs, 16 * ib, 16 * jb, acc2, 0, 4, -1.0, lane);
+    __syncthreads();
 }
 
 // Xt[k + 64 c] = X[c][k]
@@ -284,7 +358,54 @@ static __device__ __forceinline__ void store_Xt(const double* __restrict__ Xs, d
         Xt[e] = Xs[(e >> 6) * XS + (e & 63)];
 }
 
-__global__ __launch_bounds__(256) void k_diag(double* __restrict__ A, int64_t lda, int jb, double* __restrict__ Xt,
+// Half-inverse form used by the fused panel steps: L11 in place, X11^T and X22^T (the inverses of the
+// two 32 x 32 diagonal half-blocks) into the diagonal quarters of Xt; the quarter X21 is completed
+// later by k_xinv_complete, the quarter above the diagonal stays zero.  Waves 0-3 factor, wave 4
+// runs the inversion pipeline.  Full 64 x 64 blocks only.
+__global__ __launch_bounds__(320) void k_diag(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
+                                              int* __restrict__ info, int64_t goff)
+{
+    __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Ltb[4 * NB * 4];
+    __shared__ double invd[NB];
+    __shared__ int sbad;
+    const int r = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0)
+        sbad = 0;
+    double a[4][4];
+    if (w < 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 16 * q + 4 * w + e;
+                a[q][e] = (c <= r) ? A[r + (int64_t)c * lda] : 0.0; // only the lower triangle is meaningful
+            }
+    }
+    TS(0);
+    __syncthreads();
+    TS(1);
+    if (w == 4) {
+        xpipe32_wave(Ls, invd, Xt, r);
+        return;
+    }
+    DiagRound<15>::run(a, Ltb, invd, &sbad, r, w, Ls);
+    TS(2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 16 * q + 4 * w + e;
+            if (c <= r)
+                A[r + (int64_t)c * lda] = a[q][e];
+        }
+    if (threadIdx.x == 0 && sbad != 0 && *info == 0)
+        *info = (int)(goff + sbad);
+    TS(3);
+}
+
+// Full-inverse form (any jb <= 64): the three-launch panel step and its GEMM consumers need all of X.
+__global__ __launch_bounds__(256) void k_diag_full(double* __restrict__ A, int64_t lda, int jb, double* __restrict__ Xt,
                                               int* __restrict__ info, int64_t goff)
 {
     __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
@@ -309,7 +430,7 @@ __global__ __launch_bounds__(256) void k_diag(double* __restrict__ A, int64_t ld
     __syncthreads();
     TS(1);
 #if DIAG_ABL != 1
-    DiagRound<15>::run(a, Ltb, invd, &sbad, r, w);
+    DiagRound<15>::run(a, Ltb, invd, &sbad, r, w, nullptr);
 #endif
     TS(2);
 #pragma unroll
@@ -338,17 +459,20 @@ void dump_diag_timing()
 {
     long long h[32];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag_ts), sizeof(h));
-    printf("k_diag cycles: load %lld | rounds %lld | writeL %lld | zeroX %lld | inv0 %lld | inv1 %lld | inv2 %lld | storeXt %lld | total %lld\n",
-           h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[8] - h[0]);
+    printf("k_diag cycles (factor waves): load %lld | rounds %lld | writeL %lld | total %lld\n", h[1] - h[0], h[2] - h[1],
+           h[3] - h[2], h[3] - h[0]);
     printf("rounds:");
     for (int g = 0; g < 16; ++g)
         printf(" %lld", h[10 + g] - (g ? h[9 + g] : h[1]));
     printf("\n");
 }
 #endif
-void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff)
+void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff, int half_form)
 {
-    hipLaunchKernelGGL(k_diag, dim3(1), dim3(256), 0, s, A, lda, jb, Xt, info, goff);
+    if (half_form && jb == NB)
+        hipLaunchKernelGGL(k_diag, dim3(1), dim3(320), 0, s, A, lda, Xt, info, goff);
+    else
+        hipLaunchKernelGGL(k_diag_full, dim3(1), dim3(256), 0, s, A, lda, jb, Xt, info, goff);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,29 +491,81 @@ void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int*
 // ---------------------------------------------------------------------------------------------
 #define PS 80 // stride (doubles) of the [kk][i] operand tiles: == 16 mod 32
 
-// acc[m][n] += sum_k Aop[k][wm + 16 m + ..] * Bop(...)   for a 32 x 16 wave tile (8 waves), k = 64
-// BKM = true : B operand stored k-contiguous, Bk[c * XS + k]      (X as L11^-1 rows)
-// BKM = false: B operand stored [kk][n],      Bn[k * PS + n]
-template <bool BKM>
-static __device__ __forceinline__ void mm64(const double* __restrict__ Aop, const double* __restrict__ Bop, int wm, int wn,
-                                            int lane, double (&acc)[2][4])
+// acc[m][n] += sum_{k in [k0, k0+KLEN)} Aop[k][wm + 16 m + ..] * B(col, k)  — 8 waves.
+//   wave tile: 32 rows x (4 RBN) columns starting at column wn
+//   BKM = true : B stored k-contiguous, B(col, k) = Bop[col * XS + k]     (X or L blocks, [c][k])
+//   BKM = false: B stored [kk][n],      B(col, k) = Bop[k * PS + col]
+template <bool BKM, int KLEN, int RBN>
+static __device__ __forceinline__ void mmk(const double* __restrict__ Aop, int ak0, const double* __restrict__ Bop,
+                                           int bk0, int wm, int wn, int lane, double (&acc)[2][RBN])
 {
     const int ar = wm + (lane & 15), bc = wn + (lane & 3), kq = lane >> 4;
 #pragma unroll
-    for (int ks = 0; ks < NB; ks += 4) {
-        double af[2], bf[4];
+    for (int ks = 0; ks < KLEN; ks += 4) {
+        double af[2], bf[RBN];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
-            af[x] = Aop[(ks + kq) * PS + ar + 16 * x];
+            af[x] = Aop[(ak0 + ks + kq) * PS + ar + 16 * x];
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-            bf[x] = BKM ? Bop[(bc + 4 * x) * XS + ks + kq] : Bop[(ks + kq) * PS + bc + 4 * x];
+        for (int x = 0; x < RBN; ++x)
+            bf[x] = BKM ? Bop[(bc + 4 * x) * XS + bk0 + ks + kq] : Bop[(bk0 + ks + kq) * PS + bc + 4 * x];
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < RBN; ++n)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
                 acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
     }
+}
+template <bool BKM>
+static __device__ __forceinline__ void mm64(const double* __restrict__ Aop, const double* __restrict__ Bop, int wm, int wn,
+                                            int lane, double (&acc)[2][4])
+{
+    mmk<BKM, NB, 4>(Aop, 0, Bop, 0, wm, wn, lane, acc);
+}
+
+// T (64 x 64 tile, [kk = col][i = row], stride PS) <- T L11^-T with the half-block form of the inverse:
+//   Y1 = T[:, 0:32] X11^T ;  Y2 = (T[:, 32:64] - Y1 L21^T) X22^T          (L11 = [[L1, 0], [L21, L2]])
+// Bx[c * XS + k] = X[c][k] (diagonal quarters valid), Ld[c * XS + k] = L21[c][k].  512 threads, in
+// place, starts and ends with a barrier-consistent state (callers sync before reading T).
+// 8 waves: 2 (rows) x 4 (column groups of 8) per 32-column half.
+static __device__ __forceinline__ void trsm_tile_half(double* __restrict__ T, const double* __restrict__ Bx,
+                                                      const double* __restrict__ Ld, int lane, int wave)
+{
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 8; // column within the 32-column half
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+    double y1[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    mmk<true, 32, 2>(T, 0, Bx, 0, wm, wn, lane, y1); // Y1 = T1 X11^T
+    __syncthreads();                                 // all reads of T[:, 0:32] done
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            T[(wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y1[m][n];
+    __syncthreads();
+    double u[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    mmk<true, 32, 2>(T, 0, Ld, 0, wm, wn, lane, u); // Y1 L21^T
+    double t2[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            t2[m][n] = T[(32 + wn + 4 * n + dcol) * PS + wm + 16 * m + drow] - u[m][n];
+    __syncthreads(); // every wave has read its part of T[:, 32:64]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            T[(32 + wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = t2[m][n];
+    __syncthreads();
+    double y2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    mmk<true, 32, 2>(T, 32, Bx + 32 * XS + 32, 0, wm, wn, lane, y2); // Y2 = T2 X22^T
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            T[(32 + wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
+    __syncthreads();
 }
 
 // 64 x 64 tile of column-major G (rows clamped to nrows) <-> registers <-> T[kk * PS + i]; 512 threads
@@ -418,12 +594,13 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
                                                     const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                     int do_next, int* __restrict__ info, double* __restrict__ Hs)
 {
-    // one LDS array, carved: [Bx | T0 | T1]; workgroup 0 re-carves it as [Ls | Xs | Ts | Ltb | invd]
-    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS];
+    // one LDS array, carved: [Bx | T0 | T1 | Ld]; workgroup 0 re-carves it as [Ls | Ltb | invd]
+    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + 32 * XS];
     __shared__ int sbad;
     double* Bx = lds;
     double* T0 = lds + NB * XS;
     double* T1 = T0 + NB * PS;
+    double* Ld = T1 + NB * PS; // L21 of the current diagonal block, Ld[c * XS + k] = L[32 + c][k]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
     const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
@@ -446,38 +623,42 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
     for (int t = 0; t < PANEL_PRE; ++t)
         if (t <= tmax && t != b)
             head[t].load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
+    double ldv[2]; // L21 of the diagonal block at (j0, j0): rows 32..63, columns 0..31
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = threadIdx.x + 512 * q; // e = c + 32 k  (c = row of L21, contiguous in memory)
+        ldv[q] = A[j0 + 32 + (e & 31) + (j0 + (e >> 5)) * lda];
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int e = threadIdx.x + 512 * q;
         Bx[(e >> 6) * XS + (e & 63)] = xv[q]; // Bx[c][k] = X[c][k]
     }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = threadIdx.x + 512 * q;
+        Ld[(e & 31) * XS + (e >> 5)] = ldv[q];
+    }
     own.store(T0);
     __syncthreads();
 
-    // 1. L_b = A_b X^T
-    double acc[2][4];
+    // 1. L_b = A_b L11^-T  (half-block form of the inverse, in place in T0)
+    trsm_tile_half(T0, Bx, Ld, lane, wave);
+    {
+        // Row blocks b < nt are the "head" tiles other workgroups re-derive from A while this one
+        // runs: they must not be overwritten in place here.  Their L goes to the scratch tile Hs[b]
+        // and k_head_copy moves it into A after the panel's fused steps.
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-            acc[m][n] = 0.0;
-    mm64<true>(T0, Bx, wm, wn, lane, acc);
-    __syncthreads(); // every wave is done reading the A tile
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int row = wm + 16 * m + drow, col = wn + 4 * n + dcol;
-            T0[col * PS + row] = acc[m][n]; // own L as [kk = col][i = row]
-            // Row blocks b < nt are the "head" tiles other workgroups re-derive from A while this
-            // one runs: they must not be overwritten in place here.  Their L goes to the scratch
-            // tile Hs[b] and k_head_copy moves it into A after the panel's fused steps.
+        for (int q = 0; q < 8; ++q) {
+            const int col = kk0 + 8 * q;
+            const double v = T0[col * PS + i];
             if (b < nt)
-                Hs[(int64_t)b * (NB * NB) + row + NB * col] = acc[m][n];
-            else if (row < nrows)
-                A[R0 + row + (j0 + col) * lda] = acc[m][n];
+                Hs[(int64_t)b * (NB * NB) + i + NB * col] = v;
+            else if (i < nrows)
+                A[R0 + i + (j0 + col) * lda] = v;
         }
-    __syncthreads();
+    }
 
     // 2. in-panel updates of this row block
     double cres[2][4]; // workgroup 0: the updated next diagonal block
@@ -507,20 +688,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
                 late.store(T1);
             }
             __syncthreads();
-            double ah[2][4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    ah[m][n] = 0.0;
-            mm64<true>(T1, Bx, wm, wn, lane, ah);
-            __syncthreads();
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    T1[(wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = ah[m][n];
-            __syncthreads();
+            trsm_tile_half(T1, Bx, Ld, lane, wave);
             Bop = T1;
         }
         double a2[2][4];
@@ -544,52 +712,50 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
         __syncthreads(); // T1 is free again
     }
 
-    // 3. workgroup 0: factor + invert the next diagonal block (it is block t = 0 of its own rows)
+    // 3. workgroup 0: factor the next diagonal block (block t = 0 of its own rows) and invert its halves
     if (b != 0 || !do_next)
         return;
     double* Ls = lds;
-    double* Xs = Ls + NB * XS;
-    double* Ts = Xs + NB * XS;
-    double* Ltb = Ts + NB * XS;
+    double* Ltb = Ls + NB * XS;
     double* invd = Ltb + 4 * NB * 4;
-    static_assert(3 * NB * XS + 4 * NB * 4 + NB <= NB * XS + 2 * NB * PS, "diag scratch must fit the panel-step LDS");
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
             Ls[(wm + 16 * m + drow) * XS + wn + 4 * n + dcol] = cres[m][n];
     __syncthreads();
-    // the serial part runs on 4 waves (k_diag's code); waves 4..7 end here — s_barrier only counts
-    // the waves of the workgroup that are still alive
-    if (wave >= 4)
+    // the serial part runs on waves 0-3 (k_diag's code), the inversion pipeline on wave 4; waves
+    // 5..7 end here — s_barrier only counts the waves of the workgroup that are still alive
+    if (wave >= 5)
         return;
     const int r = lane, w = wave;
     double a[4][4];
+    if (w < 4) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = 16 * q + 4 * w + e;
-            a[q][e] = (c <= r) ? Ls[r * XS + c] : 0.0;
-        }
+            for (int e = 0; e < 4; ++e) {
+                const int c = 16 * q + 4 * w + e;
+                a[q][e] = (c <= r) ? Ls[r * XS + c] : 0.0;
+            }
+    }
     __syncthreads();
-    DiagRound<15>::run(a, Ltb, invd, &sbad, r, w);
+    if (w == 4) {
+        xpipe32_wave(Ls, invd, Xt_next, r);
+        return;
+    }
+    DiagRound<15>::run(a, Ltb, invd, &sbad, r, w, Ls);
     double* Ad = A + r0 + r0 * lda;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = 16 * q + 4 * w + e;
-            const double v = (c <= r) ? a[q][e] : 0.0;
-            Ls[r * XS + c] = v;
             if (c <= r)
-                Ad[r + (int64_t)c * lda] = v;
+                Ad[r + (int64_t)c * lda] = a[q][e];
         }
     if (threadIdx.x == 0 && sbad != 0 && *info == 0)
         *info = (int)(r0 + sbad);
-    __syncthreads();
-    invert_L64(Ls, invd, Xs, Ts);
-    store_Xt(Xs, Xt_next);
 }
 
 void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
@@ -624,6 +790,36 @@ void launch_head_copy(hipStream_t s, double* A, int64_t lda, int64_t p0, int nt0
         tiles += nt0 - f;
     if (tiles > 0)
         hipLaunchKernelGGL(k_head_copy, dim3((unsigned)tiles), dim3(256), 0, s, A, lda, p0, nt0, H);
+}
+
+// Off-diagonal quarter of the block inverses left by the half-form kernels: for blocks b0..b0+n-1
+// of the factor L (all full 64 x 64), X21 = -X22 L21 X11 into Xt_all + 4096 b.  Idempotent on a
+// block whose inverse is already complete.
+__global__ __launch_bounds__(256) void k_xinv_complete(const double* __restrict__ L, int64_t ldl, int64_t b0,
+                                                       double* __restrict__ Xt_all)
+{
+    __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Xs[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Ts[NB * XS];
+    const int64_t b = b0 + blockIdx.x, j0 = b * NB;
+    double* Xt = Xt_all + b * (NB * NB);
+    const double* L11 = L + j0 + j0 * ldl;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e & 63, c = e >> 6;
+        Ls[r * XS + c] = (c <= r) ? L11[r + (int64_t)c * ldl] : 0.0;
+        Xs[c * XS + r] = Xt[e]; // Xt[k + 64 c] = X[c][k]
+    }
+    __syncthreads();
+    invert_level2(Ls, Xs, Ts);
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+        const int k = e & 31, c = 32 + (e >> 5);
+        Xt[k + NB * c] = Xs[c * XS + k];
+    }
+}
+void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b0, int64_t nblocks, double* Xt_all)
+{
+    if (nblocks > 0)
+        hipLaunchKernelGGL(k_xinv_complete, dim3((unsigned)nblocks), dim3(256), 0, s, L, ldl, b0, Xt_all);
 }
 
 // inverses of the diagonal blocks of an existing factor: block b at L[64 b, 64 b]

@@ -45,7 +45,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < reps; ++r) {
         // diagonal block
         launch_copy2d(s, A0, ld, A, ld, 64, 64);
-        launch_diag(s, A, ld, 64, Xi, info, 0);
+        launch_diag(s, A, ld, 64, Xi, info, 0, 1);
         // trsm shape: (4032 x 64) x (64 x 64), in place
         {
             GemmArgs g{};
