@@ -35,6 +35,12 @@ __device__ long long g_diag_ts[32];
 #else
 #define TS(i) do { } while (0)
 #endif
+#ifdef DIAG_TIMING
+__device__ long long g_panel_ts[64];
+#define PTS(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_panel_ts[(blockIdx.x == 0 ? 0 : 32) + (i)] = clock64(); } while (0)
+#else
+#define PTS(i) do { } while (0)
+#endif
 #define XS 66 // LDS row stride (doubles) of the 64 x 64 work matrices: conflict-free MFMA operand reads
 
 static __device__ __forceinline__ double mfma4(double a, double b, double c)
@@ -613,6 +619,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
 
     // every global load this workgroup needs before its first product goes out now: X, its own
     // tile, and the head tiles it will re-derive (one exposed memory latency instead of one per tile)
+    PTS(0);
     TileRegs own, head[PANEL_PRE];
     own.load(A + R0 + j0 * lda, lda, nrows);
     double xv[8];
@@ -641,9 +648,11 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
     }
     own.store(T0);
     __syncthreads();
+    PTS(1);
 
     // 1. L_b = A_b L11^-T  (half-block form of the inverse, in place in T0)
     trsm_tile_half(T0, Bx, Ld, lane, wave);
+    PTS(2);
     {
         // Row blocks b < nt are the "head" tiles other workgroups re-derive from A while this one
         // runs: they must not be overwritten in place here.  Their L goes to the scratch tile Hs[b]
@@ -660,6 +669,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
         }
     }
 
+    PTS(3);
     // 2. in-panel updates of this row block
     double cres[2][4]; // workgroup 0: the updated next diagonal block
 #pragma unroll 1
@@ -712,6 +722,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
         __syncthreads(); // T1 is free again
     }
 
+    PTS(4);
     // 3. workgroup 0: factor the next diagonal block (block t = 0 of its own rows) and invert its halves
     if (b != 0 || !do_next)
         return;
@@ -744,7 +755,9 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
         xpipe32_wave(Ls, invd, Xt_next, r);
         return;
     }
+    PTS(5);
     DiagRound<15>::run(a, Ltb, invd, &sbad, r, w, Ls);
+    PTS(6);
     double* Ad = A + r0 + r0 * lda;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -756,8 +769,20 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
         }
     if (threadIdx.x == 0 && sbad != 0 && *info == 0)
         *info = (int)(r0 + sbad);
+    PTS(7);
 }
 
+#ifdef DIAG_TIMING
+void dump_panel_timing()
+{
+    long long h[64];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_panel_ts), sizeof(h));
+    printf("k_panel_step WG0 cycles: loads %lld | trsm %lld | writeL %lld | updates %lld | to-diag %lld | rounds %lld | tail %lld | total %lld\n",
+           h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
+    printf("k_panel_step last WG cycles: loads %lld | trsm %lld | writeL %lld | updates %lld | total %lld\n", h[33] - h[32],
+           h[34] - h[33], h[35] - h[34], h[36] - h[35], h[36] - h[32]);
+}
+#endif
 void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
                        double* Xt_next, int do_next, int* info, double* Hs)
 {

@@ -46,6 +46,13 @@ int main(int argc, char** argv)
         // diagonal block
         launch_copy2d(s, A0, ld, A, ld, 64, 64);
         launch_diag(s, A, ld, 64, Xi, info, 0, 1);
+        // fused panel step below the block just factored (3 more blocks in the panel)
+        {
+            static double* Hs = nullptr;
+            if (!Hs) CHK(hipMalloc(&Hs, sizeof(double) * 8 * 4096));
+            launch_panel_step(s, A, ld, 0, N + 1, 3, Xi, Xi + 4096, 1, info, Hs);
+            launch_copy2d(s, A0, ld, A, ld, N, 320); // restore what the step consumed
+        }
         // trsm shape: (4032 x 64) x (64 x 64), in place
         {
             GemmArgs g{};
@@ -75,6 +82,8 @@ int main(int argc, char** argv)
 #ifdef DIAG_TIMING
     extern void dump_diag_timing();
     dump_diag_timing();
+    extern void dump_panel_timing();
+    dump_panel_timing();
 #endif
     printf("kbench done\n");
     return 0;
