@@ -647,6 +647,19 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
         Ld[(e & 31) * XS + (e >> 5)] = ldv[q];
     }
     own.store(T0);
+    // the C tile of the first update (for workgroup 0: the next diagonal block) is fetched now, under
+    // the triangular solve, instead of at the top of the update loop
+    double c0v[2][4];
+    if (tmax >= 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int row = wm + 16 * m + drow, col = wn + 4 * n + dcol;
+                const int rc = row < nrows ? row : nrows - 1;
+                c0v[m][n] = A[R0 + rc + (r0 + col) * lda];
+            }
+    }
     __syncthreads();
     PTS(1);
 
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
             for (int n = 0; n < 4; ++n) {
                 const int row = wm + 16 * m + drow, col = wn + 4 * n + dcol;
                 const int rc = row < nrows ? row : nrows - 1;
-                cv[m][n] = Cg[rc + (int64_t)col * lda];
+                cv[m][n] = (t == 0) ? c0v[m][n] : Cg[rc + (int64_t)col * lda];
             }
         const double* Bop = T0;
         if (t != b) { // head tile of another row block: recompute L_t = A_t X^T
