@@ -514,6 +514,195 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
     } // logical workgroups
 }
 
+// 64 x 64 tile variant for the mid-size and latency-critical updates (a few hundred tiles, k = 256):
+// 4 waves (32 x 32 each), BKT = 16, FOUR LDS stages (74 KB, two workgroups per CU) so that three
+// k-tiles are always in flight — the register-staged 64 x 64 kernel it replaces exposes one
+// global-load latency per k-tile.  One glds instruction moves TWO k-rows of a 64-row operand (lanes
+// 0-31 / 32-63), so k-rows sit in LDS as pairs: row kk at (kk >> 1) * 144 + (kk & 1) * 64.  The two
+// k values a 32-lane half reads per MFMA step are taken from different pairs (k permutation
+// 0,2,1,3 — applied to both operands, the sum over k does not care), which keeps the reads
+// conflict-free.
+__global__ __launch_bounds__(256, 2) void k_gemm_glds64(GemmArgs g)
+{
+    constexpr int TM = 64, TN = 64, BKT = 16, NST = 4, NWV = 4;
+    constexpr int PAIR = 144;                 // doubles per k-row pair (2 x 64 + 16 pad)
+    constexpr int OPER = (BKT / 2) * PAIR;    // one operand, one stage
+    constexpr int STAGE = 2 * OPER;
+    constexpr int RA = 2, RB = 8;
+    constexpr int LPW = 2 * (BKT / 2) / NWV;  // glds instructions per wave per stage = 4
+    __shared__ __attribute__((aligned(16))) double lds[NST * STAGE];
+
+    const int tiles_m = (int)((g.m + TM - 1) / TM);
+    const int tiles_n = (int)((g.n + TN - 1) / TN);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int lwg = blockIdx.x; lwg < g.total; lwg += gridDim.x) {
+        int wg = lwg;
+        {
+            const int nwg = g.total;
+            const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+            wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        int ti, tj;
+        if (g.tri) {
+            const int sc = wg / g.fold_len;
+            int rr = wg % g.fold_len;
+            const int t0 = first_live_tile<TM, TN>(g, sc), c0 = tiles_m - t0;
+            if (rr < c0) {
+                tj = sc;
+                ti = t0 + rr;
+            }
+            else {
+                tj = tiles_n - 1 - sc;
+                const int t1 = first_live_tile<TM, TN>(g, tj);
+                rr -= c0;
+                if (tj == sc || rr >= tiles_m - t1)
+                    continue;
+                ti = t1 + rr;
+            }
+        }
+        else {
+            ti = wg % tiles_m;
+            tj = wg / tiles_m;
+        }
+        const int64_t row0 = (int64_t)ti * TM, col0 = (int64_t)tj * TN;
+        const int64_t mrows = g.m - row0, ncols = g.n - col0;
+        const int mr = (int)(mrows < TM ? mrows : TM), nc = (int)(ncols < TN ? ncols : TN);
+        const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+        const int arow = wm + (lane & 15), bcol = wn + (lane & 3);
+        const int kq = lane >> 4, kperm = ((kq & 1) << 1) | (kq >> 1); // 0,2,1,3
+
+        // this lane's 16-byte piece: rows (2 l', 2 l' + 1) of k-row kk + (lane >> 5), l' = lane & 31
+        int ra = 2 * (lane & 31), rb = ra;
+        {
+            const int ma = (mr - 1) & ~1, mb = (nc - 1) & ~1;
+            ra = ra < ma ? ra : ma;
+            rb = rb < mb ? rb : mb;
+        }
+        const int khalf = lane >> 5;
+        const double* pa = g.A + row0 + ra + (int64_t)(2 * wave + khalf) * g.lda;
+        const double* pb = g.B + col0 + rb + (int64_t)(2 * wave + khalf) * g.ldb;
+        // wave w moves pairs w and w + 4 of each operand
+        const int64_t astep8 = (int64_t)8 * g.lda, bstep8 = (int64_t)8 * g.ldb;
+        auto issue = [&](int stage) {
+            double* sa = lds + stage * STAGE + wave * PAIR;
+            double* sb = sa + OPER;
+            __builtin_amdgcn_global_load_lds(pa, (lds_void_t*)sa, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(pb, (lds_void_t*)sb, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(pa + astep8, (lds_void_t*)(sa + 4 * PAIR), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(pb + bstep8, (lds_void_t*)(sb + 4 * PAIR), 16, 0, 0);
+            pa += 2 * astep8;
+            pb += 2 * bstep8;
+        };
+
+        double acc[RA][RB];
+#pragma unroll
+        for (int a = 0; a < RA; ++a)
+#pragma unroll
+            for (int b = 0; b < RB; ++b)
+                acc[a][b] = 0.0;
+
+        const int nk = (int)(g.k / BKT);
+        for (int t = 0; t < NST - 1 && t < nk; ++t)
+            issue(t);
+        for (int t = 0; t < nk; ++t) {
+            const int st = t % NST;
+            if (t + NST - 1 < nk)
+                issue((t + NST - 1) % NST);
+            // tiles still allowed in flight after tile t has landed
+            const int ahead = nk - 1 - t < NST - 1 ? nk - 1 - t : NST - 1;
+            if (ahead >= 3)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPW) : "memory");
+            else if (ahead == 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+            else if (ahead == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * LPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // every wave's pieces of stage st have landed
+            const double* As = lds + st * STAGE;
+            const double* Bs = As + OPER;
+#pragma unroll
+            for (int ks = 0; ks < BKT; ks += 4) {
+                const int k = ks + kperm;
+                const int off = (k >> 1) * PAIR + (k & 1) * 64;
+                double af[RA], bf[RB];
+#pragma unroll
+                for (int x = 0; x < RA; ++x)
+                    af[x] = As[off + arow + 16 * x];
+#pragma unroll
+                for (int x = 0; x < RB; ++x)
+                    bf[x] = Bs[off + bcol + 4 * x];
+#pragma unroll
+                for (int n = 0; n < RB; ++n)
+#pragma unroll
+                    for (int m = 0; m < RA; ++m)
+                        acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // stage st may be refilled
+        }
+
+        const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);
+        const int dcol = lane & 3;
+        double* Cb = g.C + (col0 + wn + dcol) * g.ldc + row0 + wm + drow;
+        if (mr == TM && nc == TN) {
+#pragma unroll
+            for (int n = 0; n < RB; ++n) {
+                double cv[RA];
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    cv[m] = g.overwrite ? 0.0 : Cb[(int64_t)(4 * n) * g.ldc + 16 * m];
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = g.overwrite ? acc[m][n] : cv[m] - acc[m][n];
+            }
+        }
+        else {
+#pragma unroll
+            for (int n = 0; n < RB; ++n) {
+                const bool cok = wn + 4 * n + dcol < nc;
+#pragma unroll
+                for (int m = 0; m < RA; ++m) {
+                    if (cok && wm + 16 * m + drow < mr) {
+                        double* cp = Cb + (int64_t)(4 * n) * g.ldc + 16 * m;
+                        if (g.overwrite)
+                            *cp = acc[m][n];
+                        else
+                            *cp -= acc[m][n];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static void launch_glds64(hipStream_t s, const GemmArgs& g0)
+{
+    constexpr int TM = 64, TN = 64;
+    GemmArgs g = g0;
+    const int tiles_m = (int)((g.m + TM - 1) / TM), tiles_n = (int)((g.n + TN - 1) / TN);
+    int64_t tiles = (int64_t)tiles_m * tiles_n;
+    if (g.tri) {
+        int fold = 1;
+        const int nsup = (tiles_n + 1) / 2;
+        for (int sc = 0; sc < nsup; ++sc) {
+            const int t2 = tiles_n - 1 - sc;
+            int len = tiles_m - first_live_tile<TM, TN>(g, sc);
+            if (t2 != sc)
+                len += tiles_m - first_live_tile<TM, TN>(g, t2);
+            fold = len > fold ? len : fold;
+        }
+        g.fold_len = fold;
+        tiles = (int64_t)nsup * fold;
+    }
+    g.total = (int)tiles;
+    if (g.grid_limit > 0 && tiles > g.grid_limit)
+        tiles = g.grid_limit;
+    hipLaunchKernelGGL(k_gemm_glds64, dim3((unsigned)tiles), dim3(256), 0, s, g);
+}
+
 static bool glds_ok(const GemmArgs& g)
 {
     return !g.a_kmajor && !g.b_kmajor && !g.ktri && g.k >= 32 && g.k % 32 == 0 && (g.lda % 2) == 0 && (g.ldb % 2) == 0
@@ -576,6 +765,11 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         return;
     if (g.k <= 0 && !g.overwrite)
         return;
+    static int use_glds64 = -1;
+    if (use_glds64 < 0) {
+        const char* e = getenv("GPE_GLDS64");
+        use_glds64 = e ? atoi(e) : 1;
+    }
     static int force = -1;
     if (force < 0) {
         const char* e = getenv("GPE_GEMM_TILE"); // debug/tuning: 128, 64 or 32
@@ -593,6 +787,8 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         // 64 x 64 tile (4x the workgroups) wins; the 32 x 64 tile serves the tiny panel steps
         if (glds_ok(g) && live_tiles(g, 128, 128) >= 200)
             tile = 128;
+        else if (glds_ok(g) && use_glds64 && live_tiles(g, 64, 64) >= 96)
+            tile = 64; // deep-prefetch 64 x 64 glds kernel: also the latency-critical next-panel update
         else if (live_tiles(g, 64, 64) >= 512)
             tile = 64;
         else
@@ -602,6 +798,8 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         launch_glds128(s, g);
     else if (tile == 128)
         launch_tile<128, 128, 32, 2>(s, g);
+    else if (tile == 64 && glds_ok(g) && use_glds64)
+        launch_glds64(s, g);
     else if (tile == 64)
         launch_tile<64, 64, 32, 2>(s, g);
     else if (g.k <= 64 && !g.ktri)
