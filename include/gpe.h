@@ -107,6 +107,14 @@ int gpe_compute_inv_kernel(gpe_handle h);
 /* gp.hpp:285-311 compute_kernel_grad_log_lik (+ kernel.hpp:86-96 noise term).
  * grad has n_theta (+1 if optimize_noise) entries. */
 int gpe_log_lik_grad(gpe_handle h, double* grad, int n_grad, int optimize_noise);
+/* gp.hpp:339-351 compute_log_loo_cv (leave-one-out log predictive probability) */
+int gpe_log_loo_cv(gpe_handle h, double* out);
+/* gp.hpp:354-402 compute_kernel_grad_log_loo_cv; same layout as gpe_log_lik_grad.
+ * (The reference's 2 T dense N^3 products collapse to one: DESIGN.md.) */
+int gpe_log_loo_cv_grad(gpe_handle h, double* grad, int n_grad, int optimize_noise);
+/* the N x N weight matrix W (symmetric, col-major, ld) with d LOO / d theta_j = sum_ab W[a,b] dK_j[a,b]:
+ * for kernels whose gradient only exists as a host functor (cf. gpe_set_K_host) */
+int gpe_get_loo_weights(gpe_handle h, double* W, int64_t ld);
 /* model/gp/kernel_lf_opt.hpp:77-92 KernelLFOptimization::operator() in one
  * call, without the reference's per-evaluation deep copy: set theta (and
  * noise), recompute(false), log-lik and (optionally) its gradient. */

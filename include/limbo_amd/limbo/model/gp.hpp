@@ -324,46 +324,68 @@ namespace limbo {
                 return grad;
             }
 
-            /// gp.hpp:314-330 (host: O(N^2 P) with K^-1 from the device)
+            /// gp.hpp:314-330.  obs_mean(:, p)^T K^-1(:, n) is alpha(n, p) (gp.hpp:608-610), so the sum
+            /// needs no N x N read-back: grad = sum_n sum_p alpha(n, p) * mean.grad(x_n).row(p).
+            /// K^-1 is still produced on the device so that inv_kernel_computed() changes as in the reference.
             Eigen::VectorXd compute_mean_grad_log_lik()
             {
                 if (!_inv_kernel_updated)
                     compute_inv_kernel();
-                const Eigen::MatrixXd& Ki = _host_Kinv();
+                const Eigen::MatrixXd& al = alpha();
                 const size_t n = _samples.size();
                 const int T = _mean_function.h_params_size();
                 Eigen::VectorXd grad = Eigen::VectorXd::Zero(T);
-                for (int p = 0; p < _dim_out; ++p)
-                    for (size_t m = 0; m < n; ++m) {
-                        double c = 0.0; // obs_mean(:, p)^T K^-1(:, m)
-                        for (size_t i = 0; i < n; ++i)
-                            c += _obs_mean(i, p) * Ki(i, m);
-                        Eigen::MatrixXd gm = _mean_function.grad(_samples[m], *this);
+                for (size_t m = 0; m < n; ++m) {
+                    Eigen::MatrixXd gm = _mean_function.grad(_samples[m], *this);
+                    for (int p = 0; p < _dim_out; ++p)
                         for (int t = 0; t < T; ++t)
-                            grad(t) += c * gm(p, t);
-                    }
+                            grad(t) += al(m, p) * gm(p, t);
+                }
                 return grad;
             }
 
             double get_log_lik() const { return _log_lik; }
             void set_log_lik(double log_lik) { _log_lik = log_lik; }
 
-            /// gp.hpp:339-351 (host, from the device's K^-1 diagonal and alpha)
+            /// gp.hpp:339-351 on the device (K^-1 diagonal and alpha never leave HBM)
             double compute_log_loo_cv()
             {
-                if (!_inv_kernel_updated)
-                    compute_inv_kernel();
-                const Eigen::MatrixXd& Ki = _host_Kinv();
-                const Eigen::MatrixXd& al = alpha();
-                const size_t n = _samples.size();
-                double s = 0.0;
-                for (int p = 0; p < _dim_out; ++p)
-                    for (size_t i = 0; i < n; ++i) {
-                        const double inv_d = 1.0 / Ki(i, i);
-                        s += -0.5 * al(i, p) * al(i, p) * inv_d - 0.5 * std::log(inv_d) - 0.5 * std::log(2 * M_PI);
-                    }
-                _log_loo_cv = s;
+                double v = 0.0;
+                _eng.check(gpe_log_loo_cv(_eng.get(), &v), "gpe_log_loo_cv");
+                _inv_kernel_updated = true; // gp.hpp:342-344
+                _Kinv_stale = true;
+                _log_loo_cv = v;
                 return _log_loo_cv;
+            }
+
+            /// gp.hpp:354-402.  The reference forms K^-1 dK_j, (K^-1 dK_j) alpha and (K^-1 dK_j) K^-1 for every
+            /// hyper-parameter j; both terms of :389 are linear in dK_j, so the device builds ONE weight matrix
+            /// W (one N^3 product, limbo_amd/csrc/grad.hip) and the gradient is sum_ab W_ab dK_j,ab.
+            Eigen::VectorXd compute_kernel_grad_log_loo_cv()
+            {
+                const int T = _kernel_function.h_params_size();
+                Eigen::VectorXd grad = Eigen::VectorXd::Zero(T);
+                if (limbo_amd::device_kernel<KernelFunction>::kind != limbo_amd::KIND_HOST_K) {
+                    _push_kernel();
+                    _eng.check(gpe_log_loo_cv_grad(_eng.get(), grad.data(), T, Params::kernel::optimize_noise() ? 1 : 0), "gpe_log_loo_cv_grad");
+                    _inv_kernel_updated = true;
+                    _Kinv_stale = true;
+                    return grad;
+                }
+                // kernels without device code: W from the device, d k / d theta from the functor
+                const size_t n = _samples.size();
+                Eigen::MatrixXd W(n, n);
+                _eng.check(gpe_get_loo_weights(_eng.get(), W.data(), (int64_t)n), "gpe_get_loo_weights");
+                _inv_kernel_updated = true;
+                _Kinv_stale = true;
+                for (size_t i = 0; i < n; ++i)
+                    for (size_t j = 0; j <= i; ++j) {
+                        Eigen::VectorXd g = _kernel_function.grad(_samples[i], _samples[j], i, j);
+                        const double f = (i == j) ? W(i, j) : 2.0 * W(i, j);
+                        for (int t = 0; t < T; ++t)
+                            grad(t) += f * g(t);
+                    }
+                return grad;
             }
             double get_log_loo_cv() const { return _log_loo_cv; }
             void set_log_loo_cv(double v) { _log_loo_cv = v; }

@@ -1,0 +1,65 @@
+// limbo/model/gp/kernel_loo_opt.hpp — maximise the leave-one-out CV log probability over the kernel
+// hyper-parameters (contract: src/limbo/model/gp/kernel_loo_opt.hpp:55-97).
+// As in kernel_lf_opt.hpp here: one persistent device clone per calling host thread instead of the
+// reference's deep copy per evaluation (kernel_loo_opt.hpp:79).
+#ifndef LIMBO_MODEL_GP_KERNEL_LOO_OPT_HPP
+#define LIMBO_MODEL_GP_KERNEL_LOO_OPT_HPP
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <limbo/model/gp/hp_opt.hpp>
+namespace limbo {
+    namespace model {
+        namespace gp {
+            template <typename Params, typename Optimizer = opt::Rprop<Params>>
+            struct KernelLooOpt : public HPOpt<Params, Optimizer> {
+            public:
+                template <typename GP>
+                void operator()(GP& gp)
+                {
+                    this->_called = true;
+                    KernelLooOptimization<GP> optimization(gp);
+                    Optimizer optimizer;
+                    Eigen::VectorXd params = optimizer(optimization, gp.kernel_function().h_params(), false);
+                    gp.kernel_function().set_h_params(params);
+                    gp.recompute(false);
+                    gp.compute_log_loo_cv();
+                }
+
+            protected:
+                template <typename GP>
+                struct KernelLooOptimization {
+                public:
+                    KernelLooOptimization(const GP& gp) : _original_gp(gp) {}
+
+                    opt::eval_t operator()(const Eigen::VectorXd& params, bool compute_grad) const
+                    {
+                        GP& gp = _worker();
+                        gp.kernel_function().set_h_params(params);
+                        gp.recompute(false);
+                        const double loo = gp.compute_log_loo_cv();
+                        if (!compute_grad)
+                            return opt::no_grad(loo);
+                        return {loo, opt::optional_grad_t(gp.compute_kernel_grad_log_loo_cv())};
+                    }
+
+                protected:
+                    const GP& _original_gp;
+                    mutable std::mutex _mu;
+                    mutable std::map<std::thread::id, std::unique_ptr<GP>> _workers;
+
+                    GP& _worker() const
+                    {
+                        std::lock_guard<std::mutex> lk(_mu);
+                        auto& w = _workers[std::this_thread::get_id()];
+                        if (!w)
+                            w.reset(new GP(_original_gp));
+                        return *w;
+                    }
+                };
+            };
+        } // namespace gp
+    } // namespace model
+} // namespace limbo
+#endif

@@ -1,0 +1,81 @@
+// limbo/model/gp/kernel_mean_lf_opt.hpp — maximise the log marginal likelihood over the kernel AND
+// the mean hyper-parameters (contract: src/limbo/model/gp/kernel_mean_lf_opt.hpp:55-113).
+// Parameter vector = [kernel h_params | mean h_params] (:67-69).  One persistent device clone per
+// calling host thread instead of the reference's deep copy per evaluation (:92).
+#ifndef LIMBO_MODEL_GP_KERNEL_MEAN_LF_OPT_HPP
+#define LIMBO_MODEL_GP_KERNEL_MEAN_LF_OPT_HPP
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <limbo/model/gp/hp_opt.hpp>
+namespace limbo {
+    namespace model {
+        namespace gp {
+            template <typename Params, typename Optimizer = opt::Rprop<Params>>
+            struct KernelMeanLFOpt : public HPOpt<Params, Optimizer> {
+            public:
+                template <typename GP>
+                void operator()(GP& gp)
+                {
+                    this->_called = true;
+                    KernelMeanLFOptimization<GP> optimization(gp);
+                    Optimizer optimizer;
+                    const int nk = gp.kernel_function().h_params_size(), nm = gp.mean_function().h_params_size();
+                    Eigen::VectorXd init(nk + nm);
+                    const Eigen::VectorXd hk = gp.kernel_function().h_params(), hm = gp.mean_function().h_params();
+                    for (int i = 0; i < nk; ++i)
+                        init(i) = hk(i);
+                    for (int i = 0; i < nm; ++i)
+                        init(nk + i) = hm(i);
+                    Eigen::VectorXd params = optimizer(optimization, init, false);
+                    gp.kernel_function().set_h_params(Eigen::VectorXd(params.head(nk)));
+                    gp.mean_function().set_h_params(Eigen::VectorXd(params.tail(nm)));
+                    gp.recompute(true);
+                    gp.compute_log_lik();
+                }
+
+            protected:
+                template <typename GP>
+                struct KernelMeanLFOptimization {
+                public:
+                    KernelMeanLFOptimization(const GP& gp) : _original_gp(gp) {}
+
+                    opt::eval_t operator()(const Eigen::VectorXd& params, bool compute_grad) const
+                    {
+                        GP& gp = _worker();
+                        const int nk = gp.kernel_function().h_params_size(), nm = gp.mean_function().h_params_size();
+                        gp.kernel_function().set_h_params(Eigen::VectorXd(params.head(nk)));
+                        gp.mean_function().set_h_params(Eigen::VectorXd(params.tail(nm)));
+                        gp.recompute(true);
+                        const double lik = gp.compute_log_lik();
+                        if (!compute_grad)
+                            return opt::no_grad(lik);
+                        Eigen::VectorXd grad = Eigen::VectorXd::Zero(nk + nm);
+                        const Eigen::VectorXd gk = gp.compute_kernel_grad_log_lik(), gm = gp.compute_mean_grad_log_lik();
+                        for (int i = 0; i < nk; ++i)
+                            grad(i) = gk(i);
+                        for (int i = 0; i < nm; ++i)
+                            grad(nk + i) = gm(i);
+                        return {lik, opt::optional_grad_t(grad)};
+                    }
+
+                protected:
+                    const GP& _original_gp;
+                    mutable std::mutex _mu;
+                    mutable std::map<std::thread::id, std::unique_ptr<GP>> _workers;
+
+                    GP& _worker() const
+                    {
+                        std::lock_guard<std::mutex> lk(_mu);
+                        auto& w = _workers[std::this_thread::get_id()];
+                        if (!w)
+                            w.reset(new GP(_original_gp));
+                        return *w;
+                    }
+                };
+            };
+        } // namespace gp
+    } // namespace model
+} // namespace limbo
+#endif

@@ -1,0 +1,68 @@
+// limbo/model/gp/mean_lf_opt.hpp — maximise the log marginal likelihood over the MEAN function's
+// hyper-parameters only (contract: src/limbo/model/gp/mean_lf_opt.hpp:55-100).
+// K and L do not change during this optimisation: an evaluation is recompute(true, false), i.e. new
+// obs_mean -> two triangular sweeps on the device (gpe_update_alpha); the factor stays in HBM.
+#ifndef LIMBO_MODEL_GP_MEAN_LF_OPT_HPP
+#define LIMBO_MODEL_GP_MEAN_LF_OPT_HPP
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <limbo/model/gp/hp_opt.hpp>
+namespace limbo {
+    namespace model {
+        namespace gp {
+            template <typename Params, typename Optimizer = opt::Rprop<Params>>
+            struct MeanLFOpt : public HPOpt<Params, Optimizer> {
+            public:
+                template <typename GP>
+                void operator()(GP& gp)
+                {
+                    this->_called = true;
+                    MeanLFOptimization<GP> optimization(gp);
+                    Optimizer optimizer;
+                    Eigen::VectorXd params = optimizer(optimization, gp.mean_function().h_params(), false);
+                    gp.mean_function().set_h_params(params);
+                    gp.recompute(true, false);
+                    gp.compute_log_lik();
+                }
+
+            protected:
+                template <typename GP>
+                struct MeanLFOptimization {
+                public:
+                    MeanLFOptimization(const GP& gp) : _original_gp(gp)
+                    {
+                        _original_gp.compute_inv_kernel(); // mean_lf_opt.hpp:78: every worker copy inherits K^-1
+                    }
+
+                    opt::eval_t operator()(const Eigen::VectorXd& params, bool compute_grad) const
+                    {
+                        GP& gp = _worker();
+                        gp.mean_function().set_h_params(params);
+                        gp.recompute(true, false);
+                        const double lik = gp.compute_log_lik();
+                        if (!compute_grad)
+                            return opt::no_grad(lik);
+                        return {lik, opt::optional_grad_t(gp.compute_mean_grad_log_lik())};
+                    }
+
+                protected:
+                    GP _original_gp;
+                    mutable std::mutex _mu;
+                    mutable std::map<std::thread::id, std::unique_ptr<GP>> _workers;
+
+                    GP& _worker() const
+                    {
+                        std::lock_guard<std::mutex> lk(_mu);
+                        auto& w = _workers[std::this_thread::get_id()];
+                        if (!w)
+                            w.reset(new GP(_original_gp));
+                        return *w;
+                    }
+                };
+            };
+        } // namespace gp
+    } // namespace model
+} // namespace limbo
+#endif

@@ -57,6 +57,9 @@ def _sig(lib, prefix):
         "log_lik": [_vp, _dp],
         "compute_inv_kernel": [_vp],
         "log_lik_grad": [_vp, _dp, C.c_int, C.c_int],
+        "log_loo_cv": [_vp, _dp],
+        "log_loo_cv_grad": [_vp, _dp, C.c_int, C.c_int],
+        "get_loo_weights": [_vp, _dp, _i64],
         "hp_objective": [_vp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _dp, _dp],
         "query_batch": [_vp, _dp, _i64, _dp, _dp],
         "query_batch_cross": [_vp, _dp, _i64, _dp, _dp],
@@ -261,6 +264,22 @@ class Handle:
         g = np.zeros(n)
         self._chk(self.lib.fn("log_lik_grad")(self._h, _d(g), n, int(optimize_noise)), "log_lik_grad")
         return g
+
+    def log_loo_cv(self) -> float:
+        out = C.c_double()
+        self._chk(self.lib.fn("log_loo_cv")(self._h, C.byref(out)), "log_loo_cv")
+        return out.value
+
+    def log_loo_cv_grad(self, optimize_noise=False):
+        n = self.n_theta + (1 if optimize_noise else 0)
+        g = np.zeros(n)
+        self._chk(self.lib.fn("log_loo_cv_grad")(self._h, _d(g), n, int(optimize_noise)), "log_loo_cv_grad")
+        return g
+
+    def get_loo_weights(self):
+        W = np.zeros((self.N, self.N), order="F")
+        self._chk(self.lib.fn("get_loo_weights")(self._h, _d(W), self.N), "get_loo_weights")
+        return W
 
     def hp_objective(self, kind, log_theta, noise, optimize_noise=False, want_grad=True):
         kind = KERNEL_NAMES.get(kind, kind)

@@ -117,8 +117,15 @@ void launch_append_diag(hipStream_t s, double* Lrow, int64_t ldl, int64_t n, con
 // ---- gradient of the log-likelihood (grad.hpp:285-311) (grad.hip) ------------------
 // partial[b, t] per lower-triangle tile b; then a fixed-order final reduction into grad[T]
 void launch_grad_loglik(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, const double* Kinv,
-                        int64_t ldk, const double* alpha, int64_t lda, int P, int n_theta, int optimize_noise,
-                        double* partial, double* grad);
+                        int64_t ldk, const double* alpha, int64_t lda, const double* uvec, int P, int n_theta,
+                        int optimize_noise, double* partial, double* grad);
+// leave-one-out (gp.hpp:339-402): v = alpha / kappa, sc = sqrt(c), val[i] per-sample terms, out[0] = LOO value
+// (v, sc may be null: value only); S = sym(Kl) diag(sc); g[0..n) *= f
+void launch_loo_prep(hipStream_t s, const double* Kinv, int64_t ldk, int64_t N, const double* alpha, int64_t lda, int P,
+                     double* v, double* sc, double* val, double* out);
+void launch_sym_colscale(hipStream_t s, const double* Kl, int64_t ldk, int64_t N, const double* sc, double* S,
+                         int64_t lds_);
+void launch_scale_vec(hipStream_t s, double* g, int n, double f);
 int64_t grad_partial_size(int64_t N, int T);
 
 // ---- micro-benchmarks (microbench.hip) ---------------------------------------------

@@ -54,6 +54,7 @@ struct gpe_ctx {
     KParams kp;
     double *dXt = nullptr, *dA = nullptr, *dOm = nullptr, *dAl = nullptr, *dW = nullptr, *dY = nullptr;
     double *dLinv = nullptr, *dKinv = nullptr, *dKhost = nullptr, *dGradPartial = nullptr, *dGrad = nullptr;
+    double *dLooS = nullptr, *dLooV = nullptr; // leave-one-out scratch: N x N and N x (P + 2) (+8)
     double* dHead = nullptr; // scratch tiles of the fused panel steps (k_panel_step)
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     int64_t grad_partial_cap = 0;
@@ -155,7 +156,7 @@ void drain_phases(gpe_ctx* c)
 void free_dev(gpe_ctx* c)
 {
     double** ps[] = {&c->dXt, &c->dA, &c->dOm, &c->dAl, &c->dW, &c->dY, &c->dLinv, &c->dKinv, &c->dKhost,
-                     &c->dGradPartial, &c->dXinv};
+                     &c->dGradPartial, &c->dXinv, &c->dLooS, &c->dLooV};
     for (auto p : ps) {
         if (*p)
             hipFree(*p);
@@ -211,7 +212,7 @@ int grow_dev(gpe_ctx* c, int64_t need)
                        c->stream);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    double* old[] = {c->dXt, c->dA, c->dOm, c->dAl, c->dW, c->dY, c->dLinv, c->dKinv, c->dXinv};
+    double* old[] = {c->dXt, c->dA, c->dOm, c->dAl, c->dW, c->dY, c->dLinv, c->dKinv, c->dXinv, c->dLooS, c->dLooV};
     for (double* p : old)
         if (p)
             hipFree(p);
@@ -222,7 +223,7 @@ int grow_dev(gpe_ctx* c, int64_t need)
     c->dW = nW;
     c->dY = nY;
     c->dXinv = nXi;
-    c->dLinv = c->dKinv = nullptr;
+    c->dLinv = c->dKinv = c->dLooS = c->dLooV = nullptr;
     c->inv_ok = false;
     c->cap = ncap;
     c->ld = nld;
@@ -601,7 +602,53 @@ int ensure_inv(gpe_ctx* c)
     return GPE_OK;
 }
 
-int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise)
+static int ensure_loo_bufs(gpe_ctx* c, bool square)
+{
+    if (!c->dLooV)
+        HIPCHK(c, hipMalloc(&c->dLooV, sizeof(double) * (size_t)(c->ld * (c->P + 2) + 8)));
+    if (square && !c->dLooS)
+        HIPCHK(c, hipMalloc(&c->dLooS, sizeof(double) * (size_t)(c->ld * c->cap)));
+    return GPE_OK;
+}
+
+// Weights of the leave-one-out gradient (grad.hip header; gp.hpp:354-402): on return
+//   dLooV[:, 0:P] = u = K^-1 (alpha / kappa),   dLinv (lower) = K^-1 diag(c) K^-1,   dLooV[ld (P+2)] = LOO value.
+// dLinv (L^-1, only an intermediate of K^-1) is reused as the N x N output.
+static int loo_weights(gpe_ctx* c)
+{
+    int rc = ensure_loo_bufs(c, true);
+    if (rc)
+        return rc;
+    hipStream_t s = c->stream;
+    const int64_t N = c->N, ld = c->ld;
+    double *v = c->dLooV, *sc = c->dLooV + ld * c->P, *val = sc + ld, *outp = c->dLooV + ld * (c->P + 2);
+    {
+        PhaseScope ps(c, GPE_PH_GRAD, 0.0);
+        launch_loo_prep(s, c->dKinv, ld, N, c->dAl, ld, c->P, v, sc, val, outp);
+        for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) { // u = L^-T (L^-1 v), in place
+            int pc = std::min(GPE_MAX_P, c->P - p0);
+            launch_copy2d(s, v + (int64_t)p0 * ld, ld, c->dW, ld, N, pc);
+            launch_trsv_sweep(s, c->dA, ld, N, c->dXinv, c->dW, c->dY, ld, pc, 0);
+            launch_trsv_sweep(s, c->dA, ld, N, c->dXinv, c->dY, v + (int64_t)p0 * ld, ld, pc, 1);
+        }
+        launch_sym_colscale(s, c->dKinv, ld, N, sc, c->dLooS, ld);
+    }
+    GemmArgs g{};
+    g.C = c->dLinv;
+    g.ldc = ld;
+    g.A = c->dLooS;
+    g.lda = ld;
+    g.B = c->dLooS;
+    g.ldb = ld;
+    g.m = g.n = g.k = N;
+    g.tri = 1;
+    g.overwrite = 1;
+    PhaseScope ps(c, GPE_PH_GRAD, gemm_flops(g));
+    launch_gemm_sub(s, g);
+    return GPE_OK;
+}
+
+int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise, bool loo = false)
 {
     if (c->host_K)
         return GPE_ERR_UNSUPPORTED;
@@ -610,6 +657,11 @@ int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise)
     int rc = ensure_inv(c);
     if (rc)
         return rc;
+    if (loo) {
+        rc = loo_weights(c);
+        if (rc)
+            return rc;
+    }
     int64_t need = grad_partial_size(c->N, n_grad) + GPE_MAX_THETA + 8;
     if (need > c->grad_partial_cap) {
         if (c->dGradPartial)
@@ -620,8 +672,11 @@ int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise)
     double* dgrad = c->dGradPartial + (need - GPE_MAX_THETA - 8);
     {
         PhaseScope ps(c, GPE_PH_GRAD, 0.0);
-        launch_grad_loglik(c->stream, c->dXt, c->ld, c->N, c->kp, c->dKinv, c->ld, c->dAl, c->ld, c->P, c->n_theta,
-                           optimize_noise, c->dGradPartial, dgrad);
+        // log-likelihood: w = alpha alpha^T - K^-1;  leave-one-out: w = sym(u alpha^T) - K^-1 diag(c) K^-1, times 2
+        launch_grad_loglik(c->stream, c->dXt, c->ld, c->N, c->kp, loo ? c->dLinv : c->dKinv, c->ld, c->dAl, c->ld,
+                           loo ? c->dLooV : c->dAl, c->P, c->n_theta, optimize_noise, c->dGradPartial, dgrad);
+        if (loo)
+            launch_scale_vec(c->stream, dgrad, n_grad, 2.0);
     }
     c->dGrad = dgrad;
     return GPE_OK;
@@ -744,6 +799,11 @@ int gpe_set_data(gpe_handle c, const double* X, int64_t N, int D, const double* 
         hipFree(c->dKinv);
         c->dKinv = nullptr;
     }
+    for (double** q : {&c->dLooS, &c->dLooV})
+        if (*q) {
+            hipFree(*q);
+            *q = nullptr;
+        }
     c->N = N;
     c->D = D;
     c->P = P;
@@ -976,6 +1036,52 @@ int gpe_log_lik_grad(gpe_handle c, double* grad, int n_grad, int optimize_noise)
     return GPE_OK;
 }
 
+// GP::compute_log_loo_cv (gp.hpp:339-351)
+int gpe_log_loo_cv(gpe_handle c, double* out)
+{
+    if (!c || !out)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ensure_inv(c);
+    if (rc)
+        return rc;
+    rc = ensure_loo_bufs(c, false);
+    if (rc)
+        return rc;
+    double* outp = c->dLooV + c->ld * (c->P + 2);
+    {
+        PhaseScope ps(c, GPE_PH_LOGLIK, 0.0);
+        launch_loo_prep(c->stream, c->dKinv, c->ld, c->N, c->dAl, c->ld, c->P, nullptr, nullptr,
+                        c->dLooV + c->ld * (c->P + 1), outp);
+    }
+    HIPCHK(c, hipMemcpyAsync(out, outp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_phases(c);
+    return GPE_OK;
+}
+
+// GP::compute_kernel_grad_log_loo_cv (gp.hpp:354-402)
+int gpe_log_loo_cv_grad(gpe_handle c, double* grad, int n_grad, int optimize_noise)
+{
+    if (!c || !grad)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    digest_kernel(c);
+    int rc = grad_enqueue(c, n_grad, optimize_noise, true);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(grad, c->dGrad, sizeof(double) * n_grad, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_phases(c);
+    return GPE_OK;
+}
+
 int gpe_hp_objective(gpe_handle c, int kind, const double* th, int n_theta, double noise, int optimize_noise,
                      int want_grad, double* lik, double* grad)
 {
@@ -1193,6 +1299,43 @@ int gpe_get_Kinv(gpe_handle c, double* Kinv, int64_t ldh)
     for (int64_t j = 1; j < N; ++j) // mirror the lower triangle
         for (int64_t i = 0; i < j; ++i)
             Kinv[i + j * ldh] = Kinv[j + i * ldh];
+    return GPE_OK;
+}
+
+// Weight matrix of the leave-one-out gradient (grad.hip header) on the host, for kernels whose
+// d k / d theta only exists as a host functor: dLOO/dtheta_j = sum_ab W[a, b] dK_j[a, b].
+int gpe_get_loo_weights(gpe_handle c, double* W, int64_t ldh)
+{
+    if (!c || !W || ldh < c->N)
+        return GPE_ERR_ARG;
+    if (!c->have_L)
+        return GPE_ERR_STATE;
+    DevGuard g(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ensure_inv(c);
+    if (rc)
+        return rc;
+    rc = loo_weights(c);
+    if (rc)
+        return rc;
+    const int64_t N = c->N;
+    const int P = c->P;
+    std::vector<double> u((size_t)N * P), a((size_t)N * P);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_phases(c);
+    HIPCHK(c, hipMemcpy2D(W, sizeof(double) * ldh, c->dLinv, sizeof(double) * c->ld, sizeof(double) * N, N,
+                          hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy2D(u.data(), sizeof(double) * N, c->dLooV, sizeof(double) * c->ld, sizeof(double) * N, P,
+                          hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy2D(a.data(), sizeof(double) * N, c->dAl, sizeof(double) * c->ld, sizeof(double) * N, P,
+                          hipMemcpyDeviceToHost));
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t i = j; i < N; ++i) {
+            double w = -W[i + j * ldh];
+            for (int p = 0; p < P; ++p)
+                w += 0.5 * (u[i + (size_t)p * N] * a[j + (size_t)p * N] + a[i + (size_t)p * N] * u[j + (size_t)p * N]);
+            W[i + j * ldh] = W[j + i * ldh] = w;
+        }
     return GPE_OK;
 }
 

@@ -9,6 +9,15 @@
 // distances from the two sample panels (LDS), reads K^-1 once (coalesced, HBM-read bound:
 // N(N+1)/2 * 8 B), and keeps T partial sums in registers.  Partials are written per tile and
 // summed in a fixed order by a second kernel, so the result is run-to-run deterministic.
+//
+// The same pair sum serves the leave-one-out gradient (gp.hpp:354-402).  The reference forms, per
+// hyper-parameter j, Zeta_j = K^-1 dK_j, Zeta_j alpha and diag(Zeta_j K^-1) — 2 T dense N^3 products.
+// Both terms of gp.hpp:389 are linear in dK_j, so they collapse to ONE weight matrix shared by all j:
+//     dLOO/dtheta_j = sum_ab dK_j[a,b] W[a,b],
+//     W = sum_p sym(u_p alpha_p^T) - K^-1 diag(c) K^-1,   u_p = K^-1 (alpha_p / kappa),
+//     kappa_i = (K^-1)_ii,  c_i = sum_p 1/2 (1 + alpha_ip^2 / kappa_i) / kappa_i
+// i.e. one symmetric N^3 product (MFMA GEMM, gemm.hip) + this kernel with (u, alpha, M) in place of
+// (alpha, alpha, K^-1) and a factor 2 (the pair sum visits the lower triangle once).
 #include "dev.h"
 
 #define TILE 64
@@ -16,15 +25,19 @@
 template <int DMAX>
 __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp,
                                                     const double* __restrict__ Kinv, int64_t ldk,
-                                                    const double* __restrict__ alpha, int64_t lda, int P, int n_theta,
-                                                    int optimize_noise, double* __restrict__ partial)
+                                                    const double* __restrict__ alpha, int64_t lda,
+                                                    const double* __restrict__ uvec, int P, double kinv_scale,
+                                                    int n_theta, int optimize_noise, double* __restrict__ partial)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[]; // xj[D][64] | aj[P][64] | red[4][T]
+    // weight of pair (i, j):  w = 1/2 sum_p (u_ip alpha_jp + alpha_ip u_jp) - Kinv[i, j]
+    // (uvec == alpha for the log-likelihood gradient: w = sum_p alpha_ip alpha_jp - K^-1_ij)
+    extern __shared__ __attribute__((aligned(16))) double smem[]; // xj[D][64] | aj[P][64] | uj[P][64] | red[4][T]
     const int D = kp.D;
     const int T = n_theta + (optimize_noise ? 1 : 0);
     double* xj = smem;
     double* aj = smem + D * TILE;
-    double* red = aj + GPE_MAX_P * TILE;
+    double* uj = aj + GPE_MAX_P * TILE;
+    double* red = uj + GPE_MAX_P * TILE;
 
     long long b = blockIdx.x;
     long long t = (long long)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
@@ -44,14 +57,18 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
     for (int e = threadIdx.x; e < P * TILE; e += 256) {
         const int p = e >> 6, c = e & 63;
         aj[e] = (j0 + c < N) ? alpha[(int64_t)p * lda + j0 + c] : 0.0;
+        uj[e] = (j0 + c < N) ? 0.5 * uvec[(int64_t)p * lda + j0 + c] : 0.0;
     }
-    double xi[DMAX], ai[GPE_MAX_P];
+    double xi[DMAX], ai[GPE_MAX_P], ui[GPE_MAX_P];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
         xi[d] = (d < D && i < N) ? Xt[(int64_t)d * ldx + i] : 0.0;
 #pragma unroll
     for (int p = 0; p < GPE_MAX_P; ++p)
         ai[p] = (p < P && i < N) ? alpha[(int64_t)p * lda + i] : 0.0;
+#pragma unroll
+    for (int p = 0; p < GPE_MAX_P; ++p)
+        ui[p] = (p < P && i < N) ? 0.5 * uvec[(int64_t)p * lda + i] : 0.0;
     double acc[DMAX + 2];
 #pragma unroll
     for (int q = 0; q < DMAX + 2; ++q)
@@ -68,8 +85,8 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
 #pragma unroll
             for (int p = 0; p < GPE_MAX_P; ++p)
                 if (p < P)
-                    w = fma(ai[p], aj[p * TILE + cc], w);
-            w -= Kinv[i + j * ldk];
+                    w = fma(ai[p], uj[p * TILE + cc], fma(ui[p], aj[p * TILE + cc], w));
+            w = fma(-kinv_scale, Kinv[i + j * ldk], w); // 0 for the 2nd.. chunk of outputs when P > GPE_MAX_P
             if (i == j)
                 w *= 0.5; // gp.hpp:303-304
             double z[DMAX];
@@ -142,7 +159,7 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
 }
 
 __global__ __launch_bounds__(256) void k_grad_final(const double* __restrict__ partial, int64_t nblk, int T,
-                                                    double* __restrict__ grad)
+                                                    double* __restrict__ grad, int accumulate)
 {
     __shared__ double sh[4];
     const int t = blockIdx.x;
@@ -156,8 +173,13 @@ __global__ __launch_bounds__(256) void k_grad_final(const double* __restrict__ p
         sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0)
-        grad[t] = sh[0] + sh[1] + sh[2] + sh[3];
+        grad[t] = (accumulate ? grad[t] : 0.0) + (sh[0] + sh[1] + sh[2] + sh[3]);
 }
+
+static void launch_grad_chunk(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp,
+                              const double* Kinv, int64_t ldk, const double* alpha, int64_t lda, const double* uvec,
+                              int P, double kinv_scale, int n_theta, int optimize_noise, double* partial, double* grad,
+                              int accumulate);
 
 int64_t grad_partial_size(int64_t N, int T)
 {
@@ -166,8 +188,21 @@ int64_t grad_partial_size(int64_t N, int T)
 }
 
 void launch_grad_loglik(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, const double* Kinv,
-                        int64_t ldk, const double* alpha, int64_t lda, int P, int n_theta, int optimize_noise,
-                        double* partial, double* grad)
+                        int64_t ldk, const double* alpha, int64_t lda, const double* uvec, int P, int n_theta,
+                        int optimize_noise, double* partial, double* grad)
+{
+    // outputs go through in chunks of GPE_MAX_P: the alpha-u term is additive over outputs, K^-1 enters once
+    for (int p0 = 0; p0 < P; p0 += GPE_MAX_P) {
+        const int pc = (P - p0 < GPE_MAX_P) ? P - p0 : GPE_MAX_P;
+        launch_grad_chunk(s, Xt, ldx, N, kp, Kinv, ldk, alpha + (int64_t)p0 * lda, lda, uvec + (int64_t)p0 * lda, pc,
+                          p0 == 0 ? 1.0 : 0.0, n_theta, optimize_noise, partial, grad, p0 > 0);
+    }
+}
+
+static void launch_grad_chunk(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp,
+                              const double* Kinv, int64_t ldk, const double* alpha, int64_t lda, const double* uvec,
+                              int P, double kinv_scale, int n_theta, int optimize_noise, double* partial, double* grad,
+                              int accumulate)
 {
     const int T = n_theta + (optimize_noise ? 1 : 0);
     const int64_t nt = (N + TILE - 1) / TILE;
@@ -176,8 +211,8 @@ void launch_grad_loglik(hipStream_t s, const double* Xt, int64_t ldx, int64_t N,
     dim3 grid((unsigned)nblk), block(256);
 #define LG(DM)                                                                                                   \
     hipLaunchKernelGGL((k_grad_tiles<DM>), grid, block,                                                          \
-                       (size_t)(D * TILE + GPE_MAX_P * TILE + 4 * (DM + 2)) * sizeof(double), s, Xt, ldx, N, kp, \
-                       Kinv, ldk, alpha, lda, P, n_theta, optimize_noise, partial)
+                       (size_t)(D * TILE + 2 * GPE_MAX_P * TILE + 4 * (DM + 2)) * sizeof(double), s, Xt, ldx, N, \
+                       kp, Kinv, ldk, alpha, lda, uvec, P, kinv_scale, n_theta, optimize_noise, partial)
     if (D <= 4)
         LG(4);
     else if (D <= 8)
@@ -189,5 +224,99 @@ void launch_grad_loglik(hipStream_t s, const double* Xt, int64_t ldx, int64_t N,
     else
         LG(64);
 #undef LG
-    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)T), dim3(256), 0, s, partial, nblk, T, grad);
+    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)T), dim3(256), 0, s, partial, nblk, T, grad, accumulate);
+}
+
+// ---- leave-one-out helpers (gp.hpp:339-402) -------------------------------------------------------
+// per sample i: kappa = (K^-1)_ii;  v[i, p] = alpha[i, p] / kappa;  sc[i] = sqrt(c_i);
+// val[i] = sum_p (-1/2 alpha_ip^2 / kappa + 1/2 log kappa - 1/2 log 2 pi)        (gp.hpp:348)
+__global__ __launch_bounds__(256) void k_loo_prep(const double* __restrict__ Kinv, int64_t ldk, int64_t N,
+                                                  const double* __restrict__ alpha, int64_t lda, int P,
+                                                  double* __restrict__ v, double* __restrict__ sc,
+                                                  double* __restrict__ val)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N)
+        return;
+    const double kappa = Kinv[i + i * ldk];
+    const double inv_d = 1.0 / kappa;
+    double c = 0.0, l = 0.0;
+    for (int p = 0; p < P; ++p) {
+        const double a = alpha[i + (int64_t)p * lda];
+        if (v)
+            v[i + (int64_t)p * lda] = a * inv_d;
+        c += 0.5 * (1.0 + a * a * inv_d) * inv_d;
+        l += -0.5 * a * a * inv_d - 0.5 * log(inv_d) - 0.9189385332046727418; // 1/2 log(2 pi)
+    }
+    if (sc)
+        sc[i] = sqrt(c);
+    val[i] = l;
+}
+// out[0] = sum_i val[i], fixed order (one workgroup)
+__global__ __launch_bounds__(256) void k_sum_fixed(const double* __restrict__ val, int64_t N, double* __restrict__ out)
+{
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int64_t b = threadIdx.x; b < N; b += 256)
+        s += val[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0)
+        sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[0] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// S = sym(Kl) diag(sc): S[i, j] = K^-1[i, j] sc[j] for the full square, Kl holding the lower triangle
+__global__ __launch_bounds__(256) void k_sym_colscale(const double* __restrict__ Kl, int64_t ldk, int64_t N,
+                                                      const double* __restrict__ sc, double* __restrict__ S,
+                                                      int64_t lds_)
+{
+    __shared__ double tile[TILE][TILE + 1];
+    const int ti = blockIdx.y, tj = blockIdx.x; // lower-triangle tiles only
+    if (tj > ti)
+        return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t i0 = (int64_t)ti * TILE, j0 = (int64_t)tj * TILE;
+    for (int c = ty; c < TILE; c += 4) {
+        const int64_t i = i0 + tx, j = j0 + c;
+        double kv = 0.0;
+        if (i < N && j < N)
+            kv = (j <= i) ? Kl[i + j * ldk] : Kl[j + i * ldk];
+        tile[c][tx] = kv;
+        if (i < N && j < N)
+            S[i + j * lds_] = kv * sc[j];
+    }
+    __syncthreads();
+    if (ti == tj)
+        return;
+    for (int c = ty; c < TILE; c += 4) { // mirrored tile: S[j, i] = K^-1[i, j] sc[i]
+        const int64_t jj = j0 + tx, ii = i0 + c;
+        if (jj < N && ii < N)
+            S[jj + ii * lds_] = tile[tx][c] * sc[ii];
+    }
+}
+__global__ void k_scale_vec(double* __restrict__ g, int n, double f)
+{
+    if ((int)threadIdx.x < n)
+        g[threadIdx.x] *= f;
+}
+
+void launch_loo_prep(hipStream_t s, const double* Kinv, int64_t ldk, int64_t N, const double* alpha, int64_t lda, int P,
+                     double* v, double* sc, double* val, double* out)
+{
+    hipLaunchKernelGGL(k_loo_prep, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Kinv, ldk, N, alpha, lda, P, v,
+                       sc, val);
+    hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(256), 0, s, val, N, out);
+}
+void launch_sym_colscale(hipStream_t s, const double* Kl, int64_t ldk, int64_t N, const double* sc, double* S,
+                         int64_t lds_)
+{
+    const unsigned nt = (unsigned)((N + TILE - 1) / TILE);
+    hipLaunchKernelGGL(k_sym_colscale, dim3(nt, nt), dim3(256), 0, s, Kl, ldk, N, sc, S, lds_);
+}
+void launch_scale_vec(hipStream_t s, double* g, int n, double f)
+{
+    hipLaunchKernelGGL(k_scale_vec, dim3(1), dim3(64), 0, s, g, n, f);
 }

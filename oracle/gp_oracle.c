@@ -574,6 +574,137 @@ int orc_log_lik_grad(orc_handle c, double* grad, int n_grad, int optimize_noise)
     return 0;
 }
 
+/* GP::compute_log_loo_cv: src/limbo/model/gp.hpp:339-351
+ *   inv_diag_i = 1 / (K^-1)_ii ;  sum over (i, p) of  -1/2 alpha_ip^2 inv_diag_i - 1/2 log inv_diag_i - 1/2 log 2 pi */
+int orc_log_loo_cv(orc_handle c, double* out)
+{
+    if (!c || !c->have_L || !out)
+        return -2;
+    if (!c->inv_ok)
+        orc_compute_inv_kernel(c);
+    int64_t n = c->N;
+    double s = 0.0;
+    for (int p = 0; p < c->P; ++p)
+        for (int64_t i = 0; i < n; ++i) {
+            double inv_d = 1.0 / A_(c->Kinv, i, i, n);
+            double a = c->alpha[i + p * n];
+            s += -0.5 * a * a * inv_d - 0.5 * log(inv_d) - 0.5 * log(2.0 * M_PI);
+        }
+    *out = s;
+    return 0;
+}
+
+/* GP::compute_kernel_grad_log_loo_cv: src/limbo/model/gp.hpp:354-402, as written there: per
+ * hyper-parameter j the dense dK/dtheta_j (:380-384), Zeta_j = K^-1 dK_j (:385), Zeta_j alpha (:386),
+ * Zeta_j K^-1 (:387) and the column sums of :389.  O(T N^3): small N only. */
+int orc_log_loo_cv_grad(orc_handle c, double* grad, int n_grad, int optimize_noise)
+{
+    if (!c || !c->have_L || !grad)
+        return -2;
+    if (c->host_K)
+        return -5;
+    int64_t n = c->N;
+    int nt = c->n_theta, P = c->P;
+    if (n_grad != nt + (optimize_noise ? 1 : 0))
+        return -1;
+    if (!c->inv_ok)
+        orc_compute_inv_kernel(c);
+    double* Ki = (double*)malloc(sizeof(double) * (size_t)(n * n)); /* full symmetric K^-1 */
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j <= i; ++j)
+            Ki[i + j * n] = Ki[j + i * n] = A_(c->Kinv, i, j, n);
+    double* dK = (double*)malloc(sizeof(double) * (size_t)(n * n * n_grad)); /* full_dk (:366-376) */
+    double g[MAX_THETA + 1];
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j <= i; ++j) {
+            k_grad(c->kind, c->X + i * c->D, c->X + j * c->D, c->D, c->theta, g);
+            if (optimize_noise)
+                g[nt] = (i == j) ? 2.0 * c->noise : 0.0;
+            for (int t = 0; t < n_grad; ++t)
+                dK[(size_t)t * n * n + i + j * n] = dK[(size_t)t * n * n + j + i * n] = g[t];
+        }
+    double* Z = (double*)malloc(sizeof(double) * (size_t)(n * n));
+    double* Za = (double*)malloc(sizeof(double) * (size_t)(n * P));
+    double* Zd = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int t = 0; t < n_grad; ++t) {
+        const double* G = dK + (size_t)t * n * n;
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t k = 0; k < n; ++k) { /* Zeta = K^-1 dK */
+                double s = 0.0;
+                for (int64_t m = 0; m < n; ++m)
+                    s += Ki[i + m * n] * G[m + k * n];
+                Z[i + k * n] = s;
+            }
+        for (int64_t i = 0; i < n; ++i) {
+            for (int p = 0; p < P; ++p) { /* Zeta alpha */
+                double s = 0.0;
+                for (int64_t m = 0; m < n; ++m)
+                    s += Z[i + m * n] * c->alpha[m + p * n];
+                Za[i + p * n] = s;
+            }
+            double d = 0.0; /* diag(Zeta K^-1) */
+            for (int64_t m = 0; m < n; ++m)
+                d += Z[i + m * n] * Ki[m + i * n];
+            Zd[i] = d;
+        }
+        double acc = 0.0; /* :389 then :395 (sum over outputs) */
+        for (int p = 0; p < P; ++p)
+            for (int64_t i = 0; i < n; ++i) {
+                double inv_d = 1.0 / Ki[i + i * n];
+                double a = c->alpha[i + p * n];
+                acc += (a * Za[i + p * n] - 0.5 * (1.0 + a * a * inv_d) * Zd[i]) * inv_d;
+            }
+        grad[t] = acc;
+    }
+    free(Ki);
+    free(dK);
+    free(Z);
+    free(Za);
+    free(Zd);
+    return 0;
+}
+
+/* Not in the reference: the weight matrix W with dLOO/dtheta_j = sum_ab W[a,b] dK_j[a,b], obtained by
+ * collecting the terms of gp.hpp:385-389 that multiply dK_j (both are linear in it):
+ *   W = sum_p sym(u_p alpha_p^T) - K^-1 diag(c) K^-1,  u_p = K^-1 (alpha_p / kappa),  kappa = diag K^-1,
+ *   c_i = sum_p 1/2 (1 + alpha_ip^2 / kappa_i) / kappa_i.   Checker for gpe_get_loo_weights. */
+int orc_get_loo_weights(orc_handle c, double* W, int64_t ld)
+{
+    if (!c || !c->have_L || !W || ld < c->N)
+        return -2;
+    if (!c->inv_ok)
+        orc_compute_inv_kernel(c);
+    int64_t n = c->N;
+    int P = c->P;
+    double* Ki = (double*)malloc(sizeof(double) * (size_t)(n * n));
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j <= i; ++j)
+            Ki[i + j * n] = Ki[j + i * n] = A_(c->Kinv, i, j, n);
+    double* u = (double*)calloc((size_t)(n * P), sizeof(double));
+    double* cc = (double*)calloc((size_t)n, sizeof(double));
+    for (int p = 0; p < P; ++p)
+        for (int64_t i = 0; i < n; ++i) {
+            double a = c->alpha[i + p * n], kap = Ki[i + i * n];
+            cc[i] += 0.5 * (1.0 + a * a / kap) / kap;
+            for (int64_t m = 0; m < n; ++m)
+                u[m + p * n] += Ki[m + i * n] * (a / kap);
+        }
+    for (int64_t a = 0; a < n; ++a)
+        for (int64_t b = 0; b < n; ++b) {
+            double w = 0.0;
+            for (int p = 0; p < P; ++p)
+                w += 0.5 * (u[a + p * n] * c->alpha[b + p * n] + c->alpha[a + p * n] * u[b + p * n]);
+            double m = 0.0;
+            for (int64_t i = 0; i < n; ++i)
+                m += Ki[a + i * n] * cc[i] * Ki[i + b * n];
+            W[a + b * ld] = w - m;
+        }
+    free(Ki);
+    free(u);
+    free(cc);
+    return 0;
+}
+
 /* KernelLFOptimization::operator(): src/limbo/model/gp/kernel_lf_opt.hpp:77-92 */
 int orc_hp_objective(orc_handle c, int kind, const double* th, int n_theta, double noise,
     int optimize_noise, int want_grad, double* lik, double* grad)

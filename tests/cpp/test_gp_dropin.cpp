@@ -8,13 +8,19 @@
 #include <random>
 #include <string>
 
+#define protected public // as src/tests/test_gp.cpp:48: the tests reach the optimisers' objective functors
+
 #include <limbo/acqui/ei.hpp>
 #include <limbo/acqui/gp_ucb.hpp>
 #include <limbo/acqui/ucb.hpp>
 #include <limbo/kernel/exp.hpp>
 #include <limbo/kernel/matern_three_halves.hpp>
+#include <limbo/mean/function_ard.hpp>
 #include <limbo/mean/null_function.hpp>
 #include <limbo/model/gp.hpp>
+#include <limbo/model/gp/kernel_loo_opt.hpp>
+#include <limbo/model/gp/kernel_mean_lf_opt.hpp>
+#include <limbo/model/gp/mean_lf_opt.hpp>
 #include <limbo/model/multi_gp.hpp>
 #include <limbo/model/multi_gp/parallel_lf_opt.hpp>
 #include <limbo/serialize/binary_archive.hpp>
@@ -273,6 +279,127 @@ CASE(test_gp_check_lf_grad) { check_grad<model::GP<Params, kernel::SquaredExpARD
 CASE(test_gp_check_lf_grad_noise) { check_grad<model::GP<ParamsNoiseOpt, kernel::SquaredExpARD<ParamsNoiseOpt>, mean::Data<ParamsNoiseOpt>>>(g_failed_here); }
 CASE(test_gp_check_lf_grad_matern) { check_grad<model::GP<ParamsNoiseOpt, kernel::MaternFiveHalves<ParamsNoiseOpt>, mean::Data<ParamsNoiseOpt>>>(g_failed_here); }
 CASE(test_gp_check_lf_grad_functor_kernel) { check_grad<model::GP<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>, mean::Data<ParamsLambda>>>(g_failed_here); }
+
+// test_gp.cpp:72-92 — gradient of an optimiser objective vs central finite differences
+template <typename F>
+static double objective_grad_err(const F& f, const VectorXd& x, double e = 1e-4)
+{
+    opt::eval_t res = f(x, true);
+    VectorXd analytic = opt::grad(res);
+    VectorXd fd = VectorXd::Zero(x.size());
+    for (int j = 0; j < x.size(); j++) {
+        VectorXd a = x, b = x;
+        a[j] -= e;
+        b[j] += e;
+        fd[j] = (opt::fun(f(b, false)) - opt::fun(f(a, false))) / (2.0 * e);
+    }
+    return (analytic - fd).norm();
+}
+static void cos_sin_problem(int N, std::vector<VectorXd>& X, std::vector<VectorXd>& Y)
+{
+    for (int i = 0; i < N; i++) {
+        X.push_back(rand_vec(4, 0, 1));
+        VectorXd ob(2);
+        ob(0) = std::cos(X[i](0));
+        ob(1) = std::sin(X[i](1));
+        Y.push_back(ob);
+    }
+}
+
+// test_gp.cpp:131-193 (and :195-271 with optimize_noise): the three likelihood objectives with a
+// FunctionARD<Constant> mean — kernel only, kernel + mean, mean only
+template <typename P>
+static void check_lf_objectives(int& g_failed_here)
+{
+    using GP_t = model::GP<P, kernel::SquaredExpARD<P>, mean::FunctionARD<P, mean::Constant<P>>>;
+    GP_t gp(4, 2);
+    std::vector<VectorXd> X, Y;
+    const int N = 40, M = 25;
+    cos_sin_problem(N, X, Y);
+    gp.compute(X, Y);
+    const int nk = gp.kernel_function().h_params_size(), nm = gp.mean_function().h_params_size();
+    CHECK(nm == 2 * 3 + 1);
+    typename model::gp::KernelLFOpt<P>::template KernelLFOptimization<GP_t> k_obj(gp);
+    typename model::gp::KernelMeanLFOpt<P>::template KernelMeanLFOptimization<GP_t> km_obj(gp);
+    typename model::gp::MeanLFOpt<P>::template MeanLFOptimization<GP_t> m_obj(gp);
+    double ek = 0, ekm = 0, em = 0;
+    for (int i = 0; i < M; ++i) {
+        ek += objective_grad_err(k_obj, rand_vec(nk, 0, 1));
+        ekm += objective_grad_err(km_obj, rand_vec(nk + nm, 0, 1));
+        em += objective_grad_err(m_obj, rand_vec(nm, 0, 1));
+    }
+    CHECK(ek < M * 1e-4);
+    CHECK(ekm < M * 1e-4);
+    CHECK(em < M * 1e-4);
+}
+CASE(test_gp_check_lf_grad_objectives) { check_lf_objectives<Params>(g_failed_here); }
+CASE(test_gp_check_lf_grad_objectives_noise) { check_lf_objectives<ParamsNoiseOpt>(g_failed_here); }
+
+// test_gp.cpp:273-380 — leave-one-out CV objective (with and without noise optimisation, and with a
+// kernel that only exists as a host functor)
+template <typename P, typename K>
+static void check_loo_objective(int& g_failed_here)
+{
+    using GP_t = model::GP<P, K, mean::Constant<P>>;
+    GP_t gp(4, 2);
+    std::vector<VectorXd> X, Y;
+    const int N = 40, M = 25;
+    cos_sin_problem(N, X, Y);
+    gp.compute(X, Y);
+    typename model::gp::KernelLooOpt<P>::template KernelLooOptimization<GP_t> obj(gp);
+    double err = 0;
+    for (int i = 0; i < M; ++i)
+        err += objective_grad_err(obj, rand_vec(gp.kernel_function().h_params_size(), 0, 1));
+    CHECK(err < M * 1e-4);
+    CHECK(!gp.inv_kernel_computed()); // the objective works on its own copies
+    const double loo = gp.compute_log_loo_cv();
+    CHECK(gp.inv_kernel_computed());
+    CHECK(std::isfinite(loo) && loo == gp.get_log_loo_cv());
+}
+CASE(test_gp_check_loo_grad) { check_loo_objective<Params, kernel::SquaredExpARD<Params>>(g_failed_here); }
+CASE(test_gp_check_loo_grad_noise) { check_loo_objective<ParamsNoiseOpt, kernel::SquaredExpARD<ParamsNoiseOpt>>(g_failed_here); }
+CASE(test_gp_check_loo_grad_functor_kernel) { check_loo_objective<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>>(g_failed_here); }
+
+// the HP-optimisation policies end to end: each must not decrease its own objective, and the mean
+// policies must move the mean parameters (obs_multi_auto_mean.cpp is the reference's example of them)
+CASE(test_gp_hp_policies)
+{
+    std::vector<VectorXd> X, Y;
+    cos_sin_problem(60, X, Y);
+    {
+        using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Constant<Params>, model::gp::KernelLooOpt<Params>>;
+        GP_t gp(4, 2);
+        gp.compute(X, Y);
+        const double before = gp.compute_log_loo_cv();
+        gp.optimize_hyperparams();
+        CHECK(gp.get_log_loo_cv() >= before - 1e-9);
+    }
+    {
+        using Mean_t = mean::FunctionARD<Params, mean::Constant<Params>>;
+        using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, Mean_t, model::gp::MeanLFOpt<Params>>;
+        GP_t gp(4, 2);
+        gp.compute(X, Y);
+        const double before = gp.compute_log_lik();
+        const VectorXd h0 = gp.mean_function().h_params();
+        gp.optimize_hyperparams();
+        CHECK(gp.get_log_lik() >= before - 1e-9);
+        CHECK((gp.mean_function().h_params() - h0).norm() > 1e-6);
+    }
+    {
+        using Mean_t = mean::FunctionARD<Params, mean::Constant<Params>>;
+        using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, Mean_t, model::gp::KernelMeanLFOpt<Params>>;
+        GP_t gp(4, 2);
+        gp.compute(X, Y);
+        const double before = gp.compute_log_lik();
+        gp.optimize_hyperparams();
+        CHECK(gp.get_log_lik() >= before - 1e-9);
+        // the fitted model still interpolates (test_gp.cpp:669-695 bar)
+        VectorXd mu;
+        double s2;
+        std::tie(mu, s2) = gp.query(X[3]);
+        CHECK((mu - Y[3]).norm() < 0.2);
+    }
+}
 
 // test_gp.cpp:382-446 — _inv_kernel_updated state machine
 CASE(test_gp_check_inv_kernel_computation)
@@ -573,6 +700,12 @@ int main()
     test_gp_check_lf_grad_noise_run();
     test_gp_check_lf_grad_matern_run();
     test_gp_check_lf_grad_functor_kernel_run();
+    test_gp_check_lf_grad_objectives_run();
+    test_gp_check_lf_grad_objectives_noise_run();
+    test_gp_check_loo_grad_run();
+    test_gp_check_loo_grad_noise_run();
+    test_gp_check_loo_grad_functor_kernel_run();
+    test_gp_hp_policies_run();
     test_gp_check_inv_kernel_computation_run();
     test_gp_run();
     test_gp_no_samples_acqui_opt_run();

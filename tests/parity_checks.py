@@ -150,6 +150,38 @@ def check_grad_fd(lib, kind, optimize_noise, N=40, D=4, P=2, trials=8, seed=5):
     h.close()
 
 
+def check_loo_grad_fd(lib, kind, optimize_noise, N=40, D=4, P=2, trials=6, seed=11):
+    """test_gp.cpp:273-380: analytic gradient of the LOO-CV log probability vs central finite
+    differences of compute_log_loo_cv after recompute(false) (kernel_loo_opt.hpp:77-95), e = 1e-4."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, size=(N, D))
+    Y = np.stack([np.cos(X.sum(axis=1) * (p + 1)) for p in range(P)], axis=1)
+    om, _ = O.obs_mean_data(Y)
+    nt = D + 1 if kind == O.SE_ARD else 2
+    h = new_gp(lib, kind, X, om, np.zeros(nt), 0.01)
+    tot = 0.0
+    e = 1e-4
+    for _ in range(trials):
+        th = rng.uniform(-1.0, 1.0, size=nt + (1 if optimize_noise else 0))
+
+        def loo(t):
+            h.set_kernel(kind, t[:nt], np.exp(2 * t[nt]) if optimize_noise else 0.01)
+            assert h.compute() == 0
+            return h.log_loo_cv()
+
+        loo(th)
+        g = h.log_loo_cv_grad(optimize_noise)
+        fd = np.zeros_like(th)
+        for j in range(th.size):
+            tp, tm = th.copy(), th.copy()
+            tp[j] += e
+            tm[j] -= e
+            fd[j] = (loo(tp) - loo(tm)) / (2 * e)
+        tot += np.linalg.norm(fd - g) / max(1.0, np.linalg.norm(g))
+    assert tot < trials * 1e-4
+    h.close()
+
+
 def check_update_alpha_and_clone(lib):
     """recompute(true,false) (gp.hpp:241-252) == fresh compute on the new observations;
     clone has value semantics (kernel_lf_opt.hpp:79)."""

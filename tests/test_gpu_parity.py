@@ -76,6 +76,38 @@ def test_gpu_vs_oracle_full_path(engine_lib, oracle_lib, N, D, P, kind):
     o.close()
 
 
+@pytest.mark.parametrize("N,D,P,kind,on", [(40, 4, 2, O.SE_ARD, True), (130, 3, 1, O.MATERN52, False),
+                                           (257, 6, 3, O.SE_ARD, True), (333, 2, 1, O.EXP, True),
+                                           (200, 5, 8, O.MATERN32, False), (150, 3, 11, O.SE_ARD, True)])
+def test_gpu_loo_cv_vs_oracle(engine_lib, oracle_lib, N, D, P, kind, on):
+    """compute_log_loo_cv / compute_kernel_grad_log_loo_cv (gp.hpp:339-402): the device's one-product
+    form against the oracle's literal per-parameter Zeta products."""
+    rng = np.random.default_rng(N + 31 * D)
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) + 0.05 * rng.normal(size=N) for p in range(P)], axis=1)
+    om, _ = O.obs_mean_data(Y)
+    nt = D + 1 if kind == O.SE_ARD else 2
+    th = rng.uniform(-0.5, 0.3, size=nt)
+    g = new_gp(engine_lib, kind, X, om, th, 0.02)
+    o = new_gp(oracle_lib, kind, X, om, th, 0.02)
+    assert g.compute() == 0 and o.compute() == 0
+    lg, lo = g.log_loo_cv(), o.log_loo_cv()
+    assert abs(lg - lo) <= 1e-9 * max(1.0, abs(lo))
+    gg, go = g.log_loo_cv_grad(on), o.log_loo_cv_grad(on)
+    assert relerr_norm(gg, go) < PC.TOL_GRAD
+    assert relerr_norm(g.get_loo_weights(), o.get_loo_weights()) < 1e-8
+    # the log-likelihood gradient still works afterwards (the LOO path reuses the L^-1 scratch)
+    assert relerr_norm(g.log_lik_grad(on), o.log_lik_grad(on)) < PC.TOL_GRAD
+    assert relerr_norm(g.get_Kinv(), o.get_Kinv()) < 1e-8
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("kind,on", [(O.SE_ARD, True), (O.MATERN52, False)])
+def test_gpu_loo_grad_fd(engine_lib, kind, on):
+    PC.check_loo_grad_fd(engine_lib, kind, on)
+
+
 @pytest.mark.parametrize("dup", [False, True])
 def test_gpu_incremental_vs_full(engine_lib, dup):
     PC.check_incremental_vs_full(engine_lib, dup=dup)

@@ -102,6 +102,35 @@ def test_oracle_grad_fd(oracle_lib, kind, on):
     PC.check_grad_fd(oracle_lib, kind, on)
 
 
+@pytest.mark.parametrize("kind,on", [(O.SE_ARD, False), (O.SE_ARD, True), (O.MATERN52, True)])
+def test_oracle_loo_grad_fd(oracle_lib, kind, on):
+    PC.check_loo_grad_fd(oracle_lib, kind, on)
+
+
+def test_oracle_loo_collapsed_form(oracle_lib):
+    """The one-product form of the LOO gradient used on the device (grad.hip header) equals the
+    reference's per-parameter Zeta products (gp.hpp:380-389), evaluated here in numpy from the
+    oracle's K^-1 and alpha."""
+    rng = np.random.default_rng(77)
+    N, D, P = 57, 3, 2
+    X = rng.uniform(-1, 1, size=(N, D))
+    Y = np.stack([np.sin(X.sum(axis=1) * (p + 1)) for p in range(P)], axis=1)
+    om, _ = O.obs_mean_data(Y)
+    th = np.array([0.2, -0.3, 0.1, 0.05])
+    h = new_gp(oracle_lib, O.SE_ARD, X, om, th, 0.02)
+    assert h.compute() == 0
+    ref = h.log_loo_cv_grad(True)
+    Ki, al = h.get_Kinv(), h.get_alpha()
+    kappa = np.diag(Ki)
+    u = Ki @ (al / kappa[:, None])
+    c = (0.5 * (1 + al ** 2 / kappa[:, None]) / kappa[:, None]).sum(axis=1)
+    W = 0.5 * (u @ al.T + al @ u.T) - (Ki * c[None, :]) @ Ki
+    G = O.kernel_grad_tensor(O.SE_ARD, X, th)
+    got = np.append((G * W[None]).sum(axis=(1, 2)), 2 * 0.02 * np.trace(W))
+    assert np.linalg.norm(got - ref) < 1e-10 * max(1.0, np.linalg.norm(ref))
+    h.close()
+
+
 def test_oracle_update_alpha_and_clone(oracle_lib):
     PC.check_update_alpha_and_clone(oracle_lib)
 
