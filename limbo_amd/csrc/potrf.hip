@@ -729,7 +729,8 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
                 const double v = cv[m][n] - a2[m][n];
                 if (t == 0)
                     cres[m][n] = v;
-                if (row < nrows)
+                // workgroup 0 factors this tile next and writes L over it: no need to store the update
+                if (row < nrows && !(b == 0 && do_next))
                     Cg[row + (int64_t)col * lda] = v;
             }
         __syncthreads(); // T1 is free again

@@ -25,6 +25,7 @@
 #include <limbo/model/multi_gp/parallel_lf_opt.hpp>
 #include <limbo/serialize/binary_archive.hpp>
 #include <limbo/serialize/text_archive.hpp>
+#include <limbo/opt/batch_search.hpp>
 #include <limbo/opt/parallel_repeater.hpp>
 
 using namespace limbo;
@@ -68,6 +69,11 @@ struct Params {
     struct acqui_ei : public defaults::acqui_ei {};
     struct opt_parallelrepeater : public defaults::opt_parallelrepeater {
         BO_PARAM(int, repeats, 4);
+    };
+    struct opt_gridsearch : public defaults::opt_gridsearch {};
+    struct opt_batchrandomsearch : public defaults::opt_batchrandomsearch {
+        BO_PARAM(int, points, 4096);
+        BO_PARAM(int, seed, 7);
     };
 };
 struct ParamsNoiseOpt : public Params {
@@ -688,6 +694,53 @@ CASE(test_acqui_batch)
     CHECK(ei_max > 0.0);
 }
 
+// the batch-aware inner optimisers.  BatchGridSearch must return the point
+// opt::GridSearch returns (grid_search.hpp:84-112: same grid, first strict maximum in its visiting
+// order), whether the objective offers batch() or not.
+template <typename F>
+static VectorXd reference_grid_search(const F& f, size_t depth, const VectorXd& current, int bins)
+{
+    const size_t dim = current.size();
+    const double step = 1.0 / (double)bins, upper = 1.0 + step;
+    double best_fit = -std::numeric_limits<double>::max();
+    VectorXd res(dim);
+    for (double x = 0; x < upper; x += step) {
+        VectorXd np = current;
+        np[depth] = x;
+        VectorXd cand = (depth == dim - 1) ? np : reference_grid_search(f, depth + 1, np, bins);
+        const double val = opt::eval(f, cand);
+        if (val > best_fit) {
+            best_fit = val;
+            res = cand;
+        }
+    }
+    return res;
+}
+CASE(test_batch_search)
+{
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(120, 3, 1, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    auto first = [](const VectorXd& v) { return v(0); };
+    acqui::UCB<Params, GP_t> ucb(gp);
+    auto obj = opt::make_batch_objective(ucb, first);
+    auto plain = [&](const VectorXd& x, bool g) { return ucb(x, first, g); };
+    const VectorXd init = VectorXd::Constant(3, 0.5);
+    const VectorXd ref = reference_grid_search(plain, 0, init, Params::opt_gridsearch::bins());
+    const VectorXd got_batch = opt::BatchGridSearch<Params>()(obj, init, true);
+    const VectorXd got_plain = opt::BatchGridSearch<Params>()(plain, init, true);
+    CHECK((got_batch - ref).norm() == 0.0);
+    CHECK((got_plain - ref).norm() == 0.0);
+    const VectorXd rs = opt::BatchRandomSearch<Params>()(obj, init, true);
+    CHECK(rs.minCoeff() >= 0.0 && rs.maxCoeff() <= 1.0);
+    CHECK(opt::eval(plain, rs) >= opt::eval(plain, ref)); // 3 x 4097 samples beat the 216-point grid
+    CHECK(opt::eval(plain, rs) >= opt::eval(plain, init));
+    const VectorXd ru = opt::BatchRandomSearch<Params>()(obj, init, false);
+    CHECK(opt::eval(plain, ru) >= opt::eval(plain, init));
+}
+
 int main()
 {
     auto t0 = std::chrono::steady_clock::now();
@@ -718,6 +771,7 @@ int main()
     test_bin_archive_run();
     test_multi_gp_archive_run();
     test_acqui_batch_run();
+    test_batch_search_run();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%d checks, %d failed cases, %.1f s\n", g_checks, g_failed, s);
     return g_failed;
