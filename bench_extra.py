@@ -36,6 +36,18 @@ def main():
     dt = time.perf_counter() - t0
     out["c2_hp_objective_with_grad_per_s"] = n / dt
     out["c2_hp_objective_ms"] = 1e3 * dt / n
+    # leave-one-out objective with gradient (kernel_loo_opt.hpp:77-95): compute + LOO + its gradient
+    h.log_loo_cv(); h.log_loo_cv_grad(False)
+    t0 = time.perf_counter()
+    for i in range(n):
+        h.set_kernel(O.SE_ARD, th + 1e-3 * i, 0.01)
+        h.compute(); h.log_loo_cv(); g = h.log_loo_cv_grad(False)
+    dt = time.perf_counter() - t0
+    out["c2_loo_objective_with_grad_per_s"] = n / dt
+    # SparsifiedGP::_sparsify at N = 4096 -> 200 (sparsified_gp.hpp default max_points)
+    _capi.sparsify(eng, X[:300], 100)
+    t0 = time.perf_counter(); keep = _capi.sparsify(eng, X, 200); dt = time.perf_counter() - t0
+    out["c2_sparsify_4096_to_200_s"] = dt
     # batched query at N=4096 (M = 20000)
     M = 5000 if args.quick else 20000
     Xq = np.random.default_rng(1).uniform(0, 1, size=(M, 6))

@@ -107,6 +107,13 @@ int gpe_compute_inv_kernel(gpe_handle h);
 /* gp.hpp:285-311 compute_kernel_grad_log_lik (+ kernel.hpp:86-96 noise term).
  * grad has n_theta (+1 if optimize_noise) entries. */
 int gpe_log_lik_grad(gpe_handle h, double* grad, int n_grad, int optimize_noise);
+/* model/sparsified_gp.hpp:124-183 SparsifiedGP::_sparsify: while more than max_points samples remain,
+ * drop the one whose D nearest remaining neighbours are closest in total.  X row-major N x D (host).
+ * keep[0..*n_keep) = indices of the surviving samples, ascending.  Stand-alone (no handle): the
+ * thinning happens before the GP exists.  D <= 64; max_points > D (the reference's partial_sort
+ * is undefined otherwise). */
+int gpe_sparsify(int device_id, const double* X_rowmajor, int64_t N, int D, int64_t max_points,
+                 int64_t* keep, int64_t* n_keep);
 /* gp.hpp:339-351 compute_log_loo_cv (leave-one-out log predictive probability) */
 int gpe_log_loo_cv(gpe_handle h, double* out);
 /* gp.hpp:354-402 compute_kernel_grad_log_loo_cv; same layout as gpe_log_lik_grad.

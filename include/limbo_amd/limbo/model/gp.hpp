@@ -80,6 +80,7 @@ namespace limbo_amd {
             return _h;
         }
         gpe_handle peek() const { return _h; }
+        int device() const { return _device; }
         /// negative status = API/HIP error: loud; positive = non-positive pivot: returned
         int check(int rc, const char* what) const
         {

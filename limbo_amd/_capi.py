@@ -57,6 +57,7 @@ def _sig(lib, prefix):
         "log_lik": [_vp, _dp],
         "compute_inv_kernel": [_vp],
         "log_lik_grad": [_vp, _dp, C.c_int, C.c_int],
+        "sparsify": [C.c_int, _dp, _i64, C.c_int, _i64, C.POINTER(_i64), C.POINTER(_i64)],
         "log_loo_cv": [_vp, _dp],
         "log_loo_cv_grad": [_vp, _dp, C.c_int, C.c_int],
         "get_loo_weights": [_vp, _dp, _i64],
@@ -373,6 +374,19 @@ class Handle:
                                                    _d(th), C.byref(lik), C.byref(ne))
         self._chk(rc, "kernel_lf_opt_rprop")
         return th, lik.value, ne.value
+
+
+def sparsify(lib, X, max_points, device_id=0):
+    """SparsifiedGP::_sparsify (sparsified_gp.hpp:157-183): indices of the samples that survive."""
+    X = _c(X)
+    N, D = X.shape
+    keep = np.zeros(N, dtype=np.int64)
+    n = _i64(0)
+    rc = lib.fn("sparsify")(int(device_id), _d(X), N, D, int(max_points), keep.ctypes.data_as(C.POINTER(_i64)),
+                            C.byref(n))
+    if rc != 0:
+        raise EngineError(f"sparsify failed with status {rc}")
+    return keep[: n.value].copy()
 
 
 def batch_compute(handles):

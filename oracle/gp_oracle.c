@@ -676,6 +676,8 @@ int orc_get_loo_weights(orc_handle c, double* W, int64_t ld)
         orc_compute_inv_kernel(c);
     int64_t n = c->N;
     int P = c->P;
+    if (n <= 0 || P <= 0)
+        return -2;
     double* Ki = (double*)malloc(sizeof(double) * (size_t)(n * n));
     for (int64_t i = 0; i < n; ++i)
         for (int64_t j = 0; j <= i; ++j)
@@ -702,6 +704,74 @@ int orc_get_loo_weights(orc_handle c, double* W, int64_t ld)
     free(Ki);
     free(u);
     free(cc);
+    return 0;
+}
+
+/* SparsifiedGP::_sparsify + _get_most_dense_point: src/limbo/model/sparsified_gp.hpp:124-183, in the
+ * order of the serial build (tools::par::loop degenerates to a for loop without TBB,
+ * tools/parallel.hpp:138-152): full distance matrix (:160-166); while more than max_points remain,
+ * for every remaining i sort the distances to the others, add the D smallest in ascending order
+ * (:136-143), remove the first strict minimum (:146-149, :174-178). */
+static int cmp_double(const void* a, const void* b)
+{
+    double x = *(const double*)a, y = *(const double*)b;
+    return (x > y) - (x < y);
+}
+int orc_sparsify(int device_id, const double* X, int64_t N, int D, int64_t max_points, int64_t* keep, int64_t* n_keep)
+{
+    (void)device_id;
+    if (!X || !keep || !n_keep || N <= 0 || D <= 0 || max_points <= 0)
+        return -1;
+    int64_t n = N;
+    int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)N);
+    for (int64_t i = 0; i < N; ++i)
+        idx[i] = i;
+    if (N > max_points) {
+        if (max_points <= D) {
+            free(idx);
+            return -5;
+        }
+        double* dist = (double*)malloc(sizeof(double) * (size_t)(N * N));
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < N; ++j) {
+                double s = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    double q = X[i * D + d] - X[j * D + d];
+                    s += q * q;
+                }
+                dist[i + j * N] = sqrt(s); /* (samples[i] - samples[j]).norm() */
+            }
+        double* nb = (double*)malloc(sizeof(double) * (size_t)N);
+        while (n > max_points) {
+            double min_dist = DBL_MAX;
+            int64_t denser = -1;
+            for (int64_t a = 0; a < n; ++a) {
+                int64_t m = 0;
+                for (int64_t b = 0; b < n; ++b)
+                    if (b != a) /* neighbors.erase(begin + i) */
+                        nb[m++] = dist[idx[a] + idx[b] * N];
+                qsort(nb, (size_t)m, sizeof(double), cmp_double); /* partial_sort: same first D values */
+                double dsum = 0.0;
+                for (int j = 0; j < D; ++j)
+                    dsum += nb[j];
+                if (dsum < min_dist) {
+                    min_dist = dsum;
+                    denser = a;
+                }
+            }
+            if (denser < 0)
+                break;
+            for (int64_t a = denser; a + 1 < n; ++a) /* samp.erase / _remove_row / _remove_column */
+                idx[a] = idx[a + 1];
+            --n;
+        }
+        free(nb);
+        free(dist);
+    }
+    for (int64_t i = 0; i < n; ++i)
+        keep[i] = idx[i];
+    *n_keep = n;
+    free(idx);
     return 0;
 }
 

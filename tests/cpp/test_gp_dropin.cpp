@@ -22,6 +22,7 @@
 #include <limbo/model/gp/kernel_mean_lf_opt.hpp>
 #include <limbo/model/gp/mean_lf_opt.hpp>
 #include <limbo/model/multi_gp.hpp>
+#include <limbo/model/sparsified_gp.hpp>
 #include <limbo/model/multi_gp/parallel_lf_opt.hpp>
 #include <limbo/serialize/binary_archive.hpp>
 #include <limbo/serialize/text_archive.hpp>
@@ -741,6 +742,64 @@ CASE(test_batch_search)
     CHECK(opt::eval(plain, ru) >= opt::eval(plain, init));
 }
 
+// test_gp.cpp:815-910 (test_sparse_gp_accuracy): a GP on the thinned half of the data predicts like the
+// full GP, at the learned points and at fresh ones; plus the bookkeeping of compute / add_sample
+struct SparseParams : public Params {
+    struct model_sparse_gp {
+        BO_PARAM(int, max_points, 50);
+    };
+};
+CASE(test_sparse_gp_accuracy)
+{
+    using KF_t = kernel::SquaredExpARD<SparseParams>;
+    using MF_t = mean::Constant<SparseParams>;
+    using GP_t = model::GP<SparseParams, KF_t, MF_t, model::gp::KernelLFOpt<SparseParams>>;
+    using SGP_t = model::SparsifiedGP<SparseParams, KF_t, MF_t, model::gp::KernelLFOpt<SparseParams>>;
+    const int N = 6, M = 100;
+    int failures = 0;
+    for (int rep = 0; rep < N; ++rep) {
+        std::vector<VectorXd> X, Y, Xt, Yt;
+        for (int i = 0; i < M; ++i) {
+            X.push_back(rand_vec(1, -2, 2));
+            Y.push_back(make_v1(std::cos(X.back()[0])));
+            Xt.push_back(rand_vec(1, -2, 2));
+            Yt.push_back(make_v1(std::cos(Xt.back()[0])));
+        }
+        GP_t gp;
+        gp.compute(X, Y, false);
+        gp.optimize_hyperparams();
+        SGP_t sgp;
+        sgp.compute(X, Y, false);
+        CHECK(sgp.nb_samples() == 50);
+        sgp.optimize_hyperparams();
+        bool failed = false;
+        for (int i = 0; i < M; ++i)
+            for (const VectorXd& q : {X[i], Xt[i]}) {
+                VectorXd a, b;
+                double sa, sb;
+                std::tie(a, sa) = gp.query(q);
+                std::tie(b, sb) = sgp.query(q);
+                if (std::abs(a[0] - b[0]) > 1e-2 || std::abs(sa - sb) > 1e-2)
+                    failed = true;
+            }
+        failures += failed ? 1 : 0;
+    }
+    CHECK(failures <= 1);
+    // add_sample past the limit re-thins and recomputes (sparsified_gp.hpp:104-120)
+    std::vector<VectorXd> X, Y;
+    make_problem(50, 2, 1, X, Y);
+    SGP_t sgp;
+    sgp.compute(X, Y);
+    CHECK(sgp.nb_samples() == 50);
+    sgp.add_sample(rand_vec(2, 0, 1), make_v1(0.1));
+    CHECK(sgp.nb_samples() == 50);
+    CHECK((int)sgp.observations_matrix().rows() == 50 && (int)sgp.matrixL().rows() == 50);
+    VectorXd mu;
+    double s2;
+    std::tie(mu, s2) = sgp.query(X[0]);
+    CHECK(std::isfinite(mu[0]) && s2 >= 0.0);
+}
+
 int main()
 {
     auto t0 = std::chrono::steady_clock::now();
@@ -772,6 +831,7 @@ int main()
     test_multi_gp_archive_run();
     test_acqui_batch_run();
     test_batch_search_run();
+    test_sparse_gp_accuracy_run();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%d checks, %d failed cases, %.1f s\n", g_checks, g_failed, s);
     return g_failed;

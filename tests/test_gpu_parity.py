@@ -243,3 +243,33 @@ def test_gpu_c3_full_size_properties(engine_lib):
     assert np.array_equal(k1[:1000], k2) and np.array_equal(v1[:1000], v2)
     assert np.all(np.isfinite(v1)) and np.all(v1 > -1e-9)
     h.close()
+
+
+@pytest.mark.parametrize("N,D,mp", [(300, 2, 100), (257, 6, 64), (500, 12, 200), (90, 3, 90), (1000, 3, 150)])
+def test_gpu_sparsify_vs_oracle(engine_lib, oracle_lib, N, D, mp):
+    """SparsifiedGP::_sparsify (sparsified_gp.hpp:157-183): the device's cached-density form keeps
+    exactly the samples the reference's rescan-everything loop keeps."""
+    from limbo_amd import _capi
+    rng = np.random.default_rng(7 * N + D)
+    X = rng.uniform(0, 1, size=(N, D))
+    X[: N // 4] = 0.3 + 0.02 * rng.normal(size=(N // 4, D))
+    kg = _capi.sparsify(engine_lib, X, mp)
+    ko = _capi.sparsify(oracle_lib, X, mp)
+    assert np.array_equal(kg, ko)
+
+
+def test_gpu_sparsify_full_size(engine_lib):
+    """N = 4096 -> 200 (the reference's default max_points): result size, ordering, and the thinning
+    property — the minimum nearest-neighbour distance does not decrease."""
+    from limbo_amd import _capi
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 1, size=(4096, 6))
+    keep = _capi.sparsify(engine_lib, X, 200)
+    assert len(keep) == 200 and np.all(np.diff(keep) > 0)
+
+    def min_nn(Z):
+        d = np.sqrt(((Z[:, None, :] - Z[None, :, :]) ** 2).sum(axis=2))
+        np.fill_diagonal(d, np.inf)
+        return d.min()
+
+    assert min_nn(X[keep]) > min_nn(X[:1500])

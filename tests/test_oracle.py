@@ -177,3 +177,37 @@ def test_oracle_rprop_improves(oracle_lib):
     assert ll >= ll0
     assert abs(h.log_lik() - ll) < 1e-12 * abs(ll)
     h.close()
+
+
+def _np_sparsify(X, max_points):
+    """numpy restatement of sparsified_gp.hpp:124-183 (serial order), independent of the C oracle."""
+    idx = list(range(X.shape[0]))
+    Dm = np.sqrt(((X[:, None, :] - X[None, :, :]) ** 2).sum(axis=2))
+    D = X.shape[1]
+    while len(idx) > max_points:
+        sub = Dm[np.ix_(idx, idx)]
+        best, bi = np.inf, -1
+        for a in range(len(idx)):
+            nb = np.sort(np.delete(sub[a], a))[:D]
+            s = 0.0
+            for v in nb:
+                s += v
+            if s < best:
+                best, bi = s, a
+        idx.pop(bi)
+    return np.array(idx)
+
+
+@pytest.mark.parametrize("N,D,mp", [(60, 2, 20), (45, 3, 44), (30, 4, 30), (80, 1, 7)])
+def test_oracle_sparsify(oracle_lib, N, D, mp):
+    from limbo_amd import _capi
+    rng = np.random.default_rng(N + D)
+    X = rng.uniform(0, 1, size=(N, D))
+    X[: N // 3] = 0.5 + 0.05 * rng.normal(size=(N // 3, D))  # a dense cluster that must be thinned first
+    keep = _capi.sparsify(oracle_lib, X, mp)
+    assert len(keep) == min(N, mp) and np.all(np.diff(keep) > 0)
+    # the numpy restatement sums the squares in a different order (last-ulp differences in the
+    # distances); on continuous random data the selection is the same
+    assert np.array_equal(keep, _np_sparsify(X, mp))
+    if N > mp:  # the cluster lost proportionally more points than the background
+        assert (keep < N // 3).mean() < (N // 3) / N
