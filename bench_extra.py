@@ -116,6 +116,23 @@ def main():
     dt = time.perf_counter() - t0
     out["c5_add_sample_per_s"] = 190 / dt
     h.close()
+
+    # CPU upper bound at config 2: numpy kernel build + LAPACK dpotrf/dpotrs on all
+    # host threads — a reported side-by-side figure, not the oracle and not on any product path
+    import os
+    import scipy.linalg as sl
+    Xc, Yc = O.make_problem("c2", N=4096)
+    omc, _ = O.obs_mean_data(Yc)
+    best = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        K = O.kernel_matrix(O.SE_ARD, Xc, np.zeros(7), 0.01)
+        L = sl.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+        al = sl.cho_solve((L, True), omc, check_finite=False)
+        ll = -0.5 * float((omc * al).sum()) - float(np.log(np.diag(L)).sum()) - 0.5 * len(Xc) * np.log(2 * np.pi)
+        best = min(best, time.perf_counter() - t0)
+    out["c2_cpu_lapack_evals_per_s"] = 1.0 / best
+    out["cpu_threads"] = os.cpu_count()
     print(json.dumps(out))
 
 

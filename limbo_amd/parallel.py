@@ -6,6 +6,10 @@ and output dimensions under `tools::par::loop` (src/limbo/model/multi_gp.hpp:124
 8 GPUs of a node that is one process per GPU, each evaluating its own shard of the G units with no
 data-path collective; the only exchange is the final arg-max, an all-gather of (value, theta)
 records of a few hundred bytes (RCCL over xGMI when the backend is "nccl", gloo in the CPU tests).
+
+Batched queries shard over the M query points instead: every rank holds the
+same GP (it factors its own copy — cheaper than broadcasting a 2 GiB factor), answers a contiguous
+slice of the points, and one all-gather of (P + 1) doubles per point reassembles mu and sigma^2.
 """
 from __future__ import annotations
 
@@ -44,3 +48,44 @@ def argmax_over_ranks(values, thetas, dist=None, device="cpu"):
     allrec = torch.stack(allrec).cpu().numpy()
     owner = int(np.argmax(allrec[:, 0]))  # first maximum: deterministic tie-break by rank
     return float(allrec[owner, 0]), allrec[owner, 1:].copy(), owner
+
+
+def row_slice(n_rows: int, rank: int, world: int) -> slice:
+    """Contiguous, balanced slice of n_rows for this rank (the first n_rows % world ranks get one more)."""
+    q, r = divmod(n_rows, world)
+    lo = rank * q + min(rank, r)
+    return slice(lo, lo + q + (1 if rank < r else 0))
+
+
+def query_sharded(query_fn, Xq, dist=None, device="cpu"):
+    """query_fn(points) -> (kta [m x P], var [m]) on this rank's replica of the GP (e.g.
+    Handle.query_batch).  Returns the full (kta [M x P], var [M]) on every rank."""
+    import torch
+
+    Xq = np.ascontiguousarray(Xq, dtype=np.float64)
+    M = Xq.shape[0]
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        kta, var = query_fn(Xq)
+        return np.asarray(kta, float).reshape(M, -1), np.asarray(var, float).reshape(M)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sl = row_slice(M, rank, world)
+    m = sl.stop - sl.start
+    if m > 0:
+        kta, var = query_fn(Xq[sl])
+        kta = np.asarray(kta, float).reshape(m, -1)
+    else:  # more ranks than points: nothing to answer, P learnt from the others
+        kta, var = np.zeros((0, 0)), np.zeros(0)
+    P = torch.tensor([kta.shape[1]], dtype=torch.int64, device=device)
+    dist.all_reduce(P, op=dist.ReduceOp.MAX)  # a rank with an empty slice does not know P
+    P = int(P.item())
+    rows = (M + world - 1) // world  # all_gather wants equal shapes: pad every slice to the longest
+    buf = np.zeros((rows, P + 1))
+    if m > 0:
+        buf[:m, :P] = kta
+        buf[:m, P] = np.asarray(var, float).reshape(-1)
+    t = torch.tensor(buf, dtype=torch.float64, device=device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    out = np.concatenate([parts[r].cpu().numpy()[: row_slice(M, r, world).stop - row_slice(M, r, world).start]
+                          for r in range(world)])
+    return out[:, :P].copy(), out[:, P].copy()
