@@ -34,9 +34,16 @@
 //   row-contiguous operand : S[kk][i], row stride = ROWS + 16 doubles  (== 16 mod 32)
 //   k-contiguous operand   : S[i][kk], row stride 18 doubles
 #include "dev.h"
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 
+#ifdef GEMM_TIMING
+__device__ long long g_gemm_ts[16];
+#define GTS(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && lwg == (int)blockIdx.x) g_gemm_ts[i] = clock64(); } while (0)
+#else
+#define GTS(i) do { } while (0)
+#endif
 #ifndef GEMM_ABL
 #define GEMM_ABL 0 // debug ablations (tools/kbench): 1 = no global loads / LDS stores in the k loop, 2 = no MFMA
 #endif
@@ -127,6 +134,63 @@ static __host__ __device__ __forceinline__ int first_live_tile(const GemmArgs& g
     return (int)(t < tiles_m ? t : tiles_m);
 }
 
+// ---- C tile traffic in the lane = row layout ---------------------------------------------------------
+// The accumulator of v_mfma_f64_4x4x4 puts lane l on row 4*((l>>2)&3) + (l>>4), column l&3 of a 16 x 4
+// fragment: one global load/store of a fragment touches 4 columns x 16 rows, adjacent lanes sit in
+// different columns (ldc * 8 bytes apart).  Measured inside the kernel (tools/kbench_g): such a load
+// takes ~150 cycles to ISSUE and a store ~450, and the read-modify-write of a 128 x 128 C tile was 29 %
+// of the tile time.  Here the wave turns its (16 RA) x (4 RB) accumulator through a private LDS scratch
+// (no barrier: one wave's LDS operations execute in order) and all C traffic uses lane = row:
+// 64 / R whole columns of R = 16 RA consecutive rows per instruction (512 contiguous bytes for RA = 4).
+template <int RA, int RB>
+struct WaveTileC {
+    static constexpr int R = 16 * RA, CN = 4 * RB, SW = R + 2, CPI = 64 / R, NIT = CN / CPI;
+    static constexpr int SCRATCH = CN * SW; // doubles of LDS per wave
+    // cv[it] = C[row, col(it)] for this lane's (row, column) pairs; addresses clamped into the valid
+    // rlim x clim part of the tile (no branches; lanes outside simply do not store later)
+    static __device__ __forceinline__ void load(double (&cv)[NIT], const double* __restrict__ Cw, int64_t ldc, int rlim,
+                                                int clim, int lane)
+    {
+        const int row = lane % R, cl = lane / R;
+        const int rr = row < rlim ? row : rlim - 1;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = it * CPI + cl;
+            cv[it] = Cw[(int64_t)(col < clim ? col : clim - 1) * ldc + rr];
+        }
+    }
+    // C = cv - acc (or C = acc when overwrite)
+    static __device__ __forceinline__ void store(const double (&acc)[RA][RB], const double (&cv)[NIT], double* __restrict__ W,
+                                                 double* __restrict__ Cw, int64_t ldc, int rlim, int clim, bool overwrite,
+                                                 int lane)
+    {
+        const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+#pragma unroll
+        for (int n = 0; n < RB; ++n)
+#pragma unroll
+            for (int m = 0; m < RA; ++m)
+                W[(4 * n + dcol) * SW + 16 * m + drow] = acc[m][n];
+        const int row = lane % R, cl = lane / R;
+        double t[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            t[it] = W[(it * CPI + cl) * SW + row];
+        if (rlim == R && clim == CN) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                Cw[(int64_t)(it * CPI + cl) * ldc + row] = overwrite ? t[it] : cv[it] - t[it];
+        }
+        else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int col = it * CPI + cl;
+                if (row < rlim && col < clim)
+                    Cw[(int64_t)col * ldc + row] = overwrite ? t[it] : cv[it] - t[it];
+            }
+        }
+    }
+};
+
 // NBUF = 2: double-buffered k loop.  NBUF = 1: the whole k range (<= BKT) is staged at once — the
 // latency-critical one-shot form used by the panel steps of the Cholesky (k = 64): every global
 // load of the workgroup, including its C tile, is in flight before the first wait.
@@ -204,20 +268,15 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
         for (int b = 0; b < RB; ++b)
             acc[a][b] = 0.0;
 
-    // epilogue addressing.  D lane l -> row 4*((l>>2)&3) + (l>>4) of the 16-row slab, column l&3
-    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);
-    const int dcol = lane & 3;
-    double* Cb = g.C + (col0 + wn + dcol) * g.ldc + row0 + wm + drow;
-    const bool interior = (mr == TM && nc == TN);
+    // C tile of this wave in the lane = row layout (WaveTileC); rows/columns of the wave tile inside the matrix
+    using WT = WaveTileC<RA, RB>;
+    double* Cw = g.C + (col0 + wn) * g.ldc + row0 + wm;
+    const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
+    const bool live = rlim > 0 && clim > 0; // a ragged tile can leave a wave without any output
     constexpr bool CPRE = (NBUF == 1); // small one-shot tiles: fetch C together with the operands
-    double cpre[CPRE ? RA : 1][CPRE ? RB : 1];
-    if (CPRE && interior && !g.overwrite) {
-#pragma unroll
-        for (int n = 0; n < RB; ++n)
-#pragma unroll
-            for (int m = 0; m < RA; ++m)
-                cpre[CPRE ? m : 0][CPRE ? n : 0] = Cb[(int64_t)(4 * n) * g.ldc + 16 * m];
-    }
+    double cv[WT::NIT];
+    if (CPRE && live && !g.overwrite)
+        WT::load(cv, Cw, g.ldc, rlim, clim, lane);
 
     SA sa;
     SB sb;
@@ -277,50 +336,15 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
         }
     }
 
-    if (interior) { // no guards
-        if (g.overwrite) {
-#pragma unroll
-            for (int n = 0; n < RB; ++n)
-#pragma unroll
-                for (int m = 0; m < RA; ++m)
-                    Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = acc[m][n];
-        }
-        else if (CPRE) {
-#pragma unroll
-            for (int n = 0; n < RB; ++n)
-#pragma unroll
-                for (int m = 0; m < RA; ++m)
-                    Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = cpre[CPRE ? m : 0][CPRE ? n : 0] - acc[m][n];
-        }
-        else {
-#pragma unroll
-            for (int n = 0; n < RB; ++n) {
-                double cv[RA];
-#pragma unroll
-                for (int m = 0; m < RA; ++m)
-                    cv[m] = Cb[(int64_t)(4 * n) * g.ldc + 16 * m];
-#pragma unroll
-                for (int m = 0; m < RA; ++m)
-                    Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = cv[m] - acc[m][n];
-            }
-        }
-    }
-    else {
-#pragma unroll
-        for (int n = 0; n < RB; ++n) {
-            const bool cok = wn + 4 * n + dcol < nc;
-#pragma unroll
-            for (int m = 0; m < RA; ++m) {
-                if (cok && wm + 16 * m + drow < mr) {
-                    double* cp = Cb + (int64_t)(4 * n) * g.ldc + 16 * m;
-                    if (g.overwrite)
-                        *cp = acc[m][n];
-                    else
-                        *cp -= acc[m][n];
-                }
-            }
-        }
-    }
+    static_assert(4 * WT::SCRATCH <= NBUF * (SA::ELEMS + SB::ELEMS), "transposition scratch must fit in the operand stages");
+    if (!CPRE && live && !g.overwrite)
+        WT::load(cv, Cw, g.ldc, rlim, clim, lane);
+    // the operand stages are dead (the double-buffered k loop ends with a barrier, the one-shot form
+    // needs one here): each wave takes a private slice of them as its transposition scratch
+    if (NBUF == 1)
+        __syncthreads();
+    if (live)
+        WT::store(acc, cv, &lds[0][0] + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
 }
 
 template <int TM, int TN, int BKT, int NBUF>
@@ -448,6 +472,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
             acc[a][b] = 0.0;
 
     const int nk = (int)(g.k / BKT);
+    GTS(0);
     issue(0);
     for (int t = 0; t < nk; ++t) {
         const int st = t % NST;
@@ -458,6 +483,12 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier(); // every wave's pieces of stage st have landed
+        if (t == 0)
+            GTS(1);
+        if (t == 1)
+            GTS(2);
+        if (t == 2)
+            GTS(3);
         const double* As = lds + st * STAGE;
         const double* Bs = As + BKT * SA;
 #pragma unroll
@@ -475,44 +506,46 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
                 for (int m = 0; m < RA; ++m)
                     acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
         }
+        if (t == 1)
+            GTS(6);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier(); // stage st may be refilled
+        if (t == 1)
+            GTS(7);
     }
+    GTS(4);
 
-    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);
-    const int dcol = lane & 3;
-    double* Cb = g.C + (col0 + wn + dcol) * g.ldc + row0 + wm + drow;
-    if (mr == TM && nc == TN) {
-#pragma unroll
-        for (int n = 0; n < RB; ++n) {
-            double cv[RA];
-#pragma unroll
-            for (int m = 0; m < RA; ++m)
-                cv[m] = g.overwrite ? 0.0 : Cb[(int64_t)(4 * n) * g.ldc + 16 * m];
-#pragma unroll
-            for (int m = 0; m < RA; ++m)
-                Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = g.overwrite ? acc[m][n] : cv[m] - acc[m][n];
-        }
-    }
-    else {
-#pragma unroll
-        for (int n = 0; n < RB; ++n) {
-            const bool cok = wn + 4 * n + dcol < nc;
-#pragma unroll
-            for (int m = 0; m < RA; ++m) {
-                if (cok && wm + 16 * m + drow < mr) {
-                    double* cp = Cb + (int64_t)(4 * n) * g.ldc + 16 * m;
-                    if (g.overwrite)
-                        *cp = acc[m][n];
-                    else
-                        *cp -= acc[m][n];
-                }
-            }
+    {
+        // C traffic in the lane = row layout (WaveTileC).  Fetching the tile under the k loop instead
+        // was measured neutral to slightly worse (its loads sit in front of the stage loads in the
+        // in-order vector-memory counter).
+        using WT = WaveTileC<RA, RB>;
+        static_assert(NWV * WT::SCRATCH <= NST * STAGE, "transposition scratch must fit in the operand stages");
+        double* Cw = g.C + (col0 + wn) * g.ldc + row0 + wm;
+        const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
+        if (rlim > 0 && clim > 0) {
+            double cv[WT::NIT];
+            if (!g.overwrite)
+                WT::load(cv, Cw, g.ldc, rlim, clim, lane);
+            // the k loop ended with a barrier: the stages are free, each wave uses a private slice
+            WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
         }
     }
     __syncthreads(); // the next tile's prologue overwrites the LDS stages
+    GTS(5);
     } // logical workgroups
 }
+#ifdef GEMM_TIMING
+void dump_gemm_timing()
+{
+    long long h[16];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_ts), sizeof(h));
+    printf("k_gemm_glds WG0 first tile, cycles: prologue (first stage landed) %lld | k-tile 0 %lld | k-tile 1 %lld (mfma part %lld, closing barrier %lld) | whole k loop %lld | epilogue %lld | total %lld\n",
+           h[1] - h[0], h[2] - h[1], h[3] - h[2], h[6] - h[2], h[7] - h[6], h[4] - h[1], h[5] - h[4], h[5] - h[0]);
+    printf("  epilogue: issue 32 loads %lld | loads complete %lld | issue 32 stores %lld | stores complete %lld | tail %lld\n", h[8] - h[4],
+           h[9] - h[8], h[10] - h[9], h[11] - h[10], h[5] - h[11]);
+}
+#endif
 
 // 64 x 64 tile variant for the mid-size and latency-critical updates (a few hundred tiles, k = 256):
 // 4 waves (32 x 32 each), BKT = 16, FOUR LDS stages (74 KB, two workgroups per CU) so that three
@@ -643,35 +676,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds64(GemmArgs g)
             __builtin_amdgcn_s_barrier(); // stage st may be refilled
         }
 
-        const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);
-        const int dcol = lane & 3;
-        double* Cb = g.C + (col0 + wn + dcol) * g.ldc + row0 + wm + drow;
-        if (mr == TM && nc == TN) {
-#pragma unroll
-            for (int n = 0; n < RB; ++n) {
-                double cv[RA];
-#pragma unroll
-                for (int m = 0; m < RA; ++m)
-                    cv[m] = g.overwrite ? 0.0 : Cb[(int64_t)(4 * n) * g.ldc + 16 * m];
-#pragma unroll
-                for (int m = 0; m < RA; ++m)
-                    Cb[(int64_t)(4 * n) * g.ldc + 16 * m] = g.overwrite ? acc[m][n] : cv[m] - acc[m][n];
-            }
-        }
-        else {
-#pragma unroll
-            for (int n = 0; n < RB; ++n) {
-                const bool cok = wn + 4 * n + dcol < nc;
-#pragma unroll
-                for (int m = 0; m < RA; ++m) {
-                    if (cok && wm + 16 * m + drow < mr) {
-                        double* cp = Cb + (int64_t)(4 * n) * g.ldc + 16 * m;
-                        if (g.overwrite)
-                            *cp = acc[m][n];
-                        else
-                            *cp -= acc[m][n];
-                    }
-                }
+        {
+            using WT = WaveTileC<RA, RB>;
+            static_assert(NWV * WT::SCRATCH <= NST * STAGE, "transposition scratch must fit in the operand stages");
+            double* Cw = g.C + (col0 + wn) * g.ldc + row0 + wm;
+            const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
+            if (rlim > 0 && clim > 0) {
+                double cv[WT::NIT];
+                if (!g.overwrite)
+                    WT::load(cv, Cw, g.ldc, rlim, clim, lane);
+                WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
             }
         }
         __syncthreads();
@@ -731,15 +745,7 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
     g.total = (int)tiles;
     if (g.grid_limit > 0 && tiles > g.grid_limit)
         tiles = g.grid_limit;
-    static int variant = -1;
-    if (variant < 0) {
-        const char* e = getenv("GPE_GLDS_VARIANT"); // tuning: 0 = 8 waves x BKT 32 (1 WG/CU), 1 = 4 waves x BKT 16 (2 WG/CU)
-        variant = e ? atoi(e) : 0;
-    }
-    if (variant == 1)
-        hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 2, 16, 2>), dim3((unsigned)tiles), dim3(256), 0, s, g);
-    else
-        hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 32, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
+    hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 32, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
 }
 
 // number of TM x TN tiles that do work (triangular skipping accounted for)

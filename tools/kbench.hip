@@ -79,6 +79,10 @@ int main(int argc, char** argv)
         launch_trsv_sweep(s, A, ld, N, Xi, w, out, ld, 1, 1);
     }
     CHK(hipStreamSynchronize(s));
+#ifdef GEMM_TIMING
+    extern void dump_gemm_timing();
+    dump_gemm_timing();
+#endif
 #ifdef DIAG_TIMING
     extern void dump_diag_timing();
     dump_diag_timing();
