@@ -594,6 +594,25 @@ struct TileRegs {
     }
 };
 
+// The 32 x 16 accumulator tile of one wave of k_panel_step (acc[m][n]: v_mfma_f64_4x4x4 layout, lane l on
+// row 16 m + 4*((l>>2)&3) + (l>>4), column 4 n + (l&3)) re-arranged with cross-lane moves into the
+// lane = row layout used for all C traffic: out[it] = element (row = lane & 31, column 2 it + (lane >> 5)).
+// A global load/store in the MFMA layout touches 4 columns x 16 rows with neighbouring lanes in
+// different columns and costs ~150 (load) / ~450 (store) cycles just to issue (gemm.hip, WaveTileC);
+// in the row layout an instruction covers two whole 256-byte column pieces.
+static __device__ __forceinline__ void wave_tile_to_rows(const double (&acc)[2][4], double (&out)[8], int lane)
+{
+    const int row = lane & 31;
+    const int src_base = 16 * (row & 3) + 4 * ((row >> 2) & 3);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int src = src_base + ((2 * it + (lane >> 5)) & 3);
+        const double v0 = __shfl(acc[0][it >> 1], src);
+        const double v1 = __shfl(acc[1][it >> 1], src);
+        out[it] = (row >> 4) ? v1 : v0;
+    }
+}
+
 #define PANEL_PRE 3 // head tiles prefetched into registers at kernel start (nbo = 256 needs 3)
 
 __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
@@ -609,7 +628,6 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
     double* Ld = T1 + NB * PS; // L21 of the current diagonal block, Ld[c * XS + k] = L[32 + c][k]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
-    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
     const int b = blockIdx.x;
     const int64_t r0 = j0 + NB, R0 = r0 + (int64_t)NB * b;
     const int nrows = (int)((M - R0 < NB) ? M - R0 : NB);
@@ -649,16 +667,15 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
     own.store(T0);
     // the C tile of the first update (for workgroup 0: the next diagonal block) is fetched now, under
     // the triangular solve, instead of at the top of the update loop
-    double c0v[2][4];
+    // C tiles travel in the lane = row layout (wave_tile_to_rows): element it of a thread is
+    // row wm + (lane & 31), column wn + 2 it + (lane >> 5) of the 64 x 64 tile
+    const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
+    const int crc = crow < nrows ? crow : nrows - 1;
+    double c0v[8];
     if (tmax >= 0) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int row = wm + 16 * m + drow, col = wn + 4 * n + dcol;
-                const int rc = row < nrows ? row : nrows - 1;
-                c0v[m][n] = A[R0 + rc + (r0 + col) * lda];
-            }
+        for (int it = 0; it < 8; ++it)
+            c0v[it] = A[R0 + crc + (r0 + ccol + 2 * it) * lda];
     }
     __syncthreads();
     PTS(1);
@@ -684,19 +701,14 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
 
     PTS(3);
     // 2. in-panel updates of this row block
-    double cres[2][4]; // workgroup 0: the updated next diagonal block
+    double cres[8]; // workgroup 0: the updated next diagonal block (lane = row layout)
 #pragma unroll 1
     for (int t = 0; t <= tmax; ++t) {
         double* Cg = A + R0 + (r0 + (int64_t)NB * t) * lda;
-        double cv[2][4];
+        double cv[8];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int row = wm + 16 * m + drow, col = wn + 4 * n + dcol;
-                const int rc = row < nrows ? row : nrows - 1;
-                cv[m][n] = (t == 0) ? c0v[m][n] : Cg[rc + (int64_t)col * lda];
-            }
+        for (int it = 0; it < 8; ++it)
+            cv[it] = (t == 0) ? c0v[it] : Cg[crc + (int64_t)(ccol + 2 * it) * lda];
         const double* Bop = T0;
         if (t != b) { // head tile of another row block: recompute L_t = A_t X^T
             if (t == 0)
@@ -721,18 +733,17 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
             for (int n = 0; n < 4; ++n)
                 a2[m][n] = 0.0;
         mm64<false>(T0, Bop, wm, wn, lane, a2);
+        double a2r[8];
+        wave_tile_to_rows(a2, a2r, lane);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int row = wm + 16 * m + drow, col = wn + 4 * n + dcol;
-                const double v = cv[m][n] - a2[m][n];
-                if (t == 0)
-                    cres[m][n] = v;
-                // workgroup 0 factors this tile next and writes L over it: no need to store the update
-                if (row < nrows && !(b == 0 && do_next))
-                    Cg[row + (int64_t)col * lda] = v;
-            }
+        for (int it = 0; it < 8; ++it) {
+            const double v = cv[it] - a2r[it];
+            if (t == 0)
+                cres[it] = v;
+            // workgroup 0 factors this tile next and writes L over it: no need to store the update
+            if (crow < nrows && !(b == 0 && do_next))
+                Cg[crow + (int64_t)(ccol + 2 * it) * lda] = v;
+        }
         __syncthreads(); // T1 is free again
     }
 
@@ -744,10 +755,8 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
     double* Ltb = Ls + NB * XS;
     double* invd = Ltb + 4 * NB * 4;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-            Ls[(wm + 16 * m + drow) * XS + wn + 4 * n + dcol] = cres[m][n];
+    for (int it = 0; it < 8; ++it)
+        Ls[crow * XS + ccol + 2 * it] = cres[it];
     __syncthreads();
     // the serial part runs on waves 0-3 (k_diag's code), the inversion pipeline on wave 4; waves
     // 5..7 end here — s_barrier only counts the waves of the workgroup that are still alive
