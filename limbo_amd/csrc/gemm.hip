@@ -189,6 +189,44 @@ struct WaveTileC {
             }
         }
     }
+    // the same in NCH passes over column chunks: 1/NCH of the registers and of the LDS scratch
+    // (SCRATCH / NCH doubles per wave) — for kernels that keep two workgroups per CU
+    template <int NCH>
+    static __device__ __forceinline__ void rmw_chunked(const double (&acc)[RA][RB], double* __restrict__ W,
+                                                       double* __restrict__ Cw, int64_t ldc, int rlim, int clim,
+                                                       bool overwrite, int lane)
+    {
+        static_assert(RB % NCH == 0 && (4 * RB / NCH) % CPI == 0, "chunking");
+        constexpr int RBC = RB / NCH, CNC = 4 * RBC, NITC = CNC / CPI;
+        const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+        const int row = lane % R, cl = lane / R;
+        const int rr = row < rlim ? row : rlim - 1;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            double cv[NITC], t[NITC];
+            if (!overwrite) {
+#pragma unroll
+                for (int it = 0; it < NITC; ++it) {
+                    const int col = ch * CNC + it * CPI + cl;
+                    cv[it] = Cw[(int64_t)(col < clim ? col : clim - 1) * ldc + rr];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < RBC; ++n)
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    W[(4 * n + dcol) * SW + 16 * m + drow] = acc[m][ch * RBC + n];
+#pragma unroll
+            for (int it = 0; it < NITC; ++it)
+                t[it] = W[(it * CPI + cl) * SW + row];
+#pragma unroll
+            for (int it = 0; it < NITC; ++it) {
+                const int col = ch * CNC + it * CPI + cl;
+                if (row < rlim && col < clim)
+                    Cw[(int64_t)col * ldc + row] = overwrite ? t[it] : cv[it] - t[it];
+            }
+        }
+    }
 };
 
 // NBUF = 2: double-buffered k loop.  NBUF = 1: the whole k range (<= BKT) is staged at once — the
@@ -387,8 +425,8 @@ static void launch_tile(hipStream_t s, const GemmArgs& g0)
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int TM, int TN, int WM, int WN, int BKT, int NST>
-__global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
+template <int TM, int TN, int WM, int WN, int BKT, int NST, int EPC = 0, int MINB = 1>
+__global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g)
 {
     static_assert(TM == 128 && TN == 128, "one k-row of an operand tile = one 1 KiB glds instruction");
     constexpr int NWV = WM * WN;
@@ -520,15 +558,20 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_glds(GemmArgs g)
         // was measured neutral to slightly worse (its loads sit in front of the stage loads in the
         // in-order vector-memory counter).
         using WT = WaveTileC<RA, RB>;
-        static_assert(NWV * WT::SCRATCH <= NST * STAGE, "transposition scratch must fit in the operand stages");
+        constexpr int SCR = EPC > 0 ? WT::SCRATCH / EPC : WT::SCRATCH;
+        static_assert(NWV * SCR <= NST * STAGE, "transposition scratch must fit in the operand stages");
         double* Cw = g.C + (col0 + wn) * g.ldc + row0 + wm;
         const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
         if (rlim > 0 && clim > 0) {
-            double cv[WT::NIT];
-            if (!g.overwrite)
-                WT::load(cv, Cw, g.ldc, rlim, clim, lane);
             // the k loop ended with a barrier: the stages are free, each wave uses a private slice
-            WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+            if constexpr (EPC > 0)
+                WT::template rmw_chunked<EPC>(acc, lds + wave * SCR, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+            else {
+                double cv[WT::NIT];
+                if (!g.overwrite)
+                    WT::load(cv, Cw, g.ldc, rlim, clim, lane);
+                WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+            }
         }
     }
     __syncthreads(); // the next tile's prologue overwrites the LDS stages
@@ -745,7 +788,21 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
     g.total = (int)tiles;
     if (g.grid_limit > 0 && tiles > g.grid_limit)
         tiles = g.grid_limit;
-    hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 32, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
+    // Two shapes of the same kernel.  BKT 32 / 147 KB of LDS: one workgroup per CU, fewest barriers — best
+    // when there is at most one tile per CU, and the only choice for the look-ahead update (grid_limit:
+    // the free CUs must stay free).  BKT 16 / 74 KB / <= 128 VGPRs: two workgroups per CU, so one tile's
+    // prologue, epilogue and barrier stalls are covered by the other's MFMAs — 11 % faster on the
+    // 465-tile update of N = 4096 (94 -> 84 us), 2-4 % slower when tiles <= CUs.
+    static int variant = -1;
+    if (variant < 0) {
+        const char* e = getenv("GPE_GLDS_VARIANT"); // tuning: force 0 / 1
+        variant = e ? atoi(e) : 2;
+    }
+    const bool two_per_cu = variant == 2 ? (g.grid_limit <= 0 && g.total > 256) : variant == 1;
+    if (two_per_cu)
+        hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 16, 2, 4, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
+    else
+        hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 32, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
 }
 
 // number of TM x TN tiles that do work (triangular skipping accounted for)
