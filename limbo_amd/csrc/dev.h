@@ -82,6 +82,7 @@ struct GemmArgs {
     int total;     // set by launch_gemm_sub: logical workgroups (glds kernel)
     int grid_limit; // > 0: at most this many physical workgroups (they loop) — leaves CUs to another stream
     int tile;      // 0: pick by problem size; 128 / 64 / 32: force the 128x128 / 64x64 / 32x64 tile
+    void* stop_event; // host side only: hipEvent_t completed by this launch (null: none)
 };
 void launch_gemm_sub(hipStream_t s, const GemmArgs& g);
 double gemm_flops(const GemmArgs& g);

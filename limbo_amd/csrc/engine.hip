@@ -344,7 +344,8 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
             }
         }
         if (pe < N) { // trailing update, k = pw
-            auto upd = [&](hipStream_t st, int64_t c0, int64_t c1, int64_t rlo, int grid_limit = 0) {
+            auto upd = [&](hipStream_t st, int64_t c0, int64_t c1, int64_t rlo, int grid_limit = 0,
+                           hipEvent_t stop = nullptr, int tile = 0) {
                 // C[rlo:M, c0:c1] -= L[rlo:M, p0:pe] L[c0:c1, p0:pe]^T   (elements on/below the diagonal)
                 GemmArgs g{};
                 g.C = A + rlo + c0 * ld;
@@ -360,8 +361,9 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 g.grow0 = rlo;
                 g.gcol0 = c0;
                 g.grid_limit = grid_limit;
+                g.stop_event = stop;
                 if (grid_limit > 0)
-                    g.tile = 128; // the glds kernel is the one that honours grid_limit
+                    g.tile = tile ? tile : 128; // the direct-to-LDS kernels are the ones that honour grid_limit
                 PhaseScope ps(c, GPE_PH_POTRF_UPDATE, gemm_flops(g));
                 launch_gemm_sub(st, g);
             };
@@ -377,20 +379,28 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                     }
                     return c->la_events[i];
                 };
+                // Events per outer panel kp: 3 kp = this panel's next-panel update done (the dispatch's own
+                // completion signal: no marker packet on the critical stream), 3 kp + 1 = the bulk update has
+                // finished the columns of panel kp + 2 ("near" part, done first), 3 kp + 2 = all of it.
+                // The main stream only ever waits for a near part, which completed most of a panel earlier:
+                // waiting for an event that fires just in time cost ~10 us per panel in the kernel trace.
                 const size_t kp = (size_t)(p0 / nbo);
                 if (la_pending)
-                    hipStreamWaitEvent(s, ev(2 * (kp - 1) + 1), 0); // the previous bulk update also wrote these columns
-                upd(s, pe, pe2, pe);
-                hipEventRecord(ev(2 * kp), s); // panel kp factored and the next panel's columns updated:
-                                               // the bulk update starts now and shares the chip with panel kp+1 only
-                hipStreamWaitEvent(c->stream2, ev(2 * kp), 0);
+                    hipStreamWaitEvent(s, ev(3 * (kp - 1) + 1), 0); // the previous bulk update also wrote these columns
+                upd(s, pe, pe2, pe, 0, ev(3 * kp));
+                hipStreamWaitEvent(c->stream2, ev(3 * kp), 0); // the bulk update starts now and shares the chip
+                                                               // with panel kp + 1 only
                 if (nf > 0)
                     launch_head_copy(c->stream2, A, ld, p0, nt0, nf, Hbase);
                 nf = 0;
-                upd(c->stream2, pe2, N, pe2, c->bulk_wgs); // 1 workgroup per CU: leaves 256 - bulk_wgs CUs to the panel
-                hipEventRecord(ev(2 * kp + 1), c->stream2);
+                const int64_t pe3 = std::min<int64_t>(pe2 + nbo, N);
+                upd(c->stream2, pe2, pe3, pe2, c->bulk_wgs, nullptr, 64); // near: what panel kp + 1's update needs
+                hipEventRecord(ev(3 * kp + 1), c->stream2);
+                if (pe3 < N)
+                    upd(c->stream2, pe3, N, pe3, c->bulk_wgs); // 1 workgroup per CU: leaves 256 - bulk_wgs CUs to the panel
+                hipEventRecord(ev(3 * kp + 2), c->stream2);
                 la_pending = true;
-                la_last = 2 * kp + 1;
+                la_last = 3 * kp + 2;
             }
             else {
                 if (la_pending) {

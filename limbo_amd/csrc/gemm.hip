@@ -34,6 +34,7 @@
 //   row-contiguous operand : S[kk][i], row stride = ROWS + 16 doubles  (== 16 mod 32)
 //   k-contiguous operand   : S[i][kk], row stride 18 doubles
 #include "dev.h"
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
@@ -385,6 +386,18 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
         WT::store(acc, cv, &lds[0][0] + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
 }
 
+// Launch with the dispatch's own completion signal as an event when the caller asked for one
+// (GemmArgs::stop_event): a separate hipEventRecord is a marker packet of its own on the stream and
+// costs ~6 us on a dependent chain (rocprofv3 timeline of the factorisation).
+template <typename K>
+static void launch_k(K kern, dim3 grid, dim3 block, hipStream_t s, const GemmArgs& g)
+{
+    if (g.stop_event)
+        hipExtLaunchKernelGGL(kern, grid, block, 0, s, nullptr, (hipEvent_t)g.stop_event, 0, g);
+    else
+        hipLaunchKernelGGL(kern, grid, block, 0, s, g);
+}
+
 template <int TM, int TN, int BKT, int NBUF>
 static void launch_tile(hipStream_t s, const GemmArgs& g0)
 {
@@ -406,13 +419,13 @@ static void launch_tile(hipStream_t s, const GemmArgs& g0)
     }
     dim3 grid((unsigned)tiles), block(256);
     if (!g.a_kmajor && !g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, NBUF, false, false>), grid, block, 0, s, g);
+        launch_k(k_gemm4<TM, TN, BKT, NBUF, false, false>, grid, block, s, g);
     else if (!g.a_kmajor && g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, NBUF, false, true>), grid, block, 0, s, g);
+        launch_k(k_gemm4<TM, TN, BKT, NBUF, false, true>, grid, block, s, g);
     else if (g.a_kmajor && !g.b_kmajor)
-        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, NBUF, true, false>), grid, block, 0, s, g);
+        launch_k(k_gemm4<TM, TN, BKT, NBUF, true, false>, grid, block, s, g);
     else
-        hipLaunchKernelGGL((k_gemm4<TM, TN, BKT, NBUF, true, true>), grid, block, 0, s, g);
+        launch_k(k_gemm4<TM, TN, BKT, NBUF, true, true>, grid, block, s, g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -757,7 +770,7 @@ static void launch_glds64(hipStream_t s, const GemmArgs& g0)
     g.total = (int)tiles;
     if (g.grid_limit > 0 && tiles > g.grid_limit)
         tiles = g.grid_limit;
-    hipLaunchKernelGGL(k_gemm_glds64, dim3((unsigned)tiles), dim3(256), 0, s, g);
+    launch_k(k_gemm_glds64, dim3((unsigned)tiles), dim3(256), s, g);
 }
 
 static bool glds_ok(const GemmArgs& g)
@@ -800,9 +813,9 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
     }
     const bool two_per_cu = variant == 2 ? (g.grid_limit <= 0 && g.total > 256) : variant == 1;
     if (two_per_cu)
-        hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 16, 2, 4, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
+        launch_k(k_gemm_glds<128, 128, 2, 4, 16, 2, 4, 2>, dim3((unsigned)tiles), dim3(512), s, g);
     else
-        hipLaunchKernelGGL((k_gemm_glds<128, 128, 2, 4, 32, 2>), dim3((unsigned)tiles), dim3(512), 0, s, g);
+        launch_k(k_gemm_glds<128, 128, 2, 4, 32, 2>, dim3((unsigned)tiles), dim3(512), s, g);
 }
 
 // number of TM x TN tiles that do work (triangular skipping accounted for)
