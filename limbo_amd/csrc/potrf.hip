@@ -30,10 +30,13 @@
 #define DIAG_ABL 0 // debug ablations (tools/kbench): 1 = no factorisation rounds, 2 = no inversion
 #endif
 #ifdef DIAG_TIMING
+__device__ long long g_diag_arr[16][8]; // per round: arrival of waves 0-3 and of the inversion wave (4) at the closing barrier
+#define ARR(G, w) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_diag_arr[G][w] = clock64(); } while (0)
 __device__ long long g_diag_ts[32];
 #define TS(i) do { if (threadIdx.x == 0) g_diag_ts[i] = clock64(); } while (0)
 #else
 #define TS(i) do { } while (0)
+#define ARR(G, w) do { } while (0)
 #endif
 #ifdef DIAG_TIMING
 __device__ long long g_panel_ts[64];
@@ -194,6 +197,7 @@ struct DiagRound {
             if (G > 0)
                 rank4_update(a, Lp, r, w, G, 0);
         }
+        ARR(G, w);
         __syncthreads();
         if (G < 16)
             TS(10 + G);
@@ -219,6 +223,7 @@ struct XPipe32 {
                                                const double* __restrict__ invd, double* __restrict__ Xt, int c)
     {
         XPipe32<G - 1>::run(S, Ls, invd, Xt, c);
+        ARR(G, 4);
         __syncthreads(); // = the barrier that ends round G: columns 4G..4G+3 of L and their pivots are final
         constexpr int hb = G >> 3, i0 = 4 * (G & 7), base = 32 * hb;
         if ((c >> 5) == hb) {
@@ -463,6 +468,24 @@ __global__ __launch_bounds__(256) void k_diag_full(double* __restrict__ A, int64
 #ifdef DIAG_TIMING
 void dump_diag_timing()
 {
+    {
+        long long a[16][8];
+        (void)hipMemcpyFromSymbol(a, HIP_SYMBOL(g_diag_arr), sizeof(a));
+        printf("arrival at the closing barrier of round G, cycles after the previous barrier's last arrival (waves 0-3 factor, X = inversion wave; * = owner):\n");
+        long long prev = 0;
+        for (int G = 0; G < 16; ++G) {
+            long long last = 0;
+            for (int w = 0; w < 5; ++w)
+                last = a[G][w] > last ? a[G][w] : last;
+            if (G > 0) {
+                printf("  G=%2d:", G);
+                for (int w = 0; w < 5; ++w)
+                    printf(" %s%6lld%s", w == 4 ? "X" : "w", a[G][w] - prev, w == (G & 3) ? "*" : " ");
+                printf("\n");
+            }
+            prev = last;
+        }
+    }
     long long h[32];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag_ts), sizeof(h));
     printf("k_diag cycles (factor waves): load %lld | rounds %lld | writeL %lld | total %lld\n", h[1] - h[0], h[2] - h[1],
