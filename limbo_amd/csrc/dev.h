@@ -93,11 +93,16 @@ double gemm_flops(const GemmArgs& g);
 // Xt_all: inverses of the 64 x 64 diagonal blocks (launch_diag / launch_diag_inv).
 void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, double* w,
                        double* out, int64_t ldw, int P, int trans);
-// the whole backward sweep a = L^-T y in one data-flow launch (err: set to 1 if a hand-off timed out)
-void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, double* y,
-                          double* a, int64_t ldw, int P, int* err);
+// the whole backward sweep a = L^-T y in one data-flow launch for nblk = ceil(N/64) <= 256 (the caller
+// checks).  y[i * ysi + p * ysp]; err: set to 1 if a hand-off timed out; prefilled: `a` already holds
+// the all-ones sentinel; part (optional, 2 nblk doubles): per-block partial sums of log L_ii and
+// om . a (part_acc: add to the second half instead of overwriting)
+void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* y,
+                          int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P, int* err, int prefilled, const double* om,
+                          int64_t ldom, double* part, int part_acc);
 // Arows[p + i*lda] = V[i + p*ldv] (P rows appended under the matrix) and back
-void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N, int P, double* Arows, int64_t lda);
+void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N, int P, double* Arows, int64_t lda,
+                         double* sent = nullptr);
 void launch_rows_to_cols(hipStream_t s, const double* Arows, int64_t lda, int64_t N, int P, double* V, int64_t ldv);
 // out[0] = sum_i log L_ii ; out[1] = sum_{i,p} obs_mean * alpha   (gp.hpp:274-277)
 void launch_loglik_terms(hipStream_t s, const double* L, int64_t ldl, int64_t N, const double* om, const double* alpha,

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,6 +44,7 @@ struct gpe_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead: bulk of a trailing update runs here, behind the next panel
     std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
+    int64_t xinv_done = 0;      // diagonal blocks whose inverse is already complete (done per panel on stream2)
     bool lookahead = true;             // GPE_LOOKAHEAD=0 disables
     int bulk_wgs = 192;                // physical workgroups of a look-ahead bulk update (GPE_BULK_WGS)
     std::mutex mu;
@@ -58,8 +60,10 @@ struct gpe_ctx {
     double* dHead = nullptr; // scratch tiles of the fused panel steps (k_panel_step)
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     int64_t grad_partial_cap = 0;
-    int* dInfo = nullptr;
-    double* dScal = nullptr; // [0] sum log L_ii, [1] trace(om^T alpha), [2] knn scratch
+    int* dInfo = nullptr; // = hInfo: pinned host memory the kernels write directly (no copy-back, no device memset)
+    double* dScal = nullptr; // [0] sum log L_ii, [1] trace(om^T alpha), [2] knn scratch, [8 .. 8 + 2 nblk) per-block partials
+    int ll_partials = 0;     // > 0: the backward sweep left that many per-block partial sums instead of [0], [1]
+    bool al_prefilled = false; // alpha holds the sentinel pattern of the data-flow sweep
     int* hInfo = nullptr;    // pinned
     double* hScal = nullptr; // pinned
     bool have_L = false, inv_ok = false, host_K = false, ll_ok = false;
@@ -393,6 +397,10 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 if (nf > 0)
                     launch_head_copy(c->stream2, A, ld, p0, nt0, nf, Hbase);
                 nf = 0;
+                if (c->fuse_panel && c->xinv_done == p0 / NB && pw % NB == 0) { // this panel's block inverses:
+                    launch_xinv_complete(c->stream2, A, ld, p0 / NB, pw / NB, c->dXinv); // off the critical path
+                    c->xinv_done = pe / NB;
+                }
                 const int64_t pe3 = std::min<int64_t>(pe2 + nbo, N);
                 upd(c->stream2, pe2, pe3, pe2, c->bulk_wgs, nullptr, 64); // near: what panel kp + 1's update needs
                 hipEventRecord(ev(3 * kp + 1), c->stream2);
@@ -421,10 +429,11 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     }
     if (la_pending)
         hipStreamWaitEvent(s, c->la_events[la_last], 0);
-    if (c->fuse_panel && N >= NB) { // off-diagonal quarters of the block inverses (half-form steps)
+    if (c->fuse_panel && N / NB > c->xinv_done) { // off-diagonal quarters of the remaining block inverses
         PhaseScope ps(c, GPE_PH_POTRF_PANEL, 0.0);
-        launch_xinv_complete(s, A, ld, 0, N / NB, c->dXinv);
+        launch_xinv_complete(s, A, ld, c->xinv_done, N / NB - c->xinv_done, c->dXinv);
     }
+    c->xinv_done = 0;
 }
 
 // Z <- L^-1 B in place, B is N x M (ldb).  identity_structure: B starts as the identity, so at
@@ -500,6 +509,7 @@ void trsm_left_blocked(gpe_ctx* c, const double* L, double* B, int64_t ldb, int6
 void solve_alpha(gpe_ctx* c)
 {
     hipStream_t s = c->stream;
+    c->ll_partials = 0;
     PhaseScope ps(c, GPE_PH_SOLVE, 2.0 * (double)c->N * c->N * c->P);
     for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) {
         int pc = std::min(GPE_MAX_P, c->P - p0);
@@ -514,23 +524,32 @@ void solve_alpha_from_z(gpe_ctx* c)
 {
     hipStream_t s = c->stream;
     PhaseScope ps(c, GPE_PH_SOLVE, (double)c->N * c->N * c->P);
+    const int64_t nblk = (c->N + NB - 1) / NB;
+    const bool flow = c->flow_solve && nblk <= 256; // every workgroup of the data-flow sweep must be resident
     for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) {
         int pc = std::min(GPE_MAX_P, c->P - p0);
-        launch_rows_to_cols(s, c->dA + c->N + p0, c->ld, c->N, pc, c->dY, c->ld);
-        if (c->flow_solve)
-            launch_trsv_bwd_flow(s, c->dA, c->ld, c->N, c->dXinv, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc,
-                                 c->dInfo + 1);
-        else
+        if (flow) // reads z straight from the appended rows, leaves the log-likelihood partial sums
+            launch_trsv_bwd_flow(s, c->dA, c->ld, c->N, c->dXinv, c->dA + c->N + p0, c->ld, 1, c->dAl + (int64_t)p0 * c->ld,
+                                 c->ld, pc, c->dInfo + 1, c->al_prefilled ? 1 : 0, c->dOm + (int64_t)p0 * c->ld, c->ld,
+                                 c->hScal + 8, p0 > 0 ? 1 : 0);
+        else {
+            launch_rows_to_cols(s, c->dA + c->N + p0, c->ld, c->N, pc, c->dY, c->ld);
             launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc, 1);
+        }
     }
+    c->al_prefilled = false;
+    c->ll_partials = flow ? (int)nblk : 0;
 }
 
 void enqueue_loglik_terms(gpe_ctx* c)
 {
     PhaseScope ps(c, GPE_PH_LOGLIK, 0.0);
-    launch_loglik_terms(c->stream, c->dA, c->ld, c->N, c->dOm, c->dAl, c->ld, c->P, c->dScal);
-    hipMemcpyAsync(c->hScal, c->dScal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    hipMemcpyAsync(c->hInfo, c->dInfo, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    // flow path: gp.hpp:274-277 from the sweep's per-block partials, which it wrote straight into the pinned
+    // host buffer (hScal + 8); they are added on the host in block order.  Nothing to enqueue.
+    if (c->ll_partials == 0) {
+        launch_loglik_terms(c->stream, c->dA, c->ld, c->N, c->dOm, c->dAl, c->ld, c->P, c->dScal);
+        hipMemcpyAsync(c->hScal, c->dScal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    }
 }
 
 int compute_enqueue(gpe_ctx* c)
@@ -539,7 +558,7 @@ int compute_enqueue(gpe_ctx* c)
         return GPE_ERR_STATE;
     hipStream_t s = c->stream;
     digest_kernel(c);
-    HIPCHK(c, hipMemsetAsync(c->dInfo, 0, 2 * sizeof(int), s));
+    c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
     if (c->host_K) {
         if (!c->dKhost)
             return GPE_ERR_STATE;
@@ -548,9 +567,17 @@ int compute_enqueue(gpe_ctx* c)
     }
     else {
         PhaseScope ps(c, GPE_PH_KERNEL_BUILD, 0.0);
+        // (Building only the first panel's columns here and the rest on the second stream, underneath the
+        // first panel's factorisation, was tried: unbounded it slows the latency-bound k_diag / panel-step
+        // workgroups it shares CUs with as much as it saves; bounded to 128 looping workgroups it takes
+        // 250 us — a tile is latency-bound and needs ~8 co-resident workgroups per CU.)
         launch_build_K(s, c->dXt, c->ld, c->N, c->kp, c->dA, c->ld);
     }
-    launch_cols_to_rows(s, c->dOm, c->ld, c->N, c->P, c->dA + c->N, c->ld);
+    {
+        const bool flow = c->flow_solve && (c->N + NB - 1) / NB <= 256;
+        launch_cols_to_rows(s, c->dOm, c->ld, c->N, c->P, c->dA + c->N, c->ld, flow ? c->dAl : nullptr);
+        c->al_prefilled = flow;
+    }
     potrf_blocked(c, c->dA, c->N, c->N + c->P);
     c->have_L = true;
     c->inv_ok = false; // gp.hpp:570
@@ -559,11 +586,38 @@ int compute_enqueue(gpe_ctx* c)
     return GPE_OK;
 }
 
+// Host wait for the stream.  A blocking hipStreamSynchronize costs a sleep/wake-up of the calling thread
+// (tens of microseconds between back-to-back evaluations of a few milliseconds each); poll for up to
+// 20 ms first, then block.
+static hipError_t wait_stream(hipStream_t s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int i = 0; i < 64; ++i) {
+            hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady)
+                return e;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+            return hipStreamSynchronize(s);
+    }
+}
+
 int compute_finish(gpe_ctx* c)
 {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, wait_stream(c->stream));
     HIPCHK(c, hipGetLastError());
     drain_phases(c);
+    if (c->ll_partials > 0) {
+        long double sl = 0.0L, sa = 0.0L;
+        for (int j = 0; j < c->ll_partials; ++j) {
+            sl += c->hScal[8 + j];
+            sa += c->hScal[8 + c->ll_partials + j];
+        }
+        c->hScal[0] = (double)sl;
+        c->hScal[1] = (double)sa;
+        c->ll_partials = 0;
+    }
     c->ll_ok = true;
     if (c->hInfo[1] != 0) { // the data-flow solve gave up waiting for a producer (never legal)
         c->err = "backward sweep: inter-workgroup hand-off timed out";
@@ -738,14 +792,14 @@ int gpe_create(int device_id, gpe_handle* out)
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
         || create_bulk_stream(&c->stream2) != hipSuccess
-        || hipMalloc(&c->dInfo, 64) != hipSuccess || hipMalloc(&c->dScal, 64) != hipSuccess
+        || hipMalloc(&c->dScal, 8192) != hipSuccess
         || hipMalloc(&c->dHead, sizeof(double) * 64 * NB * NB) != hipSuccess
-        || hipHostMalloc(&c->hInfo, 64) != hipSuccess || hipHostMalloc(&c->hScal, 64) != hipSuccess) {
+        || hipHostMalloc(&c->hInfo, 64) != hipSuccess || hipHostMalloc(&c->hScal, 8192) != hipSuccess) {
         delete c;
         return GPE_ERR_HIP;
     }
-    hipMemset(c->dInfo, 0, 64);
-    c->hInfo[0] = c->hInfo[1] = 0;
+    memset(c->hInfo, 0, 64);
+    c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
     if (const char* f = getenv("GPE_BULK_WGS"))
         c->bulk_wgs = atoi(f);
     if (const char* f = getenv("GPE_LOOKAHEAD"))
@@ -774,7 +828,6 @@ int gpe_destroy(gpe_handle c)
     for (auto e : c->pool)
         hipEventDestroy(e);
     free_dev(c);
-    hipFree(c->dInfo);
     hipFree(c->dScal);
     hipFree(c->dHead);
     hipHostFree(c->hInfo);
@@ -970,7 +1023,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     launch_transpose_x(s, c->dY, 1, D, c->dXt, ld, n);
     HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * ld, obs_mean, sizeof(double) * (n + 1),
                                sizeof(double) * (n + 1), P, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(c->dInfo, 0, 2 * sizeof(int), s));
+    c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
     {
         PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)n * n);
         // k(x_i, x_new) for i = 0..n (gp.hpp:583-586), no noise yet

@@ -177,24 +177,33 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, co
 // ordering with anything else).  All nblk <= 256 workgroups are resident (1 per CU), so the
 // pipeline cannot deadlock; the poll is bounded anyway and raises *err instead of hanging.
 // ---------------------------------------------------------------------------------------------
+// y is addressed as y[i * ysi + p * ysp]: a column per right-hand side (ysi = 1, ysp = ldw) or the rows
+// appended under the factor by the fused forward solve (ysi = ld, ysp = 1) — no conversion launch.
+// part (optional, 2 nblk doubles): workgroup j also leaves sum_i log L_ii over its block in part[j] and
+// sum_{i,p} om[i,p] a[i,p] in part[nblk + j] (added to what is there when part_acc): the log-likelihood
+// terms of gp.hpp:274-277 then need no launch of their own, the host adds the nblk partials in order.
 __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict__ L, int64_t ld, int64_t N,
                                                        const double* __restrict__ Xt_all, const double* __restrict__ y,
-                                                       double* a, int64_t ldw, int P, int* __restrict__ err)
+                                                       int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
+                                                       int* __restrict__ err, const double* __restrict__ om,
+                                                       int64_t ldom, double* __restrict__ part, int part_acc)
 {
     __shared__ double Stg[NB * LSTR];
     __shared__ double xs[NB];
     __shared__ double wj[NB];
-    __shared__ double part[4][NB];
+    __shared__ double part_s[4][NB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t nblk = (N + NB - 1) / NB;
     const int64_t j = blockIdx.x, j0 = j * NB;
     const int jb = (int)((N - j0 < NB) ? N - j0 : NB);
     const unsigned long long SENT = ~0ull;
+    double ld_part = 0.0, oa_part = 0.0; // wave 0: this lane's log L_ii and sum_p om a
+    if (part && threadIdx.x < NB && lane < jb)
+        ld_part = log(L[(j0 + lane) + (j0 + lane) * ld]);
     for (int p = 0; p < P; ++p) {
-        const double* yp = y + (int64_t)p * ldw;
         double* ap = a + (int64_t)p * ldw;
         if (threadIdx.x < NB)
-            wj[lane] = (lane < jb) ? yp[j0 + lane] : 0.0;
+            wj[lane] = (lane < jb) ? y[(j0 + lane) * ysi + p * ysp] : 0.0;
         // tile of the first contributor, prefetched: T[k][c] = L[t0 + k][j0 + c], lane = k
         double tl[16];
         int64_t t = nblk - 1;
@@ -248,10 +257,10 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
                 const int k = 16 * wv + kk;
                 acc = fma(Stg[lane * LSTR + k], xs[k], acc);
             }
-            part[wv][lane] = acc;
+            part_s[wv][lane] = acc;
             __syncthreads();
             if (threadIdx.x < NB)
-                wj[lane] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+                wj[lane] -= (part_s[0][lane] + part_s[1][lane]) + (part_s[2][lane] + part_s[3][lane]);
         }
         __syncthreads();
         // a_j = X_j^T w_j :  a[c] = sum_r Xt[c + 64 r] w[r]   (coalesced along c)
@@ -262,43 +271,60 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
             const int r = 16 * wv + kk;
             acc = fma(Xt[lane + NB * r], wj[r], acc);
         }
-        part[wv][lane] = acc;
+        part_s[wv][lane] = acc;
         __syncthreads();
         if (threadIdx.x < NB && lane < jb) {
-            const double v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            const double v = (part_s[0][lane] + part_s[1][lane]) + (part_s[2][lane] + part_s[3][lane]);
             __hip_atomic_store((unsigned long long*)(ap + j0 + lane), (unsigned long long)__double_as_longlong(v),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (part)
+                oa_part = fma(om[j0 + lane + (int64_t)p * ldom], v, oa_part);
         }
         __syncthreads();
     }
+    if (part && threadIdx.x < NB) { // wave 0: fixed-order butterfly, bitwise reproducible
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ld_part += __shfl_xor(ld_part, o);
+            oa_part += __shfl_xor(oa_part, o);
+        }
+        if (lane == 0) {
+            if (!part_acc)
+                part[j] = ld_part;
+            part[nblk + j] = (part_acc ? part[nblk + j] : 0.0) + oa_part;
+        }
+    }
 }
 
-// a <- L^-T y in one launch; `a` must not alias y.  Falls back to the per-block sweep when the
-// blocks cannot all be resident.
-void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, double* y,
-                          double* a, int64_t ldw, int P, int* err)
+// a <- L^-T y in one launch (nblk <= 256: all workgroups resident); `a` must not alias y
+void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* y,
+                          int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P, int* err, int prefilled, const double* om,
+                          int64_t ldom, double* part, int part_acc)
 {
     if (N <= 0)
         return;
     const int64_t nblk = (N + NB - 1) / NB;
-    if (nblk > 256) {
-        launch_trsv_sweep(s, L, ld, N, Xt_all, y, a, ldw, P, 1);
-        return;
-    }
-    for (int p = 0; p < P; ++p)
-        hipMemsetAsync(a + (int64_t)p * ldw, 0xFF, sizeof(double) * (size_t)N, s);
-    hipLaunchKernelGGL(k_trsv_bwd_flow, dim3((unsigned)nblk), dim3(256), 0, s, L, ld, N, Xt_all, y, a, ldw, P, err);
+    if (!prefilled)
+        for (int p = 0; p < P; ++p)
+            hipMemsetAsync(a + (int64_t)p * ldw, 0xFF, sizeof(double) * (size_t)N, s);
+    hipLaunchKernelGGL(k_trsv_bwd_flow, dim3((unsigned)nblk), dim3(256), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err,
+                       om, ldom, part, part_acc);
 }
 
 // rows N..N+P-1 of the matrix <- obs_mean^T (before the factorisation) and back (z = L^-1 obs_mean
 // after it): the forward substitution rides along the Cholesky as P extra rows of the panel.
+// sent (optional): N x P vector (ld = ldv) pre-filled with the all-ones pattern the data-flow backward
+// sweep polls for — saves that sweep a memset on the critical path
 __global__ void k_cols_to_rows(const double* __restrict__ V, int64_t ldv, int64_t N, int P, double* __restrict__ Arows,
-                               int64_t lda)
+                               int64_t lda, double* __restrict__ sent)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N)
-        for (int p = 0; p < P; ++p)
+        for (int p = 0; p < P; ++p) {
             Arows[p + i * lda] = V[i + (int64_t)p * ldv];
+            if (sent)
+                ((unsigned long long*)sent)[i + (int64_t)p * ldv] = ~0ull;
+        }
 }
 __global__ void k_rows_to_cols(const double* __restrict__ Arows, int64_t lda, int64_t N, int P, double* __restrict__ V,
                                int64_t ldv)
@@ -308,10 +334,11 @@ __global__ void k_rows_to_cols(const double* __restrict__ Arows, int64_t lda, in
         for (int p = 0; p < P; ++p)
             V[i + (int64_t)p * ldv] = Arows[p + i * lda];
 }
-void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N, int P, double* Arows, int64_t lda)
+void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N, int P, double* Arows, int64_t lda,
+                         double* sent)
 {
     if (N > 0 && P > 0)
-        hipLaunchKernelGGL(k_cols_to_rows, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, V, ldv, N, P, Arows, lda);
+        hipLaunchKernelGGL(k_cols_to_rows, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, V, ldv, N, P, Arows, lda, sent);
 }
 void launch_rows_to_cols(hipStream_t s, const double* Arows, int64_t lda, int64_t N, int P, double* V, int64_t ldv)
 {
