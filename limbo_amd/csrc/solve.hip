@@ -177,6 +177,12 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, co
 // ordering with anything else).  All nblk <= 256 workgroups are resident (1 per CU), so the
 // pipeline cannot deadlock; the poll is bounded anyway and raises *err instead of hanging.
 // ---------------------------------------------------------------------------------------------
+#ifdef FLOW_TIMING
+__device__ long long g_flow_ts[256][8]; // per block j: start, after fold #1, #2, #8, last fold done, solved, published, #folds
+#define FTS(i) do { if (threadIdx.x == 0) g_flow_ts[j][i] = wall_clock64(); } while (0)
+#else
+#define FTS(i) do { } while (0)
+#endif
 // y is addressed as y[i * ysi + p * ysp]: a column per right-hand side (ysi = 1, ysp = ldw) or the rows
 // appended under the factor by the fused forward solve (ysi = ld, ysp = 1) — no conversion launch.
 // part (optional, 2 nblk doubles): workgroup j also leaves sum_i log L_ii over its block in part[j] and
@@ -193,51 +199,79 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
     __shared__ double wj[NB];
     __shared__ double part_s[4][NB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv); // the same value, known to be wave-uniform
     const int64_t nblk = (N + NB - 1) / NB;
-    const int64_t j = blockIdx.x, j0 = j * NB;
+    // Workgroup -> unknown block.  Workgroups b, b + 8, b + 16, .. share an XCD (and its L2); the chain
+    // a_j -> a_(j-1) is handed from workgroup to workgroup, so consecutive blocks go to one XCD: the
+    // XCD that holds blockIdx.x % 8 owns a contiguous range of blocks, and only 7 of the hops cross XCDs.
+    int64_t j;
+    {
+        const int64_t q = nblk / 8, r = nblk % 8, x = blockIdx.x % 8, idx = blockIdx.x / 8;
+        j = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+    }
+    const int64_t j0 = j * NB;
     const int jb = (int)((N - j0 < NB) ? N - j0 : NB);
     const unsigned long long SENT = ~0ull;
     double ld_part = 0.0, oa_part = 0.0; // wave 0: this lane's log L_ii and sum_p om a
     if (part && threadIdx.x < NB && lane < jb)
         ld_part = log(L[(j0 + lane) + (j0 + lane) * ld]);
+    FTS(0);
     for (int p = 0; p < P; ++p) {
         double* ap = a + (int64_t)p * ldw;
         if (threadIdx.x < NB)
             wj[lane] = (lane < jb) ? y[(j0 + lane) * ysi + p * ysp] : 0.0;
-        // tile of the first contributor, prefetched: T[k][c] = L[t0 + k][j0 + c], lane = k
-        double tl[16];
-        int64_t t = nblk - 1;
-        auto fetch = [&](int64_t tt) {
+        // Contributors t = nblk-1 .. j+1, software-pipelined FOUR deep: both the tile T[k][c] = L[t0 + k][j0 + c]
+        // (lane = k) and the first look at a_t are requested four folds ahead.  With one tile in flight and
+        // the poll issued at the point of use, every fold paid a full memory round trip (~2.5 us), even for
+        // contributions published long before — the last workgroup's 63 folds WERE the kernel time.
+        double tl[4][16];
+        unsigned long long pb[4] = {SENT, SENT, SENT, SENT};
+        auto fetch = [&](double (&dst)[16], unsigned long long& peek, int64_t tt) {
             const int64_t t0 = tt * NB;
             const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
             const int kc = lane < tb ? lane : tb - 1;
+            const double rowmask = lane < tb ? 1.0 : 0.0;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int c = wv + 4 * q;
+                // Unconditional load from a clamped (valid) address, masked by a multiplication: written as
+                // `cond ? load : 0` the compiler predicates every load and waits for each one in turn
+                // (s_cbranch_execz + s_waitcnt vmcnt(0) per load: 8 serial round trips per tile, 3 us a fold).
+                // The column is wave-uniform (wvu): scalar base + one 32-bit lane offset, no 64-bit vector
+                // address per load (16 of those per tile in flight x 4 tiles spilled to scratch).
+                const int c = wvu + 4 * q;
                 const int cc = c < jb ? c : jb - 1;
-                const double v = L[t0 + kc + (j0 + cc) * ld];
-                tl[q] = (lane < tb && c < jb) ? v : 0.0;
+                const double* col = L + t0 + (j0 + cc) * ld;
+                dst[q] = col[kc] * (c < jb ? rowmask : 0.0);
             }
+            // first look at a_t (clamped address; lanes past the block read a valid neighbour and ignore it)
+#ifdef FLOW_NOPOLL
+            peek = 0x3ff0000000000000ull; // timing experiment: pretend every contribution is 1.0 and already there
+#else
+            peek = __hip_atomic_load((const unsigned long long*)(ap + t0 + kc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         };
-        if (t > j)
-            fetch(t);
-        for (; t > j; --t) {
+        auto fold = [&](const double (&src)[16], unsigned long long peek, int64_t t) {
             __syncthreads(); // Stg / xs of the previous contributor are consumed
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                Stg[(wv + 4 * q) * LSTR + lane] = tl[q]; // Stg[c][k]
-            if (t - 1 > j)
-                fetch(t - 1); // in flight while we wait for a_t
+                Stg[(wv + 4 * q) * LSTR + lane] = src[q]; // Stg[c][k]
             if (threadIdx.x < NB) {
                 const int64_t t0 = t * NB;
                 const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
                 double v = 0.0;
                 if (lane < tb) {
-                    unsigned long long bits = SENT;
+                    unsigned long long bits = peek;
                     int spins = 0;
-                    while (true) {
-                        bits = __hip_atomic_load((const unsigned long long*)(ap + t0 + lane), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                    while (bits == SENT) { // not there four folds ago: poll.  Three looks that this XCD's L2 may
+                                           // serve (workgroup scope) for every one that goes to memory (agent
+                                           // scope; the producer stores with agent scope): always correct,
+                                           // quicker when producer and consumer share an XCD
+                        if ((spins & 3) != 3)
+                            bits = __hip_atomic_load((const unsigned long long*)(ap + t0 + lane), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else
+                            bits = __hip_atomic_load((const unsigned long long*)(ap + t0 + lane), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
                         if (bits != SENT)
                             break;
                         if (++spins > (1 << 24)) { // ~seconds: a lost producer, never a legal state
@@ -261,7 +295,43 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
             __syncthreads();
             if (threadIdx.x < NB)
                 wj[lane] -= (part_s[0][lane] + part_s[1][lane]) + (part_s[2][lane] + part_s[3][lane]);
+#ifdef FLOW_TIMING
+            {
+                const int64_t nf = nblk - t; // folds done so far
+                if (nf == 1) FTS(1);
+                if (nf == 2) FTS(2);
+                if (nf == 8) FTS(3);
+                if (t == j + 1) FTS(4);
+            }
+#endif
+        };
+        // branch-free main loop: tile indices are clamped instead of guarded, so the compiler knows exactly how
+        // many loads are younger than the ones a fold needs and waits for no more than that
+        int64_t t = nblk - 1;
+        auto clampt = [&](int64_t tt) { return tt > j ? tt : (j + 1 < nblk ? j + 1 : nblk - 1); };
+        if (t > j) {
+            fetch(tl[0], pb[0], clampt(t));
+            fetch(tl[1], pb[1], clampt(t - 1));
+            fetch(tl[2], pb[2], clampt(t - 2));
+            fetch(tl[3], pb[3], clampt(t - 3));
         }
+        for (; t - 3 > j; t -= 4) {
+            fold(tl[0], pb[0], t);
+            fetch(tl[0], pb[0], clampt(t - 4));
+            fold(tl[1], pb[1], t - 1);
+            fetch(tl[1], pb[1], clampt(t - 5));
+            fold(tl[2], pb[2], t - 2);
+            fetch(tl[2], pb[2], clampt(t - 6));
+            fold(tl[3], pb[3], t - 3);
+            fetch(tl[3], pb[3], clampt(t - 7));
+        }
+        // 0-3 contributors left; their tiles are in tl[0..2]
+        if (t > j)
+            fold(tl[0], pb[0], t);
+        if (t - 1 > j)
+            fold(tl[1], pb[1], t - 1);
+        if (t - 2 > j)
+            fold(tl[2], pb[2], t - 2);
         __syncthreads();
         // a_j = X_j^T w_j :  a[c] = sum_r Xt[c + 64 r] w[r]   (coalesced along c)
         const double* Xt = Xt_all + j * (NB * NB);
@@ -273,6 +343,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
         }
         part_s[wv][lane] = acc;
         __syncthreads();
+        FTS(5);
         if (threadIdx.x < NB && lane < jb) {
             const double v = (part_s[0][lane] + part_s[1][lane]) + (part_s[2][lane] + part_s[3][lane]);
             __hip_atomic_store((unsigned long long*)(ap + j0 + lane), (unsigned long long)__double_as_longlong(v),
@@ -280,6 +351,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
             if (part)
                 oa_part = fma(om[j0 + lane + (int64_t)p * ldom], v, oa_part);
         }
+        FTS(6);
         __syncthreads();
     }
     if (part && threadIdx.x < NB) { // wave 0: fixed-order butterfly, bitwise reproducible
@@ -296,6 +368,19 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
     }
 }
 
+#ifdef FLOW_TIMING
+#include <cstdio>
+void dump_flow_timing(int nblk)
+{
+    static long long h[256][8];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_flow_ts), sizeof(h));
+    long long t0 = h[nblk - 1][0];
+    printf("backward flow solve (10 ns ticks since the first workgroup started): block | start | fold1 fold2 fold8 done | last fold done | solved | published\n");
+    for (int j = nblk - 1; j >= 0; j -= (j > nblk - 4 || j < 4) ? 1 : 6)
+        printf("  %3d | %5lld | %5lld %5lld %5lld | %6lld | %6lld | %6lld\n", j, h[j][0] - t0, h[j][1] - t0, h[j][2] - t0, h[j][3] - t0, h[j][4] - t0,
+               h[j][5] - t0, h[j][6] - t0);
+}
+#endif
 // a <- L^-T y in one launch (nblk <= 256: all workgroups resident); `a` must not alias y
 void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* y,
                           int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P, int* err, int prefilled, const double* om,

@@ -79,6 +79,23 @@ int main(int argc, char** argv)
         launch_trsv_sweep(s, A, ld, N, Xi, w, out, ld, 1, 1);
     }
     CHK(hipStreamSynchronize(s));
+#ifdef FLOW_TIMING
+    {
+        int* err;
+        CHK(hipMalloc(&err, 8));
+        CHK(hipMemset(err, 0, 8));
+        double *a2, *yv;
+        CHK(hipMalloc(&a2, sizeof(double) * ld));
+        CHK(hipMalloc(&yv, sizeof(double) * ld));
+        CHK(hipMemset(yv, 0, sizeof(double) * ld));
+        for (int rep = 0; rep < 3; ++rep) { // the last (warm) repetition is the one reported
+            launch_trsv_bwd_flow(s, A0, ld, N, Xi, yv, 1, ld, a2, ld, 1, err, 0, nullptr, 0, nullptr, 0);
+            CHK(hipStreamSynchronize(s));
+        }
+        extern void dump_flow_timing(int);
+        dump_flow_timing((int)(N / 64));
+    }
+#endif
 #ifdef GEMM_TIMING
     extern void dump_gemm_timing();
     dump_gemm_timing();
