@@ -188,7 +188,19 @@ __device__ long long g_flow_ts[256][8]; // per block j: start, after fold #1, #2
 // part (optional, 2 nblk doubles): workgroup j also leaves sum_i log L_ii over its block in part[j] and
 // sum_{i,p} om[i,p] a[i,p] in part[nblk + j] (added to what is there when part_acc): the log-likelihood
 // terms of gp.hpp:274-277 then need no launch of their own, the host adds the nblk partials in order.
-__global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict__ L, int64_t ld, int64_t N,
+// fixed-order sum of the per-wave partial results (bitwise reproducible)
+template <int W>
+static __device__ __forceinline__ double flow_sum(const double (&p)[W][NB], int lane)
+{
+    double s = p[0][lane];
+#pragma unroll
+    for (int w = 1; w < W; ++w)
+        s += p[w][lane];
+    return s;
+}
+#define FW 8            // waves per workgroup of the data-flow sweep (16 measured no better)
+#define FQ (NB / FW)    // tile columns (and k-slices) per wave
+__global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow(const double* __restrict__ L, int64_t ld, int64_t N,
                                                        const double* __restrict__ Xt_all, const double* __restrict__ y,
                                                        int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
                                                        int* __restrict__ err, const double* __restrict__ om,
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
     __shared__ double Stg[NB * LSTR];
     __shared__ double xs[NB];
     __shared__ double wj[NB];
-    __shared__ double part_s[4][NB];
+    __shared__ double part_s[FW][NB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wvu = __builtin_amdgcn_readfirstlane(wv); // the same value, known to be wave-uniform
     const int64_t nblk = (N + NB - 1) / NB;
@@ -224,21 +236,21 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
         // (lane = k) and the first look at a_t are requested four folds ahead.  With one tile in flight and
         // the poll issued at the point of use, every fold paid a full memory round trip (~2.5 us), even for
         // contributions published long before — the last workgroup's 63 folds WERE the kernel time.
-        double tl[4][16];
+        double tl[4][FQ];
         unsigned long long pb[4] = {SENT, SENT, SENT, SENT};
-        auto fetch = [&](double (&dst)[16], unsigned long long& peek, int64_t tt) {
+        auto fetch = [&](double (&dst)[FQ], unsigned long long& peek, int64_t tt) {
             const int64_t t0 = tt * NB;
             const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
             const int kc = lane < tb ? lane : tb - 1;
             const double rowmask = lane < tb ? 1.0 : 0.0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < FQ; ++q) {
                 // Unconditional load from a clamped (valid) address, masked by a multiplication: written as
                 // `cond ? load : 0` the compiler predicates every load and waits for each one in turn
                 // (s_cbranch_execz + s_waitcnt vmcnt(0) per load: 8 serial round trips per tile, 3 us a fold).
                 // The column is wave-uniform (wvu): scalar base + one 32-bit lane offset, no 64-bit vector
                 // address per load (16 of those per tile in flight x 4 tiles spilled to scratch).
-                const int c = wvu + 4 * q;
+                const int c = wvu + FW * q;
                 const int cc = c < jb ? c : jb - 1;
                 const double* col = L + t0 + (j0 + cc) * ld;
                 dst[q] = col[kc] * (c < jb ? rowmask : 0.0);
@@ -250,11 +262,11 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
             peek = __hip_atomic_load((const unsigned long long*)(ap + t0 + kc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
         };
-        auto fold = [&](const double (&src)[16], unsigned long long peek, int64_t t) {
+        auto fold = [&](const double (&src)[FQ], unsigned long long peek, int64_t t) {
             __syncthreads(); // Stg / xs of the previous contributor are consumed
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                Stg[(wv + 4 * q) * LSTR + lane] = src[q]; // Stg[c][k]
+            for (int q = 0; q < FQ; ++q)
+                Stg[(wv + FW * q) * LSTR + lane] = src[q]; // Stg[c][k]
             if (threadIdx.x < NB) {
                 const int64_t t0 = t * NB;
                 const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
@@ -287,14 +299,14 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
             __syncthreads();
             double acc = 0.0;
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const int k = 16 * wv + kk;
+            for (int kk = 0; kk < FQ; ++kk) {
+                const int k = FQ * wv + kk;
                 acc = fma(Stg[lane * LSTR + k], xs[k], acc);
             }
             part_s[wv][lane] = acc;
             __syncthreads();
             if (threadIdx.x < NB)
-                wj[lane] -= (part_s[0][lane] + part_s[1][lane]) + (part_s[2][lane] + part_s[3][lane]);
+                wj[lane] -= flow_sum(part_s, lane);
 #ifdef FLOW_TIMING
             {
                 const int64_t nf = nblk - t; // folds done so far
@@ -337,15 +349,15 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_flow(const double* __restrict_
         const double* Xt = Xt_all + j * (NB * NB);
         double acc = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const int r = 16 * wv + kk;
+        for (int kk = 0; kk < FQ; ++kk) {
+            const int r = FQ * wv + kk;
             acc = fma(Xt[lane + NB * r], wj[r], acc);
         }
         part_s[wv][lane] = acc;
         __syncthreads();
         FTS(5);
         if (threadIdx.x < NB && lane < jb) {
-            const double v = (part_s[0][lane] + part_s[1][lane]) + (part_s[2][lane] + part_s[3][lane]);
+            const double v = flow_sum(part_s, lane);
             __hip_atomic_store((unsigned long long*)(ap + j0 + lane), (unsigned long long)__double_as_longlong(v),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (part)
@@ -392,7 +404,7 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
     if (!prefilled)
         for (int p = 0; p < P; ++p)
             hipMemsetAsync(a + (int64_t)p * ldw, 0xFF, sizeof(double) * (size_t)N, s);
-    hipLaunchKernelGGL(k_trsv_bwd_flow, dim3((unsigned)nblk), dim3(256), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err,
+    hipLaunchKernelGGL(k_trsv_bwd_flow, dim3((unsigned)nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err,
                        om, ldom, part, part_acc);
 }
 
