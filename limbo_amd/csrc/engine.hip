@@ -45,6 +45,7 @@ struct gpe_ctx {
     hipStream_t stream2 = nullptr;      // look-ahead: bulk of a trailing update runs here, behind the next panel
     std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
     int64_t xinv_done = 0;      // diagonal blocks whose inverse is already complete (done per panel on stream2)
+    bool stop_events = true;    // next-panel update signals through its own dispatch (hipExtLaunchKernel stop event)
     bool lookahead = true;             // GPE_LOOKAHEAD=0 disables
     int bulk_wgs = 192;                // physical workgroups of a look-ahead bulk update (GPE_BULK_WGS)
     std::mutex mu;
@@ -391,7 +392,13 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 const size_t kp = (size_t)(p0 / nbo);
                 if (la_pending)
                     hipStreamWaitEvent(s, ev(3 * (kp - 1) + 1), 0); // the previous bulk update also wrote these columns
-                upd(s, pe, pe2, pe, 0, ev(3 * kp));
+                if (c->stop_events)
+                    upd(s, pe, pe2, pe, 0, ev(3 * kp));
+                else { // GPE_STOP_EVENT=0: a marker packet instead (rocprofv3's kernel trace delays dispatches
+                       // that carry their own completion event by ~100 us; use this form under the profiler)
+                    upd(s, pe, pe2, pe);
+                    hipEventRecord(ev(3 * kp), s);
+                }
                 hipStreamWaitEvent(c->stream2, ev(3 * kp), 0); // the bulk update starts now and shares the chip
                                                                // with panel kp + 1 only
                 if (nf > 0)
@@ -802,6 +809,8 @@ int gpe_create(int device_id, gpe_handle* out)
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
     if (const char* f = getenv("GPE_BULK_WGS"))
         c->bulk_wgs = atoi(f);
+    if (const char* f = getenv("GPE_STOP_EVENT"))
+        c->stop_events = atoi(f) != 0;
     if (const char* f = getenv("GPE_LOOKAHEAD"))
         c->lookahead = atoi(f) != 0;
     if (const char* f = getenv("GPE_FLOW_SOLVE"))
