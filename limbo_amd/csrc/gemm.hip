@@ -42,8 +42,11 @@
 #ifdef GEMM_TIMING
 __device__ long long g_gemm_ts[16];
 #define GTS(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && lwg == (int)blockIdx.x) g_gemm_ts[i] = clock64(); } while (0)
+__device__ long long g_gemm64_ts[24];
+#define GTS64(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && lwg == (int)blockIdx.x) g_gemm64_ts[i] = clock64(); } while (0)
 #else
 #define GTS(i) do { } while (0)
+#define GTS64(i) do { } while (0)
 #endif
 #ifndef GEMM_ABL
 #define GEMM_ABL 0 // debug ablations (tools/kbench): 1 = no global loads / LDS stores in the k loop, 2 = no MFMA
@@ -594,6 +597,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g)
 #ifdef GEMM_TIMING
 void dump_gemm_timing()
 {
+    {
+        long long q[24];
+        (void)hipMemcpyFromSymbol(q, HIP_SYMBOL(g_gemm64_ts), sizeof(q));
+        printf("k_gemm_glds64 WG0 first tile, cycles: start->k-tile 0 begins %lld | k-tiles:", q[1] - q[0]);
+        for (int t = 1; t < 16; ++t)
+            printf(" %lld", q[1 + t] - q[t]);
+        printf(" %lld | epilogue %lld | total %lld\n", q[17] - q[16], q[18] - q[17], q[18] - q[0]);
+    }
     long long h[16];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_ts), sizeof(h));
     printf("k_gemm_glds WG0 first tile, cycles: prologue (first stage landed) %lld | k-tile 0 %lld | k-tile 1 %lld (mfma part %lld, closing barrier %lld) | whole k loop %lld | epilogue %lld | total %lld\n",
@@ -611,14 +622,16 @@ void dump_gemm_timing()
 // k values a 32-lane half reads per MFMA step are taken from different pairs (k permutation
 // 0,2,1,3 — applied to both operands, the sum over k does not care), which keeps the reads
 // conflict-free.
-__global__ __launch_bounds__(256, 2) void k_gemm_glds64(GemmArgs g)
+template <int BKT, int NST, int MINB, int NWV>
+__global__ __launch_bounds__(64 * NWV, MINB) void k_gemm_glds64(GemmArgs g)
 {
-    constexpr int TM = 64, TN = 64, BKT = 16, NST = 4, NWV = 4;
+    constexpr int TM = 64, TN = 64;
+    static_assert(NWV == 4 || NWV == 8, "2 x 2 waves of 32 x 32 or 2 x 4 waves of 32 x 16");
     constexpr int PAIR = 144;                 // doubles per k-row pair (2 x 64 + 16 pad)
     constexpr int OPER = (BKT / 2) * PAIR;    // one operand, one stage
     constexpr int STAGE = 2 * OPER;
-    constexpr int RA = 2, RB = 8;
-    constexpr int LPW = 2 * (BKT / 2) / NWV;  // glds instructions per wave per stage = 4
+    constexpr int RA = 2, RB = 64 / (NWV / 2) / 4; // wave tile 32 x (64 / (NWV / 2))
+    constexpr int LPW = 2 * (BKT / 2) / NWV;  // glds instructions per wave per stage
     __shared__ __attribute__((aligned(16))) double lds[NST * STAGE];
 
     const int tiles_m = (int)((g.m + TM - 1) / TM);
@@ -657,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds64(GemmArgs g)
         const int64_t row0 = (int64_t)ti * TM, col0 = (int64_t)tj * TN;
         const int64_t mrows = g.m - row0, ncols = g.n - col0;
         const int mr = (int)(mrows < TM ? mrows : TM), nc = (int)(ncols < TN ? ncols : TN);
-        const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+        const int wm = (wave & 1) * 32, wn = (wave >> 1) * (4 * RB);
         const int arow = wm + (lane & 15), bcol = wn + (lane & 3);
         const int kq = lane >> 4, kperm = ((kq & 1) << 1) | (kq >> 1); // 0,2,1,3
 
@@ -671,17 +684,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds64(GemmArgs g)
         const int khalf = lane >> 5;
         const double* pa = g.A + row0 + ra + (int64_t)(2 * wave + khalf) * g.lda;
         const double* pb = g.B + col0 + rb + (int64_t)(2 * wave + khalf) * g.ldb;
-        // wave w moves pairs w and w + 4 of each operand
-        const int64_t astep8 = (int64_t)8 * g.lda, bstep8 = (int64_t)8 * g.ldb;
+        // wave w moves pairs w, w + NWV, .. of each operand
+        const int64_t astep8 = (int64_t)(2 * NWV) * g.lda, bstep8 = (int64_t)(2 * NWV) * g.ldb;
         auto issue = [&](int stage) {
             double* sa = lds + stage * STAGE + wave * PAIR;
             double* sb = sa + OPER;
-            __builtin_amdgcn_global_load_lds(pa, (lds_void_t*)sa, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(pb, (lds_void_t*)sb, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(pa + astep8, (lds_void_t*)(sa + 4 * PAIR), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(pb + bstep8, (lds_void_t*)(sb + 4 * PAIR), 16, 0, 0);
-            pa += 2 * astep8;
-            pb += 2 * bstep8;
+#pragma unroll
+            for (int q = 0; q < BKT / 2 / NWV; ++q) { // BKT / 2 pairs per operand and stage
+                __builtin_amdgcn_global_load_lds(pa, (lds_void_t*)(sa + NWV * q * PAIR), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(pb, (lds_void_t*)(sb + NWV * q * PAIR), 16, 0, 0);
+                pa += astep8;
+                pb += bstep8;
+            }
         };
 
         double acc[RA][RB];
@@ -692,10 +706,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds64(GemmArgs g)
                 acc[a][b] = 0.0;
 
         const int nk = (int)(g.k / BKT);
+        GTS64(0);
         for (int t = 0; t < NST - 1 && t < nk; ++t)
             issue(t);
         for (int t = 0; t < nk; ++t) {
             const int st = t % NST;
+            if (t < 16)
+                GTS64(1 + t);
             if (t + NST - 1 < nk)
                 issue((t + NST - 1) % NST);
             // tiles still allowed in flight after tile t has landed
@@ -731,6 +748,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds64(GemmArgs g)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier(); // stage st may be refilled
         }
+        GTS64(17);
 
         {
             using WT = WaveTileC<RA, RB>;
@@ -744,6 +762,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds64(GemmArgs g)
                 WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
             }
         }
+        GTS64(18);
         __syncthreads();
     }
 }
@@ -770,7 +789,23 @@ static void launch_glds64(hipStream_t s, const GemmArgs& g0)
     g.total = (int)tiles;
     if (g.grid_limit > 0 && tiles > g.grid_limit)
         tiles = g.grid_limit;
-    launch_k(k_gemm_glds64, dim3((unsigned)tiles), dim3(256), s, g);
+    // Two shapes.  With more tiles than CUs, two workgroups share a CU (BKT 16, 4 stages, 64 KB) and fill each
+    // other's bubbles.  With at most one tile per CU — the next-panel update on the critical path of the
+    // factorisation — a workgroup is alone with one wave per SIMD and every k-tile pays its two barriers and the
+    // LDS read latency in full (in-kernel stamps: 1944 cycles per 16-deep k-tile for 1024 cycles of MFMA work;
+    // halving the number of k-tiles with BKT 32 changed nothing: it is the fragment-read latency before every
+    // group of 16 MFMAs).  Eight waves on the tile (two per SIMD) cover each other.
+    static int v64 = -1;
+    if (v64 < 0) {
+        const char* e = getenv("GPE_GLDS64_VARIANT");
+        v64 = e ? atoi(e) : 0;
+    }
+    if (g.total > 256 || g.grid_limit > 0 || v64 == 1)
+        launch_k(k_gemm_glds64<16, 4, 2, 4>, dim3((unsigned)tiles), dim3(256), s, g);
+    else if (v64 == 2)
+        launch_k(k_gemm_glds64<32, 3, 1, 4>, dim3((unsigned)tiles), dim3(256), s, g);
+    else
+        launch_k(k_gemm_glds64<16, 4, 1, 8>, dim3((unsigned)tiles), dim3(512), s, g);
 }
 
 static bool glds_ok(const GemmArgs& g)

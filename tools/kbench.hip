@@ -75,6 +75,13 @@ int main(int argc, char** argv)
             g.m = m; g.n = m; g.k = 256; g.tri = 1; g.grow0 = pe; g.gcol0 = pe;
             for (int t : {32, 64, 128}) { g.tile = t; launch_gemm_sub(s, g); }
         }
+        // next-panel update (critical path): rows >= pe of the next 256 columns, k = 256
+        for (int64_t pe : {256, 1536, 2816}) {
+            GemmArgs g{};
+            g.C = A + pe + pe * ld; g.ldc = ld; g.A = A + pe; g.lda = ld; g.B = A + pe; g.ldb = ld;
+            g.m = N - pe; g.n = 256; g.k = 256; g.tri = 1; g.grow0 = pe; g.gcol0 = pe;
+            for (int t : {32, 64, 128}) { g.tile = t; launch_gemm_sub(s, g); }
+        }
         // backward step at the last block and in the middle
         launch_trsv_sweep(s, A, ld, N, Xi, w, out, ld, 1, 1);
     }
