@@ -1,0 +1,286 @@
+// gemm_glds64.h — pieces of the fp64 MFMA GEMM shared by gemm.hip and potrf.hip (the fused next-panel update):
+// triangular tile enumeration, the lane = row C-tile traffic, and the body of the 64 x 64 direct-to-LDS kernel.
+#pragma once
+#include "dev.h"
+
+#ifndef GPE_MFMA4_DEFINED
+#define GPE_MFMA4_DEFINED
+static __device__ __forceinline__ double mfma4(double a, double b, double c)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+#endif
+typedef __attribute__((address_space(3))) void lds_void_t;
+#ifndef GTS64_
+#define GTS64_(i) do { } while (0)
+#endif
+
+// first row tile of tile column tj that touches the lower triangle (global row >= global col),
+// clamped to tiles_m
+template <int TM, int TN>
+static __host__ __device__ __forceinline__ int first_live_tile(const GemmArgs& g, int tj)
+{
+    const int tiles_m = (int)((g.m + TM - 1) / TM);
+    const int64_t need = g.gcol0 + (int64_t)tj * TN - g.grow0 - (TM - 1); // ti*TM >= need
+    int64_t t = need <= 0 ? 0 : (need + TM - 1) / TM;
+    return (int)(t < tiles_m ? t : tiles_m);
+}
+
+// ---- C tile traffic in the lane = row layout ---------------------------------------------------------
+// The accumulator of v_mfma_f64_4x4x4 puts lane l on row 4*((l>>2)&3) + (l>>4), column l&3 of a 16 x 4
+// fragment: one global load/store of a fragment touches 4 columns x 16 rows, adjacent lanes sit in
+// different columns (ldc * 8 bytes apart).  Measured inside the kernel (tools/kbench_g): such a load
+// takes ~150 cycles to ISSUE and a store ~450, and the read-modify-write of a 128 x 128 C tile was 29 %
+// of the tile time.  Here the wave turns its (16 RA) x (4 RB) accumulator through a private LDS scratch
+// (no barrier: one wave's LDS operations execute in order) and all C traffic uses lane = row:
+// 64 / R whole columns of R = 16 RA consecutive rows per instruction (512 contiguous bytes for RA = 4).
+template <int RA, int RB>
+struct WaveTileC {
+    static constexpr int R = 16 * RA, CN = 4 * RB, SW = R + 2, CPI = 64 / R, NIT = CN / CPI;
+    static constexpr int SCRATCH = CN * SW; // doubles of LDS per wave
+    // cv[it] = C[row, col(it)] for this lane's (row, column) pairs; addresses clamped into the valid
+    // rlim x clim part of the tile (no branches; lanes outside simply do not store later)
+    static __device__ __forceinline__ void load(double (&cv)[NIT], const double* __restrict__ Cw, int64_t ldc, int rlim,
+                                                int clim, int lane)
+    {
+        const int row = lane % R, cl = lane / R;
+        const int rr = row < rlim ? row : rlim - 1;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = it * CPI + cl;
+            cv[it] = Cw[(int64_t)(col < clim ? col : clim - 1) * ldc + rr];
+        }
+    }
+    // C = cv - acc (or C = acc when overwrite)
+    static __device__ __forceinline__ void store(const double (&acc)[RA][RB], const double (&cv)[NIT], double* __restrict__ W,
+                                                 double* __restrict__ Cw, int64_t ldc, int rlim, int clim, bool overwrite,
+                                                 int lane)
+    {
+        const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+#pragma unroll
+        for (int n = 0; n < RB; ++n)
+#pragma unroll
+            for (int m = 0; m < RA; ++m)
+                W[(4 * n + dcol) * SW + 16 * m + drow] = acc[m][n];
+        const int row = lane % R, cl = lane / R;
+        double t[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            t[it] = W[(it * CPI + cl) * SW + row];
+        if (rlim == R && clim == CN) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                Cw[(int64_t)(it * CPI + cl) * ldc + row] = overwrite ? t[it] : cv[it] - t[it];
+        }
+        else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int col = it * CPI + cl;
+                if (row < rlim && col < clim)
+                    Cw[(int64_t)col * ldc + row] = overwrite ? t[it] : cv[it] - t[it];
+            }
+        }
+    }
+    // the same in NCH passes over column chunks: 1/NCH of the registers and of the LDS scratch
+    // (SCRATCH / NCH doubles per wave) — for kernels that keep two workgroups per CU
+    template <int NCH>
+    static __device__ __forceinline__ void rmw_chunked(const double (&acc)[RA][RB], double* __restrict__ W,
+                                                       double* __restrict__ Cw, int64_t ldc, int rlim, int clim,
+                                                       bool overwrite, int lane)
+    {
+        static_assert(RB % NCH == 0 && (4 * RB / NCH) % CPI == 0, "chunking");
+        constexpr int RBC = RB / NCH, CNC = 4 * RBC, NITC = CNC / CPI;
+        const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+        const int row = lane % R, cl = lane / R;
+        const int rr = row < rlim ? row : rlim - 1;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            double cv[NITC], t[NITC];
+            if (!overwrite) {
+#pragma unroll
+                for (int it = 0; it < NITC; ++it) {
+                    const int col = ch * CNC + it * CPI + cl;
+                    cv[it] = Cw[(int64_t)(col < clim ? col : clim - 1) * ldc + rr];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < RBC; ++n)
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    W[(4 * n + dcol) * SW + 16 * m + drow] = acc[m][ch * RBC + n];
+#pragma unroll
+            for (int it = 0; it < NITC; ++it)
+                t[it] = W[(it * CPI + cl) * SW + row];
+#pragma unroll
+            for (int it = 0; it < NITC; ++it) {
+                const int col = ch * CNC + it * CPI + cl;
+                if (row < rlim && col < clim)
+                    Cw[(int64_t)col * ldc + row] = overwrite ? t[it] : cv[it] - t[it];
+            }
+        }
+    }
+};
+
+
+// 64 x 64 tile variant for the mid-size and latency-critical updates (a few hundred tiles, k = 256):
+// 4 waves (32 x 32 each), BKT = 16, FOUR LDS stages (74 KB, two workgroups per CU) so that three
+// k-tiles are always in flight — the register-staged 64 x 64 kernel it replaces exposes one
+// global-load latency per k-tile.  One glds instruction moves TWO k-rows of a 64-row operand (lanes
+// 0-31 / 32-63), so k-rows sit in LDS as pairs: row kk at (kk >> 1) * 144 + (kk & 1) * 64.  The two
+// k values a 32-lane half reads per MFMA step are taken from different pairs (k permutation
+// 0,2,1,3 — applied to both operands, the sum over k does not care), which keeps the reads
+// conflict-free.
+// skip00: leave tile (0, 0) alone (the fused next-panel update: that tile is the next diagonal block, which the
+// extra workgroup of the same launch updates and factors — potrf.hip:k_upd_fused)
+template <int BKT, int NST, int NWV>
+static __device__ __forceinline__ void gemm_glds64_body(const GemmArgs& g, double* __restrict__ lds, int first_wg, int n_wg,
+                                                        bool skip00)
+{
+    constexpr int TM = 64, TN = 64;
+    static_assert(NWV == 4 || NWV == 8, "2 x 2 waves of 32 x 32 or 2 x 4 waves of 32 x 16");
+    constexpr int PAIR = 144;                 // doubles per k-row pair (2 x 64 + 16 pad)
+    constexpr int OPER = (BKT / 2) * PAIR;    // one operand, one stage
+    constexpr int STAGE = 2 * OPER;
+    constexpr int RA = 2, RB = 64 / (NWV / 2) / 4; // wave tile 32 x (64 / (NWV / 2))
+    constexpr int LPW = 2 * (BKT / 2) / NWV;  // glds instructions per wave per stage
+
+    const int tiles_m = (int)((g.m + TM - 1) / TM);
+    const int tiles_n = (int)((g.n + TN - 1) / TN);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int lwg = first_wg; lwg < g.total; lwg += n_wg) {
+        int wg = lwg;
+        {
+            const int nwg = g.total;
+            const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+            wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        int ti, tj;
+        if (g.tri) {
+            const int sc = wg / g.fold_len;
+            int rr = wg % g.fold_len;
+            const int t0 = first_live_tile<TM, TN>(g, sc), c0 = tiles_m - t0;
+            if (rr < c0) {
+                tj = sc;
+                ti = t0 + rr;
+            }
+            else {
+                tj = tiles_n - 1 - sc;
+                const int t1 = first_live_tile<TM, TN>(g, tj);
+                rr -= c0;
+                if (tj == sc || rr >= tiles_m - t1)
+                    continue;
+                ti = t1 + rr;
+            }
+        }
+        else {
+            ti = wg % tiles_m;
+            tj = wg / tiles_m;
+        }
+        if (skip00 && ti == 0 && tj == 0)
+            continue;
+        const int64_t row0 = (int64_t)ti * TM, col0 = (int64_t)tj * TN;
+        const int64_t mrows = g.m - row0, ncols = g.n - col0;
+        const int mr = (int)(mrows < TM ? mrows : TM), nc = (int)(ncols < TN ? ncols : TN);
+        const int wm = (wave & 1) * 32, wn = (wave >> 1) * (4 * RB);
+        const int arow = wm + (lane & 15), bcol = wn + (lane & 3);
+        const int kq = lane >> 4, kperm = ((kq & 1) << 1) | (kq >> 1); // 0,2,1,3
+
+        // this lane's 16-byte piece: rows (2 l', 2 l' + 1) of k-row kk + (lane >> 5), l' = lane & 31
+        int ra = 2 * (lane & 31), rb = ra;
+        {
+            const int ma = (mr - 1) & ~1, mb = (nc - 1) & ~1;
+            ra = ra < ma ? ra : ma;
+            rb = rb < mb ? rb : mb;
+        }
+        const int khalf = lane >> 5;
+        const double* pa = g.A + row0 + ra + (int64_t)(2 * wave + khalf) * g.lda;
+        const double* pb = g.B + col0 + rb + (int64_t)(2 * wave + khalf) * g.ldb;
+        // wave w moves pairs w, w + NWV, .. of each operand
+        const int64_t astep8 = (int64_t)(2 * NWV) * g.lda, bstep8 = (int64_t)(2 * NWV) * g.ldb;
+        auto issue = [&](int stage) {
+            double* sa = lds + stage * STAGE + wave * PAIR;
+            double* sb = sa + OPER;
+#pragma unroll
+            for (int q = 0; q < BKT / 2 / NWV; ++q) { // BKT / 2 pairs per operand and stage
+                __builtin_amdgcn_global_load_lds(pa, (lds_void_t*)(sa + NWV * q * PAIR), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(pb, (lds_void_t*)(sb + NWV * q * PAIR), 16, 0, 0);
+                pa += astep8;
+                pb += bstep8;
+            }
+        };
+
+        double acc[RA][RB];
+#pragma unroll
+        for (int a = 0; a < RA; ++a)
+#pragma unroll
+            for (int b = 0; b < RB; ++b)
+                acc[a][b] = 0.0;
+
+        const int nk = (int)(g.k / BKT);
+        GTS64_(0);
+        for (int t = 0; t < NST - 1 && t < nk; ++t)
+            issue(t);
+        for (int t = 0; t < nk; ++t) {
+            const int st = t % NST;
+            if (t < 16)
+                GTS64_(1 + t);
+            if (t + NST - 1 < nk)
+                issue((t + NST - 1) % NST);
+            // tiles still allowed in flight after tile t has landed
+            const int ahead = nk - 1 - t < NST - 1 ? nk - 1 - t : NST - 1;
+            if (ahead >= 3)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPW) : "memory");
+            else if (ahead == 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+            else if (ahead == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * LPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // every wave's pieces of stage st have landed
+            const double* As = lds + st * STAGE;
+            const double* Bs = As + OPER;
+#pragma unroll
+            for (int ks = 0; ks < BKT; ks += 4) {
+                const int k = ks + kperm;
+                const int off = (k >> 1) * PAIR + (k & 1) * 64;
+                double af[RA], bf[RB];
+#pragma unroll
+                for (int x = 0; x < RA; ++x)
+                    af[x] = As[off + arow + 16 * x];
+#pragma unroll
+                for (int x = 0; x < RB; ++x)
+                    bf[x] = Bs[off + bcol + 4 * x];
+#pragma unroll
+                for (int n = 0; n < RB; ++n)
+#pragma unroll
+                    for (int m = 0; m < RA; ++m)
+                        acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // stage st may be refilled
+        }
+        GTS64_(17);
+
+        {
+            using WT = WaveTileC<RA, RB>;
+            static_assert(NWV * WT::SCRATCH <= NST * STAGE, "transposition scratch must fit in the operand stages");
+            double* Cw = g.C + (col0 + wn) * g.ldc + row0 + wm;
+            const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
+            if (rlim > 0 && clim > 0) {
+                double cv[WT::NIT];
+                if (!g.overwrite)
+                    WT::load(cv, Cw, g.ldc, rlim, clim, lane);
+                WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+            }
+        }
+        GTS64_(18);
+        __syncthreads();
+    }
+}
+
+
+template <int BKT>
+struct Glds64Shape {
+    static constexpr int PAIR = 144, OPER = (BKT / 2) * PAIR, STAGE = 2 * OPER;
+};
