@@ -55,8 +55,10 @@ void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b
 // factorisation + inversion of the next diagonal block (-> Xt_next).  Full 64-blocks only.
 // Hs: nt scratch tiles (64 x 64 each) for the L of the first nt row blocks; launch_head_copy moves
 // the tiles of the nf fused steps of the panel at p0 (nt0 = tiles of its first step) into A.
+// dnext / dfirst (>= 0 to enable): see k_panel_step — pieces of the next outer panel's first diagonal block
 void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
-                       double* Xt_next, int do_next, int* info, double* Hs);
+                       double* Xt_next, int do_next, int* info, double* Hs, int64_t dnext = -1, int64_t dfirst = -1,
+                       int dinit = 0, double* Dacc = nullptr);
 void launch_head_copy(hipStream_t s, double* A, int64_t lda, int64_t p0, int nt0, int nf, const double* H);
 // inverses of diagonal blocks b0 .. b0+nblocks-1 of an existing factor L (order N) into
 // Xt_all + 4096 b
@@ -85,6 +87,11 @@ struct GemmArgs {
     void* stop_event; // host side only: hipEvent_t completed by this launch (null: none)
 };
 void launch_gemm_sub(hipStream_t s, const GemmArgs& g);
+// the next-panel update g (as for launch_gemm_sub: C = A[pe:, pe:pe2], k = pe - p0, tri) and, in the same launch, the
+// update + factorisation + half-inversion of the next diagonal block A[pe:pe+64, pe:pe+64] (-> Xt_next)
+// (Dacc: sum of the pieces the panel steps already formed, subtracted as well; p0 == pe: no products here)
+void launch_upd_fused(hipStream_t s, const GemmArgs& g, double* A, int64_t lda, int64_t p0, int64_t pe, double* Xt_next,
+                      int* info, const double* Dacc);
 double gemm_flops(const GemmArgs& g);
 
 // ---- vector solves, reductions (solve.hip) -----------------------------------------

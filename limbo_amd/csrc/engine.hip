@@ -46,6 +46,7 @@ struct gpe_ctx {
     std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
     int64_t xinv_done = 0;      // diagonal blocks whose inverse is already complete (done per panel on stream2)
     bool stop_events = true;    // next-panel update signals through its own dispatch (hipExtLaunchKernel stop event)
+    bool fuse_diag = true;      // next diagonal block factored inside the next-panel update launch (k_upd_fused)
     bool lookahead = true;             // GPE_LOOKAHEAD=0 disables
     int bulk_wgs = 192;                // physical workgroups of a look-ahead bulk update (GPE_BULK_WGS)
     std::mutex mu;
@@ -275,18 +276,25 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     hipStream_t s = c->stream;
     const int64_t ld = c->ld;
     const int64_t nbo = c->nbo;
+    bool next_diag_done = false; // the fused next-panel update factored the first diagonal block of the coming panel
     bool la_pending = false; // a bulk update is (possibly) still running on stream2
     size_t la_last = 0;
     for (int64_t p0 = 0; p0 < N; p0 += nbo) {
         const int64_t pw = std::min<int64_t>(nbo, N - p0);
         const int64_t pe = p0 + pw;
-        bool diag_done = false; // the previous fused step already factored this diagonal block
+        bool diag_done = next_diag_done; // the previous fused step (or fused update) already factored this diagonal block
+        next_diag_done = false;
         int nf = 0, nt0 = 0;    // fused steps of this panel and head tiles of the first one
         int64_t htile = 0;
         // head-tile scratch, two halves by panel parity: the copy into A is off the critical path
         // (nothing before the end of the factorisation reads those tiles of A) and may still be
         // pending on the second stream while the next panel is factored
         double* const Hbase = c->dHead + ((p0 / nbo) & 1) * (32 * NB * NB);
+        // Will the trailing update of this panel be the fused launch that also factors the next panel's first
+        // diagonal block (k_upd_fused)?  Then the steps of this panel pre-apply their pieces of that block.
+        const bool fuse_diag = c->lookahead && !c->prof && std::min<int64_t>(pe + nbo, N) < N && c->fuse_panel && c->fuse_diag
+            && c->stop_events && pw == nbo && nbo % NB == 0 && nbo >= 2 * NB && ld % 2 == 0
+            && std::min<int64_t>(nbo, N - pe) % NB == 0;
         for (int64_t j0 = p0; j0 < pe; j0 += NB) {
             const int jb = (int)std::min<int64_t>(NB, pe - j0);
             const int64_t r0 = j0 + jb;
@@ -303,7 +311,14 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - r0) * NB * NB * (1 + nt));
                 if (nf == 0)
                     nt0 = nt;
-                launch_panel_step(s, A, ld, j0, M, nt, Xt, Xt + NB * NB, nt > 0 ? 1 : 0, c->dInfo, Hbase + htile * NB * NB);
+                // every step but the panel's first adds its own piece of the next panel's first diagonal block to the
+                // scratch sum (the second step starts it); the third — whose workgroup there has the most slack —
+                // also the first step's piece
+                const bool pre = fuse_diag && j0 > p0;
+                const int64_t dfirst_at = nbo >= 3 * NB ? p0 + 2 * NB : p0 + NB;
+                launch_panel_step(s, A, ld, j0, M, nt, Xt, Xt + NB * NB, nt > 0 ? 1 : 0, c->dInfo, Hbase + htile * NB * NB,
+                                  pre ? pe : -1, pre && j0 == dfirst_at ? p0 : -1, j0 == p0 + NB ? 1 : 0,
+                                  c->dHead + 64 * NB * NB);
                 htile += nt;
                 if (nt > 0)
                     ++nf;
@@ -392,7 +407,28 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 const size_t kp = (size_t)(p0 / nbo);
                 if (la_pending)
                     hipStreamWaitEvent(s, ev(3 * (kp - 1) + 1), 0); // the previous bulk update also wrote these columns
-                if (c->stop_events)
+                if (fuse_diag) {
+                    // the update and, underneath it in the same launch, the factorisation of the next panel's
+                    // first diagonal block (k_upd_fused): no k_diag launch at the head of the next panel
+                    GemmArgs g{};
+                    g.C = A + pe + pe * ld;
+                    g.ldc = ld;
+                    g.A = A + pe + p0 * ld;
+                    g.lda = ld;
+                    g.B = A + pe + p0 * ld;
+                    g.ldb = ld;
+                    g.m = M - pe;
+                    g.n = pe2 - pe;
+                    g.k = pw;
+                    g.tri = 1;
+                    g.grow0 = pe;
+                    g.gcol0 = pe;
+                    g.stop_event = ev(3 * kp);
+                    launch_upd_fused(s, g, A, ld, pe, pe, c->dXinv + (pe / NB) * (NB * NB), c->dInfo,
+                                     c->dHead + 64 * NB * NB); // the steps summed the pieces: no products here
+                    next_diag_done = true;
+                }
+                else if (c->stop_events)
                     upd(s, pe, pe2, pe, 0, ev(3 * kp));
                 else { // GPE_STOP_EVENT=0: a marker packet instead (rocprofv3's kernel trace delays dispatches
                        // that carry their own completion event by ~100 us; use this form under the profiler)
@@ -800,7 +836,7 @@ int gpe_create(int device_id, gpe_handle* out)
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
         || create_bulk_stream(&c->stream2) != hipSuccess
         || hipMalloc(&c->dScal, 8192) != hipSuccess
-        || hipMalloc(&c->dHead, sizeof(double) * 64 * NB * NB) != hipSuccess
+        || hipMalloc(&c->dHead, sizeof(double) * 65 * NB * NB) != hipSuccess
         || hipHostMalloc(&c->hInfo, 64) != hipSuccess || hipHostMalloc(&c->hScal, 8192) != hipSuccess) {
         delete c;
         return GPE_ERR_HIP;
@@ -809,6 +845,8 @@ int gpe_create(int device_id, gpe_handle* out)
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
     if (const char* f = getenv("GPE_BULK_WGS"))
         c->bulk_wgs = atoi(f);
+    if (const char* f = getenv("GPE_FUSE_DIAG"))
+        c->fuse_diag = atoi(f) != 0;
     if (const char* f = getenv("GPE_STOP_EVENT"))
         c->stop_events = atoi(f) != 0;
     if (const char* f = getenv("GPE_LOOKAHEAD"))

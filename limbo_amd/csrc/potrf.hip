@@ -23,6 +23,7 @@
 // three waves meanwhile apply the previous rank-4 update to all their later columns; the owner's
 // own non-critical columns are caught up one round later (4 LDS buffers keep that legal).
 #include "dev.h"
+#include <hip/hip_ext.h>
 #include <cstdio>
 
 #define NB 64
@@ -46,10 +47,7 @@ __device__ long long g_panel_ts[64];
 #endif
 #define XS 66 // LDS row stride (doubles) of the 64 x 64 work matrices: conflict-free MFMA operand reads
 
-static __device__ __forceinline__ double mfma4(double a, double b, double c)
-{
-    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
+#include "gemm_glds64.h" // mfma4, and the 64 x 64 GEMM body for the fused next-panel update
 
 static __device__ __forceinline__ double bcast_lane(double v, int src)
 {
@@ -638,9 +636,16 @@ static __device__ __forceinline__ void wave_tile_to_rows(const double (&acc)[2][
 
 #define PANEL_PRE 3 // head tiles prefetched into registers at kernel start (nbo = 256 needs 3)
 
+// dnext >= 0: the workgroup that owns rows dnext .. dnext+63 (the next OUTER panel's first diagonal block) also
+// adds its L L^T to the 64 x 64 scratch Dacc (lane = row order of a workgroup's C tile; dinit: starts the sum) —
+// and, when dfirst >= 0, the same product of the column block at dfirst (the panel's first, whose own step has
+// no workgroup to spare; done in the step where that workgroup has the most slack).  k_upd_fused subtracts the
+// sum from the block and only has to factor it.  (Not subtracted from A directly: the second stream's GEMMs
+// may still be updating that block.)
 __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
                                                     const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
-                                                    int do_next, int* __restrict__ info, double* __restrict__ Hs)
+                                                    int do_next, int* __restrict__ info, double* __restrict__ Hs,
+                                                    int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc)
 {
     // one LDS array, carved: [Bx | T0 | T1 | Ld]; workgroup 0 re-carves it as [Ls | Ltb | invd]
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + 32 * XS];
@@ -770,6 +775,36 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
         __syncthreads(); // T1 is free again
     }
 
+    // 2b. the piece(s) of the next outer panel's first diagonal block that this workgroup can provide
+    if (dnext >= 0 && R0 == dnext) {
+        double pr[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                pr[m][n] = 0.0;
+        double cd[8];
+        if (!dinit) { // a later step of the panel: add to the running sum
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                cd[it] = Dacc[threadIdx.x + 512 * it];
+        }
+        mm64<false>(T0, T0, wm, wn, lane, pr); // own L (this step's column block) times its transpose
+        if (dfirst >= 0) {                      // and the same rows of the column block at dfirst
+            TileRegs lf;
+            lf.load(A + dnext + dfirst * lda, lda, NB);
+            __syncthreads(); // T1's last readers (head-tile products) are done
+            lf.store(T1);
+            __syncthreads();
+            mm64<false>(T1, T1, wm, wn, lane, pr);
+        }
+        double prr[8];
+        wave_tile_to_rows(pr, prr, lane);
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            Dacc[threadIdx.x + 512 * it] = (dinit ? 0.0 : cd[it]) + prr[it];
+    }
+
     PTS(4);
     // 3. workgroup 0: factor the next diagonal block (block t = 0 of its own rows) and invert its halves
     if (b != 0 || !do_next)
@@ -818,6 +853,128 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
     PTS(7);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_upd_fused — the next-panel update (rows >= pe of columns [pe, pe2), k = pe - p0) and, in the SAME
+// launch, the factorisation of the next diagonal block.  The update is the 64 x 64 direct-to-LDS GEMM
+// (gemm_glds64.h) on gridDim.x - 1 workgroups, which leave tile (0, 0) alone; the last workgroup forms
+// that tile itself — A[pe:pe+64, pe:pe+64] - L_d L_d^T with L_d = A[pe:pe+64, p0:pe], (pe - p0) / 64
+// products of 64^3 — and then factors and half-inverts it exactly like workgroup 0 of k_panel_step.
+// k_diag used to follow the update as a launch of its own (13.6 us on the critical path of every
+// outer panel, with 255 CUs idle); here it runs underneath the update (~18 us).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restrict__ A, int64_t lda, int64_t p0, int64_t pe,
+                                                   double* __restrict__ Xt_next, int* __restrict__ info,
+                                                   const double* __restrict__ Dacc)
+{
+    constexpr int GEMM_LDS = 4 * Glds64Shape<16>::STAGE, DIAG_LDS = 2 * NB * PS;
+    __shared__ __attribute__((aligned(16))) double lds[GEMM_LDS > DIAG_LDS ? GEMM_LDS : DIAG_LDS];
+    __shared__ int sbad;
+    if (blockIdx.x + 1 < gridDim.x) {
+        gemm_glds64_body<16, 4, 8>(g, lds, (int)blockIdx.x, (int)gridDim.x - 1, true);
+        return;
+    }
+    // ---- the diagonal workgroup ----
+    static_assert(NB * XS + 4 * NB * 4 + NB <= 2 * NB * PS, "[Ls | Ltb | invd] is carved out of the two operand tiles");
+    double* T0 = lds;
+    double* T1 = lds + NB * PS;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
+    const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
+    if (threadIdx.x == 0)
+        sbad = 0;
+    double c0v[8]; // the tile before the update, lane = row layout
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        c0v[it] = A[pe + crow + (pe + ccol + 2 * it) * lda];
+    const int nkb = (int)((pe - p0) / NB); // 0: the panel steps already applied every piece (k_panel_step, dnext)
+    TileRegs tl;
+    if (nkb > 0)
+        tl.load(A + pe + p0 * lda, lda, NB);
+    double acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            acc[m][n] = 0.0;
+#pragma unroll 1
+    for (int c = 0; c < nkb; ++c) { // two tiles alternate: a wave that refills one has passed the barrier behind its last readers
+        double* T = (c & 1) ? T1 : T0;
+        tl.store(T);
+        if (c + 1 < nkb)
+            tl.load(A + pe + (p0 + (int64_t)NB * (c + 1)) * lda, lda, NB);
+        __syncthreads();
+        mm64<false>(T, T, wm, wn, lane, acc);
+    }
+    __syncthreads(); // the operand tiles are dead: re-carve
+    double* Ls = lds;
+    double* Ltb = Ls + NB * XS;
+    double* invd = Ltb + 4 * NB * 4;
+    {
+        double a2r[8];
+        wave_tile_to_rows(acc, a2r, lane);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) // Dacc: what the panel steps summed up (same thread <-> element mapping)
+            Ls[crow * XS + ccol + 2 * it] = c0v[it] - a2r[it] - (Dacc ? Dacc[threadIdx.x + 512 * it] : 0.0);
+    }
+    __syncthreads();
+    if (wave >= 5)
+        return; // s_barrier only counts the waves that are still alive
+    const int r = lane, w = wave;
+    double a[4][4];
+    if (w < 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 16 * q + 4 * w + e;
+                a[q][e] = (c <= r) ? Ls[r * XS + c] : 0.0;
+            }
+    }
+    __syncthreads();
+    if (w == 4) {
+        xpipe32_wave(Ls, invd, Xt_next, r);
+        return;
+    }
+    DiagRound<15>::run(a, Ltb, invd, &sbad, r, w, Ls);
+    double* Ad = A + pe + pe * lda;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 16 * q + 4 * w + e;
+            if (c <= r)
+                Ad[r + (int64_t)c * lda] = a[q][e];
+        }
+    if (threadIdx.x == 0 && sbad != 0 && *info == 0)
+        *info = (int)(pe + sbad);
+}
+
+// g: the next-panel update as for launch_gemm_sub (tri, 64-multiple shapes checked by the caller)
+void launch_upd_fused(hipStream_t s, const GemmArgs& g0, double* A, int64_t lda, int64_t p0, int64_t pe, double* Xt_next,
+                      int* info, const double* Dacc)
+{
+    constexpr int TM = 64, TN = 64;
+    GemmArgs g = g0;
+    const int tiles_m = (int)((g.m + TM - 1) / TM), tiles_n = (int)((g.n + TN - 1) / TN);
+    int fold = 1;
+    const int nsup = (tiles_n + 1) / 2;
+    for (int sc = 0; sc < nsup; ++sc) { // live-tile enumeration of gemm.hip:launch_glds64
+        const int t2 = tiles_n - 1 - sc;
+        int len = tiles_m - first_live_tile<TM, TN>(g, sc);
+        if (t2 != sc)
+            len += tiles_m - first_live_tile<TM, TN>(g, t2);
+        fold = len > fold ? len : fold;
+    }
+    g.fold_len = fold;
+    g.total = nsup * fold;
+    const dim3 grid((unsigned)g.total + 1), block(512);
+    if (g.stop_event)
+        hipExtLaunchKernelGGL(k_upd_fused, grid, block, 0, s, nullptr, (hipEvent_t)g.stop_event, 0, g, A, lda, p0, pe, Xt_next,
+                              info, Dacc);
+    else
+        hipLaunchKernelGGL(k_upd_fused, grid, block, 0, s, g, A, lda, p0, pe, Xt_next, info, Dacc);
+}
+
 #ifdef DIAG_TIMING
 void dump_panel_timing()
 {
@@ -830,13 +987,14 @@ void dump_panel_timing()
 }
 #endif
 void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
-                       double* Xt_next, int do_next, int* info, double* Hs)
+                       double* Xt_next, int do_next, int* info, double* Hs, int64_t dnext, int64_t dfirst, int dinit,
+                       double* Dacc)
 {
     const int64_t rows = M - (j0 + NB);
     if (rows <= 0)
         return;
     hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, j0, M, nt, Xt_cur,
-                       Xt_next, do_next, info, Hs);
+                       Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc);
 }
 
 // head tiles of the fused steps of one outer panel -> their place in A.  Step f (f = 0..nf-1) of the
