@@ -122,7 +122,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_roofline:
-        # dominant kernel: the Cholesky trailing update (k_gemm_sub, fp64 MFMA).  HIP events on
+        # dominant kernel: the Cholesky trailing update (k_gemm_glds / k_gemm_glds64 / k_gemm4, fp64 MFMA).  HIP events on
         # the handle's own stream around every launch of it (profiling mode), outside the timed region.
         h.set_profiling(True)
         h.reset_phase_ms()
@@ -145,7 +145,7 @@ def main():
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch_corrected")
         out["roofline"] = {
             "bound": "mfma",
-            "kernel": "k_gemm_glds / k_gemm4 (Cholesky trailing update A22 -= L21 L21^T, v_mfma_f64_4x4x4_4b): "
+            "kernel": "k_gemm_glds / k_gemm_glds64 / k_gemm4 (Cholesky trailing update A22 -= L21 L21^T, v_mfma_f64_4x4x4_4b): "
                       "all 15 launches of one factorisation, HIP events on the handle's stream",
             "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF,
             "traffic": traffic,
