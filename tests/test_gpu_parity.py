@@ -273,3 +273,35 @@ def test_gpu_sparsify_full_size(engine_lib):
         return d.min()
 
     assert min_nn(X[keep]) > min_nn(X[:1500])
+
+
+def test_gpu_vs_oracle_n2048_regular_panels(engine_lib, oracle_lib):
+    """N = 2048 = 8 regular outer panels: every panel goes through the look-ahead schedule, the fused
+    next-panel update (k_upd_fused) and the data-flow backward sweep — factor, alpha, log-lik and queries
+    against the oracle on the same inputs."""
+    rng = np.random.default_rng(2048)
+    N, D = 2048, 6
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = (np.cos(3 * X.sum(axis=1)) + 0.05 * rng.normal(size=N))[:, None]
+    om, mean = O.obs_mean_data(Y)
+    th = rng.uniform(-0.4, 0.2, size=D + 1)
+    g = new_gp(engine_lib, O.SE_ARD, X, om, th, 0.01)
+    o = new_gp(oracle_lib, O.SE_ARD, X, om, th, 0.01)
+    assert g.compute() == 0 and o.compute() == 0
+    Lg, Lo = g.get_L(), o.get_L()
+    assert np.max(np.abs(Lg - Lo)) < 1e-10 * np.max(np.abs(Lo))
+    assert relerr_norm(g.get_alpha(), o.get_alpha()) < 1e-7
+    llg, llo = g.log_lik(), o.log_lik()
+    assert abs(llg - llo) <= PC.TOL_LL * max(1.0, abs(llo))
+    Xq = rng.uniform(0, 1, size=(200, D))
+    kg, vg = g.query_batch(Xq)
+    ko, vo = o.query_batch(Xq)
+    mug, s2g = O.finish_query(kg, vg, mean, 0.01)
+    muo, s2o = O.finish_query(ko, vo, mean, 0.01)
+    assert relerr(mug, muo, floor=1e-3) < PC.TOL_MU
+    assert relerr(s2g, s2o) < PC.TOL_VAR
+    # bitwise reproducible from run to run (fixed-order reductions, no atomics in any sum)
+    assert g.compute() == 0
+    assert np.array_equal(g.get_L(), Lg) and g.log_lik() == llg
+    g.close()
+    o.close()
