@@ -47,7 +47,10 @@ enum gpe_status {
 };
 
 /* kernel functors with device code.
- * SE_ARD    kernel/squared_exp_ard.hpp:138-151 (k = 0 only)  theta = [log l_1..log l_D, log sigma_f]
+ * SE_ARD    kernel/squared_exp_ard.hpp:138-151               theta = [log l_1..log l_D, log sigma_f]
+ *           with k > 0 columns of Lambda (:109-126, :142-146):  [log l_1..log l_D, Lambda(:,0), ..,
+ *           Lambda(:,k-1), log sigma_f] (params_size :94; Lambda not in log-space, :100-102).  k follows
+ *           from n_theta = D + D k + 1; limits: k <= D, n_theta <= 64.
  * MATERN52  kernel/matern_five_halves.hpp:104-113            theta = [log l, log sigma_f]
  * MATERN32  kernel/matern_three_halves.hpp                   theta = [log l, log sigma_f]
  * EXP       kernel/exp.hpp                                   theta = [log l, log sigma_f]

@@ -2,7 +2,10 @@
 //   k(x, y) = sigma_f^2 exp(-1/2 (x-y)^T M (x-y)),  M = Lambda Lambda^T + diag(ell)^-2
 // hyper-parameters (log-space): [log ell_1..D, (Lambda column-major, k columns), log sigma_f]
 // (policy contract and formulas: src/limbo/kernel/squared_exp_ard.hpp:81-161).
-// With Params::kernel_squared_exp_ard::k() == 0 the MI355X engine evaluates it (GPE_KERNEL_SE_ARD).
+// The MI355X engine evaluates it for every k (GPE_KERNEL_SE_ARD; the number of Lambda columns follows from
+// the parameter count): (x-y)^T M (x-y) is a sum of squares over the D inputs scaled by 1/ell and the k
+// projections Lambda^T x, which the engine keeps as k extra rows of its sample matrix.  Engine limits:
+// k <= D and D + D k + 1 <= 64 parameters (gpe_compute returns GPE_ERR_ARG beyond them).
 #ifndef LIMBO_KERNEL_SQUARED_EXP_ARD_HPP
 #define LIMBO_KERNEL_SQUARED_EXP_ARD_HPP
 
@@ -97,7 +100,7 @@ namespace limbo {
 namespace limbo_amd {
     template <typename Params>
     struct device_kernel<limbo::kernel::SquaredExpARD<Params>> {
-        static constexpr int kind = (Params::kernel_squared_exp_ard::k() == 0) ? KIND_SE_ARD : KIND_HOST_K;
+        static constexpr int kind = KIND_SE_ARD;
     };
 } // namespace limbo_amd
 

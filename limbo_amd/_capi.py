@@ -110,6 +110,12 @@ def _sig(lib, prefix):
         f = lib.orc_kernel_grad
         f.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, _dp]
         f.restype = None
+        f = lib.orc_kernel_eval_n
+        f.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, C.c_int]
+        f.restype = C.c_double
+        f = lib.orc_kernel_grad_n
+        f.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, C.c_int, _dp]
+        f.restype = None
 
 
 class Lib:

@@ -11,7 +11,11 @@
 // per-kernel set_params: squared_exp_ard.hpp:96-105, matern_five_halves.hpp:97-102)
 struct KParams {
     int kind;  // gpe_kernel_kind
-    int D;     // input dimension
+    int D;     // rows of the SoA sample matrix that enter the distance: input dimension (+ k projection rows, below)
+    int Din;   // input dimension
+    int k_lam; // SE-ARD with M = Lambda Lambda^T + diag(ell^-2), Lambda D x k (squared_exp_ard.hpp:109-126,142-146):
+               // rows Din .. Din+k-1 of the sample matrix hold the projections Lambda^T x (inv_ell = 1 there), so
+               // (x1-x2)^T M (x1-x2) is the same sum of squares over D = Din + k rows
     double sf2;                 // sigma_f^2 = exp(2 p_last)
     double inv_l;               // 1/l (isotropic kernels)
     double diag_add;            // noise + 1e-8 (kernel.hpp:83)
@@ -41,6 +45,13 @@ void launch_build_Ks(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, co
 void launch_kvv(hipStream_t s, const double* Qt, int64_t ldq, int64_t M, const KParams& kp, double* kvv);
 // row-major (n x D) -> SoA (D x ld), writing columns [col0, col0+n)
 void launch_transpose_x(hipStream_t s, const double* Xrm, int64_t n, int D, double* Xt, int64_t ld, int64_t col0);
+// Lambda (D x k, column-major as in the parameter vector: squared_exp_ard.hpp:100-102)
+struct LamParams {
+    int D, k;
+    double A[GPE_MAX_THETA];
+};
+// rows D .. D+k-1 of Xt, columns [col0, col0+n):  Xt[(D+j) ld + i] = sum_d A[d + j D] Xt[d ld + i]
+void launch_lambda_rows(hipStream_t s, double* Xt, int64_t ld, int64_t col0, int64_t n, const LamParams& lp);
 
 // ---- Cholesky diagonal block (potrf.hip) --------------------------------------------
 // factor the jb x jb (jb <= 64) diagonal block at A (in place, lower) and write the transposed

@@ -159,6 +159,20 @@ void drain_phases(gpe_ctx* c)
     c->pending.clear();
 }
 
+// rows of the SoA sample matrix: D inputs + room for the k <= D projection rows of SE-ARD's Lambda
+int max_lam(int D) { return std::min(D, (GPE_MAX_THETA - 1 - D) / std::max(D, 1)); }
+int xt_rows(int D) { return D + std::max(0, max_lam(D)); }
+// SE-ARD: D + D k + 1 log-parameters (squared_exp_ard.hpp:94); the isotropic kernels: 2.  Returns k, or -1
+int lam_columns(int kind, int n_theta, int D)
+{
+    if (kind != GPE_KERNEL_SE_ARD)
+        return n_theta == 2 ? 0 : -1;
+    if (D <= 0 || n_theta < D + 1 || (n_theta - 1) % D != 0)
+        return -1;
+    const int k = (n_theta - 1) / D - 1;
+    return k <= max_lam(D) ? k : -1;
+}
+
 void free_dev(gpe_ctx* c)
 {
     double** ps[] = {&c->dXt, &c->dA, &c->dOm, &c->dAl, &c->dW, &c->dY, &c->dLinv, &c->dKinv, &c->dKhost,
@@ -180,7 +194,7 @@ int alloc_dev(gpe_ctx* c, int64_t cap, int D, int P)
     int64_t ld = ld_for(cap, P);
     c->cap = cap;
     c->ld = ld;
-    HIPCHK(c, hipMalloc(&c->dXt, sizeof(double) * (size_t)(ld * D)));
+    HIPCHK(c, hipMalloc(&c->dXt, sizeof(double) * (size_t)(ld * xt_rows(D))));
     HIPCHK(c, hipMalloc(&c->dA, sizeof(double) * (size_t)(ld * cap)));
     HIPCHK(c, hipMalloc(&c->dOm, sizeof(double) * (size_t)(ld * P)));
     HIPCHK(c, hipMalloc(&c->dAl, sizeof(double) * (size_t)(ld * P)));
@@ -188,7 +202,7 @@ int alloc_dev(gpe_ctx* c, int64_t cap, int D, int P)
     HIPCHK(c, hipMalloc(&c->dY, sizeof(double) * (size_t)(ld * std::max(P, 1))));
     HIPCHK(c, hipMalloc(&c->dXinv, sizeof(double) * (size_t)(cap / NB) * NB * NB));
     HIPCHK(c, hipMemsetAsync(c->dXinv, 0, sizeof(double) * (size_t)(cap / NB) * NB * NB, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->dXt, 0, sizeof(double) * (size_t)(ld * D), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dXt, 0, sizeof(double) * (size_t)(ld * xt_rows(D)), c->stream));
     return GPE_OK;
 }
 
@@ -202,7 +216,7 @@ int grow_dev(gpe_ctx* c, int64_t need)
     int D = c->D, P = c->P;
     int64_t nld = ld_for(ncap, P);
     double *nXt = nullptr, *nA = nullptr, *nOm = nullptr, *nAl = nullptr, *nW = nullptr, *nY = nullptr, *nXi = nullptr;
-    HIPCHK(c, hipMalloc(&nXt, sizeof(double) * (size_t)(nld * D)));
+    HIPCHK(c, hipMalloc(&nXt, sizeof(double) * (size_t)(nld * xt_rows(D))));
     HIPCHK(c, hipMalloc(&nA, sizeof(double) * (size_t)(nld * ncap)));
     HIPCHK(c, hipMalloc(&nOm, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nAl, sizeof(double) * (size_t)(nld * P)));
@@ -210,9 +224,9 @@ int grow_dev(gpe_ctx* c, int64_t need)
     HIPCHK(c, hipMalloc(&nY, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nXi, sizeof(double) * (size_t)(ncap / NB) * NB * NB));
     HIPCHK(c, hipMemsetAsync(nXi, 0, sizeof(double) * (size_t)(ncap / NB) * NB * NB, c->stream));
-    HIPCHK(c, hipMemsetAsync(nXt, 0, sizeof(double) * (size_t)(nld * D), c->stream));
+    HIPCHK(c, hipMemsetAsync(nXt, 0, sizeof(double) * (size_t)(nld * xt_rows(D)), c->stream));
     if (c->N > 0) {
-        launch_copy2d(c->stream, c->dXt, c->ld, nXt, nld, c->N, D);
+        launch_copy2d(c->stream, c->dXt, c->ld, nXt, nld, c->N, xt_rows(D));
         launch_copy2d(c->stream, c->dA, c->ld, nA, nld, c->N, c->N);
         hipMemcpyAsync(nXi, c->dXinv, sizeof(double) * (size_t)(c->cap / NB) * NB * NB, hipMemcpyDeviceToDevice,
                        c->stream);
@@ -241,14 +255,18 @@ void digest_kernel(gpe_ctx* c)
     KParams& k = c->kp;
     memset(&k, 0, sizeof(k));
     k.kind = c->kind;
-    k.D = c->D;
+    k.D = k.Din = c->D;
     k.noise = c->noise;
     k.diag_add = c->noise + 1e-8; // kernel.hpp:83
     if (c->kind == GPE_KERNEL_SE_ARD) {
         // SquaredExpARD::set_params, squared_exp_ard.hpp:96-105
         for (int d = 0; d < c->D && d < GPE_MAX_THETA; ++d)
             k.inv_ell[d] = 1.0 / std::exp(c->theta[d]);
-        k.sf2 = std::exp(2.0 * c->theta[c->D]);
+        k.k_lam = std::max(0, lam_columns(c->kind, c->n_theta, c->D));
+        k.D = c->D + k.k_lam; // the projections Lambda^T x are extra rows with unit length scale
+        for (int j = 0; j < k.k_lam; ++j)
+            k.inv_ell[c->D + j] = 1.0;
+        k.sf2 = std::exp(2.0 * c->theta[c->n_theta - 1]);
         k.inv_l = 1.0;
     }
     else {
@@ -259,6 +277,19 @@ void digest_kernel(gpe_ctx* c)
         for (int d = 0; d < c->D && d < GPE_MAX_THETA; ++d)
             k.inv_ell[d] = k.inv_l;
     }
+}
+
+// rows D .. D+k-1 of a SoA point matrix <- Lambda^T x for columns [col0, col0 + n)  (no-op for k = 0)
+void project_lambda(gpe_ctx* c, hipStream_t s, double* Xt, int64_t ld, int64_t col0, int64_t n)
+{
+    if (c->kp.k_lam <= 0)
+        return;
+    LamParams lp;
+    lp.D = c->D;
+    lp.k = c->kp.k_lam;
+    for (int q = 0; q < lp.D * lp.k; ++q)
+        lp.A[q] = c->theta[c->D + q]; // squared_exp_ard.hpp:100-102: _A(i, j) = p((j + 1) D + i), not in log-space
+    launch_lambda_rows(s, Xt, ld, col0, n, lp);
 }
 
 inline double* Aat(gpe_ctx* c, double* base, int64_t i, int64_t j) { return base + i + j * c->ld; }
@@ -614,6 +645,7 @@ int compute_enqueue(gpe_ctx* c)
         // first panel's factorisation, was tried: unbounded it slows the latency-bound k_diag / panel-step
         // workgroups it shares CUs with as much as it saves; bounded to 128 looping workgroups it takes
         // 250 us — a tile is latency-bound and needs ~8 co-resident workgroups per CU.)
+        project_lambda(c, s, c->dXt, c->ld, 0, c->N);
         launch_build_K(s, c->dXt, c->ld, c->N, c->kp, c->dA, c->ld);
     }
     {
@@ -987,8 +1019,7 @@ int gpe_compute(gpe_handle c)
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->host_K) {
-        int need = (c->kind == GPE_KERNEL_SE_ARD) ? c->D + 1 : 2;
-        if (c->n_theta != need) {
+        if (lam_columns(c->kind, c->n_theta, c->D) < 0) {
             c->err = "set_kernel: wrong number of hyper-parameters for this kernel/dimension";
             return GPE_ERR_ARG;
         }
@@ -1056,8 +1087,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
             return rc;
     }
     {
-        int need = (c->kind == GPE_KERNEL_SE_ARD) ? c->D + 1 : 2;
-        if (c->n_theta != need) {
+        if (lam_columns(c->kind, c->n_theta, c->D) < 0) {
             c->err = "set_kernel: wrong number of hyper-parameters for this kernel/dimension";
             return GPE_ERR_ARG;
         }
@@ -1068,6 +1098,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     // new sample -> column n of Xt (staged through dY)
     HIPCHK(c, hipMemcpyAsync(c->dY, x, sizeof(double) * D, hipMemcpyHostToDevice, s));
     launch_transpose_x(s, c->dY, 1, D, c->dXt, ld, n);
+    project_lambda(c, s, c->dXt, ld, n, 1);
     HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * ld, obs_mean, sizeof(double) * (n + 1),
                                sizeof(double) * (n + 1), P, hipMemcpyHostToDevice, s));
     c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
@@ -1230,7 +1261,7 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
     const int64_t ldq = mc_max;
     double *dQrm = nullptr, *dQt = nullptr, *dKs = nullptr, *dKta = nullptr, *dVar = nullptr, *dKvv = nullptr;
     HIPCHK(c, hipMalloc(&dQrm, sizeof(double) * (size_t)(mc_max * std::max(D, 1))));
-    HIPCHK(c, hipMalloc(&dQt, sizeof(double) * (size_t)(ldq * std::max(D, 1))));
+    HIPCHK(c, hipMalloc(&dQt, sizeof(double) * (size_t)(ldq * std::max(xt_rows(D), 1))));
     HIPCHK(c, hipMalloc(&dKs, sizeof(double) * (size_t)(ld * mc_max)));
     HIPCHK(c, hipMalloc(&dKta, sizeof(double) * (size_t)(mc_max * P)));
     HIPCHK(c, hipMalloc(&dVar, sizeof(double) * (size_t)mc_max));
@@ -1241,6 +1272,7 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
         if (Xq) {
             hipMemcpyAsync(dQrm, Xq + m0 * D, sizeof(double) * (size_t)(mc * D), hipMemcpyHostToDevice, s);
             launch_transpose_x(s, dQrm, mc, D, dQt, ldq, 0);
+            project_lambda(c, s, dQt, ldq, 0, mc);
             PhaseScope ps(c, GPE_PH_QUERY, 0.0);
             launch_build_Ks(s, c->dXt, ld, N, dQt, ldq, mc, c->kp, dKs, ld); // gp.hpp:626-632
         }
@@ -1466,6 +1498,7 @@ int gpe_get_K(gpe_handle c, double* K, int64_t ldh)
     digest_kernel(c);
     double* tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, sizeof(double) * (size_t)(c->ld * N)));
+    project_lambda(c, c->stream, c->dXt, c->ld, 0, N);
     launch_build_K_full(c->stream, c->dXt, c->ld, N, c->kp, tmp, c->ld);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess)
@@ -1508,7 +1541,8 @@ int gpe_clone(gpe_handle src, gpe_handle* out)
         c->D = src->D;
         c->P = src->P;
         const size_t mat = sizeof(double) * (size_t)(c->ld * c->cap);
-        hipMemcpyAsync(c->dXt, src->dXt, sizeof(double) * (size_t)(c->ld * c->D), hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync(c->dXt, src->dXt, sizeof(double) * (size_t)(c->ld * xt_rows(c->D)), hipMemcpyDeviceToDevice,
+                       c->stream);
         hipMemcpyAsync(c->dA, src->dA, mat, hipMemcpyDeviceToDevice, c->stream);
         hipMemcpyAsync(c->dOm, src->dOm, sizeof(double) * (size_t)(c->ld * c->P), hipMemcpyDeviceToDevice, c->stream);
         hipMemcpyAsync(c->dAl, src->dAl, sizeof(double) * (size_t)(c->ld * c->P), hipMemcpyDeviceToDevice, c->stream);

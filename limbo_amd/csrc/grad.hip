@@ -22,12 +22,16 @@
 
 #define TILE 64
 
-template <int DMAX>
+// LAM = false: the length-scale / sigma_f / noise entries (n_theta = number of those without the noise).
+// LAM = true : the Din entries of column `lam_col` of Lambda (squared_exp_ard.hpp:118-121):
+//              g = -((x1-x2)^T Lambda_col) (x1-x2) k;  n_theta = Din, optimize_noise = 0.
+template <int DMAX, bool LAM>
 __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp,
                                                     const double* __restrict__ Kinv, int64_t ldk,
                                                     const double* __restrict__ alpha, int64_t lda,
                                                     const double* __restrict__ uvec, int P, double kinv_scale,
-                                                    int n_theta, int optimize_noise, double* __restrict__ partial)
+                                                    int n_theta, int optimize_noise, int lam_col,
+                                                    double* __restrict__ partial)
 {
     // weight of pair (i, j):  w = 1/2 sum_p (u_ip alpha_jp + alpha_ip u_jp) - Kinv[i, j]
     // (uvec == alpha for the log-likelihood gradient: w = sum_p alpha_ip alpha_jp - K^-1_ij)
@@ -73,6 +77,8 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
 #pragma unroll
     for (int q = 0; q < DMAX + 2; ++q)
         acc[q] = 0.0;
+    const int lrow = kp.Din + lam_col; // LAM: the projection row of this Lambda column
+    const double fi = (LAM && i < N) ? Xt[(int64_t)lrow * ldx + i] : 0.0;
     __syncthreads();
 
     if (i < N) {
@@ -93,11 +99,19 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
             double zs = 0.0;
 #pragma unroll
             for (int d = 0; d < DMAX; ++d) {
-                double q = (d < D) ? (xi[d] - xj[d * TILE + cc]) * kp.inv_ell[d] : 0.0;
-                z[d] = q * q;
-                zs += z[d];
+                const double dd = (d < D) ? xi[d] - xj[d * TILE + cc] : 0.0;
+                const double q = dd * kp.inv_ell[d];
+                z[d] = LAM ? dd : q * q;
+                zs += q * q;
             }
-            if (kp.kind == 0) { // squared_exp_ard.hpp:127-135 (k = 0 branch)
+            if (LAM) { // squared_exp_ard.hpp:118-121
+                const double k = kp.sf2 * exp(-0.5 * zs);
+                const double wkf = -(w * k) * (fi - xj[lrow * TILE + cc]);
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d)
+                    acc[d] = fma(wkf, z[d], acc[d]);
+            }
+            else if (kp.kind == 0) { // squared_exp_ard.hpp:127-135 (k = 0 branch; k > 0: :114-116, :123)
                 const double k = kp.sf2 * exp(-0.5 * zs);
                 const double wk = w * k;
 #pragma unroll
@@ -147,7 +161,9 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
     if (threadIdx.x < T) {
         // map output slot -> accumulator slot
         int q;
-        if (optimize_noise && (int)threadIdx.x == T - 1)
+        if (LAM)
+            q = (int)threadIdx.x;
+        else if (optimize_noise && (int)threadIdx.x == T - 1)
             q = DMAX + 1;
         else if (kp.kind == 0)
             q = ((int)threadIdx.x == n_theta - 1) ? DMAX : (int)threadIdx.x;
@@ -158,11 +174,15 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
     }
 }
 
+// slot t of the launch goes to grad[out_off + t], slots >= tail_from to grad[tail_to + (t - tail_from)]
+// (with Lambda columns the parameter vector is [ell | Lambda columns | sigma_f | (noise)])
 __global__ __launch_bounds__(256) void k_grad_final(const double* __restrict__ partial, int64_t nblk, int T,
-                                                    double* __restrict__ grad, int accumulate)
+                                                    double* __restrict__ grad_, int accumulate, int out_off,
+                                                    int tail_from, int tail_to)
 {
     __shared__ double sh[4];
     const int t = blockIdx.x;
+    double* grad = grad_ + ((t >= tail_from) ? tail_to - tail_from : out_off);
     double s = 0.0;
     for (int64_t b = threadIdx.x; b < nblk; b += 256)
         s += partial[b * T + t];
@@ -178,8 +198,8 @@ __global__ __launch_bounds__(256) void k_grad_final(const double* __restrict__ p
 
 static void launch_grad_chunk(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp,
                               const double* Kinv, int64_t ldk, const double* alpha, int64_t lda, const double* uvec,
-                              int P, double kinv_scale, int n_theta, int optimize_noise, double* partial, double* grad,
-                              int accumulate);
+                              int P, double kinv_scale, int n_theta, int optimize_noise, int lam_col, double* partial,
+                              double* grad, int accumulate, int out_off, int tail_from, int tail_to);
 
 int64_t grad_partial_size(int64_t N, int T)
 {
@@ -194,37 +214,57 @@ void launch_grad_loglik(hipStream_t s, const double* Xt, int64_t ldx, int64_t N,
     // outputs go through in chunks of GPE_MAX_P: the alpha-u term is additive over outputs, K^-1 enters once
     for (int p0 = 0; p0 < P; p0 += GPE_MAX_P) {
         const int pc = (P - p0 < GPE_MAX_P) ? P - p0 : GPE_MAX_P;
-        launch_grad_chunk(s, Xt, ldx, N, kp, Kinv, ldk, alpha + (int64_t)p0 * lda, lda, uvec + (int64_t)p0 * lda, pc,
-                          p0 == 0 ? 1.0 : 0.0, n_theta, optimize_noise, partial, grad, p0 > 0);
+        const double ks = p0 == 0 ? 1.0 : 0.0;
+        const double *al = alpha + (int64_t)p0 * lda, *uv = uvec + (int64_t)p0 * lda;
+        if (kp.k_lam == 0) {
+            launch_grad_chunk(s, Xt, ldx, N, kp, Kinv, ldk, al, lda, uv, pc, ks, n_theta, optimize_noise, -1, partial,
+                              grad, p0 > 0, 0, 1 << 30, 0);
+            continue;
+        }
+        // [ell_1..ell_Din | sigma_f | (noise)] -> slots [0, Din) and [n_theta - 1, ...)
+        launch_grad_chunk(s, Xt, ldx, N, kp, Kinv, ldk, al, lda, uv, pc, ks, kp.Din + 1, optimize_noise, -1, partial,
+                          grad, p0 > 0, 0, kp.Din, n_theta - 1);
+        for (int j = 0; j < kp.k_lam; ++j) // one pass per Lambda column: the pair loop is K^-1-read bound, k is small
+            launch_grad_chunk(s, Xt, ldx, N, kp, Kinv, ldk, al, lda, uv, pc, ks, kp.Din, 0, j, partial, grad, p0 > 0,
+                              kp.Din * (j + 1), 1 << 30, 0);
     }
 }
 
 static void launch_grad_chunk(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp,
                               const double* Kinv, int64_t ldk, const double* alpha, int64_t lda, const double* uvec,
-                              int P, double kinv_scale, int n_theta, int optimize_noise, double* partial, double* grad,
-                              int accumulate)
+                              int P, double kinv_scale, int n_theta, int optimize_noise, int lam_col, double* partial,
+                              double* grad, int accumulate, int out_off, int tail_from, int tail_to)
 {
     const int T = n_theta + (optimize_noise ? 1 : 0);
     const int64_t nt = (N + TILE - 1) / TILE;
     const int64_t nblk = nt * (nt + 1) / 2;
     const int D = kp.D;
     dim3 grid((unsigned)nblk), block(256);
-#define LG(DM)                                                                                                   \
-    hipLaunchKernelGGL((k_grad_tiles<DM>), grid, block,                                                          \
+#define LG(DM, LAM)                                                                                              \
+    hipLaunchKernelGGL((k_grad_tiles<DM, LAM>), grid, block,                                                     \
                        (size_t)(D * TILE + 2 * GPE_MAX_P * TILE + 4 * (DM + 2)) * sizeof(double), s, Xt, ldx, N, \
-                       kp, Kinv, ldk, alpha, lda, uvec, P, kinv_scale, n_theta, optimize_noise, partial)
-    if (D <= 4)
-        LG(4);
-    else if (D <= 8)
-        LG(8);
-    else if (D <= 16)
-        LG(16);
-    else if (D <= 32)
-        LG(32);
-    else
-        LG(64);
+                       kp, Kinv, ldk, alpha, lda, uvec, P, kinv_scale, n_theta, optimize_noise, lam_col, partial)
+#define LGD(LAM)      \
+    if (D <= 4)       \
+        LG(4, LAM);   \
+    else if (D <= 8)  \
+        LG(8, LAM);   \
+    else if (D <= 16) \
+        LG(16, LAM);  \
+    else if (D <= 32) \
+        LG(32, LAM);  \
+    else              \
+        LG(64, LAM)
+    if (lam_col >= 0) {
+        LGD(true);
+    }
+    else {
+        LGD(false);
+    }
+#undef LGD
 #undef LG
-    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)T), dim3(256), 0, s, partial, nblk, T, grad, accumulate);
+    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)T), dim3(256), 0, s, partial, nblk, T, grad, accumulate, out_off,
+                       tail_from, tail_to);
 }
 
 // ---- leave-one-out helpers (gp.hpp:339-402) -------------------------------------------------------

@@ -52,6 +52,26 @@ void launch_transpose_x(hipStream_t s, const double* Xrm, int64_t n, int D, doub
     hipLaunchKernelGGL(k_transpose_x, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xrm, n, D, Xt, ld, col0);
 }
 
+__global__ void k_lambda_rows(double* __restrict__ Xt, int64_t ld, int64_t col0, int64_t n, LamParams lp)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    for (int j = 0; j < lp.k; ++j) {
+        double f = 0.0; // (x^T Lambda)_j: the same left-to-right sum as `(x1 - x2).transpose() * _A.col(j)`
+        for (int d = 0; d < lp.D; ++d)
+            f = fma(Xt[(int64_t)d * ld + col0 + i], lp.A[d + j * lp.D], f);
+        Xt[(int64_t)(lp.D + j) * ld + col0 + i] = f;
+    }
+}
+
+void launch_lambda_rows(hipStream_t s, double* Xt, int64_t ld, int64_t col0, int64_t n, const LamParams& lp)
+{
+    if (n <= 0 || lp.k <= 0)
+        return;
+    hipLaunchKernelGGL(k_lambda_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Xt, ld, col0, n, lp);
+}
+
 // MODE 0: lower triangle of the symmetric training matrix (+diag_add on i==j)
 // MODE 1: full symmetric training matrix (tests)
 // MODE 2: rectangular cross matrix, no noise

@@ -33,6 +33,7 @@
 
 enum { K_SE_ARD = 0, K_MATERN52 = 1, K_MATERN32 = 2, K_EXP = 3, K_HOST_K = 4 };
 #define MAX_THETA 64
+#define MAX_D_LAM 64
 
 typedef struct orc_ctx {
     int64_t N, cap;
@@ -67,6 +68,41 @@ static double k_se_ard(const double* x1, const double* x2, int D, const double* 
         z += q * q;                              /* squaredNorm() */
     }
     return exp(2.0 * th[D]) * exp(-0.5 * z); /* :150 */
+}
+
+/* SquaredExpARD with k > 0 columns of Lambda: squared_exp_ard.hpp:142-146.  Parameter vector (:96-105):
+ * [log ell_1..log ell_D | Lambda(:,0) | .. | Lambda(:,k-1) | log sigma_f], Lambda NOT in log-space.
+ * Restated literally: M = Lambda Lambda^T, M.diagonal() += ell^-2, z = d^T M d. */
+static double se_ard_lam_z(const double* x1, const double* x2, int D, int k, const double* th)
+{
+    double M[MAX_D_LAM * MAX_D_LAM], d[MAX_D_LAM], Md[MAX_D_LAM];
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b < D; ++b) {
+            double s = 0.0;
+            for (int j = 0; j < k; ++j)
+                s += th[(j + 1) * D + a] * th[(j + 1) * D + b]; /* _A(i, j) = p((j + 1) * dim + i)  :102 */
+            M[a + b * D] = s;
+        }
+    for (int a = 0; a < D; ++a) {
+        double ell = exp(th[a]);
+        double inv = 1.0 / ell;
+        M[a + a * D] += inv * inv; /* _ell.array().inverse().square()  :144 */
+        d[a] = x1[a] - x2[a];
+    }
+    for (int b = 0; b < D; ++b) { /* (x1 - x2)^T * K : a row vector ... */
+        double s = 0.0;
+        for (int a = 0; a < D; ++a)
+            s += d[a] * M[a + b * D];
+        Md[b] = s;
+    }
+    double z = 0.0; /* ... times (x1 - x2) */
+    for (int b = 0; b < D; ++b)
+        z += Md[b] * d[b];
+    return z;
+}
+static double k_se_ard_lam(const double* x1, const double* x2, int D, int k, const double* th)
+{
+    return exp(2.0 * th[D + D * k]) * exp(-0.5 * se_ard_lam_z(x1, x2, D, k, th)); /* :150 */
 }
 
 /* MaternFiveHalves::kernel: src/limbo/kernel/matern_five_halves.hpp:104-113; params :97-102 */
@@ -112,10 +148,16 @@ static double k_exp(const double* x1, const double* x2, int D, const double* th)
     return sf2 * exp(-0.5 * r);
 }
 
-static double k_eval(int kind, const double* x1, const double* x2, int D, const double* th)
+/* number of Lambda columns implied by the parameter count (params_size, squared_exp_ard.hpp:94) */
+static int se_ard_k(int D, int nth) { return (D > 0 && nth > D + 1) ? (nth - 1) / D - 1 : 0; }
+
+static double k_eval(int kind, const double* x1, const double* x2, int D, const double* th, int nth)
 {
     switch (kind) {
-    case K_SE_ARD: return k_se_ard(x1, x2, D, th);
+    case K_SE_ARD:
+        if (se_ard_k(D, nth) > 0)
+            return k_se_ard_lam(x1, x2, D, se_ard_k(D, nth), th);
+        return k_se_ard(x1, x2, D, th);
     case K_MATERN52: return k_matern52(x1, x2, D, th);
     case K_MATERN32: return k_matern32(x1, x2, D, th);
     default: return k_exp(x1, x2, D, th);
@@ -126,7 +168,7 @@ static double k_eval(int kind, const double* x1, const double* x2, int D, const 
  * two sample INDICES are equal; query-time calls use the defaults i=-1, j=-2 (no noise). */
 static double k_with_noise(const orc_ctx* c, const double* x1, const double* x2, int64_t i, int64_t j)
 {
-    return k_eval(c->kind, x1, x2, c->D, c->theta) + ((i == j) ? c->noise + 1e-8 : 0.0);
+    return k_eval(c->kind, x1, x2, c->D, c->theta, c->n_theta) + ((i == j) ? c->noise + 1e-8 : 0.0);
 }
 
 /* Kernel::gradient wrt the log-hyper-parameters (without the noise entry):
@@ -134,8 +176,26 @@ static double k_with_noise(const orc_ctx* c, const double* x1, const double* x2,
  * Matern52 matern_five_halves.hpp:115-133
  * Matern32 matern_three_halves.hpp:109-121
  * Exp      exp.hpp:104-113 */
-static void k_grad(int kind, const double* x1, const double* x2, int D, const double* th, double* g)
+static void k_grad(int kind, const double* x1, const double* x2, int D, const double* th, int nth, double* g)
 {
+    if (kind == K_SE_ARD && se_ard_k(D, nth) > 0) { /* squared_exp_ard.hpp:109-126 */
+        const int k = se_ard_k(D, nth);
+        double z = se_ard_lam_z(x1, x2, D, k, th);
+        double kv = exp(2.0 * th[D + D * k]) * exp(-0.5 * z);
+        for (int d = 0; d < D; ++d) {
+            double q = (x1[d] - x2[d]) / exp(th[d]);
+            g[d] = q * q * kv; /* :116 */
+        }
+        for (int j = 0; j < k; ++j) {
+            double proj = 0.0; /* (x1 - x2)^T _A.col(j) */
+            for (int d = 0; d < D; ++d)
+                proj += (x1[d] - x2[d]) * th[(j + 1) * D + d];
+            for (int d = 0; d < D; ++d)
+                g[(j + 1) * D + d] = -proj * (x1[d] - x2[d]) * kv; /* :119-120 */
+        }
+        g[D + D * k] = 2 * kv; /* :123 */
+        return;
+    }
     if (kind == K_SE_ARD) {
         double zs = 0.0;
         for (int d = 0; d < D; ++d) {
@@ -563,7 +623,7 @@ int orc_log_lik_grad(orc_handle c, double* grad, int n_grad, int optimize_noise)
             for (int p = 0; p < c->P; ++p)
                 w += c->alpha[i + p * n] * c->alpha[j + p * n];
             w -= A_(c->Kinv, i, j, n);
-            k_grad(c->kind, c->X + i * c->D, c->X + j * c->D, c->D, c->theta, g);
+            k_grad(c->kind, c->X + i * c->D, c->X + j * c->D, c->D, c->theta, c->n_theta, g);
             if (optimize_noise)
                 g[nt] = (i == j) ? 2.0 * c->noise : 0.0;
             double f = (i == j) ? 0.5 : 1.0; /* :303-306 */
@@ -617,7 +677,7 @@ int orc_log_loo_cv_grad(orc_handle c, double* grad, int n_grad, int optimize_noi
     double g[MAX_THETA + 1];
     for (int64_t i = 0; i < n; ++i)
         for (int64_t j = 0; j <= i; ++j) {
-            k_grad(c->kind, c->X + i * c->D, c->X + j * c->D, c->D, c->theta, g);
+            k_grad(c->kind, c->X + i * c->D, c->X + j * c->D, c->D, c->theta, c->n_theta, g);
             if (optimize_noise)
                 g[nt] = (i == j) ? 2.0 * c->noise : 0.0;
             for (int t = 0; t < n_grad; ++t)
@@ -809,7 +869,7 @@ int orc_query_batch(orc_handle c, const double* Xq, int64_t M, double* kta, doub
     for (int64_t m = 0; m < M; ++m) {
         const double* v = Xq + m * c->D;
         for (int64_t i = 0; i < n; ++i)
-            k[i] = k_eval(c->kind, c->X + i * c->D, v, c->D, c->theta); /* :626-632, no noise */
+            k[i] = k_eval(c->kind, c->X + i * c->D, v, c->D, c->theta, c->n_theta); /* :626-632, no noise */
         if (kta)
             for (int p = 0; p < c->P; ++p) {
                 double s = 0.0;
@@ -822,7 +882,7 @@ int orc_query_batch(orc_handle c, const double* Xq, int64_t M, double* kta, doub
             double zz = 0.0;
             for (int64_t i = 0; i < n; ++i)
                 zz += k[i] * k[i];
-            var[m] = k_eval(c->kind, v, v, c->D, c->theta) - zz; /* :621 */
+            var[m] = k_eval(c->kind, v, v, c->D, c->theta, c->n_theta) - zz; /* :621 */
         }
     }
     free(k);
@@ -1022,9 +1082,18 @@ int orc_kernel_lf_opt_rprop(orc_handle c, int optimize_noise, int iterations, do
 /* scalar entry points for the kernel known-answer tests (test_kernel.cpp:196-224) */
 double orc_kernel_eval(int kind, const double* x1, const double* x2, int D, const double* theta)
 {
-    return k_eval(kind, x1, x2, D, theta);
+    return k_eval(kind, x1, x2, D, theta, kind == K_SE_ARD ? D + 1 : 2);
 }
 void orc_kernel_grad(int kind, const double* x1, const double* x2, int D, const double* theta, double* g)
 {
-    k_grad(kind, x1, x2, D, theta, g);
+    k_grad(kind, x1, x2, D, theta, kind == K_SE_ARD ? D + 1 : 2, g);
+}
+/* same with an explicit parameter count: SE-ARD with k = (n_theta - 1) / D - 1 columns of Lambda */
+double orc_kernel_eval_n(int kind, const double* x1, const double* x2, int D, const double* theta, int n_theta)
+{
+    return k_eval(kind, x1, x2, D, theta, n_theta);
+}
+void orc_kernel_grad_n(int kind, const double* x1, const double* x2, int D, const double* theta, int n_theta, double* g)
+{
+    k_grad(kind, x1, x2, D, theta, n_theta, g);
 }

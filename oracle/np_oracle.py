@@ -20,6 +20,14 @@ def kernel_cross(kind, X1, X2, theta):
     X2 = np.asarray(X2, float)
     theta = np.asarray(theta, float)
     D = X1.shape[1]
+    if kind == SE_ARD and theta.size > D + 1:
+        # k = (T - 1) / D - 1 columns of Lambda: M = Lambda Lambda^T + diag(ell^-2), squared_exp_ard.hpp:142-146
+        k = (theta.size - 1) // D - 1
+        A = theta[D:D + D * k].reshape(k, D).T  # _A(i, j) = p((j + 1) D + i)
+        M = A @ A.T + np.diag(np.exp(theta[:D]) ** -2.0)
+        d = X1[:, None, :] - X2[None, :, :]
+        z = np.einsum("nma,ab,nmb->nm", d, M, d)
+        return np.exp(2.0 * theta[-1]) * np.exp(-0.5 * z)
     if kind == SE_ARD:
         ell = np.exp(theta[:D])
         sf2 = np.exp(2.0 * theta[D])
@@ -54,6 +62,20 @@ def kernel_grad_tensor(kind, X, theta):
     X = np.asarray(X, float)
     theta = np.asarray(theta, float)
     N, D = X.shape
+    if kind == SE_ARD and theta.size > D + 1:  # squared_exp_ard.hpp:109-126
+        k = (theta.size - 1) // D - 1
+        A = theta[D:D + D * k].reshape(k, D).T
+        kv = kernel_cross(kind, X, X, theta)
+        d = X[:, None, :] - X[None, :, :]
+        G = np.empty((theta.size, N, N))
+        for a in range(D):
+            G[a] = (d[:, :, a] / np.exp(theta[a])) ** 2 * kv
+        for j in range(k):
+            proj = d @ A[:, j]
+            for a in range(D):
+                G[(j + 1) * D + a] = -proj * d[:, :, a] * kv
+        G[-1] = 2 * kv
+        return G
     if kind == SE_ARD:
         ell = np.exp(theta[:D])
         sf2 = np.exp(2.0 * theta[D])

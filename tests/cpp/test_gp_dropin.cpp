@@ -83,10 +83,46 @@ struct ParamsNoiseOpt : public Params {
         BO_PARAM(bool, optimize_noise, true);
     };
 };
-struct ParamsLambda : public Params { // SE-ARD with a Lambda column: no device code -> host-built K
+struct ParamsLambda : public Params { // SE-ARD with a Lambda column (squared_exp_ard.hpp:109-126): device code
     struct kernel_squared_exp_ard : public defaults::kernel_squared_exp_ard {
         BO_PARAM(int, k, 1);
     };
+};
+struct ParamsLambda2 : public ParamsNoiseOpt {
+    struct kernel_squared_exp_ard : public defaults::kernel_squared_exp_ard {
+        BO_PARAM(int, k, 2);
+    };
+};
+
+// A user-written kernel the engine has no device code for (no limbo_amd::device_kernel specialisation):
+// the GP builds K and k* with this functor on the host and hands them to the engine (gpe_set_K_host).
+// Rational quadratic, alpha = 2:  k = sigma_f^2 (1 + r^2 / (4 l^2))^-2.
+template <typename P>
+struct RationalQuadratic : public kernel::BaseKernel<P, RationalQuadratic<P>> {
+    RationalQuadratic(int = 1) { set_params(VectorXd::Zero(2)); }
+    size_t params_size() const { return 2; }
+    VectorXd params() const { return _p; }
+    void set_params(const VectorXd& p)
+    {
+        _p = p;
+        _l2 = std::exp(2.0 * p(0));
+        _sf2 = std::exp(2.0 * p(1));
+    }
+    double kernel(const VectorXd& a, const VectorXd& b) const
+    {
+        const double u = (a - b).squaredNorm() / (4.0 * _l2);
+        return _sf2 / ((1.0 + u) * (1.0 + u));
+    }
+    VectorXd gradient(const VectorXd& a, const VectorXd& b) const
+    {
+        const double r2 = (a - b).squaredNorm() / _l2, u = r2 / 4.0;
+        VectorXd g(2);
+        g(0) = _sf2 * r2 / ((1.0 + u) * (1.0 + u) * (1.0 + u));
+        g(1) = 2.0 * kernel(a, b);
+        return g;
+    }
+    VectorXd _p;
+    double _l2 = 1.0, _sf2 = 1.0;
 };
 
 static std::mt19937_64 g_rng(20260926);
@@ -247,7 +283,9 @@ CASE(test_gp_vs_host_se_ard) { compare_with_host<model::GP<Params, kernel::Squar
 CASE(test_gp_vs_host_matern52) { compare_with_host<model::GP<Params, kernel::MaternFiveHalves<Params>, mean::Data<Params>>>(97, 3, 1, g_failed_here); }
 CASE(test_gp_vs_host_matern32) { compare_with_host<model::GP<Params, kernel::MaternThreeHalves<Params>, mean::Constant<Params>>>(64, 2, 1, g_failed_here); }
 CASE(test_gp_vs_host_exp) { compare_with_host<model::GP<Params, kernel::Exp<Params>, mean::NullFunction<Params>>>(65, 5, 3, g_failed_here); }
-CASE(test_gp_vs_host_functor_kernel) { compare_with_host<model::GP<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>, mean::Data<ParamsLambda>>>(80, 3, 2, g_failed_here); }
+CASE(test_gp_vs_host_functor_kernel) { compare_with_host<model::GP<Params, RationalQuadratic<Params>, mean::Data<Params>>>(80, 3, 2, g_failed_here); }
+CASE(test_gp_vs_host_se_ard_lambda) { compare_with_host<model::GP<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>, mean::Data<ParamsLambda>>>(80, 3, 2, g_failed_here); }
+CASE(test_gp_vs_host_se_ard_lambda2) { compare_with_host<model::GP<ParamsLambda2, kernel::SquaredExpARD<ParamsLambda2>, mean::Data<ParamsLambda2>>>(140, 5, 1, g_failed_here); }
 
 // test_gp.cpp:131-271 — analytic gradient of the log-likelihood vs central finite differences,
 // through the same calls the optimiser objective makes (set_h_params, recompute(false), compute_log_lik)
@@ -285,7 +323,9 @@ static void check_grad(int& g_failed_here)
 CASE(test_gp_check_lf_grad) { check_grad<model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>>(g_failed_here); }
 CASE(test_gp_check_lf_grad_noise) { check_grad<model::GP<ParamsNoiseOpt, kernel::SquaredExpARD<ParamsNoiseOpt>, mean::Data<ParamsNoiseOpt>>>(g_failed_here); }
 CASE(test_gp_check_lf_grad_matern) { check_grad<model::GP<ParamsNoiseOpt, kernel::MaternFiveHalves<ParamsNoiseOpt>, mean::Data<ParamsNoiseOpt>>>(g_failed_here); }
-CASE(test_gp_check_lf_grad_functor_kernel) { check_grad<model::GP<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>, mean::Data<ParamsLambda>>>(g_failed_here); }
+CASE(test_gp_check_lf_grad_functor_kernel) { check_grad<model::GP<ParamsNoiseOpt, RationalQuadratic<ParamsNoiseOpt>, mean::Data<ParamsNoiseOpt>>>(g_failed_here); }
+CASE(test_gp_check_lf_grad_se_ard_lambda) { check_grad<model::GP<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>, mean::Data<ParamsLambda>>>(g_failed_here); }
+CASE(test_gp_check_lf_grad_se_ard_lambda2) { check_grad<model::GP<ParamsLambda2, kernel::SquaredExpARD<ParamsLambda2>, mean::Data<ParamsLambda2>>>(g_failed_here); }
 
 // test_gp.cpp:72-92 — gradient of an optimiser objective vs central finite differences
 template <typename F>
@@ -365,7 +405,8 @@ static void check_loo_objective(int& g_failed_here)
 }
 CASE(test_gp_check_loo_grad) { check_loo_objective<Params, kernel::SquaredExpARD<Params>>(g_failed_here); }
 CASE(test_gp_check_loo_grad_noise) { check_loo_objective<ParamsNoiseOpt, kernel::SquaredExpARD<ParamsNoiseOpt>>(g_failed_here); }
-CASE(test_gp_check_loo_grad_functor_kernel) { check_loo_objective<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>>(g_failed_here); }
+CASE(test_gp_check_loo_grad_functor_kernel) { check_loo_objective<Params, RationalQuadratic<Params>>(g_failed_here); }
+CASE(test_gp_check_loo_grad_se_ard_lambda) { check_loo_objective<ParamsLambda, kernel::SquaredExpARD<ParamsLambda>>(g_failed_here); }
 
 // the HP-optimisation policies end to end: each must not decrease its own objective, and the mean
 // policies must move the mean parameters (obs_multi_auto_mean.cpp is the reference's example of them)
@@ -808,15 +849,20 @@ int main()
     test_gp_vs_host_matern32_run();
     test_gp_vs_host_exp_run();
     test_gp_vs_host_functor_kernel_run();
+    test_gp_vs_host_se_ard_lambda_run();
+    test_gp_vs_host_se_ard_lambda2_run();
     test_gp_check_lf_grad_run();
     test_gp_check_lf_grad_noise_run();
     test_gp_check_lf_grad_matern_run();
     test_gp_check_lf_grad_functor_kernel_run();
+    test_gp_check_lf_grad_se_ard_lambda_run();
+    test_gp_check_lf_grad_se_ard_lambda2_run();
     test_gp_check_lf_grad_objectives_run();
     test_gp_check_lf_grad_objectives_noise_run();
     test_gp_check_loo_grad_run();
     test_gp_check_loo_grad_noise_run();
     test_gp_check_loo_grad_functor_kernel_run();
+    test_gp_check_loo_grad_se_ard_lambda_run();
     test_gp_hp_policies_run();
     test_gp_check_inv_kernel_computation_run();
     test_gp_run();

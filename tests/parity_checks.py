@@ -120,14 +120,14 @@ def check_add_sample_from_empty(lib):
     f.close()
 
 
-def check_grad_fd(lib, kind, optimize_noise, N=40, D=4, P=2, trials=8, seed=5):
+def check_grad_fd(lib, kind, optimize_noise, N=40, D=4, P=2, trials=8, seed=5, lam=0):
     """test_gp.cpp:131-271: analytic grad of the log-lik vs central finite differences of the
     log-lik THROUGH the HP objective (kernel_lf_opt.hpp:77-92), e = 1e-4."""
     rng = np.random.default_rng(seed)
     X = rng.uniform(-1, 1, size=(N, D))
     Y = np.stack([np.cos(X.sum(axis=1) * (p + 1)) for p in range(P)], axis=1)
     om, _ = O.obs_mean_data(Y)
-    nt = D + 1 if kind == O.SE_ARD else 2
+    nt = D + D * lam + 1 if kind == O.SE_ARD else 2  # lam columns of Lambda (squared_exp_ard.hpp:94)
     h = new_gp(lib, kind, X, om, np.zeros(nt), 0.01)
     tot = 0.0
     e = 1e-4

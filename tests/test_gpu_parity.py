@@ -5,6 +5,7 @@ Tolerances: mu, sigma^2 <= 1e-8 rel; log-lik <= 1e-10 rel; grad
 import numpy as np
 import pytest
 
+from limbo_amd import _capi
 from oracle import np_oracle as O
 from tests import parity_checks as PC
 from tests.util import golden_files, new_gp, relerr, relerr_norm
@@ -305,3 +306,79 @@ def test_gpu_vs_oracle_n2048_regular_panels(engine_lib, oracle_lib):
     assert np.array_equal(g.get_L(), Lg) and g.log_lik() == llg
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("N,D,k,P", [(70, 3, 1, 1), (130, 1, 1, 1), (257, 6, 2, 2), (300, 12, 3, 1), (600, 6, 5, 1)])
+def test_gpu_se_ard_lambda_vs_oracle(engine_lib, oracle_lib, N, D, k, P):
+    """SquaredExpARD with k columns of Lambda (squared_exp_ard.hpp:109-126, :142-146): the device evaluates
+    d^T (Lambda Lambda^T + diag(ell^-2)) d as a sum of squares over D + k rows (inputs + projections);
+    the oracle forms M literally.  Every entry point the kernel reaches: K, L, alpha, log-lik, both
+    gradients (one pair-sum pass per Lambda column), queries, add_sample, clone."""
+    rng = np.random.default_rng(N * 3 + D + k)
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) + 0.05 * rng.normal(size=N) for p in range(P)], axis=1)
+    om, mean = O.obs_mean_data(Y)
+    th = np.concatenate([rng.uniform(-0.5, 0.3, size=D), rng.uniform(-1.0, 1.0, size=D * k), [rng.uniform(-0.2, 0.2)]])
+    noise = 0.02
+    g = new_gp(engine_lib, O.SE_ARD, X, om, th, noise)
+    o = new_gp(oracle_lib, O.SE_ARD, X, om, th, noise)
+    assert relerr(g.get_K(), o.get_K(), floor=1e-30) < 1e-11
+    assert g.compute() == 0 and o.compute() == 0
+    Lg, Lo = g.get_L(), o.get_L()
+    assert np.max(np.abs(Lg - Lo)) < 1e-10 * np.max(np.abs(Lo))
+    assert relerr_norm(g.get_alpha(), o.get_alpha()) < 1e-7
+    llg, llo = g.log_lik(), o.log_lik()
+    assert abs(llg - llo) <= PC.TOL_LL * max(1.0, abs(llo))
+    for on in (False, True):
+        gg, go = g.log_lik_grad(on), o.log_lik_grad(on)
+        assert gg.size == th.size + on
+        assert relerr_norm(gg, go) < PC.TOL_GRAD
+        # per block of the parameter vector, so that a small block cannot hide behind a large one
+        for sl in (slice(0, D), slice(D, D + D * k), slice(D + D * k, None)):
+            assert relerr_norm(gg[sl], go[sl]) < 10 * PC.TOL_GRAD
+    assert abs(g.log_loo_cv() - o.log_loo_cv()) <= 1e-9 * max(1.0, abs(o.log_loo_cv()))
+    if N <= 300:  # the oracle's LOO gradient is T dense N^3 products
+        assert relerr_norm(g.log_loo_cv_grad(True), o.log_loo_cv_grad(True)) < PC.TOL_GRAD
+    Xq = rng.uniform(0, 1, size=(130, D))
+    Xq[:3] = X[:3]
+    kg, vg = g.query_batch(Xq)
+    ko, vo = o.query_batch(Xq)
+    mug, s2g = O.finish_query(kg, vg, mean, noise)
+    muo, s2o = O.finish_query(ko, vo, mean, noise)
+    assert relerr(mug, muo, floor=1e-3) < PC.TOL_MU
+    assert relerr(s2g, s2o) < PC.TOL_VAR
+    # incremental update with the same kernel (gp.hpp:573-603), then a clone answering the same queries
+    xn = rng.uniform(0, 1, size=D)
+    Y2 = np.vstack([Y, np.cos((np.arange(P) + 1) * xn.sum())[None, :]])
+    om2, mean2 = O.obs_mean_data(Y2)
+    assert g.add_sample(xn, om2) == 0 and o.add_sample(xn, om2) == 0
+    assert np.max(np.abs(g.get_L() - o.get_L())) < 1e-9 * np.max(np.abs(Lo))
+    assert relerr_norm(g.get_alpha(), o.get_alpha()) < 1e-7
+    c = g.clone()
+    kc, vc = c.query_batch(Xq)
+    k2, v2 = g.query_batch(Xq)
+    assert np.array_equal(kc, k2) and np.array_equal(vc, v2)
+    c.close()
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("on", [False, True])
+def test_gpu_se_ard_lambda_grad_fd(engine_lib, on):
+    """test_gp.cpp:131-271's finite-difference check with a D x 1 Lambda in the parameter vector."""
+    PC.check_grad_fd(engine_lib, O.SE_ARD, on, lam=1)
+
+
+def test_gpu_se_ard_parameter_count(engine_lib):
+    """D + D k + 1 parameters, k = 0 .. D (squared_exp_ard.hpp:94); anything else is an argument error."""
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 1, size=(20, 3))
+    om = rng.normal(size=(20, 1))
+    for nt, ok in [(4, True), (7, True), (13, True), (5, False), (3, False), (16, False)]:
+        g = new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(nt), 0.01)
+        try:
+            rc = g.compute()
+        except _capi.EngineError:
+            rc = -1
+        assert (rc == 0) == ok, (nt, rc)
+        g.close()

@@ -64,6 +64,81 @@ def test_kernel_grad_fd(oracle_lib, kind):
             assert np.linalg.norm(g - fd) < 1e-5
 
 
+def _keval_n(lib, kind, x1, x2, th):
+    x1 = np.ascontiguousarray(x1, float)
+    x2 = np.ascontiguousarray(x2, float)
+    th = np.ascontiguousarray(th, float)
+    return lib.cdll.orc_kernel_eval_n(kind, x1.ctypes.data_as(_dp), x2.ctypes.data_as(_dp), x1.size,
+                                      th.ctypes.data_as(_dp), th.size)
+
+
+def _kgrad_n(lib, kind, x1, x2, th):
+    x1 = np.ascontiguousarray(x1, float)
+    x2 = np.ascontiguousarray(x2, float)
+    th = np.ascontiguousarray(th, float)
+    g = np.zeros(th.size)
+    lib.cdll.orc_kernel_grad_n(kind, x1.ctypes.data_as(_dp), x2.ctypes.data_as(_dp), x1.size, th.ctypes.data_as(_dp),
+                               th.size, g.ctypes.data_as(_dp))
+    return g
+
+
+def test_se_ard_lambda_known_answer(oracle_lib):
+    """src/tests/test_kernel.cpp:215-223: with k = 1 and all-zero parameters (Lambda = 0) the value is
+    bitwise the k = 0 one."""
+    v1, v2 = np.array([1.0, 1.0]), np.array([0.0, 1.0])
+    s1 = _keval(oracle_lib, O.SE_ARD, v1, v2, np.zeros(3))
+    assert s1 == _keval_n(oracle_lib, O.SE_ARD, v1, v2, np.zeros(2 + 2 * 1 + 1))
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_se_ard_lambda_grad_fd(oracle_lib, k):
+    """src/tests/test_kernel.cpp:184-188: the same central-FD check with set_k(1), D = 1..10 (k = 2 added;
+    the documentation asks for k < D but the code — and the test at D = 1 — do not)."""
+    rng = np.random.default_rng(40 + k)
+    e = 1e-6
+    for D in range(1, 11):
+        nt = D + D * k + 1
+        if nt > 64:
+            continue
+        for _ in range(20):
+            th = rng.uniform(-3, 3, size=nt)
+            x1 = rng.uniform(-5, 5, size=D)
+            x2 = rng.uniform(-5, 5, size=D)
+            g = _kgrad_n(oracle_lib, O.SE_ARD, x1, x2, th)
+            fd = np.zeros(nt)
+            for j in range(nt):
+                tp, tm = th.copy(), th.copy()
+                tp[j] += e
+                tm[j] -= e
+                fd[j] = (_keval_n(oracle_lib, O.SE_ARD, x1, x2, tp) - _keval_n(oracle_lib, O.SE_ARD, x1, x2, tm)) / (2 * e)
+            assert np.linalg.norm(g - fd) < 1e-5
+
+
+def test_se_ard_lambda_gp_vs_numpy(oracle_lib):
+    """K, L, alpha, log-lik, gradient (with noise) and queries of a GP with a D x 2 Lambda against the
+    numpy/LAPACK restatement (einsum over M = Lambda Lambda^T + diag(ell^-2))."""
+    rng = np.random.default_rng(77)
+    N, D, k = 61, 4, 2
+    X = rng.uniform(-2, 2, size=(N, D))
+    Y = rng.normal(size=(N, 2))
+    th = np.concatenate([rng.uniform(-0.3, 0.5, size=D), rng.uniform(-0.6, 0.6, size=D * k), [0.2]])
+    h = new_gp(oracle_lib, O.SE_ARD, X, Y, th, 0.05)
+    assert h.compute() == 0
+    K, L, al = O.gp_fit(O.SE_ARD, X, Y, th, 0.05)
+    assert relerr(h.get_K(), K, floor=1e-30) < 1e-12
+    assert relerr(h.get_L(), L, floor=1e-30) < 1e-10
+    assert relerr(h.get_alpha(), al) < 1e-9
+    assert abs(h.log_lik() - O.log_lik(L, Y, al)) < 1e-9 * abs(O.log_lik(L, Y, al))
+    g = h.log_lik_grad(True)
+    gn = O.log_lik_grad(O.SE_ARD, X, th, 0.05, L, al, True)
+    assert g.size == th.size + 1 and relerr(g, gn, floor=1e-6) < 1e-8
+    Xq = rng.uniform(-2, 2, size=(9, D))
+    kta, var = h.query_batch(Xq)
+    ktan, varn = O.query(O.SE_ARD, X, th, L, al, Xq)
+    assert relerr(kta, ktan, floor=1e-9) < 1e-9 and relerr(var, varn, floor=1e-9) < 1e-8
+    h.close()
+
+
 @pytest.mark.parametrize("kind", [O.SE_ARD, O.MATERN52, O.MATERN32, O.EXP])
 def test_kernel_matrix_vs_numpy(oracle_lib, kind):
     rng = np.random.default_rng(100 + kind)
