@@ -117,6 +117,26 @@ def main():
     out["c5_add_sample_per_s"] = 190 / dt
     h.close()
 
+    # per-point query latency (gp.hpp:159-191 as an acquisition functor calls it: one point, mu and sigma^2,
+    # host to host), N = 200 (the end of a BO run), 1000, 4096
+    lat = {}
+    for n_ in (200, 1000, 4096):
+        Xn, Yn = O.make_problem("c2", N=n_)
+        omn, _ = O.obs_mean_data(Yn)
+        hq = _capi.Handle(eng, 0)
+        hq.set_kernel(O.SE_ARD, np.zeros(7), 0.01)
+        hq.set_data(Xn, omn)
+        hq.compute()
+        pts = np.random.default_rng(3).uniform(0, 1, size=(220, 6))
+        for i in range(20):
+            hq.query_batch(pts[i:i + 1])
+        t0 = time.perf_counter()
+        for i in range(20, 220):
+            hq.query_batch(pts[i:i + 1])
+        lat[str(n_)] = 1e6 * (time.perf_counter() - t0) / 200
+        hq.close()
+    out["single_point_query_latency_us"] = lat
+
     # CPU upper bound at config 2: numpy kernel build + LAPACK dpotrf/dpotrs on all
     # host threads — a reported side-by-side figure, not the oracle and not on any product path
     import os

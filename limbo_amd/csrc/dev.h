@@ -118,6 +118,10 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, co
 void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* y,
                           int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P, int* err, int prefilled, const double* om,
                           int64_t ldom, double* part, int part_acc);
+// the whole forward sweep y = L^-1 b in one data-flow launch, nblk <= 256 (the caller checks); b: N x P (ldb),
+// y: N x P (ldy), must not alias b; err as above
+void launch_trsv_fwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* b,
+                          int64_t ldb, double* y, int64_t ldy, int P, int* err);
 // Arows[p + i*lda] = V[i + p*ldv] (P rows appended under the matrix) and back
 void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N, int P, double* Arows, int64_t lda,
                          double* sent = nullptr);

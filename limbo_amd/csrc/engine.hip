@@ -59,6 +59,8 @@ struct gpe_ctx {
     double *dXt = nullptr, *dA = nullptr, *dOm = nullptr, *dAl = nullptr, *dW = nullptr, *dY = nullptr;
     double *dLinv = nullptr, *dKinv = nullptr, *dKhost = nullptr, *dGradPartial = nullptr, *dGrad = nullptr;
     double *dLooS = nullptr, *dLooV = nullptr; // leave-one-out scratch: N x N and N x (P + 2) (+8)
+    double* dQuery = nullptr; // query scratch kept between calls while it is small (single-point queries: no malloc/free)
+    size_t query_bytes = 0;
     double* dHead = nullptr; // scratch tiles of the fused panel steps (k_panel_step)
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     int64_t grad_partial_cap = 0;
@@ -182,6 +184,10 @@ void free_dev(gpe_ctx* c)
             hipFree(*p);
         *p = nullptr;
     }
+    if (c->dQuery)
+        hipFree(c->dQuery);
+    c->dQuery = nullptr;
+    c->query_bytes = 0;
     c->grad_partial_cap = 0;
     c->cap = c->ld = 0;
 }
@@ -292,7 +298,6 @@ void project_lambda(gpe_ctx* c, hipStream_t s, double* Xt, int64_t ld, int64_t c
     launch_lambda_rows(s, Xt, ld, col0, n, lp);
 }
 
-inline double* Aat(gpe_ctx* c, double* base, int64_t i, int64_t j) { return base + i + j * c->ld; }
 
 // ---------------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky, two levels (replaces Eigen::LLT at gp.hpp:565):
@@ -1109,7 +1114,10 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         hipLaunchKernelGGL(k_knn, dim3(1), dim3(1), 0, s, c->dW, n, c->kp.diag_add, c->dScal + 2);
         if (n > 0) {
             // new row of L by forward substitution (gp.hpp:591-594): L[n, 0:n] = (L^-1 k[0:n])^T
-            launch_trsv_sweep(s, c->dA, ld, n, c->dXinv, c->dW, c->dY, ld, 1, 0);
+            if (c->flow_solve && (n + NB - 1) / NB <= 256)
+                launch_trsv_fwd_flow(s, c->dA, ld, n, c->dXinv, c->dW, ld, c->dY, ld, 1, c->dInfo + 1);
+            else
+                launch_trsv_sweep(s, c->dA, ld, n, c->dXinv, c->dW, c->dY, ld, 1, 0);
             hipLaunchKernelGGL(k_vec_to_row, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->dY, c->dA + n, ld,
                                n);
         }
@@ -1258,14 +1266,33 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
     // chunk so that the N x mc cross matrix stays under ~2 GiB
     int64_t mc_max = std::max<int64_t>(64, ((int64_t)1 << 28) / std::max<int64_t>(ld, 1));
     mc_max = round_up(std::min<int64_t>(mc_max, round_up(M, 64)), 64);
+    // a handful of points (the per-point calls of an acquisition functor, gp.hpp:159-191): the forward
+    // substitution runs as ONE data-flow launch (k_trsv_fwd_flow, <= GPE_MAX_P right-hand sides) instead of the
+    // blocked matrix solve, whose ~2 N/64 dependent matrix-core launches are all launch floor here
+    static const bool sweep_ok = !(getenv("GPE_QUERY_SWEEP") && atoi(getenv("GPE_QUERY_SWEEP")) == 0);
+    const bool few = sweep_ok && c->flow_solve && M <= GPE_MAX_P && (N + NB - 1) / NB <= 256;
+    if (few)
+        mc_max = GPE_MAX_P;
     const int64_t ldq = mc_max;
-    double *dQrm = nullptr, *dQt = nullptr, *dKs = nullptr, *dKta = nullptr, *dVar = nullptr, *dKvv = nullptr;
-    HIPCHK(c, hipMalloc(&dQrm, sizeof(double) * (size_t)(mc_max * std::max(D, 1))));
-    HIPCHK(c, hipMalloc(&dQt, sizeof(double) * (size_t)(ldq * std::max(xt_rows(D), 1))));
-    HIPCHK(c, hipMalloc(&dKs, sizeof(double) * (size_t)(ld * mc_max)));
-    HIPCHK(c, hipMalloc(&dKta, sizeof(double) * (size_t)(mc_max * P)));
-    HIPCHK(c, hipMalloc(&dVar, sizeof(double) * (size_t)mc_max));
-    HIPCHK(c, hipMalloc(&dKvv, sizeof(double) * (size_t)mc_max));
+    // one allocation, carved up; kept across calls while small so that point queries do not malloc/free
+    const size_t n_qrm = (size_t)(mc_max * std::max(D, 1)), n_qt = (size_t)(ldq * std::max(xt_rows(D), 1));
+    const size_t n_ks = (size_t)(ld * mc_max), n_z = few ? n_ks : 0, n_kta = (size_t)(mc_max * P);
+    const size_t need = sizeof(double) * (n_qrm + n_qt + n_ks + n_z + n_kta + 2 * (size_t)mc_max);
+    if (need > c->query_bytes) {
+        if (c->dQuery)
+            hipFree(c->dQuery);
+        c->dQuery = nullptr;
+        c->query_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->dQuery, need));
+        c->query_bytes = need;
+    }
+    double* dQrm = c->dQuery;
+    double* dQt = dQrm + n_qrm;
+    double* dKs = dQt + n_qt;
+    double* dZ = dKs + n_ks;
+    double* dKta = dZ + n_z;
+    double* dVar = dKta + n_kta;
+    double* dKvv = dVar + mc_max;
     int rc = GPE_OK;
     for (int64_t m0 = 0; m0 < M && rc == GPE_OK; m0 += mc_max) {
         const int64_t mc = std::min<int64_t>(mc_max, M - m0);
@@ -1288,27 +1315,38 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
                                hipMemcpyDeviceToHost, s);
         }
         if (var) {
-            trsm_left_blocked(c, c->dA, dKs, ld, N, mc, false, GPE_PH_QUERY); // gp.hpp:620
+            const double* Z = dKs;
+            if (few) {
+                PhaseScope ps(c, GPE_PH_QUERY, (double)N * N * mc);
+                launch_trsv_fwd_flow(s, c->dA, ld, N, c->dXinv, dKs, ld, dZ, ld, (int)mc, c->dInfo + 1); // gp.hpp:620
+                Z = dZ;
+            }
+            else
+                trsm_left_blocked(c, c->dA, dKs, ld, N, mc, false, GPE_PH_QUERY); // gp.hpp:620
             PhaseScope ps(c, GPE_PH_QUERY, 2.0 * N * mc);
             if (Xq)
                 launch_kvv(s, dQt, ldq, mc, c->kp, dKvv);
             else
                 hipMemsetAsync(dKvv, 0, sizeof(double) * (size_t)mc, s);
-            launch_col_var(s, dKs, ld, N, mc, dKvv, dVar); // gp.hpp:621
+            launch_col_var(s, Z, ld, N, mc, dKvv, dVar); // gp.hpp:621
             hipMemcpyAsync(var + m0, dVar, sizeof(double) * (size_t)mc, hipMemcpyDeviceToHost, s);
         }
         if (hipStreamSynchronize(s) != hipSuccess) {
             c->err = "query_batch: stream sync failed";
             rc = GPE_ERR_HIP;
         }
+        else if (c->hInfo[1] != 0) {
+            c->err = "query: inter-workgroup hand-off of the forward sweep timed out";
+            c->hInfo[1] = 0;
+            rc = GPE_ERR_HIP;
+        }
     }
     drain_phases(c);
-    hipFree(dQrm);
-    hipFree(dQt);
-    hipFree(dKs);
-    hipFree(dKta);
-    hipFree(dVar);
-    hipFree(dKvv);
+    if (c->query_bytes > ((size_t)64 << 20)) { // a large batch: give the memory back
+        hipFree(c->dQuery);
+        c->dQuery = nullptr;
+        c->query_bytes = 0;
+    }
     return rc;
 }
 

@@ -408,6 +408,145 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
                        om, ldom, part, part_acc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_trsv_fwd_flow — the forward sweep L y = b in one launch: the mirror image of k_trsv_bwd_flow, same
+// hand-off (sentinel-prefilled output, one 8-byte agent-scope store per value, value-polling loads, bounded).
+// Workgroup j owns unknown block j and folds in L[j, t] y_t for t = 0 .. j-1 as the y_t appear.  The tile
+// L[j0 + r][t0 + c] is fetched with lane = r (512 contiguous bytes per column), wave w takes columns
+// w, w + 8, ..: the product needs no transposition through LDS, only the sum over the 8 waves.
+// Used where a handful of right-hand sides meet a factor that is already there: the per-point query
+// (gp.hpp:620) and add_sample's new row of L (gp.hpp:591-594) — 2 N/64 dependent launches otherwise.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * FW) void k_trsv_fwd_flow(const double* __restrict__ L, int64_t ld, int64_t N,
+                                                       const double* __restrict__ Xt_all, const double* __restrict__ b,
+                                                       int64_t ldb, double* yout, int64_t ldy, int P,
+                                                       int* __restrict__ err)
+{
+    __shared__ double Xs[NB * LSTR]; // Xs[c][k] = (L_jj^-1)[c][k]
+    __shared__ double xs[NB];
+    __shared__ double wj[NB];
+    __shared__ double part_s[FW][NB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const int64_t nblk = (N + NB - 1) / NB;
+    int64_t j; // consecutive blocks share an XCD (see k_trsv_bwd_flow)
+    {
+        const int64_t q = nblk / 8, r = nblk % 8, x = blockIdx.x % 8, idx = blockIdx.x / 8;
+        j = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+    }
+    const int64_t j0 = j * NB;
+    const int jb = (int)((N - j0 < NB) ? N - j0 : NB);
+    const unsigned long long SENT = ~0ull;
+    {
+        const double* Xt = Xt_all + j * (NB * NB); // Xt[k + 64 c] = (L_jj^-1)[c][k], identity-padded past jb
+        for (int e = threadIdx.x; e < NB * NB; e += 64 * FW)
+            Xs[(e >> 6) * LSTR + (e & 63)] = Xt[e];
+    }
+    const int rc = lane < jb ? lane : jb - 1;
+    const double rowmask = lane < jb ? 1.0 : 0.0;
+    for (int p = 0; p < P; ++p) {
+        double* yp = yout + (int64_t)p * ldy;
+        __syncthreads(); // wj of the previous right-hand side is consumed (and Xs is in place)
+        if (threadIdx.x < NB)
+            wj[lane] = (lane < jb) ? b[j0 + lane + (int64_t)p * ldb] : 0.0;
+        // contributors t = 0 .. j-1 (all of them full blocks), tiles and first looks at y_t four folds ahead
+        double tl[4][FQ];
+        unsigned long long pb[4] = {SENT, SENT, SENT, SENT};
+        auto fetch = [&](double (&dst)[FQ], unsigned long long& peek, int64_t tt) {
+            const int64_t t0 = tt * NB;
+#pragma unroll
+            for (int q = 0; q < FQ; ++q) {
+                const double* col = L + j0 + (t0 + wvu + FW * q) * ld; // wave-uniform column base
+                dst[q] = col[rc] * rowmask; // clamped row, masked by a multiplication (no predicated loads)
+            }
+            peek = __hip_atomic_load((const unsigned long long*)(yp + t0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto fold = [&](const double (&src)[FQ], unsigned long long peek, int64_t t) {
+            __syncthreads(); // xs / part_s of the previous contributor are consumed
+            if (threadIdx.x < NB) {
+                const int64_t t0 = t * NB;
+                unsigned long long bits = peek;
+                int spins = 0;
+                while (bits == SENT) {
+                    if ((spins & 3) != 3)
+                        bits = __hip_atomic_load((const unsigned long long*)(yp + t0 + lane), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else
+                        bits = __hip_atomic_load((const unsigned long long*)(yp + t0 + lane), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                    if (bits != SENT)
+                        break;
+                    if (++spins > (1 << 24)) { // ~seconds: a lost producer, never a legal state
+                        *err = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                xs[lane] = __longlong_as_double((long long)bits);
+            }
+            __syncthreads();
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < FQ; ++q)
+                acc = fma(src[q], xs[wvu + FW * q], acc);
+            part_s[wv][lane] = acc;
+            __syncthreads();
+            if (threadIdx.x < NB)
+                wj[lane] -= flow_sum(part_s, lane);
+        };
+        int64_t t = 0;
+        auto clampt = [&](int64_t tt) { return tt < j ? tt : (j > 0 ? j - 1 : 0); };
+        if (j > 0) {
+            fetch(tl[0], pb[0], clampt(0));
+            fetch(tl[1], pb[1], clampt(1));
+            fetch(tl[2], pb[2], clampt(2));
+            fetch(tl[3], pb[3], clampt(3));
+        }
+        for (; t + 3 < j; t += 4) {
+            fold(tl[0], pb[0], t);
+            fetch(tl[0], pb[0], clampt(t + 4));
+            fold(tl[1], pb[1], t + 1);
+            fetch(tl[1], pb[1], clampt(t + 5));
+            fold(tl[2], pb[2], t + 2);
+            fetch(tl[2], pb[2], clampt(t + 6));
+            fold(tl[3], pb[3], t + 3);
+            fetch(tl[3], pb[3], clampt(t + 7));
+        }
+        if (t < j)
+            fold(tl[0], pb[0], t);
+        if (t + 1 < j)
+            fold(tl[1], pb[1], t + 1);
+        if (t + 2 < j)
+            fold(tl[2], pb[2], t + 2);
+        __syncthreads();
+        // y_j = L_jj^-1 w_j :  y[c] = sum_k Xs[c][k] w[k], the 8 waves split k
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < FQ; ++kk) {
+            const int k = FQ * wv + kk;
+            acc = fma(Xs[lane * LSTR + k], wj[k], acc);
+        }
+        part_s[wv][lane] = acc;
+        __syncthreads();
+        if (threadIdx.x < NB && lane < jb) {
+            const double v = flow_sum(part_s, lane);
+            __hip_atomic_store((unsigned long long*)(yp + j0 + lane), (unsigned long long)__double_as_longlong(v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// y <- L^-1 b in one launch (nblk <= 256: all workgroups resident; the caller checks); y must not alias b
+void launch_trsv_fwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* b,
+                          int64_t ldb, double* y, int64_t ldy, int P, int* err)
+{
+    if (N <= 0 || P <= 0)
+        return;
+    const int64_t nblk = (N + NB - 1) / NB;
+    for (int p = 0; p < P; ++p)
+        hipMemsetAsync(y + (int64_t)p * ldy, 0xFF, sizeof(double) * (size_t)N, s);
+    hipLaunchKernelGGL(k_trsv_fwd_flow, dim3((unsigned)nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, b, ldb, y, ldy, P, err);
+}
+
 // rows N..N+P-1 of the matrix <- obs_mean^T (before the factorisation) and back (z = L^-1 obs_mean
 // after it): the forward substitution rides along the Cholesky as P extra rows of the panel.
 // sent (optional): N x P vector (ld = ldv) pre-filled with the all-ones pattern the data-flow backward

@@ -270,7 +270,8 @@ static void compare_with_host(int n, int D, int P, int& g_failed_here, double to
             CHECK(mub(m, p) == mu(p)); // batched path == single-point path
         }
         CHECK(std::abs(s2 - s2r) <= tol * s2r);
-        CHECK(s2b(m) == s2);
+        // the batch runs the blocked matrix solve, a single point the vector sweep: same sums, other order
+        CHECK(std::abs(s2b(m) - s2) <= 1e-11 * s2);
         // mu()/sigma() bitwise equal to query()  (test_gp.cpp:502-510)
         VectorXd mu2 = gp.mu(pts[m]);
         for (int p = 0; p < P; ++p)
@@ -727,9 +728,12 @@ CASE(test_acqui_batch)
     auto be = ei.batch(pts, first);
     double ei_max = 0;
     for (size_t m = 0; m < pts.size(); ++m) {
-        CHECK(bu[m] == opt::fun(ucb(pts[m], first, false)));
-        CHECK(bg[m] == opt::fun(gpucb(pts[m], first, false)));
-        CHECK(be[m] == opt::fun(ei(pts[m], first, false)));
+        // same mu; sigma^2 through the blocked matrix solve (batch) vs the one-launch vector sweep (one point):
+        // the same sums in another order
+        auto close = [](double a, double b) { return std::abs(a - b) <= 1e-12 * std::max(1.0, std::abs(b)); };
+        CHECK(close(bu[m], opt::fun(ucb(pts[m], first, false))));
+        CHECK(close(bg[m], opt::fun(gpucb(pts[m], first, false))));
+        CHECK(close(be[m], opt::fun(ei(pts[m], first, false))));
         CHECK(be[m] >= 0.0);
         ei_max = std::max(ei_max, be[m]);
     }
