@@ -52,7 +52,9 @@ def main():
     M = 5000 if args.quick else 20000
     Xq = np.random.default_rng(1).uniform(0, 1, size=(M, 6))
     h.query_batch(Xq[:256])
-    t0 = time.perf_counter(); kta, var = h.query_batch(Xq); dt = time.perf_counter() - t0
+    dt = 1e30
+    for _ in range(3):  # best of 3: one call is ~10 ms, a host-side hiccup shows
+        t0 = time.perf_counter(); kta, var = h.query_batch(Xq); dt = min(dt, time.perf_counter() - t0)
     out["c2_query_batch_points_per_s_N4096"] = M / dt
     h.close()
 
@@ -72,7 +74,9 @@ def main():
     M3 = 10000 if args.quick else 100000
     Xq3 = rng.uniform(0, 1, size=(M3, 12))
     h.query_batch(Xq3[:256])
-    t0 = time.perf_counter(); kta, var = h.query_batch(Xq3); dt = time.perf_counter() - t0
+    dt = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter(); kta, var = h.query_batch(Xq3); dt = min(dt, time.perf_counter() - t0)
     out["c3_query_points"] = M3
     out["c3_query_batch_s"] = dt
     out["c3_query_points_per_s"] = M3 / dt
@@ -119,7 +123,7 @@ def main():
 
     # per-point query latency (gp.hpp:159-191 as an acquisition functor calls it: one point, mu and sigma^2,
     # host to host), N = 200 (the end of a BO run), 1000, 4096
-    lat = {}
+    lat, upd = {}, {}
     for n_ in (200, 1000, 4096):
         Xn, Yn = O.make_problem("c2", N=n_)
         omn, _ = O.obs_mean_data(Yn)
@@ -130,12 +134,23 @@ def main():
         pts = np.random.default_rng(3).uniform(0, 1, size=(220, 6))
         for i in range(20):
             hq.query_batch(pts[i:i + 1])
+        best = 1e30
+        for i0 in (20, 120):  # best of two blocks of 100
+            t0 = time.perf_counter()
+            for i in range(i0, i0 + 100):
+                hq.query_batch(pts[i:i + 1])
+            best = min(best, time.perf_counter() - t0)
+        lat[str(n_)] = 1e6 * best / 100
+        # recompute(false, false) + compute_log_lik: new observations, same factor (gp.hpp:241-252, :605-611)
+        hq.update_alpha(omn)
         t0 = time.perf_counter()
-        for i in range(20, 220):
-            hq.query_batch(pts[i:i + 1])
-        lat[str(n_)] = 1e6 * (time.perf_counter() - t0) / 200
+        for i in range(50):
+            hq.update_alpha(omn)
+            hq.log_lik()
+        upd[str(n_)] = 1e6 * (time.perf_counter() - t0) / 50
         hq.close()
     out["single_point_query_latency_us"] = lat
+    out["update_alpha_loglik_latency_us"] = upd
 
     # CPU upper bound at config 2: numpy kernel build + LAPACK dpotrf/dpotrs on all
     # host threads — a reported side-by-side figure, not the oracle and not on any product path

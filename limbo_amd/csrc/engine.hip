@@ -590,12 +590,24 @@ void solve_alpha(gpe_ctx* c)
     hipStream_t s = c->stream;
     c->ll_partials = 0;
     PhaseScope ps(c, GPE_PH_SOLVE, 2.0 * (double)c->N * c->N * c->P);
+    const int64_t nblk = (c->N + NB - 1) / NB;
+    const bool flow = c->flow_solve && nblk <= 256; // one data-flow launch per sweep instead of one launch per block
     for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) {
         int pc = std::min(GPE_MAX_P, c->P - p0);
-        launch_copy2d(s, c->dOm + (int64_t)p0 * c->ld, c->ld, c->dW, c->ld, c->N, pc);
+        const double* om = c->dOm + (int64_t)p0 * c->ld;
+        double* al = c->dAl + (int64_t)p0 * c->ld;
+        if (flow) {
+            launch_trsv_fwd_flow(s, c->dA, c->ld, c->N, c->dXinv, om, c->ld, c->dY, c->ld, pc, c->dInfo + 1);
+            launch_trsv_bwd_flow(s, c->dA, c->ld, c->N, c->dXinv, c->dY, 1, c->ld, al, c->ld, pc, c->dInfo + 1, 0, om, c->ld,
+                                 c->hScal + 8, p0 > 0 ? 1 : 0);
+            continue;
+        }
+        launch_copy2d(s, om, c->ld, c->dW, c->ld, c->N, pc);
         launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dW, c->dY, c->ld, pc, 0);
-        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc, 1);
+        launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dY, al, c->ld, pc, 1);
     }
+    c->al_prefilled = false;
+    c->ll_partials = flow ? (int)nblk : 0;
 }
 
 // second half of gp.hpp:605-611 when z = L^-1 obs_mean already sits in rows N.. of A

@@ -31,5 +31,12 @@ for n_ in (200, 1000, 4096):
     for i in range(20):
         hq.query_batch(pts[:8])
     t3 = time.perf_counter()
+    hq.update_alpha(omn)
+    t4 = time.perf_counter()
+    for i in range(20):
+        hq.update_alpha(omn)
+        hq.log_lik()
+    t5 = time.perf_counter()
+    print(f"N={n_}: update_alpha+log_lik {1e6 * (t5 - t4) / 20:.1f} us", flush=True)
     print(f"N={n_}: single point {1e6 * (t1 - t0) / 200:.1f} us, 8 points {1e6 * (t3 - t2) / 20:.1f} us", flush=True)
     hq.close()
