@@ -382,3 +382,60 @@ def test_gpu_se_ard_parameter_count(engine_lib):
             rc = -1
         assert (rc == 0) == ok, (nt, rc)
         g.close()
+
+
+@pytest.mark.parametrize("N,P", [(1, 1), (64, 2), (130, 11), (1100, 2), (2049, 1)])
+def test_gpu_update_alpha_vs_oracle(engine_lib, oracle_lib, N, P):
+    """recompute(true, false) (gp.hpp:241-252, :605-611) through the one-launch forward and backward sweeps:
+    alpha and the log-likelihood against the oracle's substitution on the same factor; ragged last block,
+    more outputs than one pass carries (P = 11 > 8: the per-block partial sums accumulate over passes)."""
+    rng = np.random.default_rng(N + P)
+    D = 3
+    X = rng.uniform(0, 1, size=(N, D))
+    Y1 = rng.normal(size=(N, P))
+    Y2 = np.stack([np.sin((p + 2) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.1 * rng.normal(size=(N, P))
+    om1, _ = O.obs_mean_data(Y1)
+    om2, _ = O.obs_mean_data(Y2)
+    th = np.array([-0.3, 0.1, -0.1, 0.05])
+    g = new_gp(engine_lib, O.SE_ARD, X, om1, th, 0.02)
+    o = new_gp(oracle_lib, O.SE_ARD, X, om1, th, 0.02)
+    assert g.compute() == 0 and o.compute() == 0
+    g.update_alpha(om2)
+    o.update_alpha(om2)
+    assert relerr_norm(g.get_alpha(), o.get_alpha()) < 1e-7
+    assert abs(g.log_lik() - o.log_lik()) <= PC.TOL_LL * max(1.0, abs(o.log_lik()))
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("N", [1, 63, 65, 700, 2049])
+def test_gpu_point_queries_vs_batch_and_oracle(engine_lib, oracle_lib, N):
+    """mu / sigma^2 for 1..8 points (one-launch forward sweep, k_trsv_fwd_flow) against the oracle and against
+    the same points inside a batch of 100 (blocked matrix solve): mu identical, sigma^2 to rounding."""
+    rng = np.random.default_rng(N)
+    D, P = 4, 2
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.05 * rng.normal(size=(N, P))
+    om, mean = O.obs_mean_data(Y)
+    th = rng.uniform(-0.4, 0.2, size=D + 1)
+    g = new_gp(engine_lib, O.SE_ARD, X, om, th, 0.01)
+    o = new_gp(oracle_lib, O.SE_ARD, X, om, th, 0.01)
+    assert g.compute() == 0 and o.compute() == 0
+    Xq = rng.uniform(0, 1, size=(100, D))
+    Xq[0] = X[0]
+    kb, vb = g.query_batch(Xq)
+    ko, vo = o.query_batch(Xq)
+    _, s2o = O.finish_query(ko, vo, mean, 0.01)
+    for m in (1, 2, 5, 8):
+        k1, v1 = g.query_batch(Xq[:m])
+        assert np.array_equal(k1, kb[:m])
+        _, s2 = O.finish_query(k1, v1, mean, 0.01)
+        _, s2b = O.finish_query(kb[:m], vb[:m], mean, 0.01)
+        assert relerr(s2, s2b) < 1e-11
+        assert relerr(s2, s2o[:m]) < PC.TOL_VAR
+    # run-to-run bitwise reproducible
+    k1, v1 = g.query_batch(Xq[:3])
+    k2, v2 = g.query_batch(Xq[:3])
+    assert np.array_equal(k1, k2) and np.array_equal(v1, v2)
+    g.close()
+    o.close()
