@@ -731,11 +731,61 @@ int ensure_inv(gpe_ctx* c)
         HIPCHK(c, hipMalloc(&c->dLinv, sizeof(double) * (size_t)(ld * c->cap)));
     if (!c->dKinv)
         HIPCHK(c, hipMalloc(&c->dKinv, sizeof(double) * (size_t)(ld * c->cap)));
-    {
-        PhaseScope ps(c, GPE_PH_INV, 0.0);
-        launch_set_identity(s, c->dLinv, ld, N);
+    static const bool inv_panels = !(getenv("GPE_INV_PANELS") && atoi(getenv("GPE_INV_PANELS")) == 0);
+    if (inv_panels && c->nbo % 128 == 0 && c->nbo <= 256) {
+        // L^-1 (gp.hpp:260) panel by panel: the diagonal nbo x nbo blocks of L^-1 come from one launch
+        // (inv.hip), the rest is Y_p = X_p Acc_p with Acc_p = -sum_{q<p} L_pq Y_q accumulated in the K^-1 buffer
+        // (not yet in use) — two matrix-core launches per panel instead of the 8-launch substitution chain.
+        // The diagonal 128-tiles of L^-1 lie inside the blocks inv.hip writes in full (zeros above the
+        // diagonal), which is all the K^-1 product reads above the diagonal: no identity fill.
+        const int64_t nbo = c->nbo;
+        {
+            PhaseScope ps(c, GPE_PH_INV, 0.0);
+            hipMemsetAsync(c->dKinv, 0, sizeof(double) * (size_t)(ld * N), s);
+            launch_inv_panels(s, c->dA, ld, N, (int)nbo, c->dXinv, c->dLinv, ld);
+        }
+        for (int64_t o0 = 0; o0 < N; o0 += nbo) {
+            const int64_t pw = std::min<int64_t>(nbo, N - o0), oe = o0 + pw;
+            if (o0 > 0) { // Y[p, 0:o0] = X_p Acc[p, 0:o0]
+                GemmArgs g{};
+                g.C = c->dLinv + o0;
+                g.ldc = ld;
+                g.A = c->dLinv + o0 + o0 * ld;
+                g.lda = ld;
+                g.B = c->dKinv + o0;
+                g.ldb = ld;
+                g.b_kmajor = 1;
+                g.m = pw;
+                g.n = o0;
+                g.k = pw;
+                g.overwrite = 1;
+                PhaseScope ps(c, GPE_PH_INV, gemm_flops(g));
+                launch_gemm_sub(s, g);
+            }
+            if (oe < N) { // Acc[below, 0:oe] -= L[below, p] Y[p, 0:oe]
+                GemmArgs g{};
+                g.C = c->dKinv + oe;
+                g.ldc = ld;
+                g.A = c->dA + oe + o0 * ld;
+                g.lda = ld;
+                g.B = c->dLinv + o0;
+                g.ldb = ld;
+                g.b_kmajor = 1;
+                g.m = N - oe;
+                g.n = oe;
+                g.k = pw;
+                PhaseScope ps(c, GPE_PH_INV, gemm_flops(g));
+                launch_gemm_sub(s, g);
+            }
+        }
     }
-    trsm_left_blocked(c, c->dA, c->dLinv, ld, N, N, true, GPE_PH_INV); // L^-1 (gp.hpp:260)
+    else {
+        {
+            PhaseScope ps(c, GPE_PH_INV, 0.0);
+            launch_set_identity(s, c->dLinv, ld, N);
+        }
+        trsm_left_blocked(c, c->dA, c->dLinv, ld, N, N, true, GPE_PH_INV); // L^-1 (gp.hpp:260)
+    }
     {
         // K^-1 = L^-T L^-1 (gp.hpp:261), lower triangle, k range from the tile diagonal down
         GemmArgs g{};
@@ -767,6 +817,16 @@ static int ensure_loo_bufs(gpe_ctx* c, bool square)
     return GPE_OK;
 }
 
+// after a stream sync: did a data-flow sweep give up waiting for a producer?  (never a legal state)
+static int check_flow(gpe_ctx* c)
+{
+    if (c->hInfo[1] == 0)
+        return GPE_OK;
+    c->err = "triangular sweep: inter-workgroup hand-off timed out";
+    c->hInfo[1] = 0;
+    return GPE_ERR_HIP;
+}
+
 // Weights of the leave-one-out gradient (grad.hip header; gp.hpp:354-402): on return
 //   dLooV[:, 0:P] = u = K^-1 (alpha / kappa),   dLinv (lower) = K^-1 diag(c) K^-1,   dLooV[ld (P+2)] = LOO value.
 // dLinv (L^-1, only an intermediate of K^-1) is reused as the N x N output.
@@ -781,8 +841,15 @@ static int loo_weights(gpe_ctx* c)
     {
         PhaseScope ps(c, GPE_PH_GRAD, 0.0);
         launch_loo_prep(s, c->dKinv, ld, N, c->dAl, ld, c->P, v, sc, val, outp);
+        const bool flow = c->flow_solve && (N + NB - 1) / NB <= 256;
         for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) { // u = L^-T (L^-1 v), in place
             int pc = std::min(GPE_MAX_P, c->P - p0);
+            if (flow) { // one launch per sweep
+                launch_trsv_fwd_flow(s, c->dA, ld, N, c->dXinv, v + (int64_t)p0 * ld, ld, c->dY, ld, pc, c->dInfo + 1);
+                launch_trsv_bwd_flow(s, c->dA, ld, N, c->dXinv, c->dY, 1, ld, v + (int64_t)p0 * ld, ld, pc, c->dInfo + 1, 0,
+                                     nullptr, 0, nullptr, 0);
+                continue;
+            }
             launch_copy2d(s, v + (int64_t)p0 * ld, ld, c->dW, ld, N, pc);
             launch_trsv_sweep(s, c->dA, ld, N, c->dXinv, c->dW, c->dY, ld, pc, 0);
             launch_trsv_sweep(s, c->dA, ld, N, c->dXinv, c->dY, v + (int64_t)p0 * ld, ld, pc, 1);
@@ -1194,7 +1261,7 @@ int gpe_log_lik_grad(gpe_handle c, double* grad, int n_grad, int optimize_noise)
     HIPCHK(c, hipMemcpyAsync(grad, c->dGrad, sizeof(double) * n_grad, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     drain_phases(c);
-    return GPE_OK;
+    return check_flow(c);
 }
 
 // GP::compute_log_loo_cv (gp.hpp:339-351)
@@ -1240,7 +1307,7 @@ int gpe_log_loo_cv_grad(gpe_handle c, double* grad, int n_grad, int optimize_noi
     HIPCHK(c, hipMemcpyAsync(grad, c->dGrad, sizeof(double) * n_grad, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     drain_phases(c);
-    return GPE_OK;
+    return check_flow(c);
 }
 
 int gpe_hp_objective(gpe_handle c, int kind, const double* th, int n_theta, double noise, int optimize_noise,
@@ -1515,6 +1582,9 @@ int gpe_get_loo_weights(gpe_handle c, double* W, int64_t ldh)
     std::vector<double> u((size_t)N * P), a((size_t)N * P);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     drain_phases(c);
+    rc = check_flow(c);
+    if (rc)
+        return rc;
     HIPCHK(c, hipMemcpy2D(W, sizeof(double) * ldh, c->dLinv, sizeof(double) * c->ld, sizeof(double) * N, N,
                           hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy2D(u.data(), sizeof(double) * N, c->dLooV, sizeof(double) * c->ld, sizeof(double) * N, P,
