@@ -138,8 +138,9 @@ void launch_kta(hipStream_t s, const double* Ks, int64_t ldk, int64_t N, int64_t
 void launch_set_identity(hipStream_t s, double* A, int64_t lda, int64_t n);
 // inv.hip: Out[o0:o0+pw, o0:o0+pw] = inv(L[o0:o0+pw, o0:o0+pw]) (full square) for every outer panel of nbo <= 256
 // columns, from the 64 x 64 block inverses Xt_all
+// OutT (optional): the same blocks transposed
 void launch_inv_panels(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
-                       int64_t ldo);
+                       int64_t ldo, double* OutT, int64_t ldt);
 void launch_zero_upper(hipStream_t s, double* A, int64_t lda, int64_t n);
 void launch_symmetrize_from_lower(hipStream_t s, double* A, int64_t lda, int64_t n);
 void launch_copy2d(hipStream_t s, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols);

@@ -733,50 +733,69 @@ int ensure_inv(gpe_ctx* c)
         HIPCHK(c, hipMalloc(&c->dKinv, sizeof(double) * (size_t)(ld * c->cap)));
     static const bool inv_panels = !(getenv("GPE_INV_PANELS") && atoi(getenv("GPE_INV_PANELS")) == 0);
     if (inv_panels && c->nbo % 128 == 0 && c->nbo <= 256) {
-        // L^-1 (gp.hpp:260) panel by panel: the diagonal nbo x nbo blocks of L^-1 come from one launch
-        // (inv.hip), the rest is Y_p = X_p Acc_p with Acc_p = -sum_{q<p} L_pq Y_q accumulated in the K^-1 buffer
-        // (not yet in use) — two matrix-core launches per panel instead of the 8-launch substitution chain.
-        // The diagonal 128-tiles of L^-1 lie inside the blocks inv.hip writes in full (zeros above the
-        // diagonal), which is all the K^-1 product reads above the diagonal: no identity fill.
+        // Transposed formulation: U = L^-T (upper triangular) is built in dLinv, K^-1 = U U^T.  Every product below
+        // is C (-/+)= A B^T with A and B contiguous along their non-k index — the operand layout of the LDS-direct
+        // matrix-core kernel (gemm.hip) — and k = the panel width, the shape of the Cholesky trailing update.
+        //   inv.hip        : X_p = inv(L_pp) for every outer panel p in one launch -> diagonal blocks of T (= the
+        //                    K^-1 buffer, free until the last step), X_p^T -> diagonal blocks of U
+        //   U[0:o0, p]     = AccT[0:o0, p] X_p^T                       (AccT = -sum_{q<p} U[:, q] L[p, q]^T, in T)
+        //   AccT[0:oe, p+1..] -= U[0:oe, p] L[p+1.., p]^T
+        //   K^-1 = U U^T                                              (one launch)
         const int64_t nbo = c->nbo;
         {
             PhaseScope ps(c, GPE_PH_INV, 0.0);
             hipMemsetAsync(c->dKinv, 0, sizeof(double) * (size_t)(ld * N), s);
-            launch_inv_panels(s, c->dA, ld, N, (int)nbo, c->dXinv, c->dLinv, ld);
+            launch_inv_panels(s, c->dA, ld, N, (int)nbo, c->dXinv, c->dKinv, ld, c->dLinv, ld);
         }
         for (int64_t o0 = 0; o0 < N; o0 += nbo) {
             const int64_t pw = std::min<int64_t>(nbo, N - o0), oe = o0 + pw;
-            if (o0 > 0) { // Y[p, 0:o0] = X_p Acc[p, 0:o0]
+            if (o0 > 0) {
                 GemmArgs g{};
-                g.C = c->dLinv + o0;
+                g.C = c->dLinv + o0 * ld;
                 g.ldc = ld;
-                g.A = c->dLinv + o0 + o0 * ld;
+                g.A = c->dKinv + o0 * ld;
                 g.lda = ld;
-                g.B = c->dKinv + o0;
+                g.B = c->dKinv + o0 + o0 * ld;
                 g.ldb = ld;
-                g.b_kmajor = 1;
-                g.m = pw;
-                g.n = o0;
+                g.m = o0;
+                g.n = pw;
                 g.k = pw;
                 g.overwrite = 1;
                 PhaseScope ps(c, GPE_PH_INV, gemm_flops(g));
                 launch_gemm_sub(s, g);
             }
-            if (oe < N) { // Acc[below, 0:oe] -= L[below, p] Y[p, 0:oe]
+            if (oe < N) {
                 GemmArgs g{};
-                g.C = c->dKinv + oe;
+                g.C = c->dKinv + oe * ld;
                 g.ldc = ld;
-                g.A = c->dA + oe + o0 * ld;
+                g.A = c->dLinv + o0 * ld;
                 g.lda = ld;
-                g.B = c->dLinv + o0;
+                g.B = c->dA + oe + o0 * ld;
                 g.ldb = ld;
-                g.b_kmajor = 1;
-                g.m = N - oe;
-                g.n = oe;
+                g.m = oe;
+                g.n = N - oe;
                 g.k = pw;
                 PhaseScope ps(c, GPE_PH_INV, gemm_flops(g));
                 launch_gemm_sub(s, g);
             }
+        }
+        {
+            // K^-1 = U U^T (gp.hpp:261) in one launch, lower triangle, k from the tile diagonal on (U is upper
+            // triangular).  (Panel by panel with the LDS-direct kernel and a C += epilogue — 16 launches, C re-read
+            // 15 times — was measured too: 761 us against 704 us for this one.)
+            GemmArgs g{};
+            g.C = c->dKinv;
+            g.ldc = ld;
+            g.A = c->dLinv;
+            g.lda = ld;
+            g.B = c->dLinv;
+            g.ldb = ld;
+            g.m = g.n = g.k = N;
+            g.tri = 1;
+            g.ktri = 1;
+            g.overwrite = 1;
+            PhaseScope ps(c, GPE_PH_INV, gemm_flops(g));
+            launch_gemm_sub(s, g);
         }
     }
     else {
@@ -785,8 +804,6 @@ int ensure_inv(gpe_ctx* c)
             launch_set_identity(s, c->dLinv, ld, N);
         }
         trsm_left_blocked(c, c->dA, c->dLinv, ld, N, N, true, GPE_PH_INV); // L^-1 (gp.hpp:260)
-    }
-    {
         // K^-1 = L^-T L^-1 (gp.hpp:261), lower triangle, k range from the tile diagonal down
         GemmArgs g{};
         g.C = c->dKinv;

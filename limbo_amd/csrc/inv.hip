@@ -8,6 +8,10 @@
 // every diagonal nbo x nbo block of L (all panels at once, they are independent), from the 64 x 64
 // block inverses the factorisation already left behind (potrf.hip:k_diag).  The substitution then
 // needs two matrix-core launches per panel: Y_p = X_p Acc_p and the update of the rows below.
+// The engine works on the transposes (U = L^-T, upper triangular): every product is then of the form
+// C -= A B^T with both operands contiguous along their non-k index, which is what the LDS-direct matrix-core
+// kernel (gemm.hip, k_gemm_glds) wants.  So each block inverse is written twice: X_p as it is (the B operand of
+// Y_p^T = Acc_p^T X_p^T) and transposed (the diagonal block of U).
 //
 // Work per panel is ~10 products of 64^3 — far too little for the matrix cores to matter; the
 // kernel is plain FMA from LDS, one workgroup per 32-column strip of a panel (8 x npanels
@@ -37,10 +41,11 @@ static __device__ __forceinline__ void strip_mm(const double* __restrict__ As, c
 }
 
 // Out[o0 : o0+pw, o0 : o0+pw] = inv(L[o0 : o0+pw, o0 : o0+pw]) for every outer panel (blockIdx.y), full square
-// (zeros above the diagonal).  Xt_all: Xt[k + 64 c] = (L_bb^-1)[c][k] per 64-block b, identity-padded.
+// (zeros above the diagonal); OutT (optional): the same blocks transposed.
+// Xt_all: Xt[k + 64 c] = (L_bb^-1)[c][k] per 64-block b, identity-padded.
 __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L, int64_t ld, int64_t N, int nbo,
                                                     const double* __restrict__ Xt_all, double* __restrict__ Out,
-                                                    int64_t ldo)
+                                                    int64_t ldo, double* __restrict__ OutT, int64_t ldt)
 {
     __shared__ double Ys[4][NB * SW]; // the strip's result tiles, Ys[i - s][kk][col]
     __shared__ double Ss[NB * SW];    // sum_k L_ik Y_ks, as the right-hand operand of X_i
@@ -62,8 +67,11 @@ __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = o0 + (int64_t)i * NB + 4 * ty + r;
-                if (row < N && col < N)
+                if (row < N && col < N) {
                     Out[row + col * ldo] = v[r][c];
+                    if (OutT)
+                        OutT[col + row * ldt] = v[r][c];
+                }
             }
         }
     };
@@ -134,10 +142,11 @@ __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L
 
 // nbo: outer panel width, a multiple of 64, at most 256
 void launch_inv_panels(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
-                       int64_t ldo)
+                       int64_t ldo, double* OutT, int64_t ldt)
 {
     if (N <= 0)
         return;
     const unsigned np = (unsigned)((N + nbo - 1) / nbo);
-    hipLaunchKernelGGL(k_inv_panels, dim3((unsigned)(nbo / SW), np), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, ldo);
+    hipLaunchKernelGGL(k_inv_panels, dim3((unsigned)(nbo / SW), np), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, ldo,
+                       OutT, ldt);
 }
