@@ -2,6 +2,8 @@
 (1) the committed mpmath / LAPACK goldens, (2) the CPU oracle on the same seeded inputs at
 sizes the oracle finishes in seconds, (3) size-independent properties at BASELINE sizes.
 Tolerances: mu, sigma^2 <= 1e-8 rel; log-lik <= 1e-10 rel; grad <= 1e-6 rel."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ from tests import parity_checks as PC
 from tests.util import golden_files, new_gp, relerr, relerr_norm
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
 
 
 @pytest.mark.parametrize("path", golden_files("mp_"), ids=lambda p: p.stem)
@@ -439,3 +442,96 @@ def test_gpu_point_queries_vs_batch_and_oracle(engine_lib, oracle_lib, N):
     assert np.array_equal(k1, k2) and np.array_equal(v1, v2)
     g.close()
     o.close()
+
+
+def _small_parity(engine_lib, oracle_lib, N=300, D=3, P=2, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.05 * rng.normal(size=(N, P))
+    om, mean = O.obs_mean_data(Y)
+    th = rng.uniform(-0.4, 0.2, size=D + 1)
+    g = new_gp(engine_lib, O.SE_ARD, X, om, th, 0.01)
+    o = new_gp(oracle_lib, O.SE_ARD, X, om, th, 0.01)
+    assert g.compute() == 0 and o.compute() == 0
+    assert np.max(np.abs(g.get_L() - o.get_L())) < 1e-10 * np.max(np.abs(o.get_L()))
+    assert relerr_norm(g.get_alpha(), o.get_alpha()) < 1e-7
+    assert abs(g.log_lik() - o.log_lik()) <= PC.TOL_LL * max(1.0, abs(o.log_lik()))
+    assert relerr_norm(g.log_lik_grad(True), o.log_lik_grad(True)) < PC.TOL_GRAD
+    assert relerr_norm(g.log_loo_cv_grad(True), o.log_loo_cv_grad(True)) < PC.TOL_GRAD
+    assert relerr_norm(g.get_Kinv(), o.get_Kinv()) < 1e-8
+    Xq = rng.uniform(0, 1, size=(5, D))
+    for m in (1, 5):
+        kg, vg = g.query_batch(Xq[:m])
+        ko, vo = o.query_batch(Xq[:m])
+        assert relerr(kg, ko, floor=1e-6) < PC.TOL_MU and relerr(vg + 0.01, vo + 0.01) < PC.TOL_VAR
+    g.update_alpha(om[::-1].copy())
+    o.update_alpha(om[::-1].copy())
+    assert relerr_norm(g.get_alpha(), o.get_alpha()) < 1e-7
+    xn = rng.uniform(0, 1, size=D)
+    om2 = np.vstack([om[::-1], np.zeros((1, P))])
+    assert g.add_sample(xn, om2) == 0 and o.add_sample(xn, om2) == 0
+    assert relerr_norm(g.get_alpha(), o.get_alpha()) < 1e-7
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("env", [{"GPE_FLOW_SOLVE": "0"}, {"GPE_LOOKAHEAD": "0"}, {"GPE_FUSE_PANEL": "0"},
+                                 {"GPE_FUSE_DIAG": "0", "GPE_STOP_EVENT": "0"}, {"GPE_NBO": "192"}],
+                         ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
+def test_gpu_alternate_schedules(engine_lib, oracle_lib, monkeypatch, env):
+    """The switches read when a handle is created select the schedules that also serve as fall-backs (per-block
+    sweeps beyond 256 blocks, one stream, unfused panel steps, a panel width the block-inverse path does not
+    take): each must give the oracle's results too.  N = 520: three outer panels, ragged last block."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _small_parity(engine_lib, oracle_lib, N=520, seed=len(env))
+
+
+def test_gpu_process_wide_switches():
+    """GPE_QUERY_SWEEP / GPE_INV_PANELS are read once per process: run the same parity check in a child."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from limbo_amd import _capi\n"
+            "from tests.test_gpu_parity import _small_parity\n"
+            "_small_parity(_capi.load_engine(), _capi.load_oracle(), N=520, seed=7)\n"
+            "print('child ok')\n") % str(ROOT)
+    env = dict(os.environ, GPE_QUERY_SWEEP="0", GPE_INV_PANELS="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_gpu_above_one_launch_sweep_limit(engine_lib):
+    """N = 16448 = 257 blocks of 64: one more than the data-flow sweeps take (every workgroup must be resident),
+    so the factorisation's tail, update_alpha and a point query run the per-block sweeps.  Size-independent
+    checks: K alpha = obs_mean on sampled rows, mu ~ y and sigma^2 <= 2 (noise + 1e-8) at training points."""
+    rng = np.random.default_rng(11)
+    N, D = 16448, 3
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = (np.cos(4 * X).sum(axis=1) + 0.05 * rng.normal(size=N))[:, None]
+    om, mean = O.obs_mean_data(Y)
+    noise = 0.01
+    h = new_gp(engine_lib, O.MATERN52, X, om, np.array([-1.0, 0.0]), noise)
+    assert h.compute() == 0
+    rows = rng.integers(0, N, size=32)
+
+    def check_alpha(a, rhs):
+        d = np.sqrt(((X[rows, None, :] - X[None, :, :]) ** 2).sum(-1)) / np.exp(-1.0)
+        t1 = np.sqrt(5.0) * d
+        Kr = (1 + t1 + 5.0 * d * d / 3.0) * np.exp(-t1)
+        Kr[np.arange(len(rows)), rows] += noise + 1e-8
+        assert np.max(np.abs(Kr @ a[:, 0] - rhs[rows, 0])) < 1e-7 * np.max(np.abs(rhs))
+
+    check_alpha(h.get_alpha(), om)
+    ll = h.log_lik()
+    assert np.isfinite(ll)
+    kta, var = h.query_batch(X[rows[:1]])  # a point query
+    mu, s2 = O.finish_query(kta, var, mean, noise)
+    assert abs(mu[0, 0] - Y[rows[0], 0]) < 1.0 and s2[0] <= 2.0 * (noise + 1e-8)
+    om2 = om[::-1].copy()
+    h.update_alpha(om2)
+    check_alpha(h.get_alpha(), om2)
+    h.update_alpha(om)
+    assert abs(h.log_lik() - ll) <= 1e-10 * abs(ll)
+    h.close()
