@@ -121,7 +121,7 @@ def main():
         "log_lik": ll,
     }
 
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline:
         # dominant kernel: the Cholesky trailing update (k_gemm_glds / k_gemm_glds64 / k_gemm4, fp64 MFMA).  HIP events on
         # the handle's own stream around every launch of it (profiling mode), outside the timed region.
         h.set_profiling(True)
