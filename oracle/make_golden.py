@@ -7,6 +7,7 @@ reference cannot be built here (no Eigen/Boost), so goldens are minted from
 and the C oracle (oracle/gp_oracle.c) is pinned against both in tests/test_oracle.py.
 
 Run:  python oracle/make_golden.py        (takes ~1-2 min; output is committed)
+      python oracle/make_golden.py --only-new   (mint only the mpmath fixtures that are not there yet)
 """
 from __future__ import annotations
 
@@ -36,32 +37,44 @@ def small_cases():
              (O.MATERN32, 20, 3, 1, 0.01, False),
              (O.EXP, 20, 3, 1, 0.01, True),
              (O.SE_ARD, 1, 2, 1, 0.01, False),      # single sample
-             (O.SE_ARD, 2, 1, 1, 0.01, False)]
-    for kind, N, D, P, noise, on in specs:
+             (O.SE_ARD, 2, 1, 1, 0.01, False),
+             # SE-ARD with Lambda columns (squared_exp_ard.hpp:109-126, :142-146); appended, so that the cases
+             # above keep their random draws
+             (O.SE_ARD, 28, 3, 1, 0.02, True, 1),
+             (O.SE_ARD, 36, 5, 2, 0.01, False, 2)]
+    for spec in specs:
+        kind, N, D, P, noise, on = spec[:6]
+        lam = spec[6] if len(spec) > 6 else 0
         X = rng.uniform(-1.5, 1.5, size=(N, D))
         Y = np.stack([np.cos(X.sum(axis=1) * (p + 1)) + 0.1 * rng.normal(size=N) for p in range(P)], axis=1)
         om, mean = O.obs_mean_data(Y)
-        nt = D + 1 if kind == O.SE_ARD else 2
+        nt = D + D * lam + 1 if kind == O.SE_ARD else 2
         theta = rng.uniform(-0.7, 0.7, size=nt)
         Xq = rng.uniform(-1.8, 1.8, size=(7, D))
         Xq[0] = X[0]  # a query ON a training point (sigma^2 cancellation / clamp path)
         cases.append(dict(kind=kind, X=X, Y=Y, obs_mean=om, mean=mean, theta=theta, noise=noise,
-                          optimize_noise=on, Xq=Xq))
+                          optimize_noise=on, Xq=Xq, lam=lam))
     return cases
 
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     # ---- mpmath ground truth, small N
+    only_new = "--only-new" in sys.argv  # mint the fixtures that do not exist yet, leave the others alone
     for i, c in enumerate(small_cases()):
+        tag = KN[c["kind"]] + (f"_lambda{c['lam']}" if c["lam"] else "")
+        name = f"mp_{i:02d}_{tag}_n{c['X'].shape[0]}_d{c['X'].shape[1]}_p{c['Y'].shape[1]}.npz"
+        if only_new and (OUT / name).exists():
+            continue
         g = O.mp_gp(c["kind"], c["X"], c["obs_mean"], c["theta"], c["noise"], Xq=c["Xq"],
                     optimize_noise=c["optimize_noise"])
-        name = f"mp_{i:02d}_{KN[c['kind']]}_n{c['X'].shape[0]}_d{c['X'].shape[1]}_p{c['Y'].shape[1]}.npz"
         np.savez_compressed(OUT / name, kind=c["kind"], X=c["X"], Y=c["Y"], obs_mean=c["obs_mean"], mean=c["mean"],
                             theta=c["theta"], noise=c["noise"], optimize_noise=c["optimize_noise"], Xq=c["Xq"],
                             L=g["L"], alpha=g["alpha"], log_lik=g["log_lik"], grad=g["grad"],
                             kta=g["kta"], var_raw=g["var_raw"], Kinv=g["Kinv"], source="mpmath-50")
         print("wrote", name, "log_lik", g["log_lik"])
+    if only_new:
+        return
     # ---- LAPACK, medium N (scalars + samples only, to keep the files small)
     for cfg, kind, N, theta_scale in (("c1", O.SE_ARD, 200, 0.3), ("c2", O.SE_ARD, 512, 0.0),
                                       ("c3", O.MATERN52, 384, 0.0)):

@@ -191,7 +191,18 @@ def mp_gp(kind, X, obs_mean, theta, noise, Xq=None, optimize_noise=False, dps=50
     th = [mp.mpf(float(t)) for t in theta]
     nz = mp.mpf(float(noise))
 
+    lam = (len(th) - 1) // D - 1 if kind == SE_ARD else 0  # columns of Lambda (squared_exp_ard.hpp:94)
+
+    def quad(a, b):
+        """(a-b)^T (Lambda Lambda^T + diag(ell^-2)) (a-b), squared_exp_ard.hpp:142-146, and the pieces of its gradient"""
+        d = [mp.mpf(float(a[i])) - mp.mpf(float(b[i])) for i in range(D)]
+        zs = [(d[i] / mp.exp(th[i])) ** 2 for i in range(D)]
+        proj = [sum(d[i] * th[(j + 1) * D + i] for i in range(D)) for j in range(lam)]
+        return d, zs, proj, sum(zs) + sum(pj * pj for pj in proj)
+
     def kf(a, b):
+        if kind == SE_ARD and lam > 0:
+            return mp.exp(2 * th[-1]) * mp.exp(-quad(a, b)[3] / 2)
         if kind == SE_ARD:
             z = mp.mpf(0)
             for d in range(D):
@@ -215,6 +226,13 @@ def mp_gp(kind, X, obs_mean, theta, noise, Xq=None, optimize_noise=False, dps=50
         return sf2 * mp.exp(-s / (2 * l * l))
 
     def gf(a, b):
+        if kind == SE_ARD and lam > 0:  # squared_exp_ard.hpp:109-126
+            d, zs, proj, z = quad(a, b)
+            k = mp.exp(2 * th[-1]) * mp.exp(-z / 2)
+            g = [zz * k for zz in zs]
+            for j in range(lam):
+                g += [-proj[j] * d[i] * k for i in range(D)]
+            return g + [2 * k]
         if kind == SE_ARD:
             zs = []
             for d in range(D):
