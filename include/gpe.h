@@ -134,7 +134,9 @@ int gpe_hp_objective(gpe_handle h, int kind, const double* log_theta, int n_thet
 /* gp.hpp:613-632 for a batch of M points (row-major M x D):
  *   kta[m + M*p] = k(X, v_m)^T alpha_p          (add m(v) on the host, :615)
  *   var[m]       = k(v_m, v_m) - ||L^-1 k*||^2  (clamp and +noise on the host, :166,:623)
- * either output may be NULL. */
+ * either output may be NULL.  M <= 8 (the per-point gp.query(v) of an acquisition functor) runs the forward
+ * substitution as one data-flow launch; larger batches the blocked matrix-core solve.  The two agree to
+ * rounding (different summation order); each is bitwise reproducible from call to call. */
 int gpe_query_batch(gpe_handle h, const double* Xq_rowmajor, int64_t M,
                     double* kta, double* var);
 
