@@ -8,6 +8,13 @@
 #define NB 64
 #define LSTR 65
 
+// solve_mp.hip: 2..4 right-hand sides in one pass of the one-launch sweeps (output already holds the sentinel)
+void launch_trsv_bwd_flow_mp(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all,
+                             const double* y, int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P, int* err,
+                             const double* om, int64_t ldom, double* part, int part_acc);
+void launch_trsv_fwd_flow_mp(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all,
+                             const double* b, int64_t ldb, double* y, int64_t ldy, int P, int* err);
+
 // xs[p][c] = sum_k M[c][k] v_p[k] with M = X (forward, TRANS = 0: M[c][k] = Xt[k + 64 c]) or
 // M = X^T (backward, TRANS = 1: M[c][k] = Xt[c + 64 k]).  256 threads; v_p = w[j0 .. j0+jb) of
 // right-hand side p (zero beyond jb).  Stg: NB*LSTR doubles of LDS scratch.  Ends with a barrier.
@@ -404,8 +411,19 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
     if (!prefilled)
         for (int p = 0; p < P; ++p)
             hipMemsetAsync(a + (int64_t)p * ldw, 0xFF, sizeof(double) * (size_t)N, s);
-    hipLaunchKernelGGL(k_trsv_bwd_flow, dim3((unsigned)nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err,
-                       om, ldom, part, part_acc);
+    // several right-hand sides travel together, four to a pass (solve_mp.hip); a single one takes the kernel above
+    for (int p0 = 0; p0 < P; p0 += 4) {
+        const int pc = P - p0 < 4 ? P - p0 : 4;
+        const double* yc = y + (int64_t)p0 * ysp;
+        double* ac = a + (int64_t)p0 * ldw;
+        const double* omc = om ? om + (int64_t)p0 * ldom : nullptr;
+        const int acc = (part_acc || p0 > 0) ? 1 : 0;
+        if (pc == 1)
+            hipLaunchKernelGGL(k_trsv_bwd_flow, dim3((unsigned)nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac, ldw,
+                               1, err, omc, ldom, part, acc);
+        else
+            launch_trsv_bwd_flow_mp(s, L, ld, N, Xt_all, yc, ysi, ysp, ac, ldw, pc, err, omc, ldom, part, acc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -544,7 +562,16 @@ void launch_trsv_fwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
     const int64_t nblk = (N + NB - 1) / NB;
     for (int p = 0; p < P; ++p)
         hipMemsetAsync(y + (int64_t)p * ldy, 0xFF, sizeof(double) * (size_t)N, s);
-    hipLaunchKernelGGL(k_trsv_fwd_flow, dim3((unsigned)nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, b, ldb, y, ldy, P, err);
+    for (int p0 = 0; p0 < P; p0 += 4) { // four right-hand sides to a pass (solve_mp.hip)
+        const int pc = P - p0 < 4 ? P - p0 : 4;
+        const double* bc = b + (int64_t)p0 * ldb;
+        double* yc = y + (int64_t)p0 * ldy;
+        if (pc == 1)
+            hipLaunchKernelGGL(k_trsv_fwd_flow, dim3((unsigned)nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, bc, ldb, yc, ldy, 1,
+                               err);
+        else
+            launch_trsv_fwd_flow_mp(s, L, ld, N, Xt_all, bc, ldb, yc, ldy, pc, err);
+    }
 }
 
 // rows N..N+P-1 of the matrix <- obs_mean^T (before the factorisation) and back (z = L^-1 obs_mean
