@@ -39,6 +39,10 @@ def test_engine_contains_gfx950_code_object():
     blob = _capi.ENGINE_SO.read_bytes()
     assert b"gfx950" in blob
     assert b"k_gemm4" in blob and b"k_gemm_glds" in blob and b"k_diag" in blob
+    # every hand-written kernel family of the path is in the shipped code object
+    for k in (b"k_build", b"k_panel_step", b"k_upd_fused", b"k_trsv_bwd_flow", b"k_trsv_fwd_flow", b"k_trsv_bwd_flow_mp",
+              b"k_trsv_fwd_flow_mp", b"k_inv_panels", b"k_grad_tiles", b"k_lambda_rows", b"k_loo_prep"):
+        assert k in blob, k
 
 
 def test_engine_is_independent_of_the_oracle():
