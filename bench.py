@@ -57,7 +57,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from limbo_amd import _capi
-    from oracle import np_oracle as O  # synthetic-problem generator + cpu_baseline leg only
+    from limbo_amd import synth as O  # synthetic-problem generator (pure numpy)
 
     eng = _capi.load_engine()
     N = args.n
@@ -197,7 +197,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU side-by-side: the oracle (C restatement of the reference's path, 1 thread = the
         # reference's default: one GP::compute is single-threaded) on a bounded sample.
-        orc = _capi.load_oracle()
+        from oracle import binding as OB  # the checker, cpu_baseline leg only
+
+        orc = OB.load_oracle()
         ho = _capi.Handle(orc)
         ho.set_kernel(O.SE_ARD, theta, 0.01)
         ho.set_data(X, om)

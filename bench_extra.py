@@ -16,7 +16,7 @@ def main():
     import torch
     assert torch.cuda.is_available()
     from limbo_amd import _capi
-    from oracle import np_oracle as O
+    from limbo_amd import synth as O  # problem generator (pure numpy)
     eng = _capi.load_engine()
     out = {}
 

@@ -1,15 +1,10 @@
 """ctypes binding of the C-ABI declared in include/gpe.h.
 
-The same binding drives two libraries that export the same signatures under
-different prefixes:
-
-* ``libgpengine.so`` (prefix ``gpe_``) — the product: hand-written HIP for gfx950.
-* ``oracle/liboracle.so`` (prefix ``orc_``) — the CPU restatement of the reference,
-  TEST INFRASTRUCTURE ONLY (loaded only from tests/, smoke() and bench.py's
-  cpu_baseline leg).
-
-There is no fallback between them: :func:`load_engine` raises if the HIP library
-is missing.
+``libgpengine.so`` (prefix ``gpe_``) is the product: hand-written HIP for gfx950.
+:func:`load_engine` raises if it is missing — there is no CPU fallback, and this module
+knows of no other implementation.  (``Lib`` takes the symbol prefix as an argument so that
+the test infrastructure under ``oracle/`` can bind its checker, which exports the same
+signatures, with the same ``Handle`` class; that loader lives in ``oracle/binding.py``.)
 """
 from __future__ import annotations
 
@@ -22,7 +17,6 @@ import numpy as np
 _PKG = Path(__file__).resolve().parent
 ROOT = _PKG.parent
 ENGINE_SO = _PKG / "libgpengine.so"
-ORACLE_SO = ROOT / "oracle" / "liboracle.so"
 
 KERNEL_SE_ARD, KERNEL_MATERN52, KERNEL_MATERN32, KERNEL_EXP, KERNEL_HOST_K = range(5)
 KERNEL_NAMES = {"se_ard": 0, "matern52": 1, "matern32": 2, "exp": 3, "host_k": 4}
@@ -100,22 +94,6 @@ def _sig(lib, prefix):
             f = getattr(lib, prefix + name)
             f.argtypes = args
             f.restype = C.c_int
-    else:
-        f = lib.orc_kernel_lf_opt_rprop
-        f.argtypes = [_vp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.POINTER(C.c_int)]
-        f.restype = C.c_int
-        f = lib.orc_kernel_eval
-        f.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp]
-        f.restype = C.c_double
-        f = lib.orc_kernel_grad
-        f.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, _dp]
-        f.restype = None
-        f = lib.orc_kernel_eval_n
-        f.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, C.c_int]
-        f.restype = C.c_double
-        f = lib.orc_kernel_grad_n
-        f.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, C.c_int, _dp]
-        f.restype = None
 
 
 class Lib:
@@ -141,15 +119,6 @@ def load_engine() -> Lib:
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
         _libs["gpe"] = Lib(ENGINE_SO, "gpe_")
     return _libs["gpe"]
-
-
-def load_oracle() -> Lib:
-    """The CPU oracle — test infrastructure only."""
-    if "orc" not in _libs:
-        if not ORACLE_SO.exists():
-            raise EngineError(f"{ORACLE_SO} is missing: run `make -C oracle`")
-        _libs["orc"] = Lib(ORACLE_SO, "orc_")
-    return _libs["orc"]
 
 
 def _d(a):
@@ -368,18 +337,6 @@ class Handle:
         self._chk(self.lib.fn("get_phase_ms")(self._h, _d(ms), ln, _d(fl), PH_COUNT), "get_phase_ms")
         return {PHASE_NAMES[i]: {"ms": float(ms[i]), "launches": int(ln[i]), "flops": float(fl[i])}
                 for i in range(PH_COUNT)}
-
-    # -- oracle-only helpers
-    def kernel_lf_opt_rprop(self, optimize_noise=False, iterations=300, eps_stop=0.0):
-        assert self.lib.prefix == "orc_"
-        n = self.n_theta + (1 if optimize_noise else 0)
-        th = np.zeros(n)
-        lik = C.c_double()
-        ne = C.c_int()
-        rc = self.lib.cdll.orc_kernel_lf_opt_rprop(self._h, int(optimize_noise), iterations, eps_stop,
-                                                   _d(th), C.byref(lik), C.byref(ne))
-        self._chk(rc, "kernel_lf_opt_rprop")
-        return th, lik.value, ne.value
 
 
 def sparsify(lib, X, max_points, device_id=0):

@@ -18,12 +18,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def oracle_lib():
     """CPU oracle (test infrastructure). Built on demand with gcc."""
-    import subprocess
-    from limbo_amd import _capi
+    from oracle import binding
 
-    if not _capi.ORACLE_SO.exists():
-        subprocess.check_call(["make", "-C", str(ROOT / "oracle")])
-    return _capi.load_oracle()
+    return binding.load_oracle()
 
 
 @pytest.fixture(scope="session")

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from limbo_amd import _capi
+from oracle import binding as OB
 from oracle import np_oracle as O
 from tests import parity_checks as PC
 from tests.util import golden_files, new_gp, relerr, relerr_norm
@@ -495,7 +496,7 @@ def test_gpu_process_wide_switches():
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from limbo_amd import _capi\n"
             "from tests.test_gpu_parity import _small_parity\n"
-            "_small_parity(_capi.load_engine(), _capi.load_oracle(), N=520, seed=7)\n"
+            "_small_parity(_capi.load_engine(), OB.load_oracle(), N=520, seed=7)\n"
             "print('child ok')\n") % str(ROOT)
     env = dict(os.environ, GPE_QUERY_SWEEP="0", GPE_INV_PANELS="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))

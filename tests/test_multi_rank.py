@@ -80,6 +80,7 @@ sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
 from limbo_amd import _capi, parallel as P
 from oracle import np_oracle as O
+from oracle import binding as OB
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 M = int(sys.argv[2])
@@ -87,7 +88,7 @@ rng = np.random.default_rng(3)
 X = rng.uniform(0, 1, size=(60, 3)); Y = np.stack([np.sin(X.sum(1)), np.cos(X[:, 0])], axis=1)
 om, _ = O.obs_mean_data(Y)
 # every rank holds its own replica of the GP (here: the CPU oracle stands in for the engine)
-h = _capi.Handle(_capi.load_oracle()); h.set_data(X, om); h.set_kernel(O.MATERN52, np.array([0.1, 0.2]), 0.01)
+h = _capi.Handle(OB.load_oracle()); h.set_data(X, om); h.set_kernel(O.MATERN52, np.array([0.1, 0.2]), 0.01)
 assert h.compute() == 0
 Xq = rng.uniform(0, 1, size=(M, 3))
 kta, var = P.query_sharded(h.query_batch, Xq, dist)

@@ -3,6 +3,7 @@ answers, the independent numpy/LAPACK restatement and the mpmath goldens.  No GP
 import numpy as np
 import pytest
 
+from oracle import binding as OB
 from oracle import np_oracle as O
 from tests import parity_checks as PC
 from tests.util import golden_files, new_gp, relerr
@@ -247,7 +248,7 @@ def test_oracle_rprop_improves(oracle_lib):
     h = new_gp(oracle_lib, O.SE_ARD, X, om, np.zeros(3), 0.01)
     h.compute()
     ll0 = h.log_lik()
-    th, ll, nev = h.kernel_lf_opt_rprop(optimize_noise=True, iterations=50, eps_stop=1e-2)
+    th, ll, nev = OB.kernel_lf_opt_rprop(h, optimize_noise=True, iterations=50, eps_stop=1e-2)
     assert nev <= 50
     assert ll >= ll0
     assert abs(h.log_lik() - ll) < 1e-12 * abs(ll)

@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from limbo_amd import _capi  # noqa: E402
-from oracle import np_oracle as O  # noqa: E402  (problem generator only)
+from limbo_amd import synth as O  # problem generator (pure numpy)
 
 eng = _capi.load_engine()
 X4, Y4 = O.make_problem("c2", N=2048)

@@ -9,7 +9,7 @@ if sys.argv[1] == "run":
     import numpy as np
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
     from limbo_amd import _capi
-    from oracle import np_oracle as O  # problem generator only
+    from limbo_amd import synth as O  # problem generator (pure numpy)
     eng = _capi.load_engine()
     X, Y = O.make_problem("c2", N=4096)
     om, _ = O.obs_mean_data(Y)
