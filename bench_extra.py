@@ -161,7 +161,9 @@ def main():
     best = 1e30
     for _ in range(2):
         t0 = time.perf_counter()
-        K = O.kernel_matrix(O.SE_ARD, Xc, np.zeros(7), 0.01)
+        sq = (Xc * Xc).sum(axis=1)
+        K = np.exp(-0.5 * np.maximum(sq[:, None] + sq[None, :] - 2.0 * (Xc @ Xc.T), 0.0))  # SE-ARD, ell = 1, sigma_f = 1
+        K[np.diag_indices(len(Xc))] += 0.01 + 1e-8
         L = sl.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
         al = sl.cho_solve((L, True), omc, check_finite=False)
         ll = -0.5 * float((omc * al).sum()) - float(np.log(np.diag(L)).sum()) - 0.5 * len(Xc) * np.log(2 * np.pi)

@@ -69,6 +69,13 @@ enum gpe_kernel_kind {
 int gpe_create(int device_id, gpe_handle* out);
 /* deep copy (value semantics of limbo::model::GP, e.g. kernel_lf_opt.hpp:79) */
 int gpe_clone(gpe_handle src, gpe_handle* out);
+/* the same onto another device of the node (peer copy over xGMI): how tools::par::loop / par::max
+ * (tools/parallel.hpp:138-191) spread the independent GPs of model::MultiGP (multi_gp.hpp:124-126) and the restarts of
+ * opt::ParallelRepeater (parallel_repeater.hpp:86-105) over the 8 MI355X of a node — the C++ header deals the clones
+ * round-robin.  gpe_device_count: devices visible to this process. */
+int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out);
+int gpe_device_count(int* n);
+int gpe_get_device(gpe_handle h, int* device_id);
 int gpe_destroy(gpe_handle h);
 const char* gpe_last_error(gpe_handle h);
 const char* gpe_version(void);
@@ -179,7 +186,9 @@ enum gpe_phase {
 int gpe_set_profiling(gpe_handle h, int on);
 int gpe_get_phase_ms(gpe_handle h, double* ms, int64_t* launches, double* flops, int n);
 int gpe_reset_phase_ms(gpe_handle h);
-/* fp64 MFMA peak micro-benchmark (v_mfma_f64_16x16x4_f64), TFLOP/s */
+/* one-launch sweeps that had to be re-run block by block after a hand-off timeout (never expected; tests) */
+int gpe_flow_retries(gpe_handle h, int64_t* n);
+/* fp64 MFMA peak micro-benchmark (v_mfma_f64_4x4x4_4b, the instruction the GEMM kernels issue), TFLOP/s */
 int gpe_mfma_f64_peak(int device_id, double* tflops);
 /* HBM write-stream micro-benchmark, GB/s */
 int gpe_hbm_stream_peak(int device_id, double* gbs);

@@ -51,10 +51,36 @@ namespace limbo_amd {
     class Engine {
     public:
         explicit Engine(int device) : _h(nullptr), _device(device) {}
-        Engine(const Engine& o) : _h(nullptr), _device(o._device)
+        Engine(const Engine& o) : Engine(o, o._device) {}
+        /// deep copy onto `device` (peer copy over xGMI when it differs from o's)
+        Engine(const Engine& o, int device) : _h(nullptr), _device(device)
         {
             if (o._h)
-                check(gpe_clone(o._h, &_h), "gpe_clone");
+                check(gpe_clone_to(o._h, _device, &_h), "gpe_clone_to");
+        }
+        Engine(Engine&& o) noexcept : _h(o._h), _device(o._device) { o._h = nullptr; }
+        Engine& operator=(Engine&& o) noexcept
+        {
+            if (this != &o) {
+                reset();
+                _h = o._h;
+                _device = o._device;
+                o._h = nullptr;
+            }
+            return *this;
+        }
+        /// move the GP to another device of the node (no-op when it is there already)
+        void set_device(int device)
+        {
+            if (device == _device)
+                return;
+            if (_h) {
+                gpe_handle n = nullptr;
+                check(gpe_clone_to(_h, device, &n), "gpe_clone_to");
+                gpe_destroy(_h);
+                _h = n;
+            }
+            _device = device;
         }
         Engine& operator=(const Engine& o)
         {
@@ -101,14 +127,21 @@ namespace limbo {
         template <typename Params, typename KernelFunction = kernel::MaternFiveHalves<Params>, typename MeanFunction = mean::Data<Params>, typename HyperParamsOptimizer = gp::NoLFOpt<Params>>
         class GP {
         public:
-            GP() : _dim_in(-1), _dim_out(-1), _log_lik(0), _log_loo_cv(0), _inv_kernel_updated(false), _eng(0) {}
+            GP() : _dim_in(-1), _dim_out(-1), _log_lik(0), _log_loo_cv(0), _inv_kernel_updated(false), _eng(limbo_amd::home_device<Params>()) {}
 
             GP(int dim_in, int dim_out)
-                : _dim_in(dim_in), _dim_out(dim_out), _kernel_function(dim_in), _mean_function(dim_out), _log_lik(0), _log_loo_cv(0), _inv_kernel_updated(false), _eng(0) {}
+                : _dim_in(dim_in), _dim_out(dim_out), _kernel_function(dim_in), _mean_function(dim_out), _log_lik(0), _log_loo_cv(0), _inv_kernel_updated(false), _eng(limbo_amd::home_device<Params>()) {}
 
             /// value semantics as in the reference: the device state is deep-copied (gpe_clone)
-            GP(const GP& o)
-                : _dim_in(o._dim_in), _dim_out(o._dim_out), _kernel_function(o._kernel_function), _mean_function(o._mean_function), _samples(o._samples), _observations(o._observations), _mean_vector(o._mean_vector), _obs_mean(o._obs_mean), _alpha(o._alpha), _mean_observation(o._mean_observation), _kernel(o._kernel), _inv_kernel(o._inv_kernel), _matrixL(o._matrixL), _log_lik(o._log_lik), _log_loo_cv(o._log_loo_cv), _inv_kernel_updated(o._inv_kernel_updated), _hp_optimize(o._hp_optimize), _eng(o._eng), _status(o._status), _L_stale(o._L_stale), _alpha_stale(o._alpha_stale), _Kinv_stale(o._Kinv_stale), _dev_theta(o._dev_theta), _dev_noise(o._dev_noise), _dev_kernel_ok(o._dev_kernel_ok) {}
+            GP(const GP& o) : GP(o, o._eng.device()) {}
+
+            /// the same onto another device of the node (addition: how the parallel policies spread independent GPs)
+            GP(const GP& o, int device)
+                : _dim_in(o._dim_in), _dim_out(o._dim_out), _kernel_function(o._kernel_function), _mean_function(o._mean_function), _samples(o._samples), _observations(o._observations), _mean_vector(o._mean_vector), _obs_mean(o._obs_mean), _alpha(o._alpha), _mean_observation(o._mean_observation), _kernel(o._kernel), _inv_kernel(o._inv_kernel), _matrixL(o._matrixL), _log_lik(o._log_lik), _log_loo_cv(o._log_loo_cv), _inv_kernel_updated(o._inv_kernel_updated), _hp_optimize(o._hp_optimize), _eng(o._eng, device), _status(o._status), _L_stale(o._L_stale), _alpha_stale(o._alpha_stale), _Kinv_stale(o._Kinv_stale), _dev_theta(o._dev_theta), _dev_noise(o._dev_noise), _dev_kernel_ok(o._dev_kernel_ok) {}
+
+            /// device this GP lives on / move it (additions)
+            int device() const { return _eng.device(); }
+            void set_device(int device) { _eng.set_device(device); }
 
             GP& operator=(const GP& o)
             {

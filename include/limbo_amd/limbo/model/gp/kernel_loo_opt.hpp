@@ -35,28 +35,18 @@ namespace limbo {
 
                     opt::eval_t operator()(const Eigen::VectorXd& params, bool compute_grad) const
                     {
-                        GP& gp = _worker();
+                        GP& gp = _workers.get(_original_gp);
                         gp.kernel_function().set_h_params(params);
                         gp.recompute(false);
                         const double loo = gp.compute_log_loo_cv();
                         if (!compute_grad)
                             return opt::no_grad(loo);
-                        return {loo, opt::optional_grad_t(gp.compute_kernel_grad_log_loo_cv())};
+                        return {loo, opt::eval_t::second_type(gp.compute_kernel_grad_log_loo_cv())};
                     }
 
                 protected:
                     const GP& _original_gp;
-                    mutable std::mutex _mu;
-                    mutable std::map<std::thread::id, std::unique_ptr<GP>> _workers;
-
-                    GP& _worker() const
-                    {
-                        std::lock_guard<std::mutex> lk(_mu);
-                        auto& w = _workers[std::this_thread::get_id()];
-                        if (!w)
-                            w.reset(new GP(_original_gp));
-                        return *w;
-                    }
+                    limbo_amd::WorkerClones<Params, GP> _workers;
                 };
             };
         } // namespace gp

@@ -38,28 +38,18 @@ namespace limbo {
 
                     opt::eval_t operator()(const Eigen::VectorXd& params, bool compute_grad) const
                     {
-                        GP& gp = _worker();
+                        GP& gp = _workers.get(_original_gp);
                         gp.mean_function().set_h_params(params);
                         gp.recompute(true, false);
                         const double lik = gp.compute_log_lik();
                         if (!compute_grad)
                             return opt::no_grad(lik);
-                        return {lik, opt::optional_grad_t(gp.compute_mean_grad_log_lik())};
+                        return {lik, opt::eval_t::second_type(gp.compute_mean_grad_log_lik())};
                     }
 
                 protected:
                     GP _original_gp;
-                    mutable std::mutex _mu;
-                    mutable std::map<std::thread::id, std::unique_ptr<GP>> _workers;
-
-                    GP& _worker() const
-                    {
-                        std::lock_guard<std::mutex> lk(_mu);
-                        auto& w = _workers[std::this_thread::get_id()];
-                        if (!w)
-                            w.reset(new GP(_original_gp));
-                        return *w;
-                    }
+                    limbo_amd::WorkerClones<Params, GP> _workers;
                 };
             };
         } // namespace gp

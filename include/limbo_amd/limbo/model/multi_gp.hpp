@@ -197,8 +197,13 @@ namespace limbo {
             void _make_models()
             {
                 _gp_models.clear();
-                for (int i = 0; i < _dim_out; i++)
+                _gp_models.reserve(_dim_out);
+                for (int i = 0; i < _dim_out; i++) {
                     _gp_models.emplace_back(_dim_in, 1);
+                    // independent GPs: dealt over the node's MI355Xs (one device: all of them there) — the
+                    // tools::par::loop of multi_gp.hpp:124-126 then drives one device per host thread
+                    _gp_models.back().set_device(limbo_amd::deal_device<Params>((size_t)i));
+                }
             }
             void _update_mean_observation()
             {

@@ -21,12 +21,19 @@
 #include <vector>
 #include <limbo/opt/optimizer.hpp>
 #include <limbo/tools/macros.hpp>
+#if defined(__has_include)
+#if __has_include(<limbo/opt/grid_search.hpp>)
+#include <limbo/opt/grid_search.hpp> // limbo's tree is on the include path: its defaults::opt_gridsearch is THE definition
+#endif
+#endif
 namespace limbo {
     namespace defaults {
+#ifndef LIMBO_OPT_GRID_SEARCH_HPP // limbo's own opt/grid_search.hpp (included above when its tree is there) defines it
         struct opt_gridsearch {
             /// number of bins for each dimension (opt/grid_search.hpp:57-61)
             BO_PARAM(int, bins, 5);
         };
+#endif
         struct opt_batchrandomsearch {
             BO_PARAM(int, points, 8192);
             BO_PARAM(int, refine_rounds, 2);
@@ -39,13 +46,13 @@ namespace limbo {
         /// (the per-point call is what bo_base's lambda does: bayes_opt/boptimizer.hpp:151-153)
         template <typename Acqui, typename Afun>
         struct BatchObjective {
-            const Acqui& acqui;
+            Acqui& acqui; // not const: acqui::EI caches f_max / nb_samples in operator() and batch() (acqui/ei.hpp:85-116)
             const Afun& afun;
             eval_t operator()(const Eigen::VectorXd& x, bool g) const { return acqui(x, afun, g); }
             std::vector<double> batch(const std::vector<Eigen::VectorXd>& pts) const { return acqui.batch(pts, afun); }
         };
         template <typename Acqui, typename Afun>
-        BatchObjective<Acqui, Afun> make_batch_objective(const Acqui& a, const Afun& f) { return BatchObjective<Acqui, Afun>{a, f}; }
+        BatchObjective<Acqui, Afun> make_batch_objective(Acqui& a, const Afun& f) { return BatchObjective<Acqui, Afun>{a, f}; }
 
         namespace detail {
             template <typename F>

@@ -2,6 +2,18 @@
 // (contract: src/limbo/opt/optimizer.hpp:61-96).  The reference spells the optional gradient
 // boost::optional<Eigen::VectorXd>; boost is used when present, otherwise an equivalent minimal
 // optional with the same accessors (is_initialized(), get(), operator bool).
+#ifndef LIMBO_AMD_OPT_OPTIMIZER_HPP
+#define LIMBO_AMD_OPT_OPTIMIZER_HPP
+// With limbo's own tree on the include path BEHIND this directory, this file steps aside: limbo's
+// <limbo/opt/optimizer.hpp> is the one that gets compiled, so every other limbo header keeps seeing exactly what it was
+// written against.  Stand-alone (no limbo tree), the definitions below provide the same names.
+#if defined(__has_include_next)
+#if __has_include_next(<limbo/opt/optimizer.hpp>)
+#define LIMBO_AMD_OPT_OPTIMIZER_HPP_FORWARDED 1
+#include_next <limbo/opt/optimizer.hpp>
+#endif
+#endif
+#ifndef LIMBO_AMD_OPT_OPTIMIZER_HPP_FORWARDED
 #ifndef LIMBO_OPT_OPTIMIZER_HPP
 #define LIMBO_OPT_OPTIMIZER_HPP
 #include <Eigen/Core>
@@ -52,4 +64,6 @@ namespace limbo {
         inline eval_t eval_grad(const F& f, const Eigen::VectorXd& x) { return f(x, true); }
     } // namespace opt
 } // namespace limbo
+#endif // LIMBO_OPT_OPTIMIZER_HPP
+#endif // stand-alone
 #endif

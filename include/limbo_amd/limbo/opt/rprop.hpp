@@ -2,6 +2,18 @@
 // (contract and constants: src/limbo/opt/rprop.hpp:82-145: delta0 0.1, delta in [1e-6, 50],
 // eta- 0.5, eta+ 1.2; maximises f; returns the best point SEEN, not the last).
 // Host code by design: it drives <= dim(theta) scalars; every f(theta) is one device evaluation.
+#ifndef LIMBO_AMD_OPT_RPROP_HPP
+#define LIMBO_AMD_OPT_RPROP_HPP
+// With limbo's own tree on the include path BEHIND this directory, this file steps aside: limbo's
+// <limbo/opt/rprop.hpp> is the one that gets compiled, so every other limbo header keeps seeing exactly what it was
+// written against.  Stand-alone (no limbo tree), the definitions below provide the same names.
+#if defined(__has_include_next)
+#if __has_include_next(<limbo/opt/rprop.hpp>)
+#define LIMBO_AMD_OPT_RPROP_HPP_FORWARDED 1
+#include_next <limbo/opt/rprop.hpp>
+#endif
+#endif
+#ifndef LIMBO_AMD_OPT_RPROP_HPP_FORWARDED
 #ifndef LIMBO_OPT_RPROP_HPP
 #define LIMBO_OPT_RPROP_HPP
 #include <algorithm>
@@ -65,4 +77,6 @@ namespace limbo {
         };
     } // namespace opt
 } // namespace limbo
+#endif // LIMBO_OPT_RPROP_HPP
+#endif // stand-alone
 #endif

@@ -3,6 +3,18 @@
 // `Params` struct is written against (reference: src/limbo/tools/macros.hpp:53-110), so they are
 // kept verbatim-compatible: BO_PARAM(T, name, v) yields `static constexpr T name()`, BO_DYN_PARAM
 // a runtime-settable static, and so on.  New MI355X knobs live in limbo::defaults::gpu below.
+#ifndef LIMBO_AMD_TOOLS_MACROS_HPP
+#define LIMBO_AMD_TOOLS_MACROS_HPP
+// With limbo's own tree on the include path BEHIND this directory, this file steps aside: limbo's
+// <limbo/tools/macros.hpp> is the one that gets compiled, so every other limbo header keeps seeing exactly what it was
+// written against.  Stand-alone (no limbo tree), the definitions below provide the same names.
+#if defined(__has_include_next)
+#if __has_include_next(<limbo/tools/macros.hpp>)
+#define LIMBO_AMD_TOOLS_MACROS_HPP_FORWARDED 1
+#include_next <limbo/tools/macros.hpp>
+#endif
+#endif
+#ifndef LIMBO_AMD_TOOLS_MACROS_HPP_FORWARDED
 #ifndef LIMBO_TOOLS_MACROS_HPP
 #define LIMBO_TOOLS_MACROS_HPP
 
@@ -49,14 +61,17 @@
             v_(i_) = _##Name[i_];                                         \
         return v_;                                                        \
     }
-
+#endif // LIMBO_TOOLS_MACROS_HPP
+#endif // stand-alone
 namespace limbo {
     namespace defaults {
-        /// device selection for the MI355X engine (not in the reference)
+        /// placement of the model on the node's MI355Xs (not in the reference).  device >= 0: that HIP device;
+        /// device = -1 (default): device 0 for a GP the user creates, and the CLONES that the parallel policies make
+        /// (opt::ParallelRepeater restarts, model::MultiGP outputs, multi_gp::ParallelLFOpt fits) are dealt round-robin
+        /// over the visible devices — with one visible device everything stays on it.
         struct gpu {
-            BO_PARAM(int, device, 0);
+            BO_PARAM(int, device, -1);
         };
     } // namespace defaults
 } // namespace limbo
-
 #endif

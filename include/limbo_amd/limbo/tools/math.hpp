@@ -1,8 +1,21 @@
 // limbo/tools/math.hpp — scalar helpers used by the optimisers (reference: src/limbo/tools/math.hpp)
+#ifndef LIMBO_AMD_TOOLS_MATH_HPP
+#define LIMBO_AMD_TOOLS_MATH_HPP
+// With limbo's own tree on the include path BEHIND this directory, this file steps aside: limbo's
+// <limbo/tools/math.hpp> is the one that gets compiled, so every other limbo header keeps seeing exactly what it was
+// written against.  Stand-alone (no limbo tree), the definitions below provide the same names.
+#if defined(__has_include_next)
+#if __has_include_next(<limbo/tools/math.hpp>)
+#define LIMBO_AMD_TOOLS_MATH_HPP_FORWARDED 1
+#include_next <limbo/tools/math.hpp>
+#endif
+#endif
+#ifndef LIMBO_AMD_TOOLS_MATH_HPP_FORWARDED
 #ifndef LIMBO_TOOLS_MATH_HPP
 #define LIMBO_TOOLS_MATH_HPP
 #include <Eigen/Core>
-#include <random>
+#include <cmath>
+#include <type_traits>
 namespace limbo {
     namespace tools {
         /// sign of x as -1, 0 or +1
@@ -17,16 +30,19 @@ namespace limbo {
             return v;
         }
 
-        /// uniform random vector in [0, 1]^dim (bounded) or [-1, 1] scaled (unbounded is caller's business)
-        inline Eigen::VectorXd random_vector(int dim, unsigned seed)
+        /// true if v is nan or +-inf (scalars), or holds such a coefficient (vectors)
+        template <typename T, typename std::enable_if<std::is_arithmetic<T>::value, int>::type = 0>
+        inline bool is_nan_or_inf(T v) { return std::isinf(v) || std::isnan(v); }
+        template <typename T, typename std::enable_if<!std::is_arithmetic<T>::value, int>::type = 0>
+        inline bool is_nan_or_inf(const T& v)
         {
-            std::mt19937_64 g(seed);
-            std::uniform_real_distribution<double> u(0.0, 1.0);
-            Eigen::VectorXd v(dim);
-            for (int i = 0; i < dim; ++i)
-                v(i) = u(g);
-            return v;
+            for (int i = 0; i < (int)v.size(); ++i)
+                if (std::isinf(v(i)) || std::isnan(v(i)))
+                    return true;
+            return false;
         }
     } // namespace tools
 } // namespace limbo
+#endif // LIMBO_TOOLS_MATH_HPP
+#endif // stand-alone
 #endif

@@ -6,12 +6,19 @@
 #define LIMBO_TOOLS_PARALLEL_HPP
 #include <algorithm>
 #include <cstddef>
+#include <exception>
 #include <thread>
 #include <vector>
 namespace limbo {
     namespace tools {
         namespace par {
-            inline void init() {}
+            /// the container alias and conversion limbo's callers use (tools/parallel.hpp:77-113)
+            template <typename X>
+            using vector = std::vector<X>;
+            template <typename V>
+            inline V convert_vector(const V& v) { return v; }
+
+            inline void init(int threads = -1) { (void)threads; }
 
             /// f(i) for i in [begin, end), one host thread per index (bounded by hardware_concurrency)
             template <typename F>
@@ -24,14 +31,46 @@ namespace limbo {
                     return;
                 }
                 const size_t nt = std::min<size_t>(n, std::max(1u, std::thread::hardware_concurrency()));
+                // an exception thrown by f (the device GP throws std::runtime_error on any engine / HIP error) travels
+                // to the caller as it would out of tbb::parallel_for: first one wins, the other workers finish
                 std::vector<std::thread> th;
+                std::vector<std::exception_ptr> err(nt);
                 for (size_t t = 0; t < nt; ++t)
                     th.emplace_back([&, t]() {
-                        for (size_t i = begin + t; i < end; i += nt)
-                            f(i);
+                        try {
+                            for (size_t i = begin + t; i < end; i += nt)
+                                f(i);
+                        }
+                        catch (...) {
+                            err[t] = std::current_exception();
+                        }
                     });
                 for (auto& x : th)
                     x.join();
+                for (auto& e : err)
+                    if (e)
+                        std::rethrow_exception(e);
+            }
+
+            /// f(*it) for every element (tools/parallel.hpp:153-163)
+            template <typename Iterator, typename F>
+            inline void for_each(Iterator begin, Iterator end, const F& f)
+            {
+                std::vector<Iterator> its;
+                for (Iterator i = begin; i != end; ++i)
+                    its.push_back(i);
+                loop(0, its.size(), [&](size_t i) { f(*its[i]); });
+            }
+
+            /// sort (tools/parallel.hpp:193-203) — host data, plain std::sort
+            template <typename T1, typename T2, typename T3>
+            inline void sort(T1 i1, T2 i2, T3 comp) { std::sort(i1, i2, comp); }
+
+            /// f() nb times (tools/parallel.hpp:205-221)
+            template <typename F>
+            inline void replicate(size_t nb, const F& f)
+            {
+                loop(0, nb, [&](size_t) { f(); });
             }
 
             /// max over body(i), i in [0, num_steps), starting from init (the reduce of :169-191)

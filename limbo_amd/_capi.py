@@ -40,6 +40,9 @@ def _sig(lib, prefix):
     S = {
         "create": [C.c_int, C.POINTER(_vp)],
         "clone": [_vp, C.POINTER(_vp)],
+        "clone_to": [_vp, C.c_int, C.POINTER(_vp)],
+        "device_count": [C.POINTER(C.c_int)],
+        "get_device": [_vp, C.POINTER(C.c_int)],
         "destroy": [_vp],
         "set_data": [_vp, _dp, _i64, C.c_int, _dp, C.c_int],
         "set_data_device": [_vp, _vp, _i64, C.c_int, _vp, C.c_int],
@@ -87,6 +90,7 @@ def _sig(lib, prefix):
             "set_profiling": [_vp, C.c_int],
             "get_phase_ms": [_vp, _dp, C.POINTER(_i64), _dp, C.c_int],
             "reset_phase_ms": [_vp],
+            "flow_retries": [_vp, C.POINTER(_i64)],
             "mfma_f64_peak": [C.c_int, _dp],
             "hbm_stream_peak": [C.c_int, _dp],
         }
@@ -166,12 +170,25 @@ class Handle:
         except Exception:
             pass
 
-    def clone(self) -> "Handle":
+    def clone(self, device=None) -> "Handle":
         h = _vp()
-        self._chk(self.lib.fn("clone")(self._h, C.byref(h)), "clone")
+        if device is None:
+            self._chk(self.lib.fn("clone")(self._h, C.byref(h)), "clone")
+        else:
+            self._chk(self.lib.fn("clone_to")(self._h, int(device), C.byref(h)), "clone_to")
         o = Handle(self.lib, _h=h)
         o.N, o.D, o.P, o.n_theta = self.N, self.D, self.P, self.n_theta
         return o
+
+    def device(self) -> int:
+        d = C.c_int()
+        self._chk(self.lib.fn("get_device")(self._h, C.byref(d)), "get_device")
+        return d.value
+
+    def flow_retries(self) -> int:
+        n = _i64()
+        self._chk(self.lib.fn("flow_retries")(self._h, C.byref(n)), "flow_retries")
+        return n.value
 
     # -- data
     def set_data(self, X, obs_mean):
@@ -370,3 +387,11 @@ def batch_log_lik(handles):
     if rc < 0:
         raise EngineError(f"batch_log_lik failed: {rc}")
     return out
+
+
+def device_count(lib) -> int:
+    n = C.c_int()
+    rc = lib.fn("device_count")(C.byref(n))
+    if rc < 0:
+        raise EngineError(f"device_count failed: {rc}")
+    return n.value

@@ -30,6 +30,27 @@ static __device__ __forceinline__ d4_t mfma_f64(double a, double b, d4_t c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// ---- workgroup -> unknown block of a one-launch data-flow sweep (solve.hip, solve_mp.hip) ------------------
+// Two requirements meet here.  (1) Progress without assuming that every workgroup is resident: a workgroup may
+// only ever wait for workgroups with a LOWER blockIdx.x — the dispatcher hands workgroups out in that order, so
+// whatever a resident workgroup polls for is resident or finished, however many CUs other streams (other handles'
+// sweeps, 147 KB-LDS GEMMs) hold.  (2) Consecutive blocks of the chain on one XCD (hops served by that XCD's L2).
+// The dispatcher deals blockIdx.x round-robin over the 8 XCDs, so a grid of nblk workgroups cannot have both.
+// The grid therefore has 8 workgroups per chain position s = blockIdx.x / 8 (s-th block to be solved: s going up
+// for the forward sweep, nblk-1-s for the backward one); only the one that sits on the XCD owning that block's
+// contiguous range of the chain works, the other seven return at once (-1).
+#define GPE_FLOW_SPIN_LIMIT (1 << 22) // bounded poll: ~a second; raises *err, and the host re-runs block by block
+static __device__ __forceinline__ int64_t flow_block_of(int64_t nblk, bool backward)
+{
+    const int64_t s = blockIdx.x >> 3;
+    const int64_t x = blockIdx.x & 7;
+    const int64_t j = backward ? nblk - 1 - s : s;
+    const int64_t q = nblk / 8, r = nblk % 8, split = r * (q + 1);
+    const int64_t owner = j < split ? j / (q + 1) : r + (j - split) / (q > 0 ? q : 1);
+    return x == owner ? j : -1;
+}
+#define GPE_FLOW_GRID(nblk) ((unsigned)(8 * (nblk)))
+
 // ---- kernel-matrix build (kbuild.hip) ----------------------------------------------
 // Xt: SoA, D x ldx (sample index contiguous).  Writes the LOWER triangle (incl. diagonal,
 // + diag_add) of K into A (col-major, lda).  gp.hpp:556-558 + kernel.hpp:81-84.

@@ -40,7 +40,8 @@ struct PhaseRec {
 } // namespace
 
 struct gpe_ctx {
-    int device = 0;
+    int device = 0;  // physical HIP device
+    int ldevice = 0; // the device id the caller used (differs from `device` only under GPE_VIRTUAL_DEVICES)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead: bulk of a trailing update runs here, behind the next panel
     std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
@@ -72,6 +73,7 @@ struct gpe_ctx {
     double* hScal = nullptr; // pinned
     bool have_L = false, inv_ok = false, host_K = false, ll_ok = false;
     int nbo = 256; // outer panel width of the two-level blocked algorithms
+    int64_t flow_retries = 0; // sweeps re-run block by block after a hand-off timeout (never expected; see flow_failed)
     bool flow_solve = true; // one data-flow launch for the backward sweep (GPE_FLOW_SOLVE=0: per-block launches)
     bool fuse_panel = true; // k_panel_step instead of the three-launch panel step (GPE_FUSE_PANEL=0 disables)
     // instrumentation
@@ -695,11 +697,29 @@ static hipError_t wait_stream(hipStream_t s)
     }
 }
 
-int compute_finish(gpe_ctx* c)
+// after a stream sync: did a data-flow sweep give up waiting for a producer?  With the dispatch-ordered block
+// mapping (dev.h, flow_block_of) that is not a reachable state; the bounded poll stays as a backstop, and the host
+// answers it by running the same work again with one launch per block (GPE_FLOW_FAULT=1 forces that path in tests).
+static bool flow_failed(gpe_ctx* c)
 {
-    HIPCHK(c, wait_stream(c->stream));
-    HIPCHK(c, hipGetLastError());
-    drain_phases(c);
+    static const bool fault = getenv("GPE_FLOW_FAULT") && atoi(getenv("GPE_FLOW_FAULT")) != 0;
+    const bool bad = c->hInfo[1] != 0 || (fault && c->flow_solve);
+    c->hInfo[1] = 0;
+    if (bad)
+        ++c->flow_retries;
+    return bad;
+}
+
+// scope in which the one-launch sweeps are off (the block-by-block re-run after a hand-off timeout)
+struct NoFlowScope {
+    gpe_ctx* c;
+    bool saved;
+    explicit NoFlowScope(gpe_ctx* c_) : c(c_), saved(c_->flow_solve) { c->flow_solve = false; }
+    ~NoFlowScope() { c->flow_solve = saved; }
+};
+
+static void sum_ll_partials(gpe_ctx* c)
+{
     if (c->ll_partials > 0) {
         long double sl = 0.0L, sa = 0.0L;
         for (int j = 0; j < c->ll_partials; ++j) {
@@ -710,13 +730,37 @@ int compute_finish(gpe_ctx* c)
         c->hScal[1] = (double)sa;
         c->ll_partials = 0;
     }
-    c->ll_ok = true;
-    if (c->hInfo[1] != 0) { // the data-flow solve gave up waiting for a producer (never legal)
-        c->err = "backward sweep: inter-workgroup hand-off timed out";
-        c->hInfo[1] = 0;
-        return GPE_ERR_HIP;
+}
+
+// redo: re-enqueues, with the one-launch sweeps off, everything that depended on a sweep of this call
+template <class Redo> int compute_finish(gpe_ctx* c, Redo redo)
+{
+    HIPCHK(c, wait_stream(c->stream));
+    HIPCHK(c, hipGetLastError());
+    drain_phases(c);
+    if (flow_failed(c)) {
+        NoFlowScope off(c);
+        redo();
+        HIPCHK(c, wait_stream(c->stream));
+        HIPCHK(c, hipGetLastError());
+        drain_phases(c);
+        if (c->hInfo[1] != 0) { // cannot happen: no data-flow kernel ran
+            c->hInfo[1] = 0;
+            c->err = "triangular sweep failed twice";
+            return GPE_ERR_HIP;
+        }
     }
+    sum_ll_partials(c);
+    c->ll_ok = true;
     return *c->hInfo; // 0 or 1-based index of the first non-positive pivot
+}
+// the common case: alpha and the log-likelihood terms from L and obs_mean
+int compute_finish(gpe_ctx* c)
+{
+    return compute_finish(c, [c] {
+        solve_alpha(c);
+        enqueue_loglik_terms(c);
+    });
 }
 
 int ensure_inv(gpe_ctx* c)
@@ -834,16 +878,6 @@ static int ensure_loo_bufs(gpe_ctx* c, bool square)
     return GPE_OK;
 }
 
-// after a stream sync: did a data-flow sweep give up waiting for a producer?  (never a legal state)
-static int check_flow(gpe_ctx* c)
-{
-    if (c->hInfo[1] == 0)
-        return GPE_OK;
-    c->err = "triangular sweep: inter-workgroup hand-off timed out";
-    c->hInfo[1] = 0;
-    return GPE_ERR_HIP;
-}
-
 // Weights of the leave-one-out gradient (grad.hip header; gp.hpp:354-402): on return
 //   dLooV[:, 0:P] = u = K^-1 (alpha / kappa),   dLinv (lower) = K^-1 diag(c) K^-1,   dLooV[ld (P+2)] = LOO value.
 // dLinv (L^-1, only an intermediate of K^-1) is reused as the N x N output.
@@ -854,6 +888,8 @@ static int loo_weights(gpe_ctx* c)
         return rc;
     hipStream_t s = c->stream;
     const int64_t N = c->N, ld = c->ld;
+    if (!c->dLinv) // a clone that inherited K^-1 never ran ensure_inv's allocation
+        HIPCHK(c, hipMalloc(&c->dLinv, sizeof(double) * (size_t)(ld * c->cap)));
     double *v = c->dLooV, *sc = c->dLooV + ld * c->P, *val = sc + ld, *outp = c->dLooV + ld * (c->P + 2);
     {
         PhaseScope ps(c, GPE_PH_GRAD, 0.0);
@@ -948,6 +984,25 @@ struct DevGuard {
     explicit DevGuard(gpe_ctx* c) { hipSetDevice(c->device); }
 };
 
+// Devices as the callers count them.  GPE_VIRTUAL_DEVICES=n (tests): n logical devices dealt round-robin over the
+// physical ones, so that the multi-device placement of the C++ policies (clones of one GP on several devices,
+// gpe_clone_to) is exercised on a one-GPU box.
+int physical_devices()
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+int logical_devices()
+{
+    const int phys = physical_devices();
+    if (const char* e = getenv("GPE_VIRTUAL_DEVICES")) {
+        const int v = atoi(e);
+        if (v > 0 && phys > 0)
+            return v;
+    }
+    return phys;
+}
+
 } // namespace
 
 // =============================================================================================
@@ -961,12 +1016,13 @@ int gpe_create(int device_id, gpe_handle* out)
 {
     if (!out)
         return GPE_ERR_ARG;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev)
+    const int phys = physical_devices();
+    if (phys <= 0 || device_id < 0 || device_id >= logical_devices())
         return GPE_ERR_HIP;
     gpe_ctx* c = new gpe_ctx();
-    c->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
+    c->ldevice = device_id;
+    c->device = device_id % phys;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
         || create_bulk_stream(&c->stream2) != hipSuccess
         || hipMalloc(&c->dScal, 8192) != hipSuccess
         || hipMalloc(&c->dHead, sizeof(double) * 65 * NB * NB) != hipSuccess
@@ -1203,11 +1259,11 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * ld, obs_mean, sizeof(double) * (n + 1),
                                sizeof(double) * (n + 1), P, hipMemcpyHostToDevice, s));
     c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
-    {
+    // k(x_i, x_new) for i = 0..n (gp.hpp:583-586), no noise yet
+    launch_build_Ks(s, c->dXt, ld, n + 1, c->dXt + n, ld, 1, c->kp, c->dW, ld);
+    hipLaunchKernelGGL(k_knn, dim3(1), dim3(1), 0, s, c->dW, n, c->kp.diag_add, c->dScal + 2);
+    auto new_row = [c, s, n, ld] {
         PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)n * n);
-        // k(x_i, x_new) for i = 0..n (gp.hpp:583-586), no noise yet
-        launch_build_Ks(s, c->dXt, ld, n + 1, c->dXt + n, ld, 1, c->kp, c->dW, ld);
-        hipLaunchKernelGGL(k_knn, dim3(1), dim3(1), 0, s, c->dW, n, c->kp.diag_add, c->dScal + 2);
         if (n > 0) {
             // new row of L by forward substitution (gp.hpp:591-594): L[n, 0:n] = (L^-1 k[0:n])^T
             if (c->flow_solve && (n + NB - 1) / NB <= 256)
@@ -1219,13 +1275,19 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         }
         launch_append_diag(s, c->dA + n, ld, n, c->dScal + 2, c->dInfo); // gp.hpp:596-597
         launch_diag_inv(s, c->dA, ld, n + 1, n / NB, 1, c->dXinv); // the last block gained a row
-    }
+    };
+    new_row();
     c->N = n + 1;
     c->have_L = true;
     c->inv_ok = false; // gp.hpp:602
     solve_alpha(c);    // gp.hpp:599
     enqueue_loglik_terms(c);
-    return compute_finish(c);
+    return compute_finish(c, [c, new_row] {
+        c->hInfo[0] = 0; // the pivot word of the failed attempt came from a row that was never completed
+        new_row();       // (the one-launch sweep leaves its input c->dW untouched)
+        solve_alpha(c);
+        enqueue_loglik_terms(c);
+    });
 }
 
 int gpe_log_lik(gpe_handle c, double* out)
@@ -1263,6 +1325,28 @@ int gpe_compute_inv_kernel(gpe_handle c)
     return GPE_OK;
 }
 
+// shared by the two gradient entry points: enqueue, fetch, and — should a one-launch sweep have given up — once more
+// with one launch per block
+static int grad_fetch(gpe_ctx* c, double* grad, int n_grad, int optimize_noise, bool loo)
+{
+    auto once = [&]() -> int {
+        int rc = grad_enqueue(c, n_grad, optimize_noise, loo);
+        if (rc)
+            return rc;
+        HIPCHK(c, hipMemcpyAsync(grad, c->dGrad, sizeof(double) * n_grad, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        drain_phases(c);
+        return GPE_OK;
+    };
+    int rc = once();
+    if (rc || !flow_failed(c))
+        return rc;
+    NoFlowScope off(c);
+    rc = once();
+    c->hInfo[1] = 0;
+    return rc;
+}
+
 int gpe_log_lik_grad(gpe_handle c, double* grad, int n_grad, int optimize_noise)
 {
     if (!c || !grad)
@@ -1272,13 +1356,7 @@ int gpe_log_lik_grad(gpe_handle c, double* grad, int n_grad, int optimize_noise)
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
     digest_kernel(c);
-    int rc = grad_enqueue(c, n_grad, optimize_noise);
-    if (rc)
-        return rc;
-    HIPCHK(c, hipMemcpyAsync(grad, c->dGrad, sizeof(double) * n_grad, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    drain_phases(c);
-    return check_flow(c);
+    return grad_fetch(c, grad, n_grad, optimize_noise, false);
 }
 
 // GP::compute_log_loo_cv (gp.hpp:339-351)
@@ -1318,13 +1396,7 @@ int gpe_log_loo_cv_grad(gpe_handle c, double* grad, int n_grad, int optimize_noi
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
     digest_kernel(c);
-    int rc = grad_enqueue(c, n_grad, optimize_noise, true);
-    if (rc)
-        return rc;
-    HIPCHK(c, hipMemcpyAsync(grad, c->dGrad, sizeof(double) * n_grad, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    drain_phases(c);
-    return check_flow(c);
+    return grad_fetch(c, grad, n_grad, optimize_noise, true);
 }
 
 int gpe_hp_objective(gpe_handle c, int kind, const double* th, int n_theta, double noise, int optimize_noise,
@@ -1431,10 +1503,15 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
             c->err = "query_batch: stream sync failed";
             rc = GPE_ERR_HIP;
         }
-        else if (c->hInfo[1] != 0) {
-            c->err = "query: inter-workgroup hand-off of the forward sweep timed out";
-            c->hInfo[1] = 0;
-            rc = GPE_ERR_HIP;
+        else if (few && var && flow_failed(c)) {
+            // the one-launch sweep gave up (never expected): the same chunk through the blocked solve, in place
+            trsm_left_blocked(c, c->dA, dKs, ld, N, mc, false, GPE_PH_QUERY);
+            launch_col_var(s, dKs, ld, N, mc, dKvv, dVar);
+            hipMemcpyAsync(var + m0, dVar, sizeof(double) * (size_t)mc, hipMemcpyDeviceToHost, s);
+            if (hipStreamSynchronize(s) != hipSuccess) {
+                c->err = "query_batch: stream sync failed";
+                rc = GPE_ERR_HIP;
+            }
         }
     }
     drain_phases(c);
@@ -1525,6 +1602,12 @@ int gpe_set_L(gpe_handle c, const double* L, int64_t ldh)
     HIPCHK(c, hipMemcpy2D(c->dA, sizeof(double) * c->ld, L, sizeof(double) * ldh, sizeof(double) * c->N, c->N,
                           hipMemcpyHostToDevice));
     launch_diag_inv(c->stream, c->dA, c->ld, c->N, 0, (c->N + NB - 1) / NB, c->dXinv);
+    if (!c->host_K && lam_columns(c->kind, c->n_theta, c->D) > 0) {
+        // compute() never ran on this handle: the Lambda^T x rows of the training samples that the cross-kernel
+        // and gradient kernels read (squared_exp_ard.hpp:142-146) are still to be formed
+        digest_kernel(c);
+        project_lambda(c, c->stream, c->dXt, c->ld, 0, c->N);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_L = true;
     c->inv_ok = false;
@@ -1599,9 +1682,15 @@ int gpe_get_loo_weights(gpe_handle c, double* W, int64_t ldh)
     std::vector<double> u((size_t)N * P), a((size_t)N * P);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     drain_phases(c);
-    rc = check_flow(c);
-    if (rc)
-        return rc;
+    if (flow_failed(c)) { // once more, one launch per block
+        NoFlowScope off(c);
+        rc = loo_weights(c);
+        if (rc)
+            return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        drain_phases(c);
+        c->hInfo[1] = 0;
+    }
     HIPCHK(c, hipMemcpy2D(W, sizeof(double) * ldh, c->dLinv, sizeof(double) * c->ld, sizeof(double) * N, N,
                           hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy2D(u.data(), sizeof(double) * N, c->dLooV, sizeof(double) * c->ld, sizeof(double) * N, P,
@@ -1646,17 +1735,52 @@ int gpe_get_K(gpe_handle c, double* K, int64_t ldh)
     return GPE_OK;
 }
 
-int gpe_clone(gpe_handle src, gpe_handle* out)
+int gpe_device_count(int* n)
+{
+    if (!n)
+        return GPE_ERR_ARG;
+    *n = logical_devices();
+    return *n > 0 ? GPE_OK : GPE_ERR_HIP;
+}
+
+int gpe_get_device(gpe_handle c, int* device_id)
+{
+    if (!c || !device_id)
+        return GPE_ERR_ARG;
+    *device_id = c->ldevice;
+    return GPE_OK;
+}
+
+int gpe_flow_retries(gpe_handle c, int64_t* n)
+{
+    if (!c || !n)
+        return GPE_ERR_ARG;
+    *n = c->flow_retries;
+    return GPE_OK;
+}
+
+int gpe_clone(gpe_handle src, gpe_handle* out) { return src ? gpe_clone_to(src, src->ldevice, out) : GPE_ERR_ARG; }
+
+int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out)
 {
     if (!src || !out)
         return GPE_ERR_ARG;
     gpe_handle c = nullptr;
-    int rc = gpe_create(src->device, &c);
+    int rc = gpe_create(device_id, &c);
     if (rc)
         return rc;
-    DevGuard g(src);
     std::lock_guard<std::mutex> lk(src->mu);
-    hipStreamSynchronize(src->stream);
+    {
+        DevGuard gs(src);
+        hipStreamSynchronize(src->stream);
+    }
+    DevGuard g(c);
+    // device-to-device on one GPU, peer copy over xGMI between two (no host staging either way)
+    const int sdev = src->device, ddev = c->device;
+    auto copy = [&](void* dst, const void* from, size_t bytes) {
+        return sdev == ddev ? hipMemcpyAsync(dst, from, bytes, hipMemcpyDeviceToDevice, c->stream)
+                            : hipMemcpyPeerAsync(dst, ddev, from, sdev, bytes, c->stream);
+    };
     c->kind = src->kind;
     c->n_theta = src->n_theta;
     memcpy(c->theta, src->theta, sizeof(c->theta));
@@ -1678,20 +1802,18 @@ int gpe_clone(gpe_handle src, gpe_handle* out)
         c->D = src->D;
         c->P = src->P;
         const size_t mat = sizeof(double) * (size_t)(c->ld * c->cap);
-        hipMemcpyAsync(c->dXt, src->dXt, sizeof(double) * (size_t)(c->ld * xt_rows(c->D)), hipMemcpyDeviceToDevice,
-                       c->stream);
-        hipMemcpyAsync(c->dA, src->dA, mat, hipMemcpyDeviceToDevice, c->stream);
-        hipMemcpyAsync(c->dOm, src->dOm, sizeof(double) * (size_t)(c->ld * c->P), hipMemcpyDeviceToDevice, c->stream);
-        hipMemcpyAsync(c->dAl, src->dAl, sizeof(double) * (size_t)(c->ld * c->P), hipMemcpyDeviceToDevice, c->stream);
-        hipMemcpyAsync(c->dXinv, src->dXinv, sizeof(double) * (size_t)(c->cap / NB) * NB * NB, hipMemcpyDeviceToDevice,
-                       c->stream);
+        copy(c->dXt, src->dXt, sizeof(double) * (size_t)(c->ld * xt_rows(c->D)));
+        copy(c->dA, src->dA, mat);
+        copy(c->dOm, src->dOm, sizeof(double) * (size_t)(c->ld * c->P));
+        copy(c->dAl, src->dAl, sizeof(double) * (size_t)(c->ld * c->P));
+        copy(c->dXinv, src->dXinv, sizeof(double) * (size_t)(c->cap / NB) * NB * NB);
         if (src->dKhost) {
             hipMalloc(&c->dKhost, mat);
-            hipMemcpyAsync(c->dKhost, src->dKhost, mat, hipMemcpyDeviceToDevice, c->stream);
+            copy(c->dKhost, src->dKhost, mat);
         }
         if (src->inv_ok && src->dKinv) {
             hipMalloc(&c->dKinv, mat);
-            hipMemcpyAsync(c->dKinv, src->dKinv, mat, hipMemcpyDeviceToDevice, c->stream);
+            copy(c->dKinv, src->dKinv, mat);
             c->inv_ok = true;
         }
         c->have_L = src->have_L;

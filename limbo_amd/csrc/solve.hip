@@ -181,8 +181,9 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, co
 // pre-filled with an all-ones bit pattern (a NaN no arithmetic produces); every value is published
 // by ONE naturally aligned 8-byte agent-scope store and consumed by agent-scope loads that poll the
 // value itself (MI355X_MICROARCH.md, "granule" hand-off: an 8-byte store is never torn and needs no
-// ordering with anything else).  All nblk <= 256 workgroups are resident (1 per CU), so the
-// pipeline cannot deadlock; the poll is bounded anyway and raises *err instead of hanging.
+// ordering with anything else).  A workgroup only waits for workgroups dispatched before it (flow_block_of,
+// dev.h), so the pipeline makes progress whatever else occupies the chip; the poll is bounded anyway and raises
+// *err instead of hanging (the host then re-runs the sweep block by block).
 // ---------------------------------------------------------------------------------------------
 #ifdef FLOW_TIMING
 __device__ long long g_flow_ts[256][8]; // per block j: start, after fold #1, #2, #8, last fold done, solved, published, #folds
@@ -220,14 +221,10 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow(const double* __restr
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wvu = __builtin_amdgcn_readfirstlane(wv); // the same value, known to be wave-uniform
     const int64_t nblk = (N + NB - 1) / NB;
-    // Workgroup -> unknown block.  Workgroups b, b + 8, b + 16, .. share an XCD (and its L2); the chain
-    // a_j -> a_(j-1) is handed from workgroup to workgroup, so consecutive blocks go to one XCD: the
-    // XCD that holds blockIdx.x % 8 owns a contiguous range of blocks, and only 7 of the hops cross XCDs.
-    int64_t j;
-    {
-        const int64_t q = nblk / 8, r = nblk % 8, x = blockIdx.x % 8, idx = blockIdx.x / 8;
-        j = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
-    }
+    // workgroup -> unknown block: dependencies only on lower blockIdx.x, consecutive blocks on one XCD (dev.h)
+    const int64_t j = flow_block_of(nblk, true);
+    if (j < 0)
+        return;
     const int64_t j0 = j * NB;
     const int jb = (int)((N - j0 < NB) ? N - j0 : NB);
     const unsigned long long SENT = ~0ull;
@@ -293,7 +290,7 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow(const double* __restr
                                                      __HIP_MEMORY_SCOPE_AGENT);
                         if (bits != SENT)
                             break;
-                        if (++spins > (1 << 24)) { // ~seconds: a lost producer, never a legal state
+                        if (++spins > GPE_FLOW_SPIN_LIMIT) { // ~seconds: a lost producer, never a legal state
                             *err = 1;
                             break;
                         }
@@ -419,7 +416,7 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
         const double* omc = om ? om + (int64_t)p0 * ldom : nullptr;
         const int acc = (part_acc || p0 > 0) ? 1 : 0;
         if (pc == 1)
-            hipLaunchKernelGGL(k_trsv_bwd_flow, dim3((unsigned)nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac, ldw,
+            hipLaunchKernelGGL(k_trsv_bwd_flow, dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac, ldw,
                                1, err, omc, ldom, part, acc);
         else
             launch_trsv_bwd_flow_mp(s, L, ld, N, Xt_all, yc, ysi, ysp, ac, ldw, pc, err, omc, ldom, part, acc);
@@ -447,11 +444,9 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_fwd_flow(const double* __restr
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     const int64_t nblk = (N + NB - 1) / NB;
-    int64_t j; // consecutive blocks share an XCD (see k_trsv_bwd_flow)
-    {
-        const int64_t q = nblk / 8, r = nblk % 8, x = blockIdx.x % 8, idx = blockIdx.x / 8;
-        j = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
-    }
+    const int64_t j = flow_block_of(nblk, false); // dev.h
+    if (j < 0)
+        return;
     const int64_t j0 = j * NB;
     const int jb = (int)((N - j0 < NB) ? N - j0 : NB);
     const unsigned long long SENT = ~0ull;
@@ -494,7 +489,7 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_fwd_flow(const double* __restr
                                                  __HIP_MEMORY_SCOPE_AGENT);
                     if (bits != SENT)
                         break;
-                    if (++spins > (1 << 24)) { // ~seconds: a lost producer, never a legal state
+                    if (++spins > GPE_FLOW_SPIN_LIMIT) { // ~seconds: a lost producer, never a legal state
                         *err = 1;
                         break;
                     }
@@ -567,7 +562,7 @@ void launch_trsv_fwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
         const double* bc = b + (int64_t)p0 * ldb;
         double* yc = y + (int64_t)p0 * ldy;
         if (pc == 1)
-            hipLaunchKernelGGL(k_trsv_fwd_flow, dim3((unsigned)nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, bc, ldb, yc, ldy, 1,
+            hipLaunchKernelGGL(k_trsv_fwd_flow, dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, bc, ldb, yc, ldy, 1,
                                err);
         else
             launch_trsv_fwd_flow_mp(s, L, ld, N, Xt_all, bc, ldb, yc, ldy, pc, err);

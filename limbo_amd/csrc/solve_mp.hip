@@ -27,20 +27,13 @@ static __device__ __forceinline__ double mp_poll(const double* addr, unsigned lo
             bits = __hip_atomic_load((const unsigned long long*)addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (bits != SENT)
             break;
-        if (++spins > (1 << 24)) { // ~seconds: a lost producer, never a legal state
+        if (++spins > GPE_FLOW_SPIN_LIMIT) { // ~seconds: a lost producer, never a legal state
             *err = 1;
             break;
         }
         __builtin_amdgcn_s_sleep(1);
     }
     return __longlong_as_double((long long)bits);
-}
-
-static __device__ __forceinline__ int64_t mp_block_of(int64_t nblk)
-{
-    // consecutive blocks share an XCD (solve.hip, k_trsv_bwd_flow)
-    const int64_t q = nblk / 8, r = nblk % 8, x = blockIdx.x % 8, idx = blockIdx.x / 8;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
 }
 
 // fixed-order sum over the 8 waves of part_s[w][p][lane]
@@ -71,7 +64,9 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow_mp(const double* __re
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     const int64_t nblk = (N + NB - 1) / NB;
-    const int64_t j = mp_block_of(nblk);
+    const int64_t j = flow_block_of(nblk, true); // dev.h
+    if (j < 0)
+        return;
     const int64_t j0 = j * NB;
     const int jb = (int)((N - j0 < NB) ? N - j0 : NB);
     const unsigned long long SENT = ~0ull;
@@ -218,7 +213,9 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_fwd_flow_mp(const double* __re
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     const int64_t nblk = (N + NB - 1) / NB;
-    const int64_t j = mp_block_of(nblk);
+    const int64_t j = flow_block_of(nblk, false); // dev.h
+    if (j < 0)
+        return;
     const int64_t j0 = j * NB;
     const int jb = (int)((N - j0 < NB) ? N - j0 : NB);
     const unsigned long long SENT = ~0ull;
@@ -326,10 +323,10 @@ void launch_trsv_bwd_flow_mp(hipStream_t s, const double* L, int64_t ld, int64_t
 {
     const unsigned nblk = (unsigned)((N + NB - 1) / NB);
     if (P <= 2)
-        hipLaunchKernelGGL((k_trsv_bwd_flow_mp<2>), dim3(nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw,
+        hipLaunchKernelGGL((k_trsv_bwd_flow_mp<2>), dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw,
                            P, err, om, ldom, part, part_acc);
     else
-        hipLaunchKernelGGL((k_trsv_bwd_flow_mp<4>), dim3(nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw,
+        hipLaunchKernelGGL((k_trsv_bwd_flow_mp<4>), dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw,
                            P, err, om, ldom, part, part_acc);
 }
 void launch_trsv_fwd_flow_mp(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all,
@@ -337,9 +334,9 @@ void launch_trsv_fwd_flow_mp(hipStream_t s, const double* L, int64_t ld, int64_t
 {
     const unsigned nblk = (unsigned)((N + NB - 1) / NB);
     if (P <= 2)
-        hipLaunchKernelGGL((k_trsv_fwd_flow_mp<2>), dim3(nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, b, ldb, y, ldy, P,
+        hipLaunchKernelGGL((k_trsv_fwd_flow_mp<2>), dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, b, ldb, y, ldy, P,
                            err);
     else
-        hipLaunchKernelGGL((k_trsv_fwd_flow_mp<4>), dim3(nblk), dim3(64 * FW), 0, s, L, ld, N, Xt_all, b, ldb, y, ldy, P,
+        hipLaunchKernelGGL((k_trsv_fwd_flow_mp<4>), dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, b, ldb, y, ldy, P,
                            err);
 }

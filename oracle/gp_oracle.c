@@ -391,6 +391,11 @@ int orc_clone(orc_handle s, orc_handle* out)
     return 0;
 }
 
+/* placement has no meaning on the CPU: one "device" */
+int orc_clone_to(orc_handle s, int device_id, orc_handle* out) { (void)device_id; return orc_clone(s, out); }
+int orc_device_count(int* n) { *n = 1; return 0; }
+int orc_get_device(orc_handle c, int* d) { (void)c; *d = 0; return 0; }
+
 const char* orc_last_error(orc_handle c) { return c ? c->err : "null handle"; }
 const char* orc_version(void) { return "oracle-1"; }
 

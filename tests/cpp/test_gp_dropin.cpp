@@ -785,6 +785,12 @@ CASE(test_batch_search)
     CHECK(opt::eval(plain, rs) >= opt::eval(plain, init));
     const VectorXd ru = opt::BatchRandomSearch<Params>()(obj, init, false);
     CHECK(opt::eval(plain, ru) >= opt::eval(plain, init));
+    // EI caches f_max / nb_samples inside operator() and batch() (acqui/ei.hpp:85-116): the objective must not be const
+    acqui::EI<Params, GP_t> ei(gp);
+    auto obj_ei = opt::make_batch_objective(ei, first);
+    auto plain_ei = [&](const VectorXd& x, bool g) { return ei(x, first, g); };
+    const VectorXd ref_ei = reference_grid_search(plain_ei, 0, init, Params::opt_gridsearch::bins());
+    CHECK((opt::BatchGridSearch<Params>()(obj_ei, init, true) - ref_ei).norm() == 0.0);
 }
 
 // test_gp.cpp:815-910 (test_sparse_gp_accuracy): a GP on the thinned half of the data predicts like the
@@ -845,6 +851,118 @@ CASE(test_sparse_gp_accuracy)
     CHECK(std::isfinite(mu[0]) && s2 >= 0.0);
 }
 
+// independent GPs / restarts spread over the devices of the node from the C++ drop-in itself —
+// tools::par::loop over MultiGP members (multi_gp.hpp:124-126), tools::par::max under opt::ParallelRepeater
+// (parallel_repeater.hpp:84-105).  With one visible device everything stays on it; GPE_VIRTUAL_DEVICES=n (the
+// pytest wrapper runs the whole binary again with 4) deals n logical devices over the physical ones, so the
+// placement logic and gpe_clone_to run on a one-GPU box too.
+struct ParamsPinned : public Params {
+    struct gpu {
+        BO_PARAM(int, device, 0);
+    };
+};
+CASE(test_multi_device_placement)
+{
+    int ndev = 0;
+    CHECK(gpe_device_count(&ndev) == GPE_OK && ndev >= 1);
+    std::printf("    %d visible device(s)\n", ndev);
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(150, 3, 1, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    CHECK(gp.device() == 0);
+    const VectorXd q = rand_vec(3, 0, 1);
+    VectorXd m0;
+    double s0;
+    std::tie(m0, s0) = gp.query(q);
+    const double ll0 = gp.compute_log_lik();
+    for (int d = 0; d < ndev; ++d) { // deep copy onto every device: same numbers (same code, same data)
+        GP_t c(gp, d);
+        CHECK(c.device() == d);
+        VectorXd m;
+        double s2;
+        std::tie(m, s2) = c.query(q);
+        CHECK(m(0) == m0(0) && s2 == s0);
+        c.recompute(false);
+        CHECK(c.compute_log_lik() == ll0);
+    }
+    {
+        GP_t c(gp);
+        c.set_device(ndev - 1); // migrate in place
+        CHECK(c.device() == ndev - 1);
+        CHECK(c.compute_log_lik() == ll0);
+        GP_t d;
+        d = c; // assignment keeps the source's placement
+        CHECK(d.device() == ndev - 1);
+    }
+    // MultiGP: member i on device i mod ndev, results as a single-device GP per output
+    using Multi_t = model::MultiGP<Params, model::GP, kernel::SquaredExpARD<Params>, mean::NullFunction<Params>>;
+    std::vector<VectorXd> Y5;
+    make_problem(150, 3, 5, X, Y5);
+    Multi_t mgp;
+    mgp.compute(X, Y5);
+    for (int p = 0; p < 5; ++p)
+        CHECK(mgp.gp_models()[p].device() == p % ndev);
+    VectorXd mu, sig;
+    std::tie(mu, sig) = mgp.query(q);
+    for (int p = 0; p < 5; ++p) {
+        model::GP<ParamsPinned, kernel::SquaredExpARD<ParamsPinned>, mean::NullFunction<ParamsPinned>> single;
+        std::vector<VectorXd> yp;
+        for (auto& y : Y5)
+            yp.push_back(make_v1(y(p)));
+        single.compute(X, yp);
+        CHECK(single.device() == 0);
+        VectorXd m;
+        double s2;
+        std::tie(m, s2) = single.query(q);
+        CHECK(m(0) == mu(p) && s2 == sig(p));
+    }
+    // restarts of a hyper-parameter fit: one private clone per restart thread, dealt over the devices
+    {
+        using Opt_t = model::gp::KernelLFOpt<Params, opt::ParallelRepeater<Params, opt::Rprop<Params>>>;
+        using GPo_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>, Opt_t>;
+        GPo_t g2;
+        g2.compute(X, Y);
+        Opt_t::KernelLFOptimization<GPo_t> objective(g2);
+        opt::ParallelRepeater<Params, opt::Rprop<Params>> rep;
+        const VectorXd best = rep(objective, g2.kernel_function().h_params(), false);
+        const std::vector<int> devs = objective._workers.devices();
+        CHECK((int)devs.size() == Params::opt_parallelrepeater::repeats());
+        std::vector<int> count(ndev, 0);
+        for (int d : devs) {
+            CHECK(d >= 0 && d < ndev);
+            ++count[d];
+        }
+        const int lo = Params::opt_parallelrepeater::repeats() / ndev;
+        for (int d = 0; d < ndev; ++d)
+            CHECK(count[d] >= lo && count[d] <= lo + 1); // round-robin
+        CHECK(opt::eval(objective, best) >= ll0 - 1e-9);
+        // a pinned Params keeps every clone on its device
+        using OptP_t = model::gp::KernelLFOpt<ParamsPinned, opt::ParallelRepeater<ParamsPinned, opt::Rprop<ParamsPinned>>>;
+        using GPp_t = model::GP<ParamsPinned, kernel::SquaredExpARD<ParamsPinned>, mean::Data<ParamsPinned>, OptP_t>;
+        GPp_t g3;
+        g3.compute(X, Y);
+        OptP_t::KernelLFOptimization<GPp_t> objp(g3);
+        opt::ParallelRepeater<ParamsPinned, opt::Rprop<ParamsPinned>> repp;
+        repp(objp, g3.kernel_function().h_params(), false);
+        for (int d : objp._workers.devices())
+            CHECK(d == 0);
+    }
+    // an exception inside a par::loop body reaches the caller (as out of tbb::parallel_for)
+    bool caught = false;
+    try {
+        tools::par::loop(0, 4, [](size_t i) {
+            if (i == 2)
+                throw std::runtime_error("worker failed");
+        });
+    }
+    catch (const std::runtime_error&) {
+        caught = true;
+    }
+    CHECK(caught);
+}
+
 int main()
 {
     auto t0 = std::chrono::steady_clock::now();
@@ -882,6 +1000,7 @@ int main()
     test_acqui_batch_run();
     test_batch_search_run();
     test_sparse_gp_accuracy_run();
+    test_multi_device_placement_run();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%d checks, %d failed cases, %.1f s\n", g_checks, g_failed, s);
     return g_failed;

@@ -38,9 +38,34 @@ def test_dropin_keeps_the_policy_api_names():
 
 
 @pytest.mark.gpu
-def test_dropin_cases_on_device():
+@pytest.mark.parametrize("virtual_devices", [0, 4])
+def test_dropin_cases_on_device(virtual_devices):
+    """all cases on the visible device(s); then once more with 4 logical devices dealt over the physical ones
+    (GPE_VIRTUAL_DEVICES): MultiGP members, restart clones and explicit copies land on devices 0..3 through
+    gpe_clone_to — the multi-GPU placement of the drop-in, exercised on a one-GPU box"""
+    import os
+
     exe = _build()
-    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    if virtual_devices:
+        env["GPE_VIRTUAL_DEVICES"] = str(virtual_devices)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 failed cases" in r.stdout
+    if virtual_devices:
+        assert f"{virtual_devices} visible device(s)" in r.stdout
+
+
+@pytest.mark.gpu
+def test_dropin_with_limbos_own_tree_behind_it():
+    """INTEGRATION.md's include-path switch with /root/reference/src behind the drop-in: limbo's opt::GridSearch /
+    RandomPoint / tools over the device model in a boptimizer.hpp-shaped loop (tests/cpp/test_mixed_tree.cpp).
+    The binary is built where the reference sources are and travels with the snapshot."""
+    _build()
+    exe = CPP / "test_mixed_tree"
+    if not exe.exists():
+        pytest.skip("test_mixed_tree was not built (no /root/reference at build time)")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,310 @@
+"""GPU parity at the sizes and regimes BASELINE.json's configs name (run with -m gpu on an MI355X), through the C-ABI:
+
+* C3 at full size (N=16384, D=12, Matern-5/2): mu / sigma^2 against LAPACK on 256 query points, 1e-8.
+* C4 as written: 64 GPs of N=2048 through gpe_batch_compute, sampled members against the oracle.
+* C5: the add_sample loop of src/benchmarks/limbo/bench.cpp:66-84 at its noise of 1e-10 and at 0.01, against the
+  oracle AND against the reference itself (oracle/_ref), tolerances stated per quantity.
+* the engine against the reference itself (limbo::model::GP compiled from /root/reference/src, oracle/_ref).
+* eight host threads driving eight handles (factorisations, point queries, alpha refreshes): bitwise equal to the
+  serial run; the block-by-block re-run of a one-launch sweep (forced) gives the oracle's numbers.
+"""
+import os
+import subprocess
+import sys
+import threading
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from limbo_amd import _capi, synth
+from oracle import binding as OB
+from oracle import np_oracle as O
+from tests import parity_checks as PC
+from tests.util import new_gp, relerr, relerr_norm
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_gpu_c3_full_size_vs_lapack(engine_lib):
+    """BASELINE configs[2]: N=16384, D=12, Matern-5/2.  K built on the host (matern_five_halves.hpp:104-113 +
+    kernel.hpp:83), LAPACK dpotrf / dtrtrs on all host cores, 256 of the query points: max rel. error of mu and of
+    sigma^2 (incl. + noise, gp.hpp:166) <= 1e-8; log-lik <= 1e-10."""
+    import scipy.linalg as sla
+    from scipy.spatial.distance import cdist
+
+    X, Y = synth.make_problem("c3")
+    N, D = X.shape
+    assert (N, D) == (16384, 12)
+    om, mean = synth.obs_mean_data(Y)
+    th, noise = np.zeros(2), 0.01
+    h = new_gp(engine_lib, O.MATERN52, X, om, th, noise)
+    assert h.compute() == 0
+    ll = h.log_lik()
+    rng = np.random.default_rng(33)
+    Xq = rng.uniform(0, 1, size=(256, D))
+    kta, var = h.query_batch(Xq)
+    mu, s2 = synth.finish_query(kta, var, mean, noise)
+
+    def matern52(A, B):
+        d = cdist(A, B)
+        t1 = np.sqrt(5.0) * d
+        return (1.0 + t1 + 5.0 * d * d / 3.0) * np.exp(-t1)
+
+    K = matern52(X, X)
+    K[np.diag_indices(N)] += noise + 1e-8
+    L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    del K
+    z = sla.solve_triangular(L, om, lower=True, check_finite=False)
+    alpha = sla.solve_triangular(L, z, lower=True, trans="T", check_finite=False)
+    ll_ref = O.log_lik(L, om, alpha)
+    assert abs(ll - ll_ref) <= PC.TOL_LL * abs(ll_ref), (ll, ll_ref)
+    Ks = matern52(X, Xq)
+    Z = sla.solve_triangular(L, Ks, lower=True, check_finite=False)
+    mur, s2r = synth.finish_query(Ks.T @ alpha, 1.0 - np.sum(Z * Z, axis=0), mean, noise)
+    e_mu, e_s2 = relerr(mu, mur, floor=1e-3), relerr(s2, s2r)
+    print(f"C3 full size vs LAPACK: mu {e_mu:.2e}  sigma^2 {e_s2:.2e}  log-lik {abs(ll - ll_ref) / abs(ll_ref):.2e}")
+    assert e_mu < PC.TOL_MU and e_s2 < PC.TOL_VAR
+    # the one-launch sweep for a handful of points agrees with the blocked solve of the batch
+    k8, v8 = h.query_batch(Xq[:8])
+    m8, s8 = synth.finish_query(k8, v8, mean, noise)
+    assert relerr(m8, mur[:8], floor=1e-3) < PC.TOL_MU and relerr(s8, s2r[:8]) < PC.TOL_VAR
+    h.close()
+
+
+def test_gpu_c4_batch_64_vs_oracle(engine_lib, oracle_lib):
+    """BASELINE configs[3]: 64 independent GPs, N=2048, D=6 (same X, 64 observation vectors and perturbed
+    theta0: multi_gp.hpp:124-126 / parallel_repeater.hpp:88), all through ONE gpe_batch_compute; 4 sampled members
+    against the oracle (log-lik 1e-10, alpha 1e-8, mu / sigma^2 1e-8), all 64 bitwise equal to one-at-a-time."""
+    G, N = 64, 2048
+    X, Y0 = synth.make_problem("c4", N=N)
+    rng = np.random.default_rng(44)
+    hs, oms, ths = [], [], []
+    for g in range(G):
+        Y = Y0 * rng.uniform(0.5, 1.5) + 0.1 * np.sin(3.0 * X[:, g % 6 : g % 6 + 1] + g)
+        om, _ = synth.obs_mean_data(Y)
+        th = rng.uniform(-1e-2, 1e-2, size=7) + (0.2 if g % 2 else 0.0)
+        hs.append(new_gp(engine_lib, O.SE_ARD, X, om, th, 0.01))
+        oms.append(om)
+        ths.append(th)
+    st = _capi.batch_compute(hs)
+    assert st == [0] * G
+    ll = _capi.batch_log_lik(hs)
+    assert np.all(np.isfinite(ll))
+    Xq = rng.uniform(0, 1, size=(64, 6))
+    for g in (0, 17, 42, 63):
+        o = new_gp(oracle_lib, O.SE_ARD, X, oms[g], ths[g], 0.01)
+        assert o.compute() == 0
+        llo = o.log_lik()
+        assert abs(ll[g] - llo) <= PC.TOL_LL * abs(llo)
+        assert relerr_norm(hs[g].get_alpha(), o.get_alpha()) < 1e-8
+        kg, vg = hs[g].query_batch(Xq)
+        ko, vo = o.query_batch(Xq)
+        assert relerr(kg, ko, floor=1e-3) < PC.TOL_MU
+        assert relerr(vg + 0.01, vo + 0.01) < PC.TOL_VAR
+        o.close()
+    single = new_gp(engine_lib, O.SE_ARD, X, oms[0], ths[0], 0.01)
+    for g in range(G):  # one at a time on one handle: the same kernels in the same order => the same bits
+        single.set_data(X, oms[g])
+        single.set_kernel(O.SE_ARD, ths[g], 0.01)
+        assert single.compute() == 0
+        assert single.log_lik() == ll[g], g
+    single.close()
+    for h in hs:
+        h.close()
+
+
+@pytest.mark.parametrize("noise", [1e-10, 0.01])
+def test_gpu_c5_add_sample_loop(engine_lib, oracle_lib, noise):
+    """BASELINE configs[4] / src/benchmarks/limbo/bench.cpp:66-84: Hartmann6, 10 random samples then 190
+    add_sample() calls, at the benchmark's noise 1e-10 and at 0.01; the device state after every 10th sample and
+    at the end against the oracle, and at the end against the reference itself where oracle/_ref is present.
+
+    What can be held.  noise 0.01: L 1e-10 (of max|L|), alpha 1e-7, mu 1e-8, sigma^2 1e-8.  noise 1e-10:
+    cond(K) ~ sigma_f^2 n / (noise + 1e-8) ~ 2e10 at n = 200, so two correct fp64 implementations that sum in a
+    different order differ by ~cond * eps: L 1e-6, mu 1e-4 of the data scale, sigma^2 1e-6 absolute (the variance
+    itself is ~1e-6 there); alpha (cond^1 amplified, ~1e5 in size) is compared through K alpha = obs_mean."""
+    rng = np.random.default_rng(2026)
+    n0, n1, D = 10, 200, 6
+    X = rng.uniform(0, 1, size=(n1, D))
+    Y = synth.hartmann6(X)[:, None]
+    th = np.zeros(D + 1)
+    tight = noise > 1e-6
+    om0, _ = synth.obs_mean_data(Y[:n0])
+    g = new_gp(engine_lib, O.SE_ARD, X[:n0], om0, th, noise)
+    o = new_gp(oracle_lib, O.SE_ARD, X[:n0], om0, th, noise)
+    assert g.compute() == 0 and o.compute() == 0
+    Xq = rng.uniform(0, 1, size=(32, D))
+    worst = dict(L=0.0, mu=0.0, s2=0.0)
+    for n in range(n0, n1):
+        om, mean = synth.obs_mean_data(Y[: n + 1])
+        assert g.add_sample(X[n], om) == 0
+        assert o.add_sample(X[n], om) == 0
+        if (n + 1) % 10 == 0:
+            Lg, Lo = g.get_L(), o.get_L()
+            worst["L"] = max(worst["L"], float(np.max(np.abs(Lg - Lo)) / np.max(np.abs(Lo))))
+            kg, vg = g.query_batch(Xq)
+            ko, vo = o.query_batch(Xq)
+            mg, sg = synth.finish_query(kg, vg, mean, noise)
+            mo, so = synth.finish_query(ko, vo, mean, noise)
+            worst["mu"] = max(worst["mu"], float(np.max(np.abs(mg - mo)) / np.max(np.abs(Y))))
+            worst["s2"] = max(worst["s2"], float(np.max(np.abs(sg - so) / so)) if tight else float(np.max(np.abs(sg - so))))
+            for q in range(2):  # the per-point path of a BO loop's acquisition functor == the batch
+                k1, v1 = g.query_batch(Xq[q : q + 1])
+                m1, s1 = synth.finish_query(k1, v1, mean, noise)
+                assert abs(m1[0, 0] - mg[q, 0]) <= (1e-8 if tight else 1e-4) * np.max(np.abs(Y))
+    print(f"C5 noise {noise:g}: worst L {worst['L']:.2e}  mu {worst['mu']:.2e}  sigma^2 {worst['s2']:.2e}")
+    tolL, tolmu, tols2 = (1e-10, 1e-8, 1e-8) if tight else (1e-6, 1e-4, 1e-6)
+    assert worst["L"] <= tolL and worst["mu"] <= tolmu and worst["s2"] <= tols2, worst
+    om, mean = synth.obs_mean_data(Y)
+    a = g.get_alpha()
+    K = O.kernel_matrix(O.SE_ARD, X, th, noise)
+    assert np.linalg.norm(K @ a - om) <= (1e-9 if tight else 1e-4) * np.linalg.norm(om)
+    if tight:
+        assert relerr_norm(a, o.get_alpha()) < 1e-7
+    # incremental == full on the device (test_gp.cpp:568-635: matrixL isApprox 1e-5)
+    f = new_gp(engine_lib, O.SE_ARD, X, om, th, noise)
+    assert f.compute() == 0
+    assert np.max(np.abs(f.get_L() - g.get_L())) <= 1e-5 * np.max(np.abs(f.get_L()))
+    f.close()
+    if OB.ref_available():  # the reference's own add_sample loop
+        r = OB.RefGP(O.SE_ARD, D, 1, noise=noise)
+        r.set_h_params(th)
+        r.compute(X[:n0], Y[:n0])
+        for n in range(n0, n1):
+            r.add_sample(X[n], Y[n])
+        Lr = r.matrixL()
+        assert np.max(np.abs(g.get_L() - Lr)) <= tolL * np.max(np.abs(Lr))
+        mu_r, s2_r = r.query(Xq)
+        kg, vg = g.query_batch(Xq)
+        mg, sg = synth.finish_query(kg, vg, mean, noise)
+        assert np.max(np.abs(mg - mu_r)) <= tolmu * np.max(np.abs(Y))
+        assert (np.max(np.abs(sg - s2_r) / s2_r) if tight else np.max(np.abs(sg - s2_r))) <= tols2
+    g.close()
+    o.close()
+
+
+@pytest.mark.skipif(not OB.ref_available(), reason="no oracle/_ref/libref.so")
+@pytest.mark.parametrize("kind,N,D,P,mean_kind,on,k_lam", [
+    (O.SE_ARD, 300, 6, 1, OB.MEAN_DATA, False, 0), (O.SE_ARD, 1000, 6, 2, OB.MEAN_DATA, True, 0),
+    (O.MATERN52, 777, 12, 1, OB.MEAN_CONSTANT, False, 0), (O.SE_ARD, 257, 4, 1, OB.MEAN_NULL, True, 2),
+    (O.MATERN32, 129, 3, 2, OB.MEAN_DATA, False, 0), (O.EXP, 64, 2, 1, OB.MEAN_DATA, True, 0)])
+def test_gpu_vs_reference(engine_lib, kind, N, D, P, mean_kind, on, k_lam):
+    """The HIP engine against limbo::model::GP itself (unmodified headers from /root/reference/src compiled into
+    oracle/_ref/libref.so): log-lik 1e-10, L 1e-10, gradient 1e-6 (norm), mu / sigma^2 1e-8 — SURVEY §8(c)'s bars."""
+    rng = np.random.default_rng(100 * kind + N)
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = np.stack([np.sin(3 * X.sum(axis=1) + p) + 0.1 * rng.normal(size=N) for p in range(P)], axis=1)
+    nt = D + D * k_lam + 1 if kind == O.SE_ARD else 2
+    th = rng.uniform(-0.5, 0.5, size=nt)
+    noise, const = 0.01, 0.3
+    r = OB.RefGP(kind, D, P, mean=mean_kind, noise=noise, optimize_noise=on, k_lambda=k_lam, constant=const)
+    r.set_h_params(np.concatenate([th, [np.log(np.sqrt(noise))]]) if on else th)
+    r.compute(X, Y)
+    m = {OB.MEAN_DATA: Y.mean(axis=0), OB.MEAN_NULL: np.zeros(P), OB.MEAN_CONSTANT: np.full(P, const)}[mean_kind]
+    g = new_gp(engine_lib, kind, X, Y - m, th, noise)
+    assert g.compute() == 0
+    ll_r = r.log_lik()
+    assert abs(g.log_lik() - ll_r) <= PC.TOL_LL * abs(ll_r)
+    Lr = r.matrixL()
+    assert np.max(np.abs(g.get_L() - Lr)) <= 1e-10 * np.max(np.abs(Lr))
+    assert relerr_norm(g.get_alpha(), r.alpha()) < 1e-8
+    gr = r.kernel_grad_log_lik()
+    assert np.linalg.norm(g.log_lik_grad(on) - gr) <= PC.TOL_GRAD * np.linalg.norm(gr)
+    Xq = np.concatenate([rng.uniform(0, 1, size=(100, D)), X[:8]])
+    mu_r, s2_r = r.query(Xq)
+    kta, var = g.query_batch(Xq)
+    mu, s2 = synth.finish_query(kta, var, m, noise)
+    assert relerr(mu, mu_r, floor=1e-3) < PC.TOL_MU and relerr(s2, s2_r) < PC.TOL_VAR
+    k1, v1 = g.query_batch(Xq[:1])  # the per-point path
+    m1, s1 = synth.finish_query(k1, v1, m, noise)
+    assert relerr(m1, mu_r[:1], floor=1e-3) < PC.TOL_MU and relerr(s1, s2_r[:1]) < PC.TOL_VAR
+    if N <= 300:  # LOO-CV value and gradient (the reference's literal N^3-per-parameter products)
+        v_r = r.log_loo_cv()
+        assert abs(g.log_loo_cv() - v_r) <= 1e-9 * abs(v_r)
+        gl = r.kernel_grad_log_loo_cv()
+        assert np.linalg.norm(g.log_loo_cv_grad(on) - gl) <= PC.TOL_GRAD * max(np.linalg.norm(gl), 1.0)
+    for i in range(3):  # add_sample keeps up with the reference's incremental row
+        xn, yn = rng.uniform(0, 1, size=D), rng.normal(size=P)
+        r.add_sample(xn, yn)
+        X, Y = np.vstack([X, xn]), np.vstack([Y, yn])
+        m = {OB.MEAN_DATA: Y.mean(axis=0), OB.MEAN_NULL: np.zeros(P), OB.MEAN_CONSTANT: np.full(P, const)}[mean_kind]
+        assert g.add_sample(xn, Y - m) == 0
+    assert relerr_norm(g.get_alpha(), r.alpha()) < 1e-8
+    assert np.max(np.abs(g.get_L() - r.matrixL())) <= 1e-10 * np.max(np.abs(Lr))
+    g.close()
+
+
+def _thread_workload(h, X, om, th, Xq, out, idx, rounds):
+    res = []
+    for it in range(rounds):
+        h.set_kernel(O.SE_ARD, th + 0.01 * it, 0.01)
+        assert h.compute() == 0
+        res.append(h.log_lik())
+        for q in range(4):  # point queries: the one-launch forward sweep
+            k, v = h.query_batch(Xq[q : q + 1])
+            res.append(float(k[0, 0]))
+            res.append(float(v[0]))
+        h.update_alpha(om[::-1].copy())  # forward + backward one-launch sweeps
+        res.append(h.log_lik())
+        h.update_alpha(om)
+        k, v = h.query_batch(Xq)  # blocked matrix-core solve
+        res.append(float(np.sum(k)))
+        res.append(float(np.sum(v)))
+    out[idx] = res
+
+
+def test_gpu_sweeps_under_contention(engine_lib):
+    """Eight host threads, eight handles of different sizes (64 .. 4096 samples, i.e. 1 .. 64 workgroups per
+    sweep next to 147 KB-LDS GEMM workgroups of the other handles): factorisations, point queries and alpha
+    refreshes all in flight together.  Every number must be bitwise what the same handle produces alone, and no
+    sweep may have needed the block-by-block re-run."""
+    sizes = [4096, 64, 2048, 700, 4096, 1500, 130, 3000]
+    rng = np.random.default_rng(8)
+    probs = []
+    for i, N in enumerate(sizes):
+        X = rng.uniform(0, 1, size=(N, 6))
+        Y = synth.hartmann6(X)[:, None] + 0.05 * rng.normal(size=(N, 1))
+        om, _ = synth.obs_mean_data(Y)
+        probs.append((X, om, rng.uniform(-0.2, 0.2, size=7), rng.uniform(0, 1, size=(40, 6))))
+    rounds = 3
+    serial = [None] * len(sizes)
+    hs = []
+    for i, (X, om, th, Xq) in enumerate(probs):
+        h = _capi.Handle(engine_lib)
+        h.set_data(X, om)
+        hs.append(h)
+        _thread_workload(h, X, om, th, Xq, serial, i, rounds)
+    conc = [None] * len(sizes)
+    ths = [threading.Thread(target=_thread_workload, args=(hs[i], *probs[i], conc, i, rounds)) for i in range(len(sizes))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(len(sizes)):
+        assert conc[i] is not None, f"thread {i} died"
+        assert conc[i] == serial[i], (i, sizes[i])
+    assert sum(h.flow_retries() for h in hs) == 0
+    for h in hs:
+        h.close()
+
+
+def test_gpu_sweep_retry_path_gives_the_same_results():
+    """GPE_FLOW_FAULT=1 makes every first attempt of a one-launch sweep count as timed out, so compute, add_sample,
+    update_alpha, point queries, gradients and the LOO weights all take the block-by-block re-run; the results must
+    still be the oracle's (child process: the switch is read once)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from limbo_amd import _capi\n"
+            "from oracle import binding as OB\n"
+            "from tests.test_gpu_parity import _small_parity\n"
+            "_small_parity(_capi.load_engine(), OB.load_oracle(), N=520, seed=3)\n"
+            "import numpy as np\n"
+            "from limbo_amd import synth\n"
+            "X, Y = synth.make_problem('c2', N=300); om, _ = synth.obs_mean_data(Y)\n"
+            "h = _capi.Handle(_capi.load_engine()); h.set_data(X, om); h.set_kernel(0, np.zeros(7), 0.01)\n"
+            "assert h.compute() == 0 and h.flow_retries() >= 1, h.flow_retries()\n"
+            "print('child ok', h.flow_retries())\n") % str(ROOT)
+    env = dict(os.environ, GPE_FLOW_FAULT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

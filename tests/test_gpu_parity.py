@@ -495,6 +495,7 @@ def test_gpu_process_wide_switches():
     import sys
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from limbo_amd import _capi\n"
+            "from oracle import binding as OB\n"
             "from tests.test_gpu_parity import _small_parity\n"
             "_small_parity(_capi.load_engine(), OB.load_oracle(), N=520, seed=7)\n"
             "print('child ok')\n") % str(ROOT)
