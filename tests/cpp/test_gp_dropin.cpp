@@ -898,10 +898,10 @@ CASE(test_multi_device_placement)
     }
     // MultiGP: member i on device i mod ndev, results as a single-device GP per output
     using Multi_t = model::MultiGP<Params, model::GP, kernel::SquaredExpARD<Params>, mean::NullFunction<Params>>;
-    std::vector<VectorXd> Y5;
-    make_problem(150, 3, 5, X, Y5);
+    std::vector<VectorXd> X5, Y5;
+    make_problem(150, 3, 5, X5, Y5);
     Multi_t mgp;
-    mgp.compute(X, Y5);
+    mgp.compute(X5, Y5);
     for (int p = 0; p < 5; ++p)
         CHECK(mgp.gp_models()[p].device() == p % ndev);
     VectorXd mu, sig;
@@ -911,7 +911,7 @@ CASE(test_multi_device_placement)
         std::vector<VectorXd> yp;
         for (auto& y : Y5)
             yp.push_back(make_v1(y(p)));
-        single.compute(X, yp);
+        single.compute(X5, yp);
         CHECK(single.device() == 0);
         VectorXd m;
         double s2;
