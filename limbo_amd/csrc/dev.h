@@ -30,6 +30,27 @@ static __device__ __forceinline__ d4_t mfma_f64(double a, double b, d4_t c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// the kernel functors' value from z = sum_d ((x1_d - x2_d) / ell_d)^2 (kbuild.hip, small.hip)
+static __device__ __forceinline__ double kfun(int kind, double z, double sf2)
+{
+    // z = sum_d ((x1_d - x2_d) / ell_d)^2   (isotropic kernels: ell_d = l for every d)
+    switch (kind) {
+    case 0: // SquaredExpARD::kernel, squared_exp_ard.hpp:148-150
+    case 3: // Exp::kernel, exp.hpp:97-102
+        return sf2 * exp(-0.5 * z);
+    case 1: { // MaternFiveHalves::kernel, matern_five_halves.hpp:104-113
+        double r = sqrt(z);
+        double term1 = 2.23606797749978969641 * r; // sqrt(5) d / l
+        double term2 = (5.0 / 3.0) * z;            // 5 d^2 / (3 l^2)
+        return sf2 * (1.0 + term1 + term2) * exp(-term1);
+    }
+    default: { // MaternThreeHalves::kernel, matern_three_halves.hpp:101-107
+        double term = 1.73205080756887729353 * sqrt(z);
+        return sf2 * (1.0 + term) * exp(-term);
+    }
+    }
+}
+
 // ---- workgroup -> unknown block of a one-launch data-flow sweep (solve.hip, solve_mp.hip) ------------------
 // Two requirements meet here.  (1) Progress without assuming that every workgroup is resident: a workgroup may
 // only ever wait for workgroups with a LOWER blockIdx.x — the dispatcher hands workgroups out in that order, so
@@ -181,6 +202,42 @@ void launch_sym_colscale(hipStream_t s, const double* Kl, int64_t ldk, int64_t N
                          int64_t lds_);
 void launch_scale_vec(hipStream_t s, double* g, int n, double f);
 int64_t grad_partial_size(int64_t N, int T);
+
+// ---- one-launch small-N path (small.hip): add_sample and point queries below ~256 samples ------------
+struct SmallAddArgs {
+    double* A;          // factor (and, on exit, its new row n)
+    int64_t ld;
+    double* Xinv;
+    double* Xt;         // SoA samples, column n is written
+    int64_t ldx;
+    double* Om;         // device obs_mean (ld), rewritten
+    double* Al;         // device alpha (ld), rewritten
+    const double* om_host; // pinned: (n + 1) x P, column-major, ld = n + 1
+    double* out;        // pinned: [0] sum log L_ii, [1] sum obs_mean . alpha
+    int* info;          // pinned: first non-positive pivot (1-based), written if zero
+    unsigned long long* seq; // pinned: sequence word, written last
+    unsigned long long seq_val;
+    int n;              // samples before this call = index of the new one
+};
+struct SmallQueryArgs {
+    const double* L;
+    int64_t ld;
+    const double* Xinv;
+    const double* Xt;
+    int64_t ldx;
+    const double* Al;
+    int P, n, M, D;
+    const double* xq_host;  // pinned: M x D row-major query points
+    double* kta_host;       // pinned: M x P, column-major (ld = M), may be null
+    double* var_host;       // pinned: M, may be null
+    unsigned long long* seq; // pinned: M sequence words (one per point)
+    unsigned long long seq_val;
+    int want_kta, want_var;
+};
+
+int small_max_n();
+void launch_small_add(hipStream_t s, const SmallAddArgs& g, int P, const KParams& kp, const LamParams& lp, const double* x);
+void launch_small_query(hipStream_t s, const SmallQueryArgs& g, const KParams& kp, const LamParams& lp);
 
 // ---- micro-benchmarks (microbench.hip) ---------------------------------------------
 double run_mfma_f64_peak(hipStream_t s);

@@ -28,6 +28,8 @@
 #include <vector>
 
 #define NB 64
+// pinned staging of the small path: results in [0, 256), inputs (obs_mean: (n + 1) x P <= 257 x 3; query points: 8 x 64) from 256 on
+#define SMALL_STAGE_DOUBLES (256 + 1024)
 
 namespace {
 
@@ -73,6 +75,12 @@ struct gpe_ctx {
     double* hScal = nullptr; // pinned
     bool have_L = false, inv_ok = false, host_K = false, ll_ok = false;
     int nbo = 256; // outer panel width of the two-level blocked algorithms
+    // one-launch small-N path (small.hip): pinned staging the kernels read / write directly, the word the host spins on
+    double* hSmall = nullptr;            // [0..2): log-lik terms | [16 .. 16+8*GPE_MAX_P+8): kta, var | [256..): obs_mean / query points in
+    unsigned long long* hSmallSeq = nullptr; // 8 sequence words (one per query point; word 0 for add_sample)
+    unsigned long long small_seq = 0;
+    bool small_path = true;              // GPE_SMALL=0 disables
+    int64_t small_calls = 0;             // calls served by the small path (instrumentation / tests)
     int64_t flow_retries = 0; // sweeps re-run block by block after a hand-off timeout (never expected; see flow_failed)
     bool flow_solve = true; // one data-flow launch for the backward sweep (GPE_FLOW_SOLVE=0: per-block launches)
     bool fuse_panel = true; // k_panel_step instead of the three-launch panel step (GPE_FUSE_PANEL=0 disables)
@@ -763,6 +771,41 @@ int compute_finish(gpe_ctx* c)
     });
 }
 
+// The small kernels write their results and then a sequence word straight into pinned host memory: spin on the
+// word(s) instead of synchronising the stream (an event round trip costs more than the kernel).  Falls back to a
+// stream synchronisation after 50 ms (a fault, or a debugger).
+static int small_wait(gpe_ctx* c, int nwords, unsigned long long want)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        bool all = true;
+        for (int i = 0; i < nwords; ++i)
+            all = all && (__atomic_load_n(c->hSmallSeq + i, __ATOMIC_ACQUIRE) == want);
+        if (all)
+            return GPE_OK;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipGetLastError());
+            for (int i = 0; i < nwords; ++i)
+                if (__atomic_load_n(c->hSmallSeq + i, __ATOMIC_ACQUIRE) != want) {
+                    c->err = "small path: the kernel finished without publishing its results";
+                    return GPE_ERR_HIP;
+                }
+            return GPE_OK;
+        }
+    }
+}
+
+static LamParams lam_params(const gpe_ctx* c)
+{
+    LamParams lp;
+    lp.D = c->D;
+    lp.k = c->kp.k_lam;
+    for (int q = 0; q < lp.D * lp.k && q < GPE_MAX_THETA; ++q)
+        lp.A[q] = c->theta[c->D + q];
+    return lp;
+}
+
 int ensure_inv(gpe_ctx* c)
 {
     if (c->inv_ok)
@@ -1026,11 +1069,18 @@ int gpe_create(int device_id, gpe_handle* out)
         || create_bulk_stream(&c->stream2) != hipSuccess
         || hipMalloc(&c->dScal, 8192) != hipSuccess
         || hipMalloc(&c->dHead, sizeof(double) * 65 * NB * NB) != hipSuccess
-        || hipHostMalloc(&c->hInfo, 64) != hipSuccess || hipHostMalloc(&c->hScal, 8192) != hipSuccess) {
+        // coherent (fine-grained) pinned memory: the small path's host side reads these while the stream is still busy
+        || hipHostMalloc(&c->hInfo, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        || hipHostMalloc(&c->hScal, 8192) != hipSuccess
+        || hipHostMalloc(&c->hSmall, sizeof(double) * SMALL_STAGE_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        || hipHostMalloc(&c->hSmallSeq, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         delete c;
         return GPE_ERR_HIP;
     }
     memset(c->hInfo, 0, 64);
+    memset(c->hSmallSeq, 0, 64);
+    if (const char* f = getenv("GPE_SMALL"))
+        c->small_path = atoi(f) != 0;
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
     if (const char* f = getenv("GPE_BULK_WGS"))
         c->bulk_wgs = atoi(f);
@@ -1068,6 +1118,8 @@ int gpe_destroy(gpe_handle c)
     hipFree(c->dHead);
     hipHostFree(c->hInfo);
     hipHostFree(c->hScal);
+    hipHostFree(c->hSmall);
+    hipHostFree(c->hSmallSeq);
     for (auto e : c->la_events)
         hipEventDestroy(e);
     hipStreamSynchronize(c->stream2);
@@ -1252,6 +1304,40 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     const int64_t n = c->N; // index of the new sample
     const int64_t ld = c->ld;
     digest_kernel(c);
+    if (c->small_path && n >= 1 && n <= small_max_n() && P <= 3 && c->have_L) {
+        // one launch, no copies (small.hip): x travels as a kernel argument, obs_mean is read from pinned memory
+        double* om_stage = c->hSmall + 256;
+        memcpy(om_stage, obs_mean, sizeof(double) * (size_t)((n + 1) * P));
+        c->hInfo[0] = c->hInfo[1] = 0;
+        SmallAddArgs a{};
+        a.A = c->dA;
+        a.ld = ld;
+        a.Xinv = c->dXinv;
+        a.Xt = c->dXt;
+        a.ldx = ld;
+        a.Om = c->dOm;
+        a.Al = c->dAl;
+        a.om_host = om_stage;
+        a.out = c->hSmall;
+        a.info = c->hInfo;
+        a.seq = c->hSmallSeq;
+        a.seq_val = ++c->small_seq;
+        a.n = (int)n;
+        launch_small_add(s, a, P, c->kp, lam_params(c), x);
+        c->N = n + 1;
+        c->have_L = true;
+        c->inv_ok = false; // gp.hpp:602
+        c->al_prefilled = false;
+        c->ll_partials = 0;
+        ++c->small_calls;
+        int rc = small_wait(c, 1, a.seq_val);
+        if (rc)
+            return rc;
+        c->hScal[0] = c->hSmall[0]; // sum log L_ii
+        c->hScal[1] = c->hSmall[1]; // sum obs_mean . alpha
+        c->ll_ok = true;
+        return *c->hInfo;
+    }
     // new sample -> column n of Xt (staged through dY)
     HIPCHK(c, hipMemcpyAsync(c->dY, x, sizeof(double) * D, hipMemcpyHostToDevice, s));
     launch_transpose_x(s, c->dY, 1, D, c->dXt, ld, n);
@@ -1431,6 +1517,39 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
     digest_kernel(c);
     const int64_t N = c->N, ld = c->ld;
     const int D = c->D, P = c->P;
+    if (c->small_path && Xq && N <= small_max_n() && M <= 8 && (int64_t)M * D <= 1024 && P <= GPE_MAX_P) {
+        // the per-point query of an acquisition functor on a small GP: one launch (one workgroup per point), the
+        // points read from and the results written to pinned host memory (small.hip)
+        memcpy(c->hSmall + 256, Xq, sizeof(double) * (size_t)(M * D));
+        SmallQueryArgs q{};
+        q.L = c->dA;
+        q.ld = ld;
+        q.Xinv = c->dXinv;
+        q.Xt = c->dXt;
+        q.ldx = ld;
+        q.Al = c->dAl;
+        q.P = P;
+        q.n = (int)N;
+        q.M = (int)M;
+        q.D = D;
+        q.xq_host = c->hSmall + 256;
+        q.kta_host = c->hSmall + 16;
+        q.var_host = c->hSmall + 16 + 8 * GPE_MAX_P;
+        q.seq = c->hSmallSeq;
+        q.seq_val = ++c->small_seq;
+        q.want_kta = kta ? 1 : 0;
+        q.want_var = var ? 1 : 0;
+        launch_small_query(s, q, c->kp, lam_params(c));
+        ++c->small_calls;
+        int rc = small_wait(c, (int)M, q.seq_val);
+        if (rc)
+            return rc;
+        if (kta)
+            memcpy(kta, q.kta_host, sizeof(double) * (size_t)(M * P));
+        if (var)
+            memcpy(var, q.var_host, sizeof(double) * (size_t)M);
+        return GPE_OK;
+    }
     // chunk so that the N x mc cross matrix stays under ~2 GiB
     int64_t mc_max = std::max<int64_t>(64, ((int64_t)1 << 28) / std::max<int64_t>(ld, 1));
     mc_max = round_up(std::min<int64_t>(mc_max, round_up(M, 64)), 64);
@@ -1759,6 +1878,14 @@ int gpe_flow_retries(gpe_handle c, int64_t* n)
     return GPE_OK;
 }
 
+int gpe_small_calls(gpe_handle c, int64_t* n)
+{
+    if (!c || !n)
+        return GPE_ERR_ARG;
+    *n = c->small_calls;
+    return GPE_OK;
+}
+
 int gpe_clone(gpe_handle src, gpe_handle* out) { return src ? gpe_clone_to(src, src->ldevice, out) : GPE_ERR_ARG; }
 
 int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out)
@@ -1788,6 +1915,7 @@ int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out)
     c->nbo = src->nbo;
     c->fuse_panel = src->fuse_panel;
     c->flow_solve = src->flow_solve;
+    c->small_path = src->small_path;
     c->lookahead = src->lookahead;
     c->bulk_wgs = src->bulk_wgs;
     c->host_K = src->host_K;

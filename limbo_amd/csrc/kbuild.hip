@@ -13,26 +13,6 @@
 
 #define TILE 64
 
-__device__ __forceinline__ double kfun(int kind, double z, double sf2)
-{
-    // z = sum_d ((x1_d - x2_d) / ell_d)^2   (isotropic kernels: ell_d = l for every d)
-    switch (kind) {
-    case 0: // SquaredExpARD::kernel, squared_exp_ard.hpp:148-150
-    case 3: // Exp::kernel, exp.hpp:97-102
-        return sf2 * exp(-0.5 * z);
-    case 1: { // MaternFiveHalves::kernel, matern_five_halves.hpp:104-113
-        double r = sqrt(z);
-        double term1 = 2.23606797749978969641 * r; // sqrt(5) d / l
-        double term2 = (5.0 / 3.0) * z;            // 5 d^2 / (3 l^2)
-        return sf2 * (1.0 + term1 + term2) * exp(-term1);
-    }
-    default: { // MaternThreeHalves::kernel, matern_three_halves.hpp:101-107
-        double term = 1.73205080756887729353 * sqrt(z);
-        return sf2 * (1.0 + term) * exp(-term);
-    }
-    }
-}
-
 __global__ void k_transpose_x(const double* __restrict__ Xrm, int64_t n, int D, double* __restrict__ Xt, int64_t ld,
                               int64_t col0)
 {

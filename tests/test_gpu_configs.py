@@ -308,3 +308,69 @@ def test_gpu_sweep_retry_path_gives_the_same_results():
     env = dict(os.environ, GPE_FLOW_FAULT="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("kind,D,P,lam", [(O.SE_ARD, 6, 1, 0), (O.MATERN52, 3, 2, 0), (O.SE_ARD, 4, 3, 1), (O.EXP, 2, 1, 0)])
+def test_gpu_small_path_vs_oracle(engine_lib, oracle_lib, kind, D, P, lam):
+    """The one-launch small-N path (csrc/small.hip: add_sample and point queries below 256 samples) across every
+    block boundary (63/64/65, 127.., 255/256/257: the last call it serves and the first the general path takes
+    back), P = 1..3, a Lambda column: L, alpha, log-lik, mu and sigma^2 against the oracle after every step."""
+    rng = np.random.default_rng(900 + 10 * kind + P)
+    n0, n1 = 50, 262
+    X = rng.uniform(0, 1, size=(n1, D))
+    Y = np.stack([np.sin(3 * X.sum(axis=1) + p) + 0.05 * rng.normal(size=n1) for p in range(P)], axis=1)
+    nt = D + D * lam + 1 if kind == O.SE_ARD else 2
+    th = rng.uniform(-0.4, 0.4, size=nt)
+    noise = 0.01
+    om0, _ = synth.obs_mean_data(Y[:n0])
+    g = new_gp(engine_lib, kind, X[:n0], om0, th, noise)
+    o = new_gp(oracle_lib, kind, X[:n0], om0, th, noise)
+    assert g.compute() == 0 and o.compute() == 0
+    Xq = rng.uniform(0, 1, size=(8, D))
+    watch = {62, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 254, 255, 256, 257, 258, 261}
+    for n in range(n0, n1):
+        om, mean = synth.obs_mean_data(Y[: n + 1])
+        assert g.add_sample(X[n], om) == 0
+        assert o.add_sample(X[n], om) == 0
+        if n in watch:
+            llg, llo = g.log_lik(), o.log_lik()
+            assert abs(llg - llo) <= PC.TOL_LL * abs(llo), n
+            Lo = o.get_L()
+            assert np.max(np.abs(g.get_L() - Lo)) <= 1e-10 * np.max(np.abs(Lo)), n
+            assert relerr_norm(g.get_alpha(), o.get_alpha()) < 1e-8, n
+            for M in (1, 3, 8):
+                kg, vg = g.query_batch(Xq[:M])
+                ko, vo = o.query_batch(Xq[:M])
+                mg, sg = synth.finish_query(kg, vg, mean, noise)
+                mo, so = synth.finish_query(ko, vo, mean, noise)
+                assert relerr(mg, mo, floor=1e-3) < PC.TOL_MU and relerr(sg, so) < PC.TOL_VAR, (n, M)
+            k1, _ = g.query_batch(Xq[:2], want_var=False)  # mu only / sigma^2 only
+            _, v1 = g.query_batch(Xq[:2], want_mu=False)
+            kg, vg = g.query_batch(Xq[:2])
+            assert np.array_equal(k1, kg) and np.array_equal(v1, vg)
+    if os.environ.get("GPE_SMALL", "1") != "0":
+        assert g.small_calls() > 0  # the path under test did serve these calls
+    else:
+        assert g.small_calls() == 0
+    # the gradient and K^-1 work from the state the small path left (block inverses included)
+    go, gg = o.log_lik_grad(False), g.log_lik_grad(False)
+    assert np.linalg.norm(gg - go) <= PC.TOL_GRAD * np.linalg.norm(go)
+    g.close()
+    o.close()
+
+
+def test_gpu_general_path_at_small_n():
+    """GPE_SMALL=0: the same BO-sized loops through the general (multi-launch) path, in a child process"""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from limbo_amd import _capi\n"
+            "from oracle import binding as OB, np_oracle as O\n"
+            "from tests import test_gpu_configs as T\n"
+            "eng, orc = _capi.load_engine(), OB.load_oracle()\n"
+            "T.test_gpu_small_path_vs_oracle(eng, orc, O.SE_ARD, 6, 1, 0)\n"
+            "T.test_gpu_small_path_vs_oracle(eng, orc, O.SE_ARD, 4, 3, 1)\n"
+            "T.test_gpu_c5_add_sample_loop(eng, orc, 0.01)\n"
+            "print('child ok')\n") % str(ROOT)
+    env = dict(os.environ, GPE_SMALL="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
