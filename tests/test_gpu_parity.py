@@ -414,8 +414,9 @@ def test_gpu_update_alpha_vs_oracle(engine_lib, oracle_lib, N, P):
 
 @pytest.mark.parametrize("N", [1, 63, 65, 700, 2049])
 def test_gpu_point_queries_vs_batch_and_oracle(engine_lib, oracle_lib, N):
-    """mu / sigma^2 for 1..8 points (one-launch forward sweep, k_trsv_fwd_flow) against the oracle and against
-    the same points inside a batch of 100 (blocked matrix solve): mu identical, sigma^2 to rounding."""
+    """mu / sigma^2 for 1..8 points (N <= 256: the one-workgroup small path, csrc/small.hip; above: one-launch forward
+    sweep, k_trsv_fwd_flow) against the oracle and against the same points inside a batch of 100 (blocked matrix
+    solve): mu identical above 256 samples and equal to rounding below, sigma^2 to rounding."""
     rng = np.random.default_rng(N)
     D, P = 4, 2
     X = rng.uniform(0, 1, size=(N, D))
@@ -432,7 +433,9 @@ def test_gpu_point_queries_vs_batch_and_oracle(engine_lib, oracle_lib, N):
     _, s2o = O.finish_query(ko, vo, mean, 0.01)
     for m in (1, 2, 5, 8):
         k1, v1 = g.query_batch(Xq[:m])
-        assert np.array_equal(k1, kb[:m])
+        if N > 256:  # same k*^T alpha kernel inside and outside a batch; below, the one-launch small path sums
+            assert np.array_equal(k1, kb[:m])  # k*^T alpha in another (fixed) order: equal to rounding
+        assert np.max(np.abs(k1 - kb[:m])) <= 1e-12 * max(np.max(np.abs(kb[:m])), 1.0)
         _, s2 = O.finish_query(k1, v1, mean, 0.01)
         _, s2b = O.finish_query(kb[:m], vb[:m], mean, 0.01)
         assert relerr(s2, s2b) < 1e-11
