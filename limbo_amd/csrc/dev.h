@@ -30,6 +30,45 @@ static __device__ __forceinline__ d4_t mfma_f64(double a, double b, d4_t c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// ---- batched launches: G independent GPs of the same shape stepped by ONE launch per stage ------------------------
+// (multi_gp.hpp:124-126 / parallel_repeater.hpp:86-105 as gpe_batch_compute runs them: config 4, 64 x N = 2048.)
+// Every GP has its own buffers, allocated separately.  The launch sequence is built once, from GP 0's pointers, with
+// gridDim.z = G; workgroup z translates each pointer argument from GP 0's buffer into GP z's buffer of the same class
+// (wave-uniform: a handful of scalar compares per pointer).  The per-GP kernel parameters travel in the same table.
+#define GPE_BT_CLS 10
+#define GPE_BT_MAXG 64
+struct BatchTab {
+    int G;
+    int ncls;
+    const char* base0[GPE_BT_CLS];              // GP 0's buffers ...
+    unsigned long long size[GPE_BT_CLS];         // ... and their sizes in bytes
+    const char* base[GPE_BT_CLS][GPE_BT_MAXG];   // the same buffer of every GP
+    KParams kp[GPE_BT_MAXG];
+};
+template <class T>
+static __device__ __forceinline__ T* bt_rebase(const BatchTab* __restrict__ bt, int g, T* p)
+{
+    const char* q = (const char*)p;
+#pragma unroll
+    for (int c = 0; c < GPE_BT_CLS; ++c) {
+        const unsigned long long off = (unsigned long long)(q - bt->base0[c]);
+        if (off < bt->size[c])
+            return (T*)(bt->base[c][g] + off);
+    }
+    return p;
+}
+#define BT_REBASE(bt, p)                          \
+    do {                                          \
+        if (bt)                                   \
+            p = bt_rebase(bt, (int)blockIdx.z, p); \
+    } while (0)
+// what the launch wrappers of this thread add to every launch (set by gpe_batch_compute around the enqueue)
+struct BatchLaunch {
+    const BatchTab* bt = nullptr; // device copy
+    int G = 1;
+};
+extern thread_local BatchLaunch g_batch;
+
 // the kernel functors' value from z = sum_d ((x1_d - x2_d) / ell_d)^2 (kbuild.hip, small.hip)
 static __device__ __forceinline__ double kfun(int kind, double z, double sf2)
 {
@@ -138,7 +177,17 @@ struct GemmArgs {
     int grid_limit; // > 0: at most this many physical workgroups (they loop) — leaves CUs to another stream
     int tile;      // 0: pick by problem size; 128 / 64 / 32: force the 128x128 / 64x64 / 32x64 tile
     void* stop_event; // host side only: hipEvent_t completed by this launch (null: none)
+    const BatchTab* bt; // batched launch (gridDim.z GPs): set by the launch wrapper, null otherwise
 };
+static __device__ __forceinline__ void gemm_rebase(GemmArgs& g)
+{
+    if (g.bt) {
+        const int z = (int)blockIdx.z;
+        g.C = bt_rebase(g.bt, z, g.C);
+        g.A = bt_rebase(g.bt, z, g.A);
+        g.B = bt_rebase(g.bt, z, g.B);
+    }
+}
 void launch_gemm_sub(hipStream_t s, const GemmArgs& g);
 // the next-panel update g (as for launch_gemm_sub: C = A[pe:, pe:pe2], k = pe - p0, tri) and, in the same launch, the
 // update + factorisation + half-inversion of the next diagonal block A[pe:pe+64, pe:pe+64] (-> Xt_next)

@@ -27,6 +27,8 @@
 #include <string>
 #include <vector>
 
+thread_local BatchLaunch g_batch; // dev.h: what this thread's launch wrappers add to every launch
+
 #define NB 64
 // pinned staging of the small path: results in [0, 256), inputs (obs_mean: (n + 1) x P <= 257 x 3; query points: 8 x 64) from 256 on
 #define SMALL_STAGE_DOUBLES (256 + 1024)
@@ -1958,13 +1960,122 @@ int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out)
     return GPE_OK;
 }
 
+// Can these two GPs be stepped by the same launches (dev.h, BatchTab)?  Same shape, same schedule, device code for K.
+static bool batch_compatible(const gpe_ctx* a, const gpe_ctx* b)
+{
+    return a->device == b->device && a->N == b->N && a->D == b->D && a->P == b->P && a->cap == b->cap && a->ld == b->ld
+        && a->nbo == b->nbo && a->fuse_panel == b->fuse_panel && a->flow_solve == b->flow_solve && !a->host_K && !b->host_K
+        && a->kind != GPE_KERNEL_HOST_K && b->kind != GPE_KERNEL_HOST_K && a->n_theta == b->n_theta
+        && ((a->kind == GPE_KERNEL_SE_ARD) == (b->kind == GPE_KERNEL_SE_ARD)) && a->dA && b->dA && !a->prof && !b->prof;
+}
+
+// gpe_compute on Gc <= GPE_BT_MAXG compatible handles as ONE launch sequence (gridDim.z = Gc): the chain of small
+// latency-bound kernels of one factorisation does not fill the chip, Gc of them in lock-step do.  The handles' mutexes
+// are held by the caller.
+static int batch_compute_fused(gpe_ctx** cs, int Gc, int* rc)
+{
+    gpe_ctx* c0 = cs[0];
+    DevGuard g(c0);
+    static thread_local BatchTab* dtab[16] = {nullptr}; // one device table per device, kept
+    if (c0->device >= 16)
+        return GPE_ERR_UNSUPPORTED;
+    if (!dtab[c0->device])
+        HIPCHK(c0, hipMalloc(&dtab[c0->device], sizeof(BatchTab)));
+    std::vector<BatchTab> tabv(1);
+    BatchTab& t = tabv[0];
+    memset(&t, 0, sizeof(t));
+    t.G = Gc;
+    t.ncls = 8;
+    for (int q = 0; q < Gc; ++q) {
+        gpe_ctx* c = cs[q];
+        digest_kernel(c);
+        c->hInfo[0] = c->hInfo[1] = 0;
+        const char* b[GPE_BT_CLS] = {(const char*)c->dA, (const char*)c->dXt, (const char*)c->dOm, (const char*)c->dAl,
+                                     (const char*)c->dXinv, (const char*)c->dHead, (const char*)c->hInfo, (const char*)c->hScal,
+                                     nullptr, nullptr};
+        for (int k = 0; k < GPE_BT_CLS; ++k)
+            t.base[k][q] = b[k];
+        t.kp[q] = c->kp;
+        hipStreamSynchronize(c->stream); // nothing of this handle may still be in flight on its own stream
+    }
+    const size_t dbl = sizeof(double);
+    const unsigned long long sz[GPE_BT_CLS] = {(unsigned long long)(dbl * c0->ld * c0->cap), (unsigned long long)(dbl * c0->ld * xt_rows(c0->D)),
+                                               (unsigned long long)(dbl * c0->ld * c0->P), (unsigned long long)(dbl * c0->ld * c0->P),
+                                               (unsigned long long)(dbl * (c0->cap / NB) * NB * NB), (unsigned long long)(dbl * 65 * NB * NB), 64, 8192,
+                                               0, 0};
+    for (int k = 0; k < GPE_BT_CLS; ++k) {
+        t.base0[k] = t.base[k][0];
+        t.size[k] = sz[k];
+    }
+    HIPCHK(c0, hipMemcpyAsync(dtab[c0->device], &t, sizeof(BatchTab), hipMemcpyHostToDevice, c0->stream));
+    HIPCHK(c0, hipStreamSynchronize(c0->stream)); // `t` is pageable: the copy must have left it before it goes out of scope
+    const bool la = c0->lookahead;
+    c0->lookahead = false; // the batch fills the chip: one stream, no look-ahead split
+    g_batch.bt = dtab[c0->device];
+    g_batch.G = Gc;
+    int e = compute_enqueue(c0);
+    g_batch = BatchLaunch{};
+    c0->lookahead = la;
+    if (e)
+        return e;
+    HIPCHK(c0, wait_stream(c0->stream));
+    HIPCHK(c0, hipGetLastError());
+    const int64_t nblk = (c0->N + NB - 1) / NB;
+    for (int q = 0; q < Gc; ++q) {
+        gpe_ctx* c = cs[q];
+        c->have_L = true;
+        c->inv_ok = false;
+        c->al_prefilled = false;
+        c->ll_partials = c0->flow_solve && nblk <= 256 ? (int)nblk : 0;
+        c->xinv_done = 0;
+        // the usual finish on the handle's own (idle) stream: sums the per-block partials; a sweep that gave up
+        // (never expected) is re-run block by block for that GP alone
+        rc[q] = compute_finish(c);
+    }
+    return GPE_OK;
+}
+
 int gpe_batch_compute(gpe_handle* hs, int G, int* status)
 {
     if (!hs || G < 0)
         return GPE_ERR_ARG;
+    std::vector<int> rc(G, 0);
+    static const bool fused_ok = !(getenv("GPE_BATCH") && atoi(getenv("GPE_BATCH")) == 0);
+    bool fused = fused_ok && G >= 2;
+    for (int g = 0; g < G && fused; ++g) {
+        gpe_ctx* c = hs[g];
+        fused = c && c->N > 0 && batch_compatible(hs[0], c) && lam_columns(c->kind, c->n_theta, c->D) == 0
+            && c->flow_solve && (c->N + NB - 1) / NB <= 256;
+        for (int q = 0; q < g && fused; ++q)
+            fused = hs[q] != c; // the same handle twice cannot be stepped in parallel
+    }
+    if (fused) {
+        for (int g = 0; g < G; ++g)
+            hs[g]->mu.lock();
+        int worst = GPE_OK;
+        for (int g0 = 0; g0 < G; g0 += GPE_BT_MAXG) {
+            const int Gc = std::min(GPE_BT_MAXG, G - g0);
+            int e = Gc >= 2 ? batch_compute_fused(hs + g0, Gc, rc.data() + g0) : GPE_OK;
+            if (Gc < 2) {
+                DevGuard dg(hs[g0]);
+                rc[g0] = compute_enqueue(hs[g0]);
+                if (rc[g0] == GPE_OK)
+                    rc[g0] = compute_finish(hs[g0]);
+            }
+            if (e < 0)
+                worst = e;
+        }
+        for (int g = 0; g < G; ++g) {
+            hs[g]->mu.unlock();
+            if (status)
+                status[g] = rc[g];
+            if (rc[g] < 0)
+                worst = rc[g];
+        }
+        return worst;
+    }
     // enqueue everything first (each GP on its own stream), then collect: kernels of different
     // GPs overlap on the device — the TBB par::loop of multi_gp.hpp:124-126, on one GPU.
-    std::vector<int> rc(G, 0);
     for (int g = 0; g < G; ++g) {
         gpe_ctx* c = hs[g];
         if (!c) {

@@ -133,6 +133,7 @@ struct Stager {
 template <int TM, int TN, int BKT, int NBUF, bool AK, bool BK>
 __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
 {
+    gemm_rebase(g);
     using SA = Stager<AK, TM, BKT>;
     using SB = Stager<BK, TN, BKT>;
     constexpr int RA = TM / 2 / 16; // 16-row slabs per wave
@@ -287,14 +288,16 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
 // (GemmArgs::stop_event): a separate hipEventRecord is a marker packet of its own on the stream and
 // costs ~6 us on a dependent chain (rocprofv3 timeline of the factorisation).
 template <typename K>
-static void launch_k(K kern, dim3 grid, dim3 block, hipStream_t s, const GemmArgs& g)
+static void launch_k(K kern, dim3 grid, dim3 block, hipStream_t s, const GemmArgs& g0)
 {
+    GemmArgs g = g0;
+    g.bt = g_batch.bt; // batched launch: gridDim.z GPs, pointers rebased per GP in the kernel (dev.h)
+    grid.z = (unsigned)g_batch.G;
     if (g.stop_event)
         hipExtLaunchKernelGGL(kern, grid, block, 0, s, nullptr, (hipEvent_t)g.stop_event, 0, g);
     else
         hipLaunchKernelGGL(kern, grid, block, 0, s, g);
 }
-
 template <int TM, int TN, int BKT, int NBUF>
 static void launch_tile(hipStream_t s, const GemmArgs& g0)
 {
@@ -337,6 +340,7 @@ static void launch_tile(hipStream_t s, const GemmArgs& g0)
 template <int TM, int TN, int WM, int WN, int BKT, int NST, int EPC = 0, int MINB = 1>
 __global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g)
 {
+    gemm_rebase(g);
     static_assert(TM == 128 && TN == 128, "one k-row of an operand tile = one 1 KiB glds instruction");
     constexpr int NWV = WM * WN;
     constexpr int SA = TM + 16, SB = TN + 16; // k-row strides (doubles), == 16 mod 32
@@ -511,6 +515,7 @@ template <int BKT, int NST, int MINB, int NWV>
 __global__ __launch_bounds__(64 * NWV, MINB) void k_gemm_glds64(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) double lds[NST * Glds64Shape<BKT>::STAGE];
+    gemm_rebase(g);
     gemm_glds64_body<BKT, NST, NWV>(g, lds, (int)blockIdx.x, (int)gridDim.x, false);
 }
 
@@ -547,7 +552,7 @@ static void launch_glds64(hipStream_t s, const GemmArgs& g0)
         const char* e = getenv("GPE_GLDS64_VARIANT");
         v64 = e ? atoi(e) : 0;
     }
-    if (g.total > 256 || g.grid_limit > 0 || v64 == 1)
+    if ((int64_t)g.total * g_batch.G > 256 || g.grid_limit > 0 || v64 == 1)
         launch_k(k_gemm_glds64<16, 4, 2, 4>, dim3((unsigned)tiles), dim3(256), s, g);
     else if (v64 == 2)
         launch_k(k_gemm_glds64<32, 3, 1, 4>, dim3((unsigned)tiles), dim3(256), s, g);
@@ -593,7 +598,7 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
         const char* e = getenv("GPE_GLDS_VARIANT"); // tuning: force 0 / 1
         variant = e ? atoi(e) : 2;
     }
-    const bool two_per_cu = variant == 2 ? (g.grid_limit <= 0 && g.total > 256) : variant == 1;
+    const bool two_per_cu = variant == 2 ? (g.grid_limit <= 0 && (int64_t)g.total * g_batch.G > 256) : variant == 1;
     if (two_per_cu)
         launch_k(k_gemm_glds<128, 128, 2, 4, 16, 2, 4, 2>, dim3((unsigned)tiles), dim3(512), s, g);
     else
@@ -643,11 +648,12 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         // measured at k = 256 (tools/kbench): one 128 x 128 glds workgroup per CU runs at the
         // LDS-fed MFMA rate (~48 us per tile); below ~200 live tiles too many CUs idle and the
         // 64 x 64 tile (4x the workgroups) wins; the 32 x 64 tile serves the tiny panel steps
-        if (glds_ok(g) && live_tiles(g, 128, 128) >= 200)
+        const int64_t GB = g_batch.G; // a batched launch runs GB problems of this shape at once
+        if (glds_ok(g) && GB * live_tiles(g, 128, 128) >= 200)
             tile = 128;
-        else if (glds_ok(g) && use_glds64 && live_tiles(g, 64, 64) >= 96)
+        else if (glds_ok(g) && use_glds64 && GB * live_tiles(g, 64, 64) >= 96)
             tile = 64; // deep-prefetch 64 x 64 glds kernel: also the latency-critical next-panel update
-        else if (live_tiles(g, 64, 64) >= 512)
+        else if (GB * live_tiles(g, 64, 64) >= 512)
             tile = 64;
         else
             tile = 32;

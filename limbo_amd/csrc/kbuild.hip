@@ -55,11 +55,24 @@ void launch_lambda_rows(hipStream_t s, double* Xt, int64_t ld, int64_t col0, int
 // MODE 0: lower triangle of the symmetric training matrix (+diag_add on i==j)
 // MODE 1: full symmetric training matrix (tests)
 // MODE 2: rectangular cross matrix, no noise
-template <int DMAX, int MODE>
+template <int DMAX, int MODE, bool BATCH = false>
 __global__ __launch_bounds__(256) void k_build(const double* __restrict__ Xt, int64_t ldx, int64_t N,
-                                               const double* __restrict__ Qt, int64_t ldq, int64_t M, KParams kp,
-                                               double* __restrict__ A, int64_t lda)
+                                               const double* __restrict__ Qt, int64_t ldq, int64_t M, KParams kp_,
+                                               double* __restrict__ A, int64_t lda, const BatchTab* __restrict__ bt)
 {
+    // batched (gridDim.z GPs): this GP's buffers and ITS kernel parameters (theta differs from GP to GP)
+    if (BATCH) {
+        Xt = bt_rebase(bt, (int)blockIdx.z, Xt);
+        A = bt_rebase(bt, (int)blockIdx.z, A);
+    }
+#define KPF(field) (BATCH ? bt->kp[blockIdx.z].field : kp_.field)
+    const int kp_D = KPF(D), kp_kind = KPF(kind);
+    const double kp_sf2 = KPF(sf2), kp_diag_add = KPF(diag_add);
+    double ie[DMAX]; // 1 / ell_d in registers (the loops over d are fully unrolled)
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+        ie[d] = d < kp_D ? KPF(inv_ell[d]) : 0.0;
+#undef KPF
     extern __shared__ __attribute__((aligned(16))) double smem[]; // xj[D][TILE]
     int ti, tj;
     if (MODE == 0) {
@@ -77,7 +90,7 @@ __global__ __launch_bounds__(256) void k_build(const double* __restrict__ Xt, in
         ti = blockIdx.x;
         tj = blockIdx.y;
     }
-    const int D = kp.D;
+    const int D = kp_D;
     const int tx = threadIdx.x & 63; // row inside the tile
     const int ty = threadIdx.x >> 6; // 4 column groups of 16
     const int64_t i = (int64_t)ti * TILE + tx;
@@ -111,13 +124,13 @@ __global__ __launch_bounds__(256) void k_build(const double* __restrict__ Xt, in
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
             if (d < D) {
-                double q = (xi[d] - smem[d * TILE + cc]) * kp.inv_ell[d]; // cwiseQuotient(_ell)
+                double q = (xi[d] - smem[d * TILE + cc]) * ie[d]; // cwiseQuotient(_ell)
                 z = fma(q, q, z);
             }
         }
-        double v = kfun(kp.kind, z, kp.sf2);
+        double v = kfun(kp_kind, z, kp_sf2);
         if (MODE != 2 && i == j)
-            v += kp.diag_add;
+            v += kp_diag_add;
         A[i + j * lda] = v;
     }
 }
@@ -138,7 +151,16 @@ static void launch_build(hipStream_t s, const double* Xt, int64_t ldx, int64_t N
         grid = dim3((unsigned)nt, (unsigned)((M + TILE - 1) / TILE));
     size_t sh = (size_t)kp.D * TILE * sizeof(double);
     int D = kp.D;
-#define LB(DM) hipLaunchKernelGGL((k_build<DM, MODE>), grid, dim3(256), sh, s, Xt, ldx, N, Qt, ldq, M, kp, A, lda)
+    const BatchTab* bt = (MODE == 0) ? g_batch.bt : nullptr;
+    if (bt)
+        grid.z = (unsigned)g_batch.G;
+#define LB(DM)                                                                                                                  \
+    do {                                                                                                                        \
+        if (bt)                                                                                                                 \
+            hipLaunchKernelGGL((k_build<DM, MODE, true>), grid, dim3(256), sh, s, Xt, ldx, N, Qt, ldq, M, kp, A, lda, bt);      \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_build<DM, MODE, false>), grid, dim3(256), sh, s, Xt, ldx, N, Qt, ldq, M, kp, A, lda, bt);     \
+    } while (0)
     if (D <= 4)
         LB(4);
     else if (D <= 8)

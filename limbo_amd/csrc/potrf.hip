@@ -372,8 +372,11 @@ static __device__ __forceinline__ void store_Xt(const double* __restrict__ Xs, d
 // later by k_xinv_complete, the quarter above the diagonal stays zero.  Waves 0-3 factor, wave 4
 // runs the inversion pipeline.  Full 64 x 64 blocks only.
 __global__ __launch_bounds__(320) void k_diag(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
-                                              int* __restrict__ info, int64_t goff)
+                                              int* __restrict__ info, int64_t goff, const BatchTab* __restrict__ bt)
 {
+    BT_REBASE(bt, A);
+    BT_REBASE(bt, Xt);
+    BT_REBASE(bt, info);
     __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ltb[4 * NB * 4];
     __shared__ double invd[NB];
@@ -415,8 +418,11 @@ __global__ __launch_bounds__(320) void k_diag(double* __restrict__ A, int64_t ld
 
 // Full-inverse form (any jb <= 64): the three-launch panel step and its GEMM consumers need all of X.
 __global__ __launch_bounds__(256) void k_diag_full(double* __restrict__ A, int64_t lda, int jb, double* __restrict__ Xt,
-                                              int* __restrict__ info, int64_t goff)
+                                              int* __restrict__ info, int64_t goff, const BatchTab* __restrict__ bt)
 {
+    BT_REBASE(bt, A);
+    BT_REBASE(bt, Xt);
+    BT_REBASE(bt, info);
     __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
     __shared__ __attribute__((aligned(16))) double Xs[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ts[NB * XS];
@@ -497,9 +503,9 @@ void dump_diag_timing()
 void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff, int half_form)
 {
     if (half_form && jb == NB)
-        hipLaunchKernelGGL(k_diag, dim3(1), dim3(320), 0, s, A, lda, Xt, info, goff);
+        hipLaunchKernelGGL(k_diag, dim3(1, 1, g_batch.G), dim3(320), 0, s, A, lda, Xt, info, goff, g_batch.bt);
     else
-        hipLaunchKernelGGL(k_diag_full, dim3(1), dim3(256), 0, s, A, lda, jb, Xt, info, goff);
+        hipLaunchKernelGGL(k_diag_full, dim3(1, 1, g_batch.G), dim3(256), 0, s, A, lda, jb, Xt, info, goff, g_batch.bt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -645,8 +651,15 @@ static __device__ __forceinline__ void wave_tile_to_rows(const double (&acc)[2][
 __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
                                                     const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                     int do_next, int* __restrict__ info, double* __restrict__ Hs,
-                                                    int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc)
+                                                    int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
+                                                    const BatchTab* __restrict__ bt)
 {
+    BT_REBASE(bt, A);
+    BT_REBASE(bt, Xt_cur);
+    BT_REBASE(bt, Xt_next);
+    BT_REBASE(bt, info);
+    BT_REBASE(bt, Hs);
+    BT_REBASE(bt, Dacc);
     // one LDS array, carved: [Bx | T0 | T1 | Ld]; workgroup 0 re-carves it as [Ls | Ltb | invd]
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + 32 * XS];
     __shared__ int sbad;
@@ -993,15 +1006,17 @@ void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_
     const int64_t rows = M - (j0 + NB);
     if (rows <= 0)
         return;
-    hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, j0, M, nt, Xt_cur,
-                       Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc);
+    hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB), 1, g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
+                       Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, g_batch.bt);
 }
 
 // head tiles of the fused steps of one outer panel -> their place in A.  Step f (f = 0..nf-1) of the
 // panel starting at column p0 left nt0 - f tiles: tile t = rows p0 + 64 (f + 1 + t), columns p0 + 64 f.
 __global__ __launch_bounds__(256) void k_head_copy(double* __restrict__ A, int64_t lda, int64_t p0, int nt0,
-                                                   const double* __restrict__ H)
+                                                   const double* __restrict__ H, const BatchTab* __restrict__ bt)
 {
+    BT_REBASE(bt, A);
+    BT_REBASE(bt, H);
     int f = 0, t = blockIdx.x;
     while (t >= nt0 - f) {
         t -= nt0 - f;
@@ -1018,15 +1033,17 @@ void launch_head_copy(hipStream_t s, double* A, int64_t lda, int64_t p0, int nt0
     for (int f = 0; f < nf; ++f)
         tiles += nt0 - f;
     if (tiles > 0)
-        hipLaunchKernelGGL(k_head_copy, dim3((unsigned)tiles), dim3(256), 0, s, A, lda, p0, nt0, H);
+        hipLaunchKernelGGL(k_head_copy, dim3((unsigned)tiles, 1, g_batch.G), dim3(256), 0, s, A, lda, p0, nt0, H, g_batch.bt);
 }
 
 // Off-diagonal quarter of the block inverses left by the half-form kernels: for blocks b0..b0+n-1
 // of the factor L (all full 64 x 64), X21 = -X22 L21 X11 into Xt_all + 4096 b.  Idempotent on a
 // block whose inverse is already complete.
 __global__ __launch_bounds__(256) void k_xinv_complete(const double* __restrict__ L, int64_t ldl, int64_t b0,
-                                                       double* __restrict__ Xt_all)
+                                                       double* __restrict__ Xt_all, const BatchTab* __restrict__ bt)
 {
+    BT_REBASE(bt, L);
+    BT_REBASE(bt, Xt_all);
     __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
     __shared__ __attribute__((aligned(16))) double Xs[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ts[NB * XS];
@@ -1048,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_xinv_complete(const double* __restrict_
 void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b0, int64_t nblocks, double* Xt_all)
 {
     if (nblocks > 0)
-        hipLaunchKernelGGL(k_xinv_complete, dim3((unsigned)nblocks), dim3(256), 0, s, L, ldl, b0, Xt_all);
+        hipLaunchKernelGGL(k_xinv_complete, dim3((unsigned)nblocks, 1, g_batch.G), dim3(256), 0, s, L, ldl, b0, Xt_all, g_batch.bt);
 }
 
 // inverses of the diagonal blocks of an existing factor: block b at L[64 b, 64 b]

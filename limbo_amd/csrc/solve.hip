@@ -212,8 +212,16 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow(const double* __restr
                                                        const double* __restrict__ Xt_all, const double* __restrict__ y,
                                                        int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
                                                        int* __restrict__ err, const double* __restrict__ om,
-                                                       int64_t ldom, double* __restrict__ part, int part_acc)
+                                                       int64_t ldom, double* __restrict__ part, int part_acc,
+                                                       const BatchTab* __restrict__ bt)
 {
+    BT_REBASE(bt, L);
+    BT_REBASE(bt, Xt_all);
+    BT_REBASE(bt, y);
+    BT_REBASE(bt, a);
+    BT_REBASE(bt, err);
+    BT_REBASE(bt, om);
+    BT_REBASE(bt, part);
     __shared__ double Stg[NB * LSTR];
     __shared__ double xs[NB];
     __shared__ double wj[NB];
@@ -416,8 +424,8 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
         const double* omc = om ? om + (int64_t)p0 * ldom : nullptr;
         const int acc = (part_acc || p0 > 0) ? 1 : 0;
         if (pc == 1)
-            hipLaunchKernelGGL(k_trsv_bwd_flow, dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac, ldw,
-                               1, err, omc, ldom, part, acc);
+            hipLaunchKernelGGL(k_trsv_bwd_flow, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi,
+                               ysp, ac, ldw, 1, err, omc, ldom, part, acc, g_batch.bt);
         else
             launch_trsv_bwd_flow_mp(s, L, ld, N, Xt_all, yc, ysi, ysp, ac, ldw, pc, err, omc, ldom, part, acc);
     }
@@ -574,8 +582,11 @@ void launch_trsv_fwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
 // sent (optional): N x P vector (ld = ldv) pre-filled with the all-ones pattern the data-flow backward
 // sweep polls for — saves that sweep a memset on the critical path
 __global__ void k_cols_to_rows(const double* __restrict__ V, int64_t ldv, int64_t N, int P, double* __restrict__ Arows,
-                               int64_t lda, double* __restrict__ sent)
+                               int64_t lda, double* __restrict__ sent, const BatchTab* __restrict__ bt)
 {
+    BT_REBASE(bt, V);
+    BT_REBASE(bt, Arows);
+    BT_REBASE(bt, sent);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N)
         for (int p = 0; p < P; ++p) {
@@ -596,7 +607,8 @@ void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N,
                          double* sent)
 {
     if (N > 0 && P > 0)
-        hipLaunchKernelGGL(k_cols_to_rows, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, V, ldv, N, P, Arows, lda, sent);
+        hipLaunchKernelGGL(k_cols_to_rows, dim3((unsigned)((N + 255) / 256), 1, g_batch.G), dim3(256), 0, s, V, ldv, N, P, Arows, lda, sent,
+                           g_batch.bt);
 }
 void launch_rows_to_cols(hipStream_t s, const double* Arows, int64_t lda, int64_t N, int P, double* V, int64_t ldv)
 {

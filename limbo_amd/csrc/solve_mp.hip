@@ -54,8 +54,16 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow_mp(const double* __re
                                                           const double* __restrict__ y, int64_t ysi, int64_t ysp,
                                                           double* a, int64_t ldw, int P, int* __restrict__ err,
                                                           const double* __restrict__ om, int64_t ldom,
-                                                          double* __restrict__ part, int part_acc)
+                                                          double* __restrict__ part, int part_acc,
+                                                          const BatchTab* __restrict__ bt)
 {
+    BT_REBASE(bt, L);
+    BT_REBASE(bt, Xt_all);
+    BT_REBASE(bt, y);
+    BT_REBASE(bt, a);
+    BT_REBASE(bt, err);
+    BT_REBASE(bt, om);
+    BT_REBASE(bt, part);
     __shared__ double Stg[NB * LSTR];
     __shared__ double xs[NP][NB];
     __shared__ double wj[NP][NB];
@@ -323,11 +331,11 @@ void launch_trsv_bwd_flow_mp(hipStream_t s, const double* L, int64_t ld, int64_t
 {
     const unsigned nblk = (unsigned)((N + NB - 1) / NB);
     if (P <= 2)
-        hipLaunchKernelGGL((k_trsv_bwd_flow_mp<2>), dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw,
-                           P, err, om, ldom, part, part_acc);
+        hipLaunchKernelGGL((k_trsv_bwd_flow_mp<2>), dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi,
+                           ysp, a, ldw, P, err, om, ldom, part, part_acc, g_batch.bt);
     else
-        hipLaunchKernelGGL((k_trsv_bwd_flow_mp<4>), dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi, ysp, a, ldw,
-                           P, err, om, ldom, part, part_acc);
+        hipLaunchKernelGGL((k_trsv_bwd_flow_mp<4>), dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi,
+                           ysp, a, ldw, P, err, om, ldom, part, part_acc, g_batch.bt);
 }
 void launch_trsv_fwd_flow_mp(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all,
                              const double* b, int64_t ldb, double* y, int64_t ldy, int P, int* err)

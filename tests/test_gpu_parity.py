@@ -163,7 +163,11 @@ def test_gpu_batch_compute_matches_single(engine_lib):
     st = _capi.batch_compute(hs)
     assert st == [0] * 6
     ll = _capi.batch_log_lik(hs)
-    assert np.array_equal(ll, np.array(ref))  # same kernels, same order: bitwise
+    # one launch sequence steps all six (gridDim.z = GP): same arithmetic per GP, but the one-stream schedule and the
+    # tile shapes chosen for a six-fold launch differ from a lone evaluation's => equal to rounding, not bitwise
+    assert np.max(np.abs(ll - np.array(ref)) / np.abs(np.array(ref))) < 1e-12
+    assert _capi.batch_compute(hs) == [0] * 6
+    assert np.array_equal(_capi.batch_log_lik(hs), ll)  # run to run: bitwise
     for h in hs:
         h.close()
 
