@@ -654,12 +654,19 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
                                                     int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
                                                     const BatchTab* __restrict__ bt)
 {
-    BT_REBASE(bt, A);
-    BT_REBASE(bt, Xt_cur);
-    BT_REBASE(bt, Xt_next);
-    BT_REBASE(bt, info);
-    BT_REBASE(bt, Hs);
-    BT_REBASE(bt, Dacc);
+    // batched launch: blockIdx.x = b * G + gp, so that workgroup 0 of every GP (the one that goes on to factor the
+    // next diagonal block, twice as long as the others) is dispatched first instead of trailing each GP's rows
+    int bx = blockIdx.x;
+    if (bt) {
+        const int G = bt->G, gp = bx % G;
+        bx /= G;
+        A = bt_rebase(bt, gp, A);
+        Xt_cur = bt_rebase(bt, gp, Xt_cur);
+        Xt_next = bt_rebase(bt, gp, Xt_next);
+        info = bt_rebase(bt, gp, info);
+        Hs = bt_rebase(bt, gp, Hs);
+        Dacc = bt_rebase(bt, gp, Dacc);
+    }
     // one LDS array, carved: [Bx | T0 | T1 | Ld]; workgroup 0 re-carves it as [Ls | Ltb | invd]
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + 32 * XS];
     __shared__ int sbad;
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
     double* Ld = T1 + NB * PS; // L21 of the current diagonal block, Ld[c * XS + k] = L[32 + c][k]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
-    const int b = blockIdx.x;
+    const int b = bx;
     const int64_t r0 = j0 + NB, R0 = r0 + (int64_t)NB * b;
     const int nrows = (int)((M - R0 < NB) ? M - R0 : NB);
     const int tmax = (b < nt - 1) ? b : nt - 1;
@@ -1006,7 +1013,7 @@ void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_
     const int64_t rows = M - (j0 + NB);
     if (rows <= 0)
         return;
-    hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB), 1, g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
+    hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB) * g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
                        Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, g_batch.bt);
 }
 

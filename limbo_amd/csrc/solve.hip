@@ -4,6 +4,7 @@
 // (GP::_compute_alpha, src/limbo/model/gp.hpp:605-611), using the inverses of the 64 x 64
 // diagonal blocks that the factorisation leaves behind (potrf.hip).
 #include "dev.h"
+#include <cstdlib>
 
 #define NB 64
 #define LSTR 65
@@ -208,7 +209,10 @@ static __device__ __forceinline__ double flow_sum(const double (&p)[W][NB], int 
 }
 #define FW 8            // waves per workgroup of the data-flow sweep (16 measured no better)
 #define FQ (NB / FW)    // tile columns (and k-slices) per wave
-__global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow(const double* __restrict__ L, int64_t ld, int64_t N,
+// MINW: minimum waves per SIMD the register allocation must allow (1: as without the bound, the single-GP launch;
+// 4: two per CU, <= 128 VGPRs — the batched launch, where 64 chains of 32 workgroups compete for the CUs)
+template <int MINW>
+__global__ __launch_bounds__(64 * FW, MINW) void k_trsv_bwd_flow(const double* __restrict__ L, int64_t ld, int64_t N,
                                                        const double* __restrict__ Xt_all, const double* __restrict__ y,
                                                        int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
                                                        int* __restrict__ err, const double* __restrict__ om,
@@ -424,8 +428,15 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
         const double* omc = om ? om + (int64_t)p0 * ldom : nullptr;
         const int acc = (part_acc || p0 > 0) ? 1 : 0;
         if (pc == 1)
-            hipLaunchKernelGGL(k_trsv_bwd_flow, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi,
-                               ysp, ac, ldw, 1, err, omc, ldom, part, acc, g_batch.bt);
+        {
+            static const bool occ2 = !(getenv("GPE_BATCH_FLOW_OCC") && atoi(getenv("GPE_BATCH_FLOW_OCC")) == 1);
+            if (g_batch.G > 1 && occ2)
+                hipLaunchKernelGGL(k_trsv_bwd_flow<4>, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc,
+                                   ysi, ysp, ac, ldw, 1, err, omc, ldom, part, acc, g_batch.bt);
+            else
+                hipLaunchKernelGGL(k_trsv_bwd_flow<1>, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac,
+                                   ldw, 1, err, omc, ldom, part, acc, g_batch.bt);
+        }
         else
             launch_trsv_bwd_flow_mp(s, L, ld, N, Xt_all, yc, ysi, ysp, ac, ldw, pc, err, omc, ldom, part, acc);
     }

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Config 4 on one GPU: G independent GPs of N = 2048, D = 6 through gpe_batch_compute (+ log_lik each).
-Measured on MI355X: G = 8: 1900 evaluations/s, G = 64: 1880; enqueueing from 8 host threads instead of one
-changed nothing (1910 vs 1897: not host-launch bound); GPU_MAX_HW_QUEUES=16 (default 4 hardware queues for
-the 2 x G streams): 1963 / 2006."""
+Round 1 (every GP its own launch chain on its own streams): G = 8: 1900 evaluations/s, G = 64: 1880 whatever the
+host threading / queue count.  Round 2 (one launch sequence for all G, gridDim.z = GP): G = 8: 4100, G = 64: 7200
+(GPE_BATCH=0 restores the per-GP chains).  usage: c4bench.py [G ...]"""
 import sys
 import time
 from pathlib import Path
@@ -16,7 +16,7 @@ from limbo_amd import synth as O  # problem generator (pure numpy)
 eng = _capi.load_engine()
 X4, Y4 = O.make_problem("c2", N=2048)
 om4, _ = O.obs_mean_data(Y4)
-for G in (8, 64):
+for G in ([int(a) for a in sys.argv[1:]] or [8, 64]):
     hs = []
     for g_ in range(G):
         hh = _capi.Handle(eng, 0)
