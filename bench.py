@@ -12,6 +12,12 @@ no data-path collective; the only RCCL traffic is the final all-gather of (log_l
 the arg-max (tools/parallel.hpp:169-191 `par::max`), issued inside the timed region.
 value = (N ranks x K steps) / max-over-ranks time.  Scaling is weak.
 
+Besides the headline (`value`: X resident in HBM when the timed region starts) the line carries
+`value_incl_h2d` (the same step with gpe_set_data — 196 KB of X + 32 KB of obs_mean over PCIe — inside the timed
+region: the reference's compute() includes that ingest, gp.hpp:88-116), `config4` (BASELINE configs[3] as written:
+8 independent GPs of N=2048 per GPU through ONE gpe_batch_compute, aggregated over the ranks => 64 GPs on 8 GPUs),
+`roofline`, and two CPU baselines timed on this box (single-core port; all-core numpy + LAPACK).
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -102,6 +108,58 @@ def main():
     evals = world * args.steps
     value = evals / dt
 
+    # the same step with the host -> device ingest of (X, obs_mean) inside: gp.hpp:88-116 as the reference times it
+    n_h2d = max(5, args.steps // 2)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n_h2d):
+        h.set_data(X, om)
+        step()
+    sync()
+    dt_h2d = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt_h2d], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_h2d = float(tmax.item())
+    value_incl_h2d = world * n_h2d / dt_h2d
+
+    # BASELINE configs[3] as written: 64 independent GPs of N=2048, D=6 sharded 8 per GPU (multi_gp.hpp:124-126 /
+    # parallel_repeater.hpp:86-105); each rank steps its 8 through ONE launch sequence (gpe_batch_compute), the final
+    # arg-max over all of them is the same all-gather.  Weak scaling: 8 GPs per GPU at every N.
+    G4, N4 = 8, 2048
+    X4, Y4 = O.make_problem("c4", N=N4)
+    rng4 = np.random.default_rng(4000 + rank)
+    hs4, th4 = [], []
+    for g4 in range(G4):
+        om4, _ = O.obs_mean_data(Y4 * rng4.uniform(0.5, 1.5) + 0.1 * np.sin(3.0 * X4[:, g4 % 6: g4 % 6 + 1] + g4 + 8 * rank))
+        t4 = rng4.uniform(-1e-2, 1e-2, size=D_C2 + 1)
+        h4 = _capi.Handle(eng, local_rank)
+        h4.set_kernel(O.SE_ARD, t4, 0.01)
+        h4.set_data(X4, om4)
+        hs4.append(h4)
+        th4.append(t4)
+    _capi.batch_compute(hs4)
+    reps4 = max(3, args.steps // 5)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps4):
+        st4 = _capi.batch_compute(hs4)
+        ll4 = _capi.batch_log_lik(hs4)
+    best4 = PAR.argmax_over_ranks(list(ll4), th4, dist, device=f"cuda:{local_rank}")
+    sync()
+    dt4 = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt4], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt4 = float(tmax.item())
+    assert all(s4 == 0 for s4 in st4) and np.all(np.isfinite(ll4))
+    for h4 in hs4:
+        h4.close()
+    config4 = {"workload": f"configs[3]: {G4 * world} independent SquaredExpARD GPs, N={N4}, D={D_C2}, {G4} per GPU, one batched launch "
+                           "sequence per GPU (gpe_batch_compute), compute()+log_lik each, arg-max over all by all-gather",
+               "value": world * G4 * reps4 / dt4, "unit": "evaluations/s", "gps_total": G4 * world, "ms_per_batch": 1e3 * dt4 / reps4,
+               "tflops": world * G4 * reps4 / dt4 * (N4 ** 3 / 3.0 + 2.0 * N4 * N4) / 1e12, "best_log_lik": float(best4[0])}
+
     out = {
         "metric": "GP compute()+log_lik evaluations/sec at N=4096 D=6 fp64",
         "value": value,
@@ -119,6 +177,9 @@ def main():
                                "step = compute()+compute_log_lik(), X resident in HBM",
                    "parallelism": f"{world} independent GP restart(s), 1 per GPU, final RCCL all-gather arg-max"},
         "log_lik": ll,
+        "value_incl_h2d": value_incl_h2d,
+        "value_incl_h2d_note": "same step with gpe_set_data (X: 196 KB, obs_mean: 32 KB, host -> HBM) inside the timed region",
+        "config4": config4,
     }
 
     if rank == 0 and not args.no_roofline:
@@ -140,7 +201,7 @@ def main():
         # HBM traffic of the dominant launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md): profiles/, not live
         traffic = None
-        pmc = ROOT / "profiles" / "r01_pmc_trailing_update.json"
+        pmc = next((q for q in (ROOT / "profiles" / "r02_pmc_trailing_update.json", ROOT / "profiles" / "r01_pmc_trailing_update.json") if q.exists()), ROOT / "none")
         if pmc.exists() and N == N_C2:
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch_corrected")
         out["roofline"] = {
@@ -149,7 +210,7 @@ def main():
                       "all 15 launches of one factorisation, HIP events on the handle's stream",
             "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF,
             "traffic": traffic,
-            "traffic_note": "bytes of the first (largest) update launch, PMC (profiles/r01_pmc_trailing_update.json); "
+            "traffic_note": f"bytes of the first (largest) update launch, PMC (profiles/{pmc.name}); "
                             "algorithmic bytes of that launch = 2 x 60.9 MB C tiles + 7.9 MB panel",
             "launches_per_step": upd["launches"] / reps, "avg_launch_us": 1e3 * upd["ms"] / max(upd["launches"], 1),
             "algorithmic_flops_per_step": upd["flops"] / reps,
@@ -210,6 +271,23 @@ def main():
             llo = ho.log_lik()
         tc = time.perf_counter() - t0
         ho.close()
+        # all host cores: numpy kernel build + LAPACK dpotrf / dpotrs through scipy, a reported
+        # upper bound for a CPU, not the reference's code path
+        import scipy.linalg as sl
+
+        best_all = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sq = (X * X).sum(axis=1)
+            Kc = np.exp(-0.5 * np.maximum(sq[:, None] + sq[None, :] - 2.0 * (X @ X.T), 0.0))
+            Kc[np.diag_indices(N)] += 0.01 + 1e-8
+            Lc = sl.cholesky(Kc, lower=True, overwrite_a=True, check_finite=False)
+            ac = sl.cho_solve((Lc, True), om, check_finite=False)
+            ll_all = -0.5 * float((om * ac).sum()) - float(np.log(np.diag(Lc)).sum()) - 0.5 * N * np.log(2 * np.pi)
+            best_all = min(best_all, time.perf_counter() - t0)
+        out["cpu_baseline_all_cores"] = {"value": 1.0 / best_all, "unit": "evaluations/s", "cores": os.cpu_count(), "kind": "port",
+                                         "sample": f"best of 3 compute()+log_lik at N={N}: numpy kernel build + LAPACK dpotrf/dpotrs (scipy/OpenBLAS) "
+                                                   "on all host cores", "log_lik": ll_all}
         out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "evaluations/s", "cores": 1, "kind": "port",
                                "sample": f"{n_cpu} full compute()+log_lik at N={N}, D={D_C2} (oracle/gp_oracle.c, "
                                          f"gcc -O3, {os.cpu_count()} host cores present, 1 used)",

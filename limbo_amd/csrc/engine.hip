@@ -1072,7 +1072,7 @@ int gpe_create(int device_id, gpe_handle* out)
         || hipMalloc(&c->dScal, 8192) != hipSuccess
         || hipMalloc(&c->dHead, sizeof(double) * 65 * NB * NB) != hipSuccess
         // coherent (fine-grained) pinned memory: the small path's host side reads these while the stream is still busy
-        || hipHostMalloc(&c->hInfo, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        || hipHostMalloc(&c->hInfo, 64, getenv("GPE_INFO_COHERENT") ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault) != hipSuccess
         || hipHostMalloc(&c->hScal, 8192) != hipSuccess
         || hipHostMalloc(&c->hSmall, sizeof(double) * SMALL_STAGE_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
         || hipHostMalloc(&c->hSmallSeq, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {

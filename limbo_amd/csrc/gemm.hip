@@ -130,10 +130,16 @@ struct Stager {
 // NBUF = 2: double-buffered k loop.  NBUF = 1: the whole k range (<= BKT) is staged at once — the
 // latency-critical one-shot form used by the panel steps of the Cholesky (k = 64): every global
 // load of the workgroup, including its C tile, is in flight before the first wait.
-template <int TM, int TN, int BKT, int NBUF, bool AK, bool BK>
-__global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
+template <int TM, int TN, int BKT, int NBUF, bool AK, bool BK, bool BATCH = false>
+__global__ __launch_bounds__(256) void k_gemm4(GemmArgs g_)
 {
-    gemm_rebase(g);
+    // BATCH (gridDim.z GPs): a rebased copy of the arguments; otherwise the kernel argument itself (the round-1 kernel)
+    GemmArgs gb;
+    if (BATCH) {
+        gb = g_;
+        gemm_rebase(gb);
+    }
+    const GemmArgs& g = BATCH ? gb : g_;
     using SA = Stager<AK, TM, BKT>;
     using SB = Stager<BK, TN, BKT>;
     constexpr int RA = TM / 2 / 16; // 16-row slabs per wave
@@ -288,11 +294,12 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g)
 // (GemmArgs::stop_event): a separate hipEventRecord is a marker packet of its own on the stream and
 // costs ~6 us on a dependent chain (rocprofv3 timeline of the factorisation).
 template <typename K>
-static void launch_k(K kern, dim3 grid, dim3 block, hipStream_t s, const GemmArgs& g0)
+static void launch_k(K kern_single, K kern_batched, dim3 grid, dim3 block, hipStream_t s, const GemmArgs& g0)
 {
     GemmArgs g = g0;
     g.bt = g_batch.bt; // batched launch: gridDim.z GPs, pointers rebased per GP in the kernel (dev.h)
     grid.z = (unsigned)g_batch.G;
+    K kern = g.bt ? kern_batched : kern_single;
     if (g.stop_event)
         hipExtLaunchKernelGGL(kern, grid, block, 0, s, nullptr, (hipEvent_t)g.stop_event, 0, g);
     else
@@ -319,13 +326,13 @@ static void launch_tile(hipStream_t s, const GemmArgs& g0)
     }
     dim3 grid((unsigned)tiles), block(256);
     if (!g.a_kmajor && !g.b_kmajor)
-        launch_k(k_gemm4<TM, TN, BKT, NBUF, false, false>, grid, block, s, g);
+        launch_k(k_gemm4<TM, TN, BKT, NBUF, false, false>, k_gemm4<TM, TN, BKT, NBUF, false, false, true>, grid, block, s, g);
     else if (!g.a_kmajor && g.b_kmajor)
-        launch_k(k_gemm4<TM, TN, BKT, NBUF, false, true>, grid, block, s, g);
+        launch_k(k_gemm4<TM, TN, BKT, NBUF, false, true>, k_gemm4<TM, TN, BKT, NBUF, false, true, true>, grid, block, s, g);
     else if (g.a_kmajor && !g.b_kmajor)
-        launch_k(k_gemm4<TM, TN, BKT, NBUF, true, false>, grid, block, s, g);
+        launch_k(k_gemm4<TM, TN, BKT, NBUF, true, false>, k_gemm4<TM, TN, BKT, NBUF, true, false, true>, grid, block, s, g);
     else
-        launch_k(k_gemm4<TM, TN, BKT, NBUF, true, true>, grid, block, s, g);
+        launch_k(k_gemm4<TM, TN, BKT, NBUF, true, true>, k_gemm4<TM, TN, BKT, NBUF, true, true, true>, grid, block, s, g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -337,10 +344,15 @@ static void launch_tile(hipStream_t s, const GemmArgs& g0)
 // LDS reads and waits sit under the other's MFMAs.
 // ---------------------------------------------------------------------------------------------
 
-template <int TM, int TN, int WM, int WN, int BKT, int NST, int EPC = 0, int MINB = 1>
-__global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g)
+template <int TM, int TN, int WM, int WN, int BKT, int NST, int EPC = 0, int MINB = 1, bool BATCH = false>
+__global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g_)
 {
-    gemm_rebase(g);
+    GemmArgs gb;
+    if (BATCH) {
+        gb = g_;
+        gemm_rebase(gb);
+    }
+    const GemmArgs& g = BATCH ? gb : g_;
     static_assert(TM == 128 && TN == 128, "one k-row of an operand tile = one 1 KiB glds instruction");
     constexpr int NWV = WM * WN;
     constexpr int SA = TM + 16, SB = TN + 16; // k-row strides (doubles), == 16 mod 32
@@ -511,11 +523,16 @@ void dump_gemm_timing()
 }
 #endif
 
-template <int BKT, int NST, int MINB, int NWV>
-__global__ __launch_bounds__(64 * NWV, MINB) void k_gemm_glds64(GemmArgs g)
+template <int BKT, int NST, int MINB, int NWV, bool BATCH = false>
+__global__ __launch_bounds__(64 * NWV, MINB) void k_gemm_glds64(GemmArgs g_)
 {
+    GemmArgs gb;
+    if (BATCH) {
+        gb = g_;
+        gemm_rebase(gb);
+    }
+    const GemmArgs& g = BATCH ? gb : g_;
     __shared__ __attribute__((aligned(16))) double lds[NST * Glds64Shape<BKT>::STAGE];
-    gemm_rebase(g);
     gemm_glds64_body<BKT, NST, NWV>(g, lds, (int)blockIdx.x, (int)gridDim.x, false);
 }
 
@@ -553,11 +570,11 @@ static void launch_glds64(hipStream_t s, const GemmArgs& g0)
         v64 = e ? atoi(e) : 0;
     }
     if ((int64_t)g.total * g_batch.G > 256 || g.grid_limit > 0 || v64 == 1)
-        launch_k(k_gemm_glds64<16, 4, 2, 4>, dim3((unsigned)tiles), dim3(256), s, g);
+        launch_k(k_gemm_glds64<16, 4, 2, 4>, k_gemm_glds64<16, 4, 2, 4, true>, dim3((unsigned)tiles), dim3(256), s, g);
     else if (v64 == 2)
-        launch_k(k_gemm_glds64<32, 3, 1, 4>, dim3((unsigned)tiles), dim3(256), s, g);
+        launch_k(k_gemm_glds64<32, 3, 1, 4>, k_gemm_glds64<32, 3, 1, 4, true>, dim3((unsigned)tiles), dim3(256), s, g);
     else
-        launch_k(k_gemm_glds64<16, 4, 1, 8>, dim3((unsigned)tiles), dim3(512), s, g);
+        launch_k(k_gemm_glds64<16, 4, 1, 8>, k_gemm_glds64<16, 4, 1, 8, true>, dim3((unsigned)tiles), dim3(512), s, g);
 }
 
 static bool glds_ok(const GemmArgs& g)
@@ -600,9 +617,9 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
     }
     const bool two_per_cu = variant == 2 ? (g.grid_limit <= 0 && (int64_t)g.total * g_batch.G > 256) : variant == 1;
     if (two_per_cu)
-        launch_k(k_gemm_glds<128, 128, 2, 4, 16, 2, 4, 2>, dim3((unsigned)tiles), dim3(512), s, g);
+        launch_k(k_gemm_glds<128, 128, 2, 4, 16, 2, 4, 2>, k_gemm_glds<128, 128, 2, 4, 16, 2, 4, 2, true>, dim3((unsigned)tiles), dim3(512), s, g);
     else
-        launch_k(k_gemm_glds<128, 128, 2, 4, 32, 2>, dim3((unsigned)tiles), dim3(512), s, g);
+        launch_k(k_gemm_glds<128, 128, 2, 4, 32, 2>, k_gemm_glds<128, 128, 2, 4, 32, 2, 0, 1, true>, dim3((unsigned)tiles), dim3(512), s, g);
 }
 
 // number of TM x TN tiles that do work (triangular skipping accounted for)

@@ -10,6 +10,7 @@
 // column-major, so a wave's 64 lanes store 512 contiguous bytes per column.  Only the lower
 // triangle is produced (N(N+1)/2 * 8 B of HBM writes: the HBM-write roofline of this kernel).
 #include "dev.h"
+#include <cstdlib>
 
 #define TILE 64
 
@@ -174,9 +175,268 @@ static void launch_build(hipStream_t s, const double* Xt, int64_t ldx, int64_t N
 #undef LB
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_build_lower<KIND, BATCH> — the training matrix's lower triangle, tuned for the HBM-write roofline
+// (N (N + 1) / 2 * 8 B out, N * D * 8 B in).  Differences from the generic k_build above:
+//   * specialised on the kernel functor: no switch inside the pair loop;
+//   * a wave's 16 columns are wave-uniform, so the column sample's coordinates come through the SCALAR unit
+//     (s_load, SGPR operands of the VALU ops) — no LDS staging, no ds_read per dimension and pair, no barrier;
+//   * branch-free pair loop: out-of-range rows/columns are clamped for the loads and masked at the store (diagonal
+//     tiles compute the few upper-triangle pairs and drop them);
+//   * exp(-h), h >= 0, without libm's special cases: n = rint(x log2 e), r = x - n ln 2 (two-term), degree-13 Taylor
+//     polynomial on |r| <= 0.347 (remainder 4e-18 relative), ldexp.  < 1 ulp from the correctly rounded value.
+// Same pair formula and summation order as k_build: z = sum_d ((x_i,d - x_j,d) / ell_d)^2, d ascending, fma.
+// ---------------------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ double exp_nonpos(double x)
+{
+    const double n = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.60590438368216145994e-10; // 1/13!
+    p = fma(p, r, 2.08767569878680989792e-09);
+    p = fma(p, r, 2.50521083854417187751e-08);
+    p = fma(p, r, 2.75573192239858906526e-07);
+    p = fma(p, r, 2.75573192239858906526e-06);
+    p = fma(p, r, 2.48015873015873015873e-05);
+    p = fma(p, r, 1.98412698412698412698e-04);
+    p = fma(p, r, 1.38888888888888888889e-03);
+    p = fma(p, r, 8.33333333333333333333e-03);
+    p = fma(p, r, 4.16666666666666666667e-02);
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return x < -745.2 ? 0.0 : ldexp(p, (int)n);
+}
+template <int KIND>
+static __device__ __forceinline__ double kfun_fast(double z, double sf2)
+{
+    if (KIND == 0 || KIND == 3)
+        return sf2 * exp_nonpos(-0.5 * z);
+    if (KIND == 1) {
+        const double t1 = 2.23606797749978969641 * sqrt(z);
+        return sf2 * (1.0 + t1 + (5.0 / 3.0) * z) * exp_nonpos(-t1);
+    }
+    const double t = 1.73205080756887729353 * sqrt(z);
+    return sf2 * (1.0 + t) * exp_nonpos(-t);
+}
+
+template <int KIND, int DMAX, bool BATCH>
+__global__ __launch_bounds__(256) void k_build_lower(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp_,
+                                                      double* __restrict__ A, int64_t lda, const BatchTab* __restrict__ bt)
+{
+    if (BATCH) {
+        Xt = bt_rebase(bt, (int)blockIdx.z, Xt);
+        A = bt_rebase(bt, (int)blockIdx.z, A);
+    }
+#define KPF(field) (BATCH ? bt->kp[blockIdx.z].field : kp_.field)
+    const int D = KPF(D);
+    const double sf2 = KPF(sf2), diag_add = KPF(diag_add);
+    int ti, tj;
+    {
+        long long b = blockIdx.x;
+        long long t = (long long)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+        while ((t + 1) * (t + 2) / 2 <= b)
+            ++t;
+        while (t * (t + 1) / 2 > b)
+            --t;
+        ti = (int)t;
+        tj = (int)(b - t * (t + 1) / 2);
+    }
+    const int tx = threadIdx.x & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t i = (int64_t)ti * TILE + tx;
+    const int64_t ic = i < N ? i : N - 1;
+    const int64_t j0 = (int64_t)tj * TILE + 16 * ty;
+    double xi[DMAX], ie[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        ie[d] = d < D ? KPF(inv_ell[d]) : 0.0;
+        xi[d] = d < D ? Xt[(int64_t)d * ldx + ic] : 0.0;
+    }
+#undef KPF
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+        const int64_t j = j0 + c; // wave-uniform
+        if (j >= N)
+            break; // uniform
+        double z = 0.0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            if (d < D) { // uniform
+                const double xj = Xt[(int64_t)d * ldx + j]; // uniform address: scalar load
+                const double q = (xi[d] - xj) * ie[d];
+                z = fma(q, q, z);
+            }
+        }
+        double v = kfun_fast<KIND>(z, sf2);
+        if (i == j)
+            v += diag_add;
+        if (i < N && j <= i)
+            A[i + j * lda] = v;
+    }
+}
+
+template <int KIND>
+static void launch_build_lower_kind(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A, int64_t lda)
+{
+    const int64_t nt = (N + TILE - 1) / TILE;
+    dim3 grid((unsigned)(nt * (nt + 1) / 2), 1, (unsigned)g_batch.G);
+    const BatchTab* bt = g_batch.bt;
+#define LBL(DM)                                                                                                   \
+    do {                                                                                                          \
+        if (bt)                                                                                                   \
+            hipLaunchKernelGGL((k_build_lower<KIND, DM, true>), grid, dim3(256), 0, s, Xt, ldx, N, kp, A, lda, bt);  \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_build_lower<KIND, DM, false>), grid, dim3(256), 0, s, Xt, ldx, N, kp, A, lda, bt); \
+    } while (0)
+    if (kp.D <= 4)
+        LBL(4);
+    else if (kp.D <= 8)
+        LBL(8);
+    else if (kp.D <= 16)
+        LBL(16);
+    else if (kp.D <= 32)
+        LBL(32);
+    else
+        LBL(64);
+#undef LBL
+}
+
+// k_build_wide<KIND, DMAX, BATCH> — as k_build_lower, but shaped for the memory side: a workgroup owns 128 rows x 64
+// columns, a lane owns TWO consecutive rows and stores them as one 16-byte double2 (1 KiB contiguous per wave store
+// instead of 512 B), the 64 column samples are staged once through LDS (wave-uniform LDS reads: broadcasts).
+template <int KIND, int DMAX, bool BATCH>
+__global__ __launch_bounds__(256) void k_build_wide(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp_,
+                                                     double* __restrict__ A, int64_t lda, const BatchTab* __restrict__ bt)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[]; // xj[D][64]
+    if (BATCH) {
+        Xt = bt_rebase(bt, (int)blockIdx.z, Xt);
+        A = bt_rebase(bt, (int)blockIdx.z, A);
+    }
+#define KPF(field) (BATCH ? bt->kp[blockIdx.z].field : kp_.field)
+    const int D = KPF(D);
+    const double sf2 = KPF(sf2), diag_add = KPF(diag_add);
+    // tile (ti: 128-row block, tj: 64-column block), live iff 128 ti + 127 >= 64 tj  <=>  tj <= 2 ti + 1
+    int ti, tj;
+    {
+        const long long b = blockIdx.x; // b = ti (ti + 1) + tj
+        long long t = (long long)((sqrt(4.0 * (double)b + 1.0) - 1.0) * 0.5);
+        while ((t + 1) * (t + 2) <= b)
+            ++t;
+        while (t * (t + 1) > b)
+            --t;
+        ti = (int)t;
+        tj = (int)(b - t * (t + 1));
+    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t i0 = (int64_t)ti * 128 + 2 * tx; // rows i0, i0 + 1
+    const int64_t j0 = (int64_t)tj * TILE;
+    for (int e = threadIdx.x; e < D * TILE; e += 256) {
+        const int d = e >> 6, c = e & 63;
+        const int64_t j = j0 + c;
+        smem[e] = (j < N) ? Xt[(int64_t)d * ldx + j] : 0.0;
+    }
+    double xa[DMAX], xb[DMAX], ie[DMAX];
+    const int64_t ia = i0 < N ? i0 : N - 1, ib = i0 + 1 < N ? i0 + 1 : N - 1;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        ie[d] = d < D ? KPF(inv_ell[d]) : 0.0;
+        xa[d] = d < D ? Xt[(int64_t)d * ldx + ia] : 0.0;
+        xb[d] = d < D ? Xt[(int64_t)d * ldx + ib] : 0.0;
+    }
+#undef KPF
+    __syncthreads();
+#pragma unroll 2
+    for (int c = 0; c < 16; ++c) {
+        const int cc = ty * 16 + c;
+        const int64_t j = j0 + cc; // wave-uniform
+        if (j >= N)
+            break;
+        double za = 0.0, zb = 0.0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            if (d < D) {
+                const double xj = smem[d * TILE + cc];
+                const double qa = (xa[d] - xj) * ie[d], qb = (xb[d] - xj) * ie[d];
+                za = fma(qa, qa, za);
+                zb = fma(qb, qb, zb);
+            }
+        }
+        double va = kfun_fast<KIND>(za, sf2), vb = kfun_fast<KIND>(zb, sf2);
+        if (i0 == j)
+            va += diag_add;
+        if (i0 + 1 == j)
+            vb += diag_add;
+        double* dst = A + i0 + j * lda;
+        if (i0 + 1 < N && j <= i0) // both rows on/below the diagonal: one 16-byte store (i0 and lda are even)
+            *reinterpret_cast<double2*>(dst) = double2{va, vb};
+        else {
+            if (i0 < N && j <= i0)
+                dst[0] = va;
+            if (i0 + 1 < N && j <= i0 + 1)
+                dst[1] = vb;
+        }
+    }
+}
+
+template <int KIND>
+static void launch_build_wide_kind(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A, int64_t lda)
+{
+    const int64_t nt = (N + 127) / 128;
+    // live tiles: sum over ti of min(2 ti + 2, column blocks)
+    const int64_t ncb = (N + TILE - 1) / TILE;
+    int64_t tiles = nt * (nt + 1); // the last block-row may count a column block past N: those workgroups find j >= N and leave
+    (void)ncb;
+    dim3 grid((unsigned)tiles, 1, (unsigned)g_batch.G);
+    const BatchTab* bt = g_batch.bt;
+    const size_t sh = (size_t)kp.D * TILE * sizeof(double);
+#define LBW(DM)                                                                                                     \
+    do {                                                                                                            \
+        if (bt)                                                                                                     \
+            hipLaunchKernelGGL((k_build_wide<KIND, DM, true>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt);  \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_build_wide<KIND, DM, false>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt); \
+    } while (0)
+    if (kp.D <= 4)
+        LBW(4);
+    else if (kp.D <= 8)
+        LBW(8);
+    else if (kp.D <= 16)
+        LBW(16);
+    else if (kp.D <= 32)
+        LBW(32);
+    else
+        LBW(64);
+#undef LBW
+}
+
 void launch_build_K(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A, int64_t lda)
 {
-    launch_build<0>(s, Xt, ldx, N, nullptr, 0, 0, kp, A, lda);
+    // GPE_KBUILD: 0 = the generic tile kernel (k_build), 1 = k_build_lower (scalar-unit column samples), 2 = k_build_wide
+    static const int variant = getenv("GPE_KBUILD") ? atoi(getenv("GPE_KBUILD")) : 2;
+    const bool fast = variant != 0;
+    if (!fast || N <= 0 || (lda & 1)) {
+        launch_build<0>(s, Xt, ldx, N, nullptr, 0, 0, kp, A, lda);
+        return;
+    }
+    if (variant == 2) {
+        switch (kp.kind) {
+        case 0:
+        case 3: launch_build_wide_kind<0>(s, Xt, ldx, N, kp, A, lda); break;
+        case 1: launch_build_wide_kind<1>(s, Xt, ldx, N, kp, A, lda); break;
+        default: launch_build_wide_kind<2>(s, Xt, ldx, N, kp, A, lda); break;
+        }
+        return;
+    }
+    switch (kp.kind) {
+    case 0:
+    case 3: launch_build_lower_kind<0>(s, Xt, ldx, N, kp, A, lda); break;
+    case 1: launch_build_lower_kind<1>(s, Xt, ldx, N, kp, A, lda); break;
+    default: launch_build_lower_kind<2>(s, Xt, ldx, N, kp, A, lda); break;
+    }
 }
 void launch_build_K_full(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A,
                          int64_t lda)

@@ -371,12 +371,9 @@ static __device__ __forceinline__ void store_Xt(const double* __restrict__ Xs, d
 // two 32 x 32 diagonal half-blocks) into the diagonal quarters of Xt; the quarter X21 is completed
 // later by k_xinv_complete, the quarter above the diagonal stays zero.  Waves 0-3 factor, wave 4
 // runs the inversion pipeline.  Full 64 x 64 blocks only.
-__global__ __launch_bounds__(320) void k_diag(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
-                                              int* __restrict__ info, int64_t goff, const BatchTab* __restrict__ bt)
+static __device__ __forceinline__ void diag_body(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
+                                                 int* __restrict__ info, int64_t goff)
 {
-    BT_REBASE(bt, A);
-    BT_REBASE(bt, Xt);
-    BT_REBASE(bt, info);
     __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ltb[4 * NB * 4];
     __shared__ double invd[NB];
@@ -414,6 +411,20 @@ __global__ __launch_bounds__(320) void k_diag(double* __restrict__ A, int64_t ld
     if (threadIdx.x == 0 && sbad != 0 && *info == 0)
         *info = (int)(goff + sbad);
     TS(3);
+}
+// entry points: single GP (the round-1 kernel, unchanged) / batched (gridDim.z GPs, pointers rebased; dev.h)
+__global__ __launch_bounds__(320) void k_diag(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
+                                              int* __restrict__ info, int64_t goff)
+{
+    diag_body(A, lda, Xt, info, goff);
+}
+__global__ __launch_bounds__(320) void k_diag_b(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
+                                                int* __restrict__ info, int64_t goff, const BatchTab* __restrict__ bt)
+{
+    BT_REBASE(bt, A);
+    BT_REBASE(bt, Xt);
+    BT_REBASE(bt, info);
+    diag_body(A, lda, Xt, info, goff);
 }
 
 // Full-inverse form (any jb <= 64): the three-launch panel step and its GEMM consumers need all of X.
@@ -503,7 +514,12 @@ void dump_diag_timing()
 void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff, int half_form)
 {
     if (half_form && jb == NB)
-        hipLaunchKernelGGL(k_diag, dim3(1, 1, g_batch.G), dim3(320), 0, s, A, lda, Xt, info, goff, g_batch.bt);
+    {
+        if (g_batch.bt)
+            hipLaunchKernelGGL(k_diag_b, dim3(1, 1, g_batch.G), dim3(320), 0, s, A, lda, Xt, info, goff, g_batch.bt);
+        else
+            hipLaunchKernelGGL(k_diag, dim3(1), dim3(320), 0, s, A, lda, Xt, info, goff);
+    }
     else
         hipLaunchKernelGGL(k_diag_full, dim3(1, 1, g_batch.G), dim3(256), 0, s, A, lda, jb, Xt, info, goff, g_batch.bt);
 }
@@ -648,25 +664,12 @@ static __device__ __forceinline__ void wave_tile_to_rows(const double (&acc)[2][
 // no workgroup to spare; done in the step where that workgroup has the most slack).  k_upd_fused subtracts the
 // sum from the block and only has to factor it.  (Not subtracted from A directly: the second stream's GEMMs
 // may still be updating that block.)
-__global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
-                                                    const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
-                                                    int do_next, int* __restrict__ info, double* __restrict__ Hs,
-                                                    int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
-                                                    const BatchTab* __restrict__ bt)
+static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
+                                                       const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
+                                                       int do_next, int* __restrict__ info, double* __restrict__ Hs,
+                                                       int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
+                                                       const int bx)
 {
-    // batched launch: blockIdx.x = b * G + gp, so that workgroup 0 of every GP (the one that goes on to factor the
-    // next diagonal block, twice as long as the others) is dispatched first instead of trailing each GP's rows
-    int bx = blockIdx.x;
-    if (bt) {
-        const int G = bt->G, gp = bx % G;
-        bx /= G;
-        A = bt_rebase(bt, gp, A);
-        Xt_cur = bt_rebase(bt, gp, Xt_cur);
-        Xt_next = bt_rebase(bt, gp, Xt_next);
-        info = bt_rebase(bt, gp, info);
-        Hs = bt_rebase(bt, gp, Hs);
-        Dacc = bt_rebase(bt, gp, Dacc);
-    }
     // one LDS array, carved: [Bx | T0 | T1 | Ld]; workgroup 0 re-carves it as [Ls | Ltb | invd]
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + 32 * XS];
     __shared__ int sbad;
@@ -872,6 +875,31 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
         *info = (int)(r0 + sbad);
     PTS(7);
 }
+// entry points: single GP (the round-1 kernel, unchanged) / batched.  Batched: blockIdx.x = b * G + gp, so that workgroup 0
+// of every GP (the one that goes on to factor the next diagonal block, twice as long as the others) is dispatched first
+// instead of trailing each GP's rows.
+__global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
+                                                    const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
+                                                    int do_next, int* __restrict__ info, double* __restrict__ Hs,
+                                                    int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc)
+{
+    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
+                                                      const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
+                                                      int do_next, int* __restrict__ info, double* __restrict__ Hs,
+                                                      int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
+                                                      const BatchTab* __restrict__ bt)
+{
+    const int G = bt->G, gp = (int)blockIdx.x % G;
+    A = bt_rebase(bt, gp, A);
+    Xt_cur = bt_rebase(bt, gp, Xt_cur);
+    Xt_next = bt_rebase(bt, gp, Xt_next);
+    info = bt_rebase(bt, gp, info);
+    Hs = bt_rebase(bt, gp, Hs);
+    Dacc = bt_rebase(bt, gp, Dacc);
+    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, (int)blockIdx.x / G);
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_upd_fused — the next-panel update (rows >= pe of columns [pe, pe2), k = pe - p0) and, in the SAME
@@ -1013,8 +1041,12 @@ void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_
     const int64_t rows = M - (j0 + NB);
     if (rows <= 0)
         return;
-    hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB) * g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
-                       Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, g_batch.bt);
+    if (g_batch.bt)
+        hipLaunchKernelGGL(k_panel_step_b, dim3((unsigned)((rows + NB - 1) / NB) * g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
+                           Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, g_batch.bt);
+    else
+        hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, j0, M, nt, Xt_cur,
+                           Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc);
 }
 
 // head tiles of the fused steps of one outer panel -> their place in A.  Step f (f = 0..nf-1) of the

@@ -209,23 +209,12 @@ static __device__ __forceinline__ double flow_sum(const double (&p)[W][NB], int 
 }
 #define FW 8            // waves per workgroup of the data-flow sweep (16 measured no better)
 #define FQ (NB / FW)    // tile columns (and k-slices) per wave
-// MINW: minimum waves per SIMD the register allocation must allow (1: as without the bound, the single-GP launch;
-// 4: two per CU, <= 128 VGPRs — the batched launch, where 64 chains of 32 workgroups compete for the CUs)
-template <int MINW>
-__global__ __launch_bounds__(64 * FW, MINW) void k_trsv_bwd_flow(const double* __restrict__ L, int64_t ld, int64_t N,
-                                                       const double* __restrict__ Xt_all, const double* __restrict__ y,
-                                                       int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
-                                                       int* __restrict__ err, const double* __restrict__ om,
-                                                       int64_t ldom, double* __restrict__ part, int part_acc,
-                                                       const BatchTab* __restrict__ bt)
+static __device__ __forceinline__ void trsv_bwd_flow_body(const double* __restrict__ L, int64_t ld, int64_t N,
+                                                           const double* __restrict__ Xt_all, const double* __restrict__ y,
+                                                           int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
+                                                           int* __restrict__ err, const double* __restrict__ om,
+                                                           int64_t ldom, double* __restrict__ part, int part_acc)
 {
-    BT_REBASE(bt, L);
-    BT_REBASE(bt, Xt_all);
-    BT_REBASE(bt, y);
-    BT_REBASE(bt, a);
-    BT_REBASE(bt, err);
-    BT_REBASE(bt, om);
-    BT_REBASE(bt, part);
     __shared__ double Stg[NB * LSTR];
     __shared__ double xs[NB];
     __shared__ double wj[NB];
@@ -395,6 +384,32 @@ __global__ __launch_bounds__(64 * FW, MINW) void k_trsv_bwd_flow(const double* _
         }
     }
 }
+// entry points: the single-GP launch (exactly the round-1 kernel: no extra parameter, no occupancy bound) and the batched
+// one (gridDim.z GPs, pointers rebased per GP; dev.h)
+__global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow(const double* __restrict__ L, int64_t ld, int64_t N,
+                                                       const double* __restrict__ Xt_all, const double* __restrict__ y,
+                                                       int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
+                                                       int* __restrict__ err, const double* __restrict__ om,
+                                                       int64_t ldom, double* __restrict__ part, int part_acc)
+{
+    trsv_bwd_flow_body(L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err, om, ldom, part, part_acc);
+}
+__global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow_b(const double* __restrict__ L, int64_t ld, int64_t N,
+                                                         const double* __restrict__ Xt_all, const double* __restrict__ y,
+                                                         int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
+                                                         int* __restrict__ err, const double* __restrict__ om,
+                                                         int64_t ldom, double* __restrict__ part, int part_acc,
+                                                         const BatchTab* __restrict__ bt)
+{
+    BT_REBASE(bt, L);
+    BT_REBASE(bt, Xt_all);
+    BT_REBASE(bt, y);
+    BT_REBASE(bt, a);
+    BT_REBASE(bt, err);
+    BT_REBASE(bt, om);
+    BT_REBASE(bt, part);
+    trsv_bwd_flow_body(L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err, om, ldom, part, part_acc);
+}
 
 #ifdef FLOW_TIMING
 #include <cstdio>
@@ -429,13 +444,12 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
         const int acc = (part_acc || p0 > 0) ? 1 : 0;
         if (pc == 1)
         {
-            static const bool occ2 = !(getenv("GPE_BATCH_FLOW_OCC") && atoi(getenv("GPE_BATCH_FLOW_OCC")) == 1);
-            if (g_batch.G > 1 && occ2)
-                hipLaunchKernelGGL(k_trsv_bwd_flow<4>, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc,
+            if (g_batch.bt)
+                hipLaunchKernelGGL(k_trsv_bwd_flow_b, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc,
                                    ysi, ysp, ac, ldw, 1, err, omc, ldom, part, acc, g_batch.bt);
             else
-                hipLaunchKernelGGL(k_trsv_bwd_flow<1>, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac,
-                                   ldw, 1, err, omc, ldom, part, acc, g_batch.bt);
+                hipLaunchKernelGGL(k_trsv_bwd_flow, dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac,
+                                   ldw, 1, err, omc, ldom, part, acc);
         }
         else
             launch_trsv_bwd_flow_mp(s, L, ld, N, Xt_all, yc, ysi, ysp, ac, ldw, pc, err, omc, ldom, part, acc);
