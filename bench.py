@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--n", type=int, default=N_C2, help="override N (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="profiling runs: only the N=4096 evaluation loop (no H2D variant, no config 4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,57 +109,59 @@ def main():
     evals = world * args.steps
     value = evals / dt
 
-    # the same step with the host -> device ingest of (X, obs_mean) inside: gp.hpp:88-116 as the reference times it
-    n_h2d = max(5, args.steps // 2)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(n_h2d):
-        h.set_data(X, om)
-        step()
-    sync()
-    dt_h2d = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt_h2d], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_h2d = float(tmax.item())
-    value_incl_h2d = world * n_h2d / dt_h2d
+    value_incl_h2d, config4 = None, None
+    if not args.headline_only:
+        # the same step with the host -> device ingest of (X, obs_mean) inside: gp.hpp:88-116 as the reference times it
+        n_h2d = max(5, args.steps // 2)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n_h2d):
+            h.set_data(X, om)
+            step()
+        sync()
+        dt_h2d = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt_h2d], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_h2d = float(tmax.item())
+        value_incl_h2d = world * n_h2d / dt_h2d
 
-    # BASELINE configs[3] as written: 64 independent GPs of N=2048, D=6 sharded 8 per GPU (multi_gp.hpp:124-126 /
-    # parallel_repeater.hpp:86-105); each rank steps its 8 through ONE launch sequence (gpe_batch_compute), the final
-    # arg-max over all of them is the same all-gather.  Weak scaling: 8 GPs per GPU at every N.
-    G4, N4 = 8, 2048
-    X4, Y4 = O.make_problem("c4", N=N4)
-    rng4 = np.random.default_rng(4000 + rank)
-    hs4, th4 = [], []
-    for g4 in range(G4):
-        om4, _ = O.obs_mean_data(Y4 * rng4.uniform(0.5, 1.5) + 0.1 * np.sin(3.0 * X4[:, g4 % 6: g4 % 6 + 1] + g4 + 8 * rank))
-        t4 = rng4.uniform(-1e-2, 1e-2, size=D_C2 + 1)
-        h4 = _capi.Handle(eng, local_rank)
-        h4.set_kernel(O.SE_ARD, t4, 0.01)
-        h4.set_data(X4, om4)
-        hs4.append(h4)
-        th4.append(t4)
-    _capi.batch_compute(hs4)
-    reps4 = max(3, args.steps // 5)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(reps4):
-        st4 = _capi.batch_compute(hs4)
-        ll4 = _capi.batch_log_lik(hs4)
-    best4 = PAR.argmax_over_ranks(list(ll4), th4, dist, device=f"cuda:{local_rank}")
-    sync()
-    dt4 = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt4], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt4 = float(tmax.item())
-    assert all(s4 == 0 for s4 in st4) and np.all(np.isfinite(ll4))
-    for h4 in hs4:
-        h4.close()
-    config4 = {"workload": f"configs[3]: {G4 * world} independent SquaredExpARD GPs, N={N4}, D={D_C2}, {G4} per GPU, one batched launch "
-                           "sequence per GPU (gpe_batch_compute), compute()+log_lik each, arg-max over all by all-gather",
-               "value": world * G4 * reps4 / dt4, "unit": "evaluations/s", "gps_total": G4 * world, "ms_per_batch": 1e3 * dt4 / reps4,
-               "tflops": world * G4 * reps4 / dt4 * (N4 ** 3 / 3.0 + 2.0 * N4 * N4) / 1e12, "best_log_lik": float(best4[0])}
+        # BASELINE configs[3] as written: 64 independent GPs of N=2048, D=6 sharded 8 per GPU (multi_gp.hpp:124-126 /
+        # parallel_repeater.hpp:86-105); each rank steps its 8 through ONE launch sequence (gpe_batch_compute), the final
+        # arg-max over all of them is the same all-gather.  Weak scaling: 8 GPs per GPU at every N.
+        G4, N4 = 8, 2048
+        X4, Y4 = O.make_problem("c4", N=N4)
+        rng4 = np.random.default_rng(4000 + rank)
+        hs4, th4 = [], []
+        for g4 in range(G4):
+            om4, _ = O.obs_mean_data(Y4 * rng4.uniform(0.5, 1.5) + 0.1 * np.sin(3.0 * X4[:, g4 % 6: g4 % 6 + 1] + g4 + 8 * rank))
+            t4 = rng4.uniform(-1e-2, 1e-2, size=D_C2 + 1)
+            h4 = _capi.Handle(eng, local_rank)
+            h4.set_kernel(O.SE_ARD, t4, 0.01)
+            h4.set_data(X4, om4)
+            hs4.append(h4)
+            th4.append(t4)
+        _capi.batch_compute(hs4)
+        reps4 = max(3, args.steps // 5)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps4):
+            st4 = _capi.batch_compute(hs4)
+            ll4 = _capi.batch_log_lik(hs4)
+        best4 = PAR.argmax_over_ranks(list(ll4), th4, dist, device=f"cuda:{local_rank}")
+        sync()
+        dt4 = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt4], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt4 = float(tmax.item())
+        assert all(s4 == 0 for s4 in st4) and np.all(np.isfinite(ll4))
+        for h4 in hs4:
+            h4.close()
+        config4 = {"workload": f"configs[3]: {G4 * world} independent SquaredExpARD GPs, N={N4}, D={D_C2}, {G4} per GPU, one batched launch "
+                               "sequence per GPU (gpe_batch_compute), compute()+log_lik each, arg-max over all by all-gather",
+                   "value": world * G4 * reps4 / dt4, "unit": "evaluations/s", "gps_total": G4 * world, "ms_per_batch": 1e3 * dt4 / reps4,
+                   "tflops": world * G4 * reps4 / dt4 * (N4 ** 3 / 3.0 + 2.0 * N4 * N4) / 1e12, "best_log_lik": float(best4[0])}
 
     out = {
         "metric": "GP compute()+log_lik evaluations/sec at N=4096 D=6 fp64",

@@ -102,6 +102,8 @@ static __device__ __forceinline__ double kfun(int kind, double z, double sf2)
 #define GPE_FLOW_SPIN_LIMIT (1 << 22) // bounded poll: ~a second; raises *err, and the host re-runs block by block
 static __device__ __forceinline__ int64_t flow_block_of(int64_t nblk, bool backward)
 {
+    if ((int64_t)gridDim.x == nblk) // plain form (GPE_FLOW_XCD=0): chain position = dispatch position, no XCD locality
+        return backward ? nblk - 1 - (int64_t)blockIdx.x : (int64_t)blockIdx.x;
     const int64_t s = blockIdx.x >> 3;
     const int64_t x = blockIdx.x & 7;
     const int64_t j = backward ? nblk - 1 - s : s;
@@ -109,7 +111,8 @@ static __device__ __forceinline__ int64_t flow_block_of(int64_t nblk, bool backw
     const int64_t owner = j < split ? j / (q + 1) : r + (j - split) / (q > 0 ? q : 1);
     return x == owner ? j : -1;
 }
-#define GPE_FLOW_GRID(nblk) ((unsigned)(8 * (nblk)))
+unsigned flow_grid(int64_t nblk); // 8 nblk (XCD-local chains) or nblk (GPE_FLOW_XCD=0)
+#define GPE_FLOW_GRID(nblk) flow_grid(nblk)
 
 // ---- kernel-matrix build (kbuild.hip) ----------------------------------------------
 // Xt: SoA, D x ldx (sample index contiguous).  Writes the LOWER triangle (incl. diagonal,

@@ -207,6 +207,11 @@ static __device__ __forceinline__ double flow_sum(const double (&p)[W][NB], int 
         s += p[w][lane];
     return s;
 }
+unsigned flow_grid(int64_t nblk)
+{
+    static const bool xcd = !(getenv("GPE_FLOW_XCD") && atoi(getenv("GPE_FLOW_XCD")) == 0);
+    return (unsigned)(xcd ? 8 * nblk : nblk);
+}
 #define FW 8            // waves per workgroup of the data-flow sweep (16 measured no better)
 #define FQ (NB / FW)    // tile columns (and k-slices) per wave
 static __device__ __forceinline__ void trsv_bwd_flow_body(const double* __restrict__ L, int64_t ld, int64_t N,

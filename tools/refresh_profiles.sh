@@ -10,7 +10,7 @@ root=$(pwd)
 out=$root/gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline"
+B="python $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --headline-only"
 GPE_STOP_EVENT=0 rocprofv3 --kernel-trace -d /tmp/p_kt -o p -- $B > /dev/null 2>&1
 db=$(find /tmp/p_kt -name "*.db" | head -1)
 { echo "# rocprofv3 --kernel-trace (GPE_STOP_EVENT=0) over: bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline  (N=4096 D=6 SE-ARD, MI355X)"; python $root/tools/kstats.py $db; } > $out/${tag}_rocprofv3_kernel_stats.txt
@@ -27,4 +27,21 @@ python bench.py > $out/${tag}_bench_n4096.json 2> $out/bench.err
 python bench_extra.py > $out/${tag}_bench_extra.json 2> $out/bench_extra.err
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/${tag}_s1_gpu_tests.log
 tests/cpp/test_gp_dropin >> $out/${tag}_s1_gpu_tests.log 2>&1
+tests/cpp/test_mixed_tree >> $out/${tag}_s1_gpu_tests.log 2>&1
+python tools/small_bench.py > $out/${tag}_small_path_latency.json 2> $out/small_bench.err
+python tools/c4bench.py 8 64 > $out/${tag}_c4bench.log 2>&1
+GPE_BATCH=0 python tools/c4bench.py 8 64 >> $out/${tag}_c4bench.log 2>&1
+python - > $out/${tag}_hbm_write_stream.log 2>&1 <<'PY'
+import ctypes as C, sys
+sys.path.insert(0, ".")
+from limbo_amd import _capi
+e = _capi.load_engine()
+g = C.c_double()
+e.fn("hbm_stream_peak")(0, C.byref(g))
+print(f"write-only stream, 1 GiB, 16 B per lane, best of 5: {g.value:.0f} GB/s  (the kernel-matrix build writes 67.3 MB per evaluation at N = 4096)")
+PY
+cd /tmp
+for v in 2 0; do GPE_KBUILD=$v GPE_STOP_EVENT=0 rocprofv3 --kernel-trace -d /tmp/p_kb$v -o p -- $B > /dev/null 2>&1; db=$(find /tmp/p_kb$v -name "*.db" | head -1); echo "GPE_KBUILD=$v" >> $out/${tag}_kernel_build_trace.txt; python $root/tools/kstats.py $db | grep -i "k_build" >> $out/${tag}_kernel_build_trace.txt; done
+for cnt in WRITE_SIZE FETCH_SIZE; do rocprofv3 --kernel-trace --pmc $cnt -d /tmp/p_kbp_$cnt -o p -- $B > /dev/null 2>&1; db=$(find /tmp/p_kbp_$cnt -name "*.db" | head -1); KSTATS_GRID=0 python $root/tools/kpmc.py $db | grep -i "k_build" >> $out/${tag}_kernel_build_trace.txt; done
+cd $root
 ls -la $out
