@@ -78,6 +78,7 @@ struct gpe_ctx {
     bool have_L = false, inv_ok = false, host_K = false, ll_ok = false;
     int nbo = 256; // outer panel width of the two-level blocked algorithms
     // one-launch small-N path (small.hip): pinned staging the kernels read / write directly, the word the host spins on
+    char* hPinned = nullptr;             // the one pinned allocation behind hInfo / hSmallSeq / hScal / hSmall
     double* hSmall = nullptr;            // [0..2): log-lik terms | [16 .. 16+8*GPE_MAX_P+8): kta, var | [256..): obs_mean / query points in
     unsigned long long* hSmallSeq = nullptr; // 8 sequence words (one per query point; word 0 for add_sample)
     unsigned long long small_seq = 0;
@@ -1069,18 +1070,20 @@ int gpe_create(int device_id, gpe_handle* out)
     c->device = device_id % phys;
     if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
         || create_bulk_stream(&c->stream2) != hipSuccess
-        || hipMalloc(&c->dScal, 8192) != hipSuccess
-        || hipMalloc(&c->dHead, sizeof(double) * 65 * NB * NB) != hipSuccess
-        // coherent (fine-grained) pinned memory: the small path's host side reads these while the stream is still busy
-        || hipHostMalloc(&c->hInfo, 64, getenv("GPE_INFO_COHERENT") ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault) != hipSuccess
-        || hipHostMalloc(&c->hScal, 8192) != hipSuccess
-        || hipHostMalloc(&c->hSmall, sizeof(double) * SMALL_STAGE_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
-        || hipHostMalloc(&c->hSmallSeq, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        // one device block [dScal 8 KiB | dHead 65 tiles] and one coherent (fine-grained) pinned block
+        // [hInfo 64 B | hSmallSeq 64 B | hScal 8 KiB | hSmall]: the small path's host side reads the pinned words while the
+        // stream is still busy; a fresh GP costs two allocations instead of six (each ~0.5-1 ms)
+        || hipMalloc(&c->dScal, 8192 + sizeof(double) * 65 * NB * NB) != hipSuccess
+        || hipHostMalloc(&c->hPinned, 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         delete c;
         return GPE_ERR_HIP;
     }
-    memset(c->hInfo, 0, 64);
-    memset(c->hSmallSeq, 0, 64);
+    c->dHead = c->dScal + 1024;
+    c->hInfo = (int*)c->hPinned;
+    c->hSmallSeq = (unsigned long long*)(c->hPinned + 64);
+    c->hScal = (double*)(c->hPinned + 128);
+    c->hSmall = c->hScal + 1024;
+    memset(c->hPinned, 0, 128);
     if (const char* f = getenv("GPE_SMALL"))
         c->small_path = atoi(f) != 0;
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
@@ -1117,11 +1120,7 @@ int gpe_destroy(gpe_handle c)
         hipEventDestroy(e);
     free_dev(c);
     hipFree(c->dScal);
-    hipFree(c->dHead);
-    hipHostFree(c->hInfo);
-    hipHostFree(c->hScal);
-    hipHostFree(c->hSmall);
-    hipHostFree(c->hSmallSeq);
+    hipHostFree(c->hPinned);
     for (auto e : c->la_events)
         hipEventDestroy(e);
     hipStreamSynchronize(c->stream2);

@@ -377,3 +377,29 @@ def test_gpu_general_path_at_small_n():
     env = dict(os.environ, GPE_SMALL="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_gpu_set_L_with_lambda_columns(engine_lib):
+    """load(archive, recompute=false) (gp.hpp:506-509) on an SE-ARD kernel with Lambda columns: gpe_set_L must also form the
+    projections Lambda^T x of the training samples that the cross-kernel reads — a handle that never ran
+    compute() answers queries exactly like the one the factor came from."""
+    rng = np.random.default_rng(12)
+    N, D, lam = 150, 4, 2
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = np.sin(3 * X.sum(axis=1))[:, None]
+    om, mean = synth.obs_mean_data(Y)
+    th = rng.uniform(-0.4, 0.4, size=D + D * lam + 1)
+    a = new_gp(engine_lib, O.SE_ARD, X, om, th, 0.01)
+    assert a.compute() == 0
+    b = _capi.Handle(engine_lib)
+    b.set_data(X, om)
+    b.set_kernel(O.SE_ARD, th, 0.01)
+    b.set_L(a.get_L())
+    b.set_alpha(a.get_alpha())
+    Xq = rng.uniform(0, 1, size=(20, D))
+    for M in (1, 20):  # the small path and the batched one
+        ka, va = a.query_batch(Xq[:M])
+        kb, vb = b.query_batch(Xq[:M])
+        assert np.max(np.abs(ka - kb)) <= 1e-12 * np.max(np.abs(ka)) and np.max(np.abs(va - vb)) <= 1e-12
+    a.close()
+    b.close()
