@@ -1030,6 +1030,15 @@ struct DevGuard {
     explicit DevGuard(gpe_ctx* c) { hipSetDevice(c->device); }
 };
 
+// what survives a handle: see gpe_create
+struct HandleShell {
+    hipStream_t stream, stream2;
+    double* dScal;
+    char* hPinned;
+};
+std::mutex g_shell_mu;
+std::vector<HandleShell> g_shells[16];
+
 // Devices as the callers count them.  GPE_VIRTUAL_DEVICES=n (tests): n logical devices dealt round-robin over the
 // physical ones, so that the multi-device placement of the C++ policies (clones of one GP on several devices,
 // gpe_clone_to) is exercised on a one-GPU box.
@@ -1068,13 +1077,34 @@ int gpe_create(int device_id, gpe_handle* out)
     gpe_ctx* c = new gpe_ctx();
     c->ldevice = device_id;
     c->device = device_id % phys;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
-        || create_bulk_stream(&c->stream2) != hipSuccess
-        // one device block [dScal 8 KiB | dHead 65 tiles] and one coherent (fine-grained) pinned block
-        // [hInfo 64 B | hSmallSeq 64 B | hScal 8 KiB | hSmall]: the small path's host side reads the pinned words while the
-        // stream is still busy; a fresh GP costs two allocations instead of six (each ~0.5-1 ms)
-        || hipMalloc(&c->dScal, 8192 + sizeof(double) * 65 * NB * NB) != hipSuccess
-        || hipHostMalloc(&c->hPinned, 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    if (hipSetDevice(c->device) != hipSuccess) {
+        delete c;
+        return GPE_ERR_HIP;
+    }
+    // Streams, the scratch block and the pinned block of a destroyed handle are kept for the next one on that device
+    // (limbo creates and drops GPs freely: value semantics, one clone per hyper-parameter fit and thread —
+    // kernel_lf_opt.hpp:79; creating two streams and a pinned allocation costs milliseconds).
+    bool reused = false;
+    if (c->device < 16) {
+        std::lock_guard<std::mutex> lk(g_shell_mu);
+        auto& pool = g_shells[c->device];
+        if (!pool.empty()) {
+            const HandleShell sh = pool.back();
+            pool.pop_back();
+            c->stream = sh.stream;
+            c->stream2 = sh.stream2;
+            c->dScal = sh.dScal;
+            c->hPinned = sh.hPinned;
+            reused = true;
+        }
+    }
+    if (!reused
+        && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || create_bulk_stream(&c->stream2) != hipSuccess
+            // one device block [dScal 8 KiB | dHead 65 tiles] and one coherent (fine-grained) pinned block
+            // [hInfo 64 B | hSmallSeq 64 B | hScal 8 KiB | hSmall]: the small path's host side reads the pinned words while
+            // the stream is still busy
+            || hipMalloc(&c->dScal, 8192 + sizeof(double) * 65 * NB * NB) != hipSuccess
+            || hipHostMalloc(&c->hPinned, 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)) {
         delete c;
         return GPE_ERR_HIP;
     }
@@ -1119,13 +1149,24 @@ int gpe_destroy(gpe_handle c)
     for (auto e : c->pool)
         hipEventDestroy(e);
     free_dev(c);
-    hipFree(c->dScal);
-    hipHostFree(c->hPinned);
     for (auto e : c->la_events)
         hipEventDestroy(e);
     hipStreamSynchronize(c->stream2);
-    hipStreamDestroy(c->stream2);
-    hipStreamDestroy(c->stream);
+    bool kept = false;
+    if (c->device < 16) {
+        std::lock_guard<std::mutex> lk(g_shell_mu);
+        auto& pool = g_shells[c->device];
+        if (pool.size() < 64) {
+            pool.push_back(HandleShell{c->stream, c->stream2, c->dScal, c->hPinned});
+            kept = true;
+        }
+    }
+    if (!kept) {
+        hipFree(c->dScal);
+        hipHostFree(c->hPinned);
+        hipStreamDestroy(c->stream2);
+        hipStreamDestroy(c->stream);
+    }
     delete c;
     return GPE_OK;
 }
