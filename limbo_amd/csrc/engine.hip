@@ -2012,15 +2012,15 @@ static bool batch_compatible(const gpe_ctx* a, const gpe_ctx* b)
 // gpe_compute on Gc <= GPE_BT_MAXG compatible handles as ONE launch sequence (gridDim.z = Gc): the chain of small
 // latency-bound kernels of one factorisation does not fill the chip, Gc of them in lock-step do.  The handles' mutexes
 // are held by the caller.
-static int batch_compute_fused(gpe_ctx** cs, int Gc, int* rc)
+static int batch_enqueue_fused(gpe_ctx** cs, int Gc, int slot)
 {
     gpe_ctx* c0 = cs[0];
     DevGuard g(c0);
-    static thread_local BatchTab* dtab[16] = {nullptr}; // one device table per device, kept
-    if (c0->device >= 16)
+    static thread_local BatchTab* dtab[16][4] = {{nullptr}}; // device tables, kept: one per device and concurrent sub-batch
+    if (c0->device >= 16 || slot >= 4)
         return GPE_ERR_UNSUPPORTED;
-    if (!dtab[c0->device])
-        HIPCHK(c0, hipMalloc(&dtab[c0->device], sizeof(BatchTab)));
+    if (!dtab[c0->device][slot])
+        HIPCHK(c0, hipMalloc(&dtab[c0->device][slot], sizeof(BatchTab)));
     std::vector<BatchTab> tabv(1);
     BatchTab& t = tabv[0];
     memset(&t, 0, sizeof(t));
@@ -2047,17 +2047,22 @@ static int batch_compute_fused(gpe_ctx** cs, int Gc, int* rc)
         t.base0[k] = t.base[k][0];
         t.size[k] = sz[k];
     }
-    HIPCHK(c0, hipMemcpyAsync(dtab[c0->device], &t, sizeof(BatchTab), hipMemcpyHostToDevice, c0->stream));
+    HIPCHK(c0, hipMemcpyAsync(dtab[c0->device][slot], &t, sizeof(BatchTab), hipMemcpyHostToDevice, c0->stream));
     HIPCHK(c0, hipStreamSynchronize(c0->stream)); // `t` is pageable: the copy must have left it before it goes out of scope
     const bool la = c0->lookahead;
     c0->lookahead = false; // the batch fills the chip: one stream, no look-ahead split
-    g_batch.bt = dtab[c0->device];
+    g_batch.bt = dtab[c0->device][slot];
     g_batch.G = Gc;
     int e = compute_enqueue(c0);
     g_batch = BatchLaunch{};
     c0->lookahead = la;
-    if (e)
-        return e;
+    return e;
+}
+
+static int batch_finish_fused(gpe_ctx** cs, int Gc, int* rc)
+{
+    gpe_ctx* c0 = cs[0];
+    DevGuard g(c0);
     HIPCHK(c0, wait_stream(c0->stream));
     HIPCHK(c0, hipGetLastError());
     const int64_t nblk = (c0->N + NB - 1) / NB;
@@ -2093,17 +2098,47 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
         for (int g = 0; g < G; ++g)
             hs[g]->mu.lock();
         int worst = GPE_OK;
-        for (int g0 = 0; g0 < G; g0 += GPE_BT_MAXG) {
-            const int Gc = std::min(GPE_BT_MAXG, G - g0);
-            int e = Gc >= 2 ? batch_compute_fused(hs + g0, Gc, rc.data() + g0) : GPE_OK;
-            if (Gc < 2) {
-                DevGuard dg(hs[g0]);
-                rc[g0] = compute_enqueue(hs[g0]);
-                if (rc[g0] == GPE_OK)
-                    rc[g0] = compute_finish(hs[g0]);
+        // Sub-batches of <= GPE_BT_MAXG GPs, up to four in flight on their own streams: while one sub-batch is in its
+        // panel steps (latency-bound workgroups, one per CU) another one's matrix-core updates fill the chip.
+        static const int nsub_env = getenv("GPE_BATCH_SPLIT") ? atoi(getenv("GPE_BATCH_SPLIT")) : 2;
+        int nsub = std::max(1, std::min(4, nsub_env));
+        if (G < 16)
+            nsub = 1;
+        const int per = std::min(GPE_BT_MAXG, (G + nsub - 1) / nsub);
+        for (int g0 = 0; g0 < G;) {
+            // one wave of sub-batches
+            int starts[4], counts[4], nw = 0;
+            for (; nw < nsub && g0 < G; ++nw) {
+                starts[nw] = g0;
+                counts[nw] = std::min(per, G - g0);
+                g0 += counts[nw];
             }
-            if (e < 0)
-                worst = e;
+            int en[4];
+            for (int w = 0; w < nw; ++w) {
+                if (counts[w] >= 2)
+                    en[w] = batch_enqueue_fused(hs + starts[w], counts[w], w);
+                else {
+                    DevGuard dg(hs[starts[w]]);
+                    en[w] = compute_enqueue(hs[starts[w]]);
+                }
+            }
+            for (int w = 0; w < nw; ++w) {
+                if (en[w] != GPE_OK) {
+                    for (int q = 0; q < counts[w]; ++q)
+                        rc[starts[w] + q] = en[w];
+                    worst = en[w];
+                    continue;
+                }
+                if (counts[w] >= 2) {
+                    int e = batch_finish_fused(hs + starts[w], counts[w], rc.data() + starts[w]);
+                    if (e < 0)
+                        worst = e;
+                }
+                else {
+                    DevGuard dg(hs[starts[w]]);
+                    rc[starts[w]] = compute_finish(hs[starts[w]]);
+                }
+            }
         }
         for (int g = 0; g < G; ++g) {
             hs[g]->mu.unlock();
