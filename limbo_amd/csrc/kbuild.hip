@@ -358,14 +358,26 @@ __global__ __launch_bounds__(256) void k_build_wide(const double* __restrict__ X
         double za = 0.0, zb = 0.0;
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
-            if (d < D) {
+            if (KIND == 9) {
+                za = xa[0] + smem[cc];
+                zb = xb[0] + smem[cc];
+            }
+            else if (d < D) {
                 const double xj = smem[d * TILE + cc];
                 const double qa = (xa[d] - xj) * ie[d], qb = (xb[d] - xj) * ie[d];
                 za = fma(qa, qa, za);
                 zb = fma(qb, qb, zb);
             }
         }
-        double va = kfun_fast<KIND>(za, sf2), vb = kfun_fast<KIND>(zb, sf2);
+        double va, vb;
+        if (KIND == 9) { // measurement only (GPE_KBUILD=9): the store pattern without the arithmetic
+            va = za;
+            vb = zb;
+        }
+        else {
+            va = kfun_fast<KIND>(za, sf2);
+            vb = kfun_fast<KIND>(zb, sf2);
+        }
         if (i0 == j)
             va += diag_add;
         if (i0 + 1 == j)
@@ -420,6 +432,10 @@ void launch_build_K(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, con
     const bool fast = variant != 0;
     if (!fast || N <= 0 || (lda & 1)) {
         launch_build<0>(s, Xt, ldx, N, nullptr, 0, 0, kp, A, lda);
+        return;
+    }
+    if (variant == 9) {
+        launch_build_wide_kind<9>(s, Xt, ldx, N, kp, A, lda);
         return;
     }
     if (variant == 2) {
