@@ -411,8 +411,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g_)
         ra = ra < ma ? ra : ma;
         rb = rb < mb ? rb : mb;
     }
-    const double* pa = g.A + row0 + ra + (int64_t)wave * g.lda;
-    const double* pb = g.B + col0 + rb + (int64_t)wave * g.ldb;
+    // ktri (U U^T with U upper triangular, K^-1 = L^-T L^-1): the k range of a tile starts at max(row0, col0), which is a
+    // multiple of the tile edge and hence of BKT
+    const int64_t kbeg = g.ktri ? (row0 > col0 ? row0 : col0) : 0;
+    const double* pa = g.A + row0 + ra + ((int64_t)wave + kbeg) * g.lda;
+    const double* pb = g.B + col0 + rb + ((int64_t)wave + kbeg) * g.ldb;
     const int64_t astep = (int64_t)NWV * g.lda, bstep = (int64_t)NWV * g.ldb;
 
     auto issue = [&](int stage) {
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g_)
         for (int b = 0; b < RB; ++b)
             acc[a][b] = 0.0;
 
-    const int nk = (int)(g.k / BKT);
+    const int nk = (int)((g.k - kbeg) / BKT);
     GTS(0);
     issue(0);
     for (int t = 0; t < nk; ++t) {
@@ -579,6 +582,8 @@ static void launch_glds64(hipStream_t s, const GemmArgs& g0)
 
 static bool glds_ok(const GemmArgs& g)
 {
+    // (ktri — the U U^T product of K^-1 — is served by the register-staged kernel: through this one, which supports it, the
+    // product measured 12 % slower: tiles with k ranges from N down to 128 do not balance over two-per-CU workgroups)
     return !g.a_kmajor && !g.b_kmajor && !g.ktri && g.k >= 32 && g.k % 32 == 0 && (g.lda % 2) == 0 && (g.ldb % 2) == 0
         && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0;
 }
@@ -668,7 +673,7 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         const int64_t GB = g_batch.G; // a batched launch runs GB problems of this shape at once
         if (glds_ok(g) && GB * live_tiles(g, 128, 128) >= 200)
             tile = 128;
-        else if (glds_ok(g) && use_glds64 && GB * live_tiles(g, 64, 64) >= 96)
+        else if (glds_ok(g) && !g.ktri && use_glds64 && GB * live_tiles(g, 64, 64) >= 96) // (the 64 x 64 body has no ktri form)
             tile = 64; // deep-prefetch 64 x 64 glds kernel: also the latency-critical next-panel update
         else if (GB * live_tiles(g, 64, 64) >= 512)
             tile = 64;
@@ -679,7 +684,7 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         launch_glds128(s, g);
     else if (tile == 128)
         launch_tile<128, 128, 32, 2>(s, g);
-    else if (tile == 64 && glds_ok(g) && use_glds64)
+    else if (tile == 64 && glds_ok(g) && !g.ktri && use_glds64)
         launch_glds64(s, g);
     else if (tile == 64)
         launch_tile<64, 64, 32, 2>(s, g);
