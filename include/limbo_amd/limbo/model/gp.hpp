@@ -23,6 +23,7 @@
 #ifndef LIMBO_MODEL_GP_HPP
 #define LIMBO_MODEL_GP_HPP
 
+#include <algorithm>
 #include <cassert>
 #include <cfloat>
 #include <cmath>
@@ -43,6 +44,7 @@
 #include <limbo/model/gp/kernel_lf_opt.hpp>
 #include <limbo/model/gp/no_lf_opt.hpp>
 #include <limbo/tools/math.hpp>
+#include <limbo/tools/parallel.hpp>
 
 #include "../../../gpe.h"
 
@@ -653,6 +655,16 @@ namespace limbo {
             /// gp.hpp:550-571: K -> L -> alpha, all on the device
             void _compute_full_kernel()
             {
+                _stage_full_kernel();
+                _commit_full_kernel(_eng.check(gpe_compute(_eng.get()), "gpe_compute"));
+            }
+
+        public:
+            /// Additions: the two halves of `_compute_full_kernel` around the device factorisation, so that a caller
+            /// holding several independent GPs (model::MultiGP: one per output, multi_gp.hpp:124-126) can run all their
+            /// factorisations as ONE batched launch sequence (`compute_full_kernels_batched` -> gpe_batch_compute).
+            void _stage_full_kernel()
+            {
                 if (!_data_on_device)
                     _push_data();
                 else
@@ -668,10 +680,40 @@ namespace limbo {
                         }
                     _eng.check(gpe_set_K_host(_eng.get(), _kernel.data(), n), "gpe_set_K_host");
                 }
-                _status = _eng.check(gpe_compute(_eng.get()), "gpe_compute");
+            }
+            void _commit_full_kernel(int status)
+            {
+                _status = status;
                 _L_stale = _alpha_stale = _Kinv_stale = true;
                 _inv_kernel_updated = false; // gp.hpp:570
             }
+            /// `_compute_full_kernel()` of every GP in `gps` (data already set: compute(samples, obs, false) or an earlier
+            /// compute): GPs on the same device are stepped together by gpe_batch_compute (one launch sequence,
+            /// gridDim.z = GP, when they agree in shape; the engine falls back to per-GP chains otherwise)
+            static void compute_full_kernels_batched(const std::vector<GP*>& gps)
+            {
+                std::vector<int> devs;
+                for (GP* g : gps) {
+                    g->_stage_full_kernel();
+                    if (std::find(devs.begin(), devs.end(), g->device()) == devs.end())
+                        devs.push_back(g->device());
+                }
+                limbo::tools::par::loop(0, devs.size(), [&](size_t di) { // one host thread per device
+                    std::vector<GP*> mine;
+                    std::vector<gpe_handle> hs;
+                    for (GP* g : gps)
+                        if (g->device() == devs[di]) {
+                            mine.push_back(g);
+                            hs.push_back(g->_eng.get());
+                        }
+                    std::vector<int> st(hs.size(), 0);
+                    const int rc = gpe_batch_compute(hs.data(), (int)hs.size(), st.data());
+                    for (size_t i = 0; i < mine.size(); ++i)
+                        mine[i]->_commit_full_kernel(mine[i]->_eng.check(st[i] < 0 ? st[i] : (rc < 0 ? rc : st[i]), "gpe_batch_compute"));
+                });
+            }
+
+        protected:
 
             /// gp.hpp:573-603
             void _compute_incremental_kernel()

@@ -41,7 +41,11 @@ namespace limbo {
                     for (int i = 0; i < _dim_out; i++)
                         obs[i].push_back(limbo::tools::make_vector(observations[j](i) - mv(i)));
                 }
-                limbo::tools::par::loop(0, _dim_out, [&](size_t i) { _gp_models[i].compute(samples, obs[i], compute_kernel); });
+                // ingest per member (host work), then all factorisations as one batched launch sequence per device —
+                // the tools::par::loop of multi_gp.hpp:124-126 with the device doing the looping
+                limbo::tools::par::loop(0, _dim_out, [&](size_t i) { _gp_models[i].compute(samples, obs[i], false); });
+                if (compute_kernel)
+                    _compute_kernels();
             }
 
             void optimize_hyperparams() { _hp_optimize(*this); }
@@ -113,7 +117,10 @@ namespace limbo {
                     const std::vector<Eigen::VectorXd> samples = _gp_models[0].samples();
                     return compute(samples, std::vector<Eigen::VectorXd>(_observations), update_full_kernel);
                 }
-                limbo::tools::par::loop(0, _dim_out, [&](size_t i) { _gp_models[i].recompute(false, update_full_kernel); });
+                if (update_full_kernel)
+                    _compute_kernels();
+                else
+                    limbo::tools::par::loop(0, _dim_out, [&](size_t i) { _gp_models[i].recompute(false, false); });
             }
 
             const std::vector<Eigen::VectorXd>& samples() const
@@ -194,6 +201,13 @@ namespace limbo {
             std::vector<Eigen::VectorXd> _observations;
             Eigen::VectorXd _mean_observation;
 
+            void _compute_kernels()
+            {
+                std::vector<GP_t*> ptrs;
+                for (auto& g : _gp_models)
+                    ptrs.push_back(&g);
+                GP_t::compute_full_kernels_batched(ptrs);
+            }
             void _make_models()
             {
                 _gp_models.clear();

@@ -972,7 +972,8 @@ CASE(test_multi_device_placement)
         VectorXd m;
         double s2;
         std::tie(m, s2) = single.query(q);
-        CHECK(m(0) == mu(p) && s2 == sig(p));
+        // (the members' factorisations run as one batched launch sequence: equal to a lone GP to rounding, not bitwise)
+        CHECK(std::abs(m(0) - mu(p)) <= 1e-10 * std::max(1.0, std::abs(mu(p))) && std::abs(s2 - sig(p)) <= 1e-10 * sig(p));
     }
     // restarts of a hyper-parameter fit: one private clone per restart thread, dealt over the devices
     {

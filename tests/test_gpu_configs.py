@@ -403,3 +403,69 @@ def test_gpu_set_L_with_lambda_columns(engine_lib):
         assert np.max(np.abs(ka - kb)) <= 1e-12 * np.max(np.abs(ka)) and np.max(np.abs(va - vb)) <= 1e-12
     a.close()
     b.close()
+
+
+def _rprop(f, init, iterations, eps_stop=0.0):
+    """opt::Rprop as written (src/limbo/opt/rprop.hpp:84-144): maximises f, returns the best point SEEN"""
+    delta0, dmin, dmax, em, ep = 0.1, 1e-6, 50.0, 0.5, 1.2
+    params = np.array(init, float)
+    delta = np.full(params.size, delta0)
+    grad_old = np.zeros(params.size)
+    best, best_params = -np.inf, params.copy()
+    for _ in range(iterations):
+        lik, g = f(params)
+        if lik > best:
+            best, best_params = lik, params.copy()
+        grad = -g
+        grad_old = grad_old * grad
+        for j in range(params.size):
+            if grad_old[j] > 0:
+                delta[j] = min(delta[j] * ep, dmax)
+            elif grad_old[j] < 0:
+                delta[j] = max(delta[j] * em, dmin)
+                grad[j] = 0
+            params[j] += -np.sign(grad[j]) * delta[j]
+        grad_old = grad
+        if np.linalg.norm(grad_old) < eps_stop:
+            break
+    return best_params, best
+
+
+@pytest.mark.parametrize("N,on", [(300, False), (700, True)])
+def test_gpu_kernel_lf_opt_fit_vs_oracle_and_reference(engine_lib, oracle_lib, N, on):
+    """BASELINE configs[1]'s workload end to end: a KernelLFOpt fit (model/gp/kernel_lf_opt.hpp:60-92 + opt/rprop.hpp) whose
+    objective — likelihood and gradient — comes from the device (gpe_hp_objective), 30 iterations.  Rprop only looks at the
+    SIGNS of the gradient, so the device-driven fit walks the same iterates as the oracle's and, at N = 300, as the
+    reference's own optimize_hyperparams() on limbo::model::GP: same parameters, same likelihood."""
+    rng = np.random.default_rng(31 + N)
+    D = 3
+    X = rng.uniform(-2, 2, size=(N, D))
+    Y = (np.sin(X[:, 0]) * np.cos(X[:, 1]) + 0.3 * X[:, 2])[:, None] + 0.05 * rng.normal(size=(N, 1))
+    om, _ = synth.obs_mean_data(Y)
+    g = new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(D + 1), 0.01)
+    calls = []
+
+    def objective(p):
+        th, noise = (p[:-1], float(np.exp(2 * p[-1]))) if on else (p, 0.01)
+        lik, grad, info = g.hp_objective(O.SE_ARD, th, noise, optimize_noise=on, want_grad=True)
+        assert info == 0
+        calls.append(lik)
+        return lik, grad
+
+    init = np.concatenate([np.zeros(D + 1), [np.log(np.sqrt(0.01))]]) if on else np.zeros(D + 1)
+    th_g, ll_g = _rprop(objective, init, 30)
+    o = new_gp(oracle_lib, O.SE_ARD, X, om, np.zeros(D + 1), 0.01)
+    assert o.compute() == 0
+    th_o, ll_o, nev = OB.kernel_lf_opt_rprop(o, optimize_noise=on, iterations=30, eps_stop=0.0)
+    assert nev == 30 and len(calls) == 30
+    assert np.max(np.abs(th_g - th_o)) <= 1e-9, (th_g, th_o)
+    assert abs(ll_g - ll_o) <= 1e-9 * abs(ll_o)
+    assert ll_g > calls[0]  # the fit improved the likelihood
+    if N <= 300 and OB.ref_available():
+        r = OB.RefGP(O.SE_ARD, D, 1, noise=0.01, optimize_noise=on)
+        r.compute(X, Y)
+        r.optimize_hyperparams(OB.OPT_KERNEL_LF, iterations=30, eps_stop=0.0)
+        assert np.max(np.abs(th_g - r.h_params())) <= 1e-9
+        assert abs(ll_g - r.log_lik()) <= 1e-9 * abs(ll_g)
+    g.close()
+    o.close()
