@@ -54,6 +54,7 @@ struct gpe_ctx {
     bool fuse_diag = true;      // next diagonal block factored inside the next-panel update launch (k_upd_fused)
     bool lookahead = true;             // GPE_LOOKAHEAD=0 disables
     int bulk_wgs = 192;                // physical workgroups of a look-ahead bulk update (GPE_BULK_WGS)
+    int64_t bulk_free_tiles = 384;     // ... unless it has at least this many 128 x 128 tiles (GPE_BULK_FREE_TILES): N > 4096
     std::mutex mu;
     int64_t N = 0, cap = 0, ld = 0;
     int D = 0, P = 0;
@@ -496,8 +497,14 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 const int64_t pe3 = std::min<int64_t>(pe2 + nbo, N);
                 upd(c->stream2, pe2, pe3, pe2, c->bulk_wgs, nullptr, 64); // near: what panel kp + 1's update needs
                 hipEventRecord(ev(3 * kp + 1), c->stream2);
-                if (pe3 < N)
-                    upd(c->stream2, pe3, N, pe3, c->bulk_wgs); // 1 workgroup per CU: leaves 256 - bulk_wgs CUs to the panel
+                if (pe3 < N) {
+                    // 1 looping workgroup per CU on bulk_wgs CUs leaves 256 - bulk_wgs CUs to the panel.  When the update
+                    // is many times longer than a panel (large trailing matrices: N = 16384 has 8 k tiles in its first
+                    // ones) the reserve idles most of the time: above bulk_free_tiles tiles the update is dispatched
+                    // unrestricted and the panel's workgroups take CUs as tiles retire (43.4 -> 34.6 ms at N = 16384)
+                    const int64_t nt128 = (N - pe3 + 127) / 128, far_tiles = nt128 * (nt128 + 1) / 2;
+                    upd(c->stream2, pe3, N, pe3, far_tiles >= c->bulk_free_tiles ? 0 : c->bulk_wgs);
+                }
                 hipEventRecord(ev(3 * kp + 2), c->stream2);
                 la_pending = true;
                 la_last = 3 * kp + 2;
@@ -1119,6 +1126,8 @@ int gpe_create(int device_id, gpe_handle* out)
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
     if (const char* f = getenv("GPE_BULK_WGS"))
         c->bulk_wgs = atoi(f);
+    if (const char* f = getenv("GPE_BULK_FREE_TILES"))
+        c->bulk_free_tiles = atoll(f);
     if (const char* f = getenv("GPE_FUSE_DIAG"))
         c->fuse_diag = atoi(f) != 0;
     if (const char* f = getenv("GPE_STOP_EVENT"))
@@ -1960,6 +1969,7 @@ int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out)
     c->small_path = src->small_path;
     c->lookahead = src->lookahead;
     c->bulk_wgs = src->bulk_wgs;
+    c->bulk_free_tiles = src->bulk_free_tiles;
     c->host_K = src->host_K;
     if (src->dA) {
         rc = alloc_dev(c, src->cap, src->D, src->P);
