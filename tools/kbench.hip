@@ -8,6 +8,7 @@
 #include <vector>
 #include <random>
 
+thread_local BatchLaunch g_batch; // dev.h: single-GP launches
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 int main(int argc, char** argv)
