@@ -287,7 +287,21 @@ struct SmallQueryArgs {
     int want_kta, want_var;
 };
 
+struct SmallAlphaArgs {
+    const double* L;
+    int64_t ld;
+    const double* Xinv;
+    const double* om_src; // obs_mean to solve for: pinned host memory (ldom = n) or the device copy (ldom = ld)
+    int64_t ldom;
+    double* Om;           // device obs_mean to refresh (null: om_src IS the device copy)
+    double* Al;
+    double* out;          // pinned: [0] sum log L_ii, [1] sum obs_mean . alpha
+    unsigned long long* seq;
+    unsigned long long seq_val;
+    int n;
+};
 int small_max_n();
+void launch_small_alpha(hipStream_t s, const SmallAlphaArgs& g, int P);
 void launch_small_add(hipStream_t s, const SmallAddArgs& g, int P, const KParams& kp, const LamParams& lp, const double* x);
 void launch_small_query(hipStream_t s, const SmallQueryArgs& g, const KParams& kp, const LamParams& lp);
 

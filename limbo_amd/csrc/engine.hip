@@ -1298,6 +1298,40 @@ int gpe_update_alpha(gpe_handle c, const double* obs_mean)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->small_path && c->N <= small_max_n() && c->P <= 4 && (int64_t)c->N * c->P <= 1024) {
+        // one launch, no copies (small.hip): obs_mean read from pinned memory (or the device copy when none is given)
+        SmallAlphaArgs a{};
+        a.L = c->dA;
+        a.ld = c->ld;
+        a.Xinv = c->dXinv;
+        if (obs_mean) {
+            memcpy(c->hSmall + 256, obs_mean, sizeof(double) * (size_t)(c->N * c->P));
+            a.om_src = c->hSmall + 256;
+            a.ldom = c->N;
+            a.Om = c->dOm;
+        }
+        else {
+            a.om_src = c->dOm;
+            a.ldom = c->ld;
+            a.Om = nullptr;
+        }
+        a.Al = c->dAl;
+        a.out = c->hSmall;
+        a.seq = c->hSmallSeq;
+        a.seq_val = ++c->small_seq;
+        a.n = (int)c->N;
+        launch_small_alpha(c->stream, a, c->P);
+        c->al_prefilled = false;
+        c->ll_partials = 0;
+        ++c->small_calls;
+        int rc = small_wait(c, 1, a.seq_val);
+        if (rc)
+            return rc;
+        c->hScal[0] = c->hSmall[0];
+        c->hScal[1] = c->hSmall[1];
+        c->ll_ok = true;
+        return GPE_OK;
+    }
     if (obs_mean)
         HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * c->ld, obs_mean, sizeof(double) * c->N,
                                    sizeof(double) * c->N, c->P, hipMemcpyHostToDevice, c->stream));

@@ -407,6 +407,58 @@ __global__ __launch_bounds__(SM_T) void k_small_query(SmallQueryArgs g, KParams 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// recompute(., false) / _compute_alpha (gp.hpp:241-252, :605-611) below 256 samples: new obs_mean, same factor.
+// alpha = L^-T L^-1 obs_mean and the two log-likelihood sums, one launch, obs_mean read from pinned host memory.
+template <int P>
+__global__ __launch_bounds__(SM_T) void k_small_alpha(SmallAlphaArgs g)
+{
+    __shared__ SmallLds S;
+    const int tid = threadIdx.x;
+    const int n = g.n;
+    SmallCtx c{g.L, g.ld, g.Xinv, n};
+    double T[SM_NT];
+    load_tiles(c, T, S);
+    const int ic = tid < n ? tid : 0;
+    const double ldiag = (tid < n) ? g.L[ic + (int64_t)ic * g.ld] : 1.0;
+    double om_i[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        om_i[p] = (tid < n) ? g.om_src[tid + (int64_t)p * g.ldom] : 0.0;
+    if (tid < SM_NBLK * NB) {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            S.v[p][tid] = om_i[p];
+    }
+    __syncthreads();
+    small_fwd<P>(c, T, S);
+    small_bwd<P>(c, T, S, 0);
+    double s_oa = 0.0;
+    if (tid < n) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const double a = S.v[p][tid];
+            g.Al[tid + (int64_t)p * g.ld] = a;
+            if (g.Om)
+                g.Om[tid + (int64_t)p * g.ld] = om_i[p];
+            s_oa = fma(om_i[p], a, s_oa);
+        }
+    }
+    const double s_ld = block_sum(tid < n ? log(ldiag) : 0.0, S.red);
+    const double s_tot = block_sum(s_oa, S.red);
+    if (tid == 0) {
+        g.out[0] = s_ld;
+        g.out[1] = s_tot;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence_system();
+        __hip_atomic_store(g.seq, g.seq_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 int small_max_n() { return SM_NBLK * NB; }
 
@@ -426,4 +478,16 @@ void launch_small_add(hipStream_t s, const SmallAddArgs& g, int P, const KParams
 void launch_small_query(hipStream_t s, const SmallQueryArgs& g, const KParams& kp, const LamParams& lp)
 {
     hipLaunchKernelGGL(k_small_query, dim3((unsigned)g.M), dim3(SM_T), 0, s, g, kp, lp);
+}
+
+void launch_small_alpha(hipStream_t s, const SmallAlphaArgs& g, int P)
+{
+    if (P == 1)
+        hipLaunchKernelGGL(k_small_alpha<1>, dim3(1), dim3(SM_T), 0, s, g);
+    else if (P == 2)
+        hipLaunchKernelGGL(k_small_alpha<2>, dim3(1), dim3(SM_T), 0, s, g);
+    else if (P == 3)
+        hipLaunchKernelGGL(k_small_alpha<3>, dim3(1), dim3(SM_T), 0, s, g);
+    else
+        hipLaunchKernelGGL(k_small_alpha<4>, dim3(1), dim3(SM_T), 0, s, g);
 }

@@ -355,6 +355,22 @@ def test_gpu_small_path_vs_oracle(engine_lib, oracle_lib, kind, D, P, lam):
         assert g.small_calls() > 0  # the path under test did serve these calls
     else:
         assert g.small_calls() == 0
+    # recompute(., false): new observations, same factor — the small path's alpha refresh at 262 samples is the general one;
+    # at 200 (a second pair of handles) it is the one-launch form
+    for M in (n1, 200):
+        omM, _ = synth.obs_mean_data(Y[:M])
+        g2 = new_gp(engine_lib, kind, X[:M], omM, th, noise)
+        o2 = new_gp(oracle_lib, kind, X[:M], omM, th, noise)
+        assert g2.compute() == 0 and o2.compute() == 0
+        om2 = omM[::-1].copy() * 1.5
+        g2.update_alpha(om2)
+        o2.update_alpha(om2)
+        assert relerr_norm(g2.get_alpha(), o2.get_alpha()) < 1e-8
+        assert abs(g2.log_lik() - o2.log_lik()) <= PC.TOL_LL * abs(o2.log_lik())
+        g2.update_alpha()  # no new observations: the device copy
+        assert relerr_norm(g2.get_alpha(), o2.get_alpha()) < 1e-8
+        g2.close()
+        o2.close()
     # the gradient and K^-1 work from the state the small path left (block inverses included)
     go, gg = o.log_lik_grad(False), g.log_lik_grad(False)
     assert np.linalg.norm(gg - go) <= PC.TOL_GRAD * np.linalg.norm(go)
