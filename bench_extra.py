@@ -76,6 +76,16 @@ def main():
     out["c3_compute_loglik_s"] = dt
     out["c3_compute_tflops"] = (N3 ** 3 / 3.0 + 2.0 * N3 * N3) / dt / 1e12
     out["c3_compute_frac_of_fp64_peak"] = (N3 ** 3 / 3.0 + 2.0 * N3 * N3) / dt / PEAK
+    # the trailing updates of this factorisation, each launch timed alone with HIP events on the handle's stream (as bench.py's
+    # `roofline` does at N = 4096): 63 launches, 1.4e12 flop
+    h.set_profiling(True)
+    h.reset_phase_ms()
+    h.compute()
+    ph3 = h.get_phase_ms()["potrf_update"]
+    h.set_profiling(False)
+    out["c3_trailing_update_tflops"] = ph3["flops"] / (ph3["ms"] * 1e-3) / 1e12
+    out["c3_trailing_update_frac_of_fp64_peak"] = ph3["flops"] / (ph3["ms"] * 1e-3) / PEAK
+    out["c3_trailing_update_launches"] = ph3["launches"]
     out["c3_info"] = int(info)
     M3 = 10000 if args.quick else 100000
     Xq3 = rng.uniform(0, 1, size=(M3, 12))
