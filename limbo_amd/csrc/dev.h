@@ -152,8 +152,11 @@ void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b
 // the tiles of the nf fused steps of the panel at p0 (nt0 = tiles of its first step) into A.
 // dnext / dfirst (>= 0 to enable): see k_panel_step — pieces of the next outer panel's first diagonal block
 void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
-                       double* Xt_next, int do_next, int* info, double* Hs, int64_t dnext = -1, int64_t dfirst = -1,
-                       int dinit = 0, double* Dacc = nullptr);
+                       double* Xt_next, int do_next, int* info, double* Hs, int64_t dnext, int64_t dfirst, int dinit,
+                       double* Dacc, unsigned* hflag);
+// the device block behind gpe_ctx::dHead: 32 + 32 head tiles (by panel parity), the scratch sum of the next diagonal
+// block, and one tile's worth of hand-over flag words (hflag: one unsigned per head tile, same indexing as the tiles)
+#define GPE_HEAD_TILES 66
 void launch_head_copy(hipStream_t s, double* A, int64_t lda, int64_t p0, int nt0, int nf, const double* H);
 // inverses of diagonal blocks b0 .. b0+nblocks-1 of an existing factor L (order N) into
 // Xt_all + 4096 b

@@ -368,7 +368,8 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 const int64_t dfirst_at = nbo >= 3 * NB ? p0 + 2 * NB : p0 + NB;
                 launch_panel_step(s, A, ld, j0, M, nt, Xt, Xt + NB * NB, nt > 0 ? 1 : 0, c->dInfo, Hbase + htile * NB * NB,
                                   pre ? pe : -1, pre && j0 == dfirst_at ? p0 : -1, j0 == p0 + NB ? 1 : 0,
-                                  c->dHead + 64 * NB * NB);
+                                  c->dHead + 64 * NB * NB,
+                                  (unsigned*)(c->dHead + 65 * NB * NB) + ((p0 / nbo) & 1) * 32 + htile);
                 htile += nt;
                 if (nt > 0)
                     ++nf;
@@ -1107,10 +1108,12 @@ int gpe_create(int device_id, gpe_handle* out)
     }
     if (!reused
         && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || create_bulk_stream(&c->stream2) != hipSuccess
-            // one device block [dScal 8 KiB | dHead 65 tiles] and one coherent (fine-grained) pinned block
+            // one device block [dScal 8 KiB | dHead GPE_HEAD_TILES tiles] and one coherent (fine-grained) pinned block
             // [hInfo 64 B | hSmallSeq 64 B | hScal 8 KiB | hSmall]: the small path's host side reads the pinned words while
             // the stream is still busy
-            || hipMalloc(&c->dScal, 8192 + sizeof(double) * 65 * NB * NB) != hipSuccess
+            || hipMalloc(&c->dScal, 8192 + sizeof(double) * GPE_HEAD_TILES * NB * NB) != hipSuccess
+            // the hand-over flag words start from zero, in the order of the stream the panel steps run on
+            || hipMemsetAsync(c->dScal + 1024 + 65 * NB * NB, 0, sizeof(double) * NB * NB, c->stream) != hipSuccess
             || hipHostMalloc(&c->hPinned, 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)) {
         delete c;
         return GPE_ERR_HIP;
@@ -2085,7 +2088,7 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, int slot)
     const size_t dbl = sizeof(double);
     const unsigned long long sz[GPE_BT_CLS] = {(unsigned long long)(dbl * c0->ld * c0->cap), (unsigned long long)(dbl * c0->ld * xt_rows(c0->D)),
                                                (unsigned long long)(dbl * c0->ld * c0->P), (unsigned long long)(dbl * c0->ld * c0->P),
-                                               (unsigned long long)(dbl * (c0->cap / NB) * NB * NB), (unsigned long long)(dbl * 65 * NB * NB), 64, 8192,
+                                               (unsigned long long)(dbl * (c0->cap / NB) * NB * NB), (unsigned long long)(dbl * GPE_HEAD_TILES * NB * NB), 64, 8192,
                                                0, 0};
     for (int k = 0; k < GPE_BT_CLS; ++k) {
         t.base0[k] = t.base[k][0];

@@ -24,6 +24,7 @@
 // own non-critical columns are caught up one round later (4 LDS buffers keep that legal).
 #include "dev.h"
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <cstdio>
 
 #define NB 64
@@ -32,9 +33,14 @@
 #endif
 #ifdef DIAG_TIMING
 __device__ long long g_diag_arr[16][8]; // per round: arrival of waves 0-3 and of the inversion wave (4) at the closing barrier
-#define ARR(G, w) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_diag_arr[G][w] = clock64(); } while (0)
 __device__ long long g_diag_ts[32];
+#ifdef DIAG_NO_STAMPS // the arrays exist for tools/diagbench.hip, the kernel is the shipped one
+#define ARR(G, w) do { } while (0)
+#define TS(i) do { } while (0)
+#else
+#define ARR(G, w) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_diag_arr[G][w] = clock64(); } while (0)
 #define TS(i) do { if (threadIdx.x == 0) g_diag_ts[i] = clock64(); } while (0)
+#endif
 #else
 #define TS(i) do { } while (0)
 #define ARR(G, w) do { } while (0)
@@ -481,6 +487,16 @@ static __device__ __forceinline__ void xpipe32_wave(const double* __restrict__ L
 #endif
 }
 
+#ifndef DIAG_FLOW
+#define DIAG_FLOW 1 // 1: the data-flow form of the block factorisation (diag_flow.h); 0: the barrier rounds above
+#endif
+#include "diag_flow.h"
+#if DIAG_FLOW
+#define DIAG_THREADS 448
+#else
+#define DIAG_THREADS 320
+#endif
+
 // ---- inversion of the 64 x 64 lower-triangular L (in LDS, Ls[row * XS + col]) --------------------
 // acc[n] += sum_{k < 16} P[i0 + i][pk0 + k] * Q[qk0 + k][j0 + 4 n + j]   (16 x 16 x 16, n in [n0, n1))
 static __device__ __forceinline__ void mm16(const double* __restrict__ P, int i0, int pk0, const double* __restrict__ Q,
@@ -591,9 +607,22 @@ static __device__ __forceinline__ void diag_body(double* __restrict__ A, int64_t
 {
     __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ltb[DIAG_LTB];
-    __shared__ double invd[NB];
-    __shared__ int sbad;
+    __shared__ __attribute__((aligned(16))) double invd[NB];
     const int r = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if DIAG_FLOW
+    __shared__ DiagSync sy;
+    static_assert(DIAG_H_DOUBLES <= DIAG_LTB, "H fits where the round buffers were");
+    TS(0);
+    for (int e = threadIdx.x; e < NB * NB; e += DIAG_THREADS)
+        Ls[(e & 63) * XS + (e >> 6)] = A[(e & 63) + (int64_t)(e >> 6) * lda];
+    diag_flow_init(&sy);
+    __syncthreads();
+    TS(1);
+    diag_flow(Ls, Ltb, invd, &sy, A, lda, Xt, info, goff, w, r);
+    TS(2);
+    return;
+#endif
+    __shared__ int sbad;
     if (threadIdx.x == 0)
         sbad = 0;
     double a[4][4];
@@ -628,12 +657,12 @@ static __device__ __forceinline__ void diag_body(double* __restrict__ A, int64_t
     TS(3);
 }
 // entry points: single GP (the round-1 kernel, unchanged) / batched (gridDim.z GPs, pointers rebased; dev.h)
-__global__ __launch_bounds__(320) void k_diag(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
+__global__ __launch_bounds__(DIAG_THREADS) void k_diag(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
                                               int* __restrict__ info, int64_t goff)
 {
     diag_body(A, lda, Xt, info, goff);
 }
-__global__ __launch_bounds__(320) void k_diag_b(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
+__global__ __launch_bounds__(DIAG_THREADS) void k_diag_b(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
                                                 int* __restrict__ info, int64_t goff, const BatchTab* __restrict__ bt)
 {
     BT_REBASE(bt, A);
@@ -731,9 +760,9 @@ void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int*
     if (half_form && jb == NB)
     {
         if (g_batch.bt)
-            hipLaunchKernelGGL(k_diag_b, dim3(1, 1, g_batch.G), dim3(320), 0, s, A, lda, Xt, info, goff, g_batch.bt);
+            hipLaunchKernelGGL(k_diag_b, dim3(1, 1, g_batch.G), dim3(DIAG_THREADS), 0, s, A, lda, Xt, info, goff, g_batch.bt);
         else
-            hipLaunchKernelGGL(k_diag, dim3(1), dim3(320), 0, s, A, lda, Xt, info, goff);
+            hipLaunchKernelGGL(k_diag, dim3(1), dim3(DIAG_THREADS), 0, s, A, lda, Xt, info, goff);
     }
     else
         hipLaunchKernelGGL(k_diag_full, dim3(1, 1, g_batch.G), dim3(256), 0, s, A, lda, jb, Xt, info, goff, g_batch.bt);
@@ -871,7 +900,10 @@ static __device__ __forceinline__ void wave_tile_to_rows(const double (&acc)[2][
     }
 }
 
-#define PANEL_PRE 3 // head tiles prefetched into registers at kernel start (nbo = 256 needs 3)
+#define PANEL_PRE 3 // head tiles held in registers (nbo = 256 needs 3)
+#ifndef PANEL_HANDOVER
+#define PANEL_HANDOVER 1 // 1: head tiles are handed over through Hs + flags; 0: every workgroup re-derives them (round 1)
+#endif
 
 // dnext >= 0: the workgroup that owns rows dnext .. dnext+63 (the next OUTER panel's first diagonal block) also
 // adds its L L^T to the 64 x 64 scratch Dacc (lane = row order of a workgroup's C tile; dinit: starts the sum) —
@@ -883,7 +915,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                                                        const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                        int do_next, int* __restrict__ info, double* __restrict__ Hs,
                                                        int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
-                                                       const int bx)
+                                                       unsigned* hflag, unsigned epoch, const int bx)
 {
     // one LDS array, carved: [Bx | T0 | T1 | Ld]; workgroup 0 re-carves it as [Ls | Ltb | invd]
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + 32 * XS];
@@ -910,10 +942,12 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
 #pragma unroll
     for (int q = 0; q < 8; ++q)
         xv[q] = Xt_cur[threadIdx.x + 512 * q];
+#if !PANEL_HANDOVER
 #pragma unroll
     for (int t = 0; t < PANEL_PRE; ++t)
         if (t <= tmax && t != b)
             head[t].load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
+#endif
     double ldv[2]; // L21 of the diagonal block at (j0, j0): rows 32..63, columns 0..31
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -966,6 +1000,59 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
     }
 
     PTS(3);
+#if PANEL_HANDOVER
+    // Head tiles change hands instead of being re-derived by every workgroup (round 2; the stamps of tools/kbench_t showed
+    // the last workgroup of a first step at 66 k cycles, 47 k of them three re-derived head tiles + updates, against 40 k for
+    // workgroup 0 INCLUDING the diagonal block).  A head workgroup publishes: its tile is in Hs, device-wide, then
+    // hflag[b] = this launch's epoch (a value no earlier launch used: the words are never reset).  Consumers need only
+    // lower-numbered head tiles and the heads wait for nobody but lower-numbered heads, so with workgroups dispatched in
+    // index order nobody can wait for a workgroup that is not running; the wait is bounded all the same and a workgroup that
+    // runs out of patience re-derives the tiles from A as before (A's head rows are intact until k_head_copy).
+    if (b < nt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's stores have reached the L2 of this XCD ...
+        __syncthreads();
+        if (threadIdx.x == 0) { // ... and ONE release writes that L2 back for the other XCDs (one per wave cost 7.5 k cycles)
+            __threadfence();
+            __hip_atomic_store(hflag + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    bool handed = true;
+    {
+        const int nneed = tmax < b ? tmax + 1 : tmax; // tiles t <= tmax, t != b  (b > tmax: all of 0..tmax; else all but b)
+        if (nneed > 0) {
+            if (threadIdx.x == 0) {
+                int ok = 1;
+                for (int t = 0; t <= tmax && ok; ++t) {
+                    if (t == b)
+                        continue;
+                    int spins = 0;
+                    while (__hip_atomic_load(hflag + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                        if (++spins > GPE_FLOW_SPIN_LIMIT) {
+                            ok = 0;
+                            break;
+                        }
+                }
+                sbad = ok; // (sbad is free until workgroup 0's factorisation, which has nneed == 0)
+            }
+            __syncthreads();
+            handed = sbad != 0;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                sbad = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // this CU's vector cache may hold last step's tiles
+#pragma unroll
+            for (int t = 0; t < PANEL_PRE; ++t)
+                if (t <= tmax && t != b) {
+                    if (handed)
+                        head[t].load(Hs + (int64_t)t * (NB * NB), NB, NB);
+                    else
+                        head[t].load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
+                }
+        }
+    }
+#else
+    const bool handed = false;
+#endif
     // 2. in-panel updates of this row block
     double cres[8]; // workgroup 0: the updated next diagonal block (lane = row layout)
 #pragma unroll 1
@@ -985,11 +1072,15 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                 head[2].store(T1);
             else {
                 TileRegs late;
-                late.load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
+                if (handed)
+                    late.load(Hs + (int64_t)t * (NB * NB), NB, NB);
+                else
+                    late.load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
                 late.store(T1);
             }
             __syncthreads();
-            trsm_tile_half(T1, Bx, Ld, lane, wave);
+            if (!handed)
+                trsm_tile_half(T1, Bx, Ld, lane, wave);
             Bop = T1;
         }
         double a2[2][4];
@@ -1053,6 +1144,17 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
 #pragma unroll
     for (int it = 0; it < 8; ++it)
         Ls[crow * XS + ccol + 2 * it] = cres[it];
+#if DIAG_FLOW
+    {
+        DiagSync* sy = reinterpret_cast<DiagSync*>(invd + NB);
+        diag_flow_init(sy);
+        __syncthreads();
+        PTS(5);
+        diag_flow(Ls, Ltb, invd, sy, A + r0 + r0 * lda, lda, Xt_next, info, r0, wave, lane);
+        PTS(6);
+        return;
+    }
+#endif
     __syncthreads();
     // the serial part runs on waves 0-3 (k_diag's code), the inversion pipeline on wave 4; waves
     // 5..7 end here — s_barrier only counts the waves of the workgroup that are still alive
@@ -1096,15 +1198,17 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
 __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
                                                     const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                     int do_next, int* __restrict__ info, double* __restrict__ Hs,
-                                                    int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc)
+                                                    int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
+                                                    unsigned* hflag, unsigned epoch)
 {
-    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, (int)blockIdx.x);
+    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch,
+                    (int)blockIdx.x);
 }
 __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
                                                       const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                       int do_next, int* __restrict__ info, double* __restrict__ Hs,
                                                       int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
-                                                      const BatchTab* __restrict__ bt)
+                                                      unsigned* hflag, unsigned epoch, const BatchTab* __restrict__ bt)
 {
     const int G = bt->G, gp = (int)blockIdx.x % G;
     A = bt_rebase(bt, gp, A);
@@ -1113,7 +1217,9 @@ __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, in
     info = bt_rebase(bt, gp, info);
     Hs = bt_rebase(bt, gp, Hs);
     Dacc = bt_rebase(bt, gp, Dacc);
-    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, (int)blockIdx.x / G);
+    hflag = bt_rebase(bt, gp, hflag);
+    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch,
+                    (int)blockIdx.x / G);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1179,6 +1285,15 @@ __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restric
         for (int it = 0; it < 8; ++it) // Dacc: what the panel steps summed up (same thread <-> element mapping)
             Ls[crow * XS + ccol + 2 * it] = c0v[it] - a2r[it] - (Dacc ? Dacc[threadIdx.x + 512 * it] : 0.0);
     }
+#if DIAG_FLOW
+    {
+        DiagSync* sy = reinterpret_cast<DiagSync*>(invd + NB);
+        diag_flow_init(sy);
+        __syncthreads();
+        diag_flow(Ls, Ltb, invd, sy, A + pe + pe * lda, lda, Xt_next, info, pe, wave, lane);
+        return;
+    }
+#endif
     __syncthreads();
     if (wave >= 5)
         return; // s_barrier only counts the waves that are still alive
@@ -1251,17 +1366,22 @@ void dump_panel_timing()
 #endif
 void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
                        double* Xt_next, int do_next, int* info, double* Hs, int64_t dnext, int64_t dfirst, int dinit,
-                       double* Dacc)
+                       double* Dacc, unsigned* hflag)
 {
+    // a value no earlier launch of this process has used (0 is what fresh flag words hold)
+    static std::atomic<unsigned> g_epoch{0};
+    unsigned epoch = ++g_epoch;
+    if (epoch == 0)
+        epoch = ++g_epoch;
     const int64_t rows = M - (j0 + NB);
     if (rows <= 0)
         return;
     if (g_batch.bt)
         hipLaunchKernelGGL(k_panel_step_b, dim3((unsigned)((rows + NB - 1) / NB) * g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
-                           Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, g_batch.bt);
+                           Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch, g_batch.bt);
     else
         hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, j0, M, nt, Xt_cur,
-                           Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc);
+                           Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch);
 }
 
 // head tiles of the fused steps of one outer panel -> their place in A.  Step f (f = 0..nf-1) of the

@@ -50,8 +50,8 @@ int main(int argc, char** argv)
         // fused panel step below the block just factored (3 more blocks in the panel)
         {
             static double* Hs = nullptr;
-            if (!Hs) CHK(hipMalloc(&Hs, sizeof(double) * 8 * 4096));
-            launch_panel_step(s, A, ld, 0, N + 1, 3, Xi, Xi + 4096, 1, info, Hs);
+            if (!Hs) { CHK(hipMalloc(&Hs, sizeof(double) * 8 * 4096)); CHK(hipMemset(Hs, 0, sizeof(double) * 8 * 4096)); }
+            launch_panel_step(s, A, ld, 0, N + 1, 3, Xi, Xi + 4096, 1, info, Hs, -1, -1, 0, nullptr, (unsigned*)(Hs + 7 * 4096));
             launch_copy2d(s, A0, ld, A, ld, N, 320); // restore what the step consumed
         }
         // trsm shape: (4032 x 64) x (64 x 64), in place
@@ -113,6 +113,31 @@ int main(int argc, char** argv)
     dump_diag_timing();
     extern void dump_panel_timing();
     dump_panel_timing();
+    { // the four steps of an outer panel one by one (nt = blocks of the panel still to come), full 64-row blocks only
+        static double* Hs2 = nullptr;
+        CHK(hipMalloc(&Hs2, sizeof(double) * 8 * 4096));
+        CHK(hipMemset(Hs2, 0, sizeof(double) * 8 * 4096));
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int nt = 3; nt >= 0; --nt) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                launch_copy2d(s, A0, ld, A, ld, N, 320);
+                launch_diag(s, A, ld, 64, Xi, info, 0, 1);
+                CHK(hipStreamSynchronize(s));
+                hipEventRecord(e0, s);
+                launch_panel_step(s, A, ld, 0, N, nt, Xi, Xi + 4096, nt > 0, info, Hs2, -1, -1, 0, nullptr, (unsigned*)(Hs2 + 7 * 4096));
+                hipEventRecord(e1, s);
+                CHK(hipStreamSynchronize(s));
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                best = ms < best ? ms : best;
+            }
+            printf("step with nt = %d: %.2f us (events)\n", nt, 1e3 * best);
+            dump_panel_timing();
+        }
+    }
 #endif
     printf("kbench done\n");
     return 0;
