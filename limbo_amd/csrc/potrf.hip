@@ -872,6 +872,15 @@ struct TileRegs {
         for (int q = 0; q < 8; ++q)
             v[q] = G[ic + (int64_t)(kk0 + 8 * q) * ld];
     }
+    // the same tile (ld = 64) straight from device-coherent memory: written by another workgroup of THIS launch with
+    // write-through stores (panel_step_body, head-tile hand-over), possibly on another XCD behind another L2
+    __device__ __forceinline__ void load_coherent(const double* G)
+    {
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            v[q] = __hip_atomic_load(G + i + (int64_t)(kk0 + 8 * q) * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __device__ __forceinline__ void store(double* __restrict__ T) const
     {
         const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
@@ -992,8 +1001,8 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
         for (int q = 0; q < 8; ++q) {
             const int col = kk0 + 8 * q;
             const double v = T0[col * PS + i];
-            if (b < nt)
-                Hs[(int64_t)b * (NB * NB) + i + NB * col] = v;
+            if (b < nt) // write-through: other XCDs read this tile during this launch (PANEL_HANDOVER)
+                __hip_atomic_store(Hs + (int64_t)b * (NB * NB) + i + NB * col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (i < nrows)
                 A[R0 + i + (j0 + col) * lda] = v;
         }
@@ -1009,12 +1018,14 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
     // index order nobody can wait for a workgroup that is not running; the wait is bounded all the same and a workgroup that
     // runs out of patience re-derives the tiles from A as before (A's head rows are intact until k_head_copy).
     if (b < nt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's stores have reached the L2 of this XCD ...
+        // The tile went out with device-scope (write-through) stores, the consumers read it and the flag with device-scope
+        // loads: no release/acquire fence anywhere.  (An agent-scope release writes back the whole L2 of this XCD — every
+        // dirty C tile of every workgroup on it: 7.5 k cycles when each wave issued one, 3 k for a single one, growing
+        // with the number of updates in flight; tools/kbench_t.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's part of the tile is acknowledged
         __syncthreads();
-        if (threadIdx.x == 0) { // ... and ONE release writes that L2 back for the other XCDs (one per wave cost 7.5 k cycles)
-            __threadfence();
+        if (threadIdx.x == 0)
             __hip_atomic_store(hflag + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
     bool handed = true;
     {
@@ -1039,12 +1050,11 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
             __syncthreads();
             if (threadIdx.x == 0)
                 sbad = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // this CU's vector cache may hold last step's tiles
 #pragma unroll
             for (int t = 0; t < PANEL_PRE; ++t)
                 if (t <= tmax && t != b) {
                     if (handed)
-                        head[t].load(Hs + (int64_t)t * (NB * NB), NB, NB);
+                        head[t].load_coherent(Hs + (int64_t)t * (NB * NB));
                     else
                         head[t].load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
                 }
@@ -1073,7 +1083,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
             else {
                 TileRegs late;
                 if (handed)
-                    late.load(Hs + (int64_t)t * (NB * NB), NB, NB);
+                    late.load_coherent(Hs + (int64_t)t * (NB * NB));
                 else
                     late.load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
                 late.store(T1);
