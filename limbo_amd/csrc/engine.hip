@@ -68,6 +68,7 @@ struct gpe_ctx {
     double* dQuery = nullptr; // query scratch kept between calls while it is small (single-point queries: no malloc/free)
     size_t query_bytes = 0;
     double* dHead = nullptr; // scratch tiles of the fused panel steps (k_panel_step)
+    bool panel_handover = true; // head tiles of a panel step change hands (potrf.hip); GPE_PANEL_HANDOVER=0: re-derived
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     int64_t grad_partial_cap = 0;
     int* dInfo = nullptr; // = hInfo: pinned host memory the kernels write directly (no copy-back, no device memset)
@@ -369,7 +370,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 launch_panel_step(s, A, ld, j0, M, nt, Xt, Xt + NB * NB, nt > 0 ? 1 : 0, c->dInfo, Hbase + htile * NB * NB,
                                   pre ? pe : -1, pre && j0 == dfirst_at ? p0 : -1, j0 == p0 + NB ? 1 : 0,
                                   c->dHead + 64 * NB * NB,
-                                  (unsigned*)(c->dHead + 65 * NB * NB) + ((p0 / nbo) & 1) * 32 + htile);
+                                  c->panel_handover ? (unsigned*)(c->dHead + 65 * NB * NB) + ((p0 / nbo) & 1) * 32 + htile : nullptr);
                 htile += nt;
                 if (nt > 0)
                     ++nf;
@@ -1129,6 +1130,8 @@ int gpe_create(int device_id, gpe_handle* out)
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
     if (const char* f = getenv("GPE_BULK_WGS"))
         c->bulk_wgs = atoi(f);
+    if (const char* f = getenv("GPE_PANEL_HANDOVER"))
+        c->panel_handover = atoi(f) != 0;
     if (const char* f = getenv("GPE_BULK_FREE_TILES"))
         c->bulk_free_tiles = atoll(f);
     if (const char* f = getenv("GPE_FUSE_DIAG"))

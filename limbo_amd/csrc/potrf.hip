@@ -1017,7 +1017,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
     // lower-numbered head tiles and the heads wait for nobody but lower-numbered heads, so with workgroups dispatched in
     // index order nobody can wait for a workgroup that is not running; the wait is bounded all the same and a workgroup that
     // runs out of patience re-derives the tiles from A as before (A's head rows are intact until k_head_copy).
-    if (b < nt) {
+    if (b < nt && hflag) {
         // The tile went out with device-scope (write-through) stores, the consumers read it and the flag with device-scope
         // loads: no release/acquire fence anywhere.  (An agent-scope release writes back the whole L2 of this XCD — every
         // dirty C tile of every workgroup on it: 7.5 k cycles when each wave issued one, 3 k for a single one, growing
@@ -1032,7 +1032,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
         const int nneed = tmax < b ? tmax + 1 : tmax; // tiles t <= tmax, t != b  (b > tmax: all of 0..tmax; else all but b)
         if (nneed > 0) {
             if (threadIdx.x == 0) {
-                int ok = 1;
+                int ok = hflag != nullptr; // nullptr: no hand-over in this launch (GPE_PANEL_HANDOVER=0; tests): re-derive
                 for (int t = 0; t <= tmax && ok; ++t) {
                     if (t == b)
                         continue;

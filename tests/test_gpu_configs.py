@@ -313,6 +313,41 @@ def test_gpu_sweep_retry_path_gives_the_same_results():
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_gpu_panel_head_tiles_handed_over_or_rederived_give_the_same_factor(engine_lib):
+    """A fused panel step gets the L tiles of the panel's head row blocks from the workgroups that own them (potrf.hip:
+    write-through stores + a flag word per tile); a workgroup that runs out of patience re-derives them from A, which is
+    also what GPE_PANEL_HANDOVER=0 selects for every workgroup.  Both orders of arithmetic are the same products, so L
+    must agree to the last bit; and it is LAPACK's L to rounding.  N = 1100 covers full panels, a ragged last panel and
+    steps with 3, 2 and 1 head tiles (child process: the switch is read once)."""
+    import scipy.linalg as sl
+    N = 1100
+    X, Y = synth.make_problem("c2", N=N)
+    om, _ = synth.obs_mean_data(Y)
+    h = new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(7), 0.01)
+    assert h.compute() == 0
+    L1 = np.tril(h.get_L())
+    K = h.get_K()
+    h.close()
+    Lref = sl.cholesky(np.tril(K) + np.tril(K, -1).T, lower=True)
+    assert np.max(np.abs(L1 - Lref)) <= 1e-10 * np.max(np.abs(Lref))
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    f = out / "L_no_handover.npy"
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from limbo_amd import _capi, synth\n"
+            "X, Y = synth.make_problem('c2', N=%d); om, _ = synth.obs_mean_data(Y)\n"
+            "h = _capi.Handle(_capi.load_engine()); h.set_data(X, om); h.set_kernel(0, np.zeros(7), 0.01)\n"
+            "assert h.compute() == 0\n"
+            "np.save(%r, np.tril(h.get_L()))\n"
+            "print('child ok')\n") % (str(ROOT), N, str(f))
+    env = dict(os.environ, GPE_PANEL_HANDOVER="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    L0 = np.load(f)
+    assert np.array_equal(L0, L1), float(np.max(np.abs(L0 - L1)))
+
+
 @pytest.mark.parametrize("kind,D,P,lam", [(O.SE_ARD, 6, 1, 0), (O.MATERN52, 3, 2, 0), (O.SE_ARD, 4, 3, 1), (O.EXP, 2, 1, 0)])
 def test_gpu_small_path_vs_oracle(engine_lib, oracle_lib, kind, D, P, lam):
     """The one-launch small-N path (csrc/small.hip: add_sample and point queries below 256 samples) across every
