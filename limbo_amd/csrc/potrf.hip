@@ -3,9 +3,11 @@
 // Together with gemm.hip this replaces Eigen::LLT<MatrixXd>(K).matrixL()
 // (src/limbo/model/gp.hpp:565) and the TriangularView solves (gp.hpp:260-261, :608-610, :620).
 //
-//   k_diag      one 256-thread workgroup: factor the diagonal block D = L11 L11^T in registers
-//               and then invert L11 with the fp64 matrix cores; writes L11 in place and
-//               X^T = L11^-T (as Xt[k + 64 c] = X[c][k]) to a side buffer.
+//   k_diag      one workgroup: factor the diagonal block D = L11 L11^T and invert its two 32 x 32 diagonal
+//               half-blocks; writes L11 in place and X^T = L11^-T (as Xt[k + 64 c] = X[c][k]) to a side
+//               buffer.  Since round 2 this is a data-flow of seven specialised waves (diag_flow.h, the
+//               default, also inside k_panel_step / k_upd_fused); the barrier rounds described below are
+//               what k_diag_full (ragged blocks, add_sample, load) still runs, and DIAG_FLOW=0 selects.
 //   k_diag_inv  the inversion alone, batched over blocks (load(..., recompute = false) and
 //               add_sample need the inverses of blocks they did not factor).
 //

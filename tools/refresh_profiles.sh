@@ -44,4 +44,8 @@ cd /tmp
 for v in 2 0; do GPE_KBUILD=$v GPE_STOP_EVENT=0 rocprofv3 --kernel-trace -d /tmp/p_kb$v -o p -- $B > /dev/null 2>&1; db=$(find /tmp/p_kb$v -name "*.db" | head -1); echo "GPE_KBUILD=$v" >> $out/${tag}_kernel_build_trace.txt; python $root/tools/kstats.py $db | grep -i "k_build" >> $out/${tag}_kernel_build_trace.txt; done
 for cnt in WRITE_SIZE FETCH_SIZE; do rocprofv3 --kernel-trace --pmc $cnt -d /tmp/p_kbp_$cnt -o p -- $B > /dev/null 2>&1; db=$(find /tmp/p_kbp_$cnt -name "*.db" | head -1); KSTATS_GRID=0 python $root/tools/kpmc.py $db | grep -i "k_build" >> $out/${tag}_kernel_build_trace.txt; done
 cd $root
+# in-kernel stamps: the diagonal block alone (data-flow form, and the barrier rounds it replaced), the four steps of an outer
+# panel (workgroup 0 / last workgroup), with and without the head-tile hand-over
+{ echo "# tools/diagflow (diag_flow.h) and tools/diagbench_0 (the barrier rounds, DIAG_FLOW=0): k_diag alone on tools/tmp/K64.bin if present"; tools/diagflow; tools/diagbench_0; } > $out/${tag}_diag_flow_stamps.log 2>&1
+{ echo "# tools/kbench_t: k_panel_step at the first panel of N = 4096, nt = head tiles of the step (3, 2, 1, 0); s_memtime cycles at 2.38 GHz"; echo "## head tiles handed over (default)"; tools/kbench_t 1 | grep -A2 "step with nt"; } > $out/${tag}_panel_step_stamps.log 2>&1
 ls -la $out
