@@ -148,12 +148,13 @@ void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b
 // one fused 64-column step below the factored diagonal block at (j0, j0): L21 = A21 X^T for rows
 // j0+64 .. M-1, the updates of the next `nt` 64-column blocks of the outer panel, and (do_next) the
 // factorisation + inversion of the next diagonal block (-> Xt_next).  Full 64-blocks only.
+typedef unsigned long long gpe_epoch_t; // the value of a hand-over flag word: the serial number of the launch that set it
 // Hs: nt scratch tiles (64 x 64 each) for the L of the first nt row blocks; launch_head_copy moves
 // the tiles of the nf fused steps of the panel at p0 (nt0 = tiles of its first step) into A.
 // dnext / dfirst (>= 0 to enable): see k_panel_step — pieces of the next outer panel's first diagonal block
 void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
                        double* Xt_next, int do_next, int* info, double* Hs, int64_t dnext, int64_t dfirst, int dinit,
-                       double* Dacc, unsigned* hflag);
+                       double* Dacc, gpe_epoch_t* hflag);
 // the device block behind gpe_ctx::dHead: 32 + 32 head tiles (by panel parity), the scratch sum of the next diagonal
 // block, and one tile's worth of hand-over flag words (hflag: one unsigned per head tile, same indexing as the tiles)
 #define GPE_HEAD_TILES 66

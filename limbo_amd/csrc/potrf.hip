@@ -926,7 +926,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                                                        const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                        int do_next, int* __restrict__ info, double* __restrict__ Hs,
                                                        int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
-                                                       unsigned* hflag, unsigned epoch, const int bx)
+                                                       gpe_epoch_t* hflag, gpe_epoch_t epoch, const int bx)
 {
     // one LDS array, carved: [Bx | T0 | T1 | Ld]; workgroup 0 re-carves it as [Ls | Ltb | invd]
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + 32 * XS];
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
                                                     const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                     int do_next, int* __restrict__ info, double* __restrict__ Hs,
                                                     int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
-                                                    unsigned* hflag, unsigned epoch)
+                                                    gpe_epoch_t* hflag, gpe_epoch_t epoch)
 {
     panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch,
                     (int)blockIdx.x);
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, in
                                                       const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                       int do_next, int* __restrict__ info, double* __restrict__ Hs,
                                                       int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
-                                                      unsigned* hflag, unsigned epoch, const BatchTab* __restrict__ bt)
+                                                      gpe_epoch_t* hflag, gpe_epoch_t epoch, const BatchTab* __restrict__ bt)
 {
     const int G = bt->G, gp = (int)blockIdx.x % G;
     A = bt_rebase(bt, gp, A);
@@ -1378,13 +1378,11 @@ void dump_panel_timing()
 #endif
 void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
                        double* Xt_next, int do_next, int* info, double* Hs, int64_t dnext, int64_t dfirst, int dinit,
-                       double* Dacc, unsigned* hflag)
+                       double* Dacc, gpe_epoch_t* hflag)
 {
-    // a value no earlier launch of this process has used (0 is what fresh flag words hold)
-    static std::atomic<unsigned> g_epoch{0};
-    unsigned epoch = ++g_epoch;
-    if (epoch == 0)
-        epoch = ++g_epoch;
+    // a value no earlier launch of this process has used; 64 bits: never wraps (0 is what fresh flag words hold)
+    static std::atomic<gpe_epoch_t> g_epoch{0};
+    const gpe_epoch_t epoch = ++g_epoch;
     const int64_t rows = M - (j0 + NB);
     if (rows <= 0)
         return;

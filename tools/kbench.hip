@@ -51,7 +51,7 @@ int main(int argc, char** argv)
         {
             static double* Hs = nullptr;
             if (!Hs) { CHK(hipMalloc(&Hs, sizeof(double) * 8 * 4096)); CHK(hipMemset(Hs, 0, sizeof(double) * 8 * 4096)); }
-            launch_panel_step(s, A, ld, 0, N + 1, 3, Xi, Xi + 4096, 1, info, Hs, -1, -1, 0, nullptr, (unsigned*)(Hs + 7 * 4096));
+            launch_panel_step(s, A, ld, 0, N + 1, 3, Xi, Xi + 4096, 1, info, Hs, -1, -1, 0, nullptr, (gpe_epoch_t*)(Hs + 7 * 4096));
             launch_copy2d(s, A0, ld, A, ld, N, 320); // restore what the step consumed
         }
         // trsm shape: (4032 x 64) x (64 x 64), in place
@@ -127,7 +127,7 @@ int main(int argc, char** argv)
                 launch_diag(s, A, ld, 64, Xi, info, 0, 1);
                 CHK(hipStreamSynchronize(s));
                 hipEventRecord(e0, s);
-                launch_panel_step(s, A, ld, 0, N, nt, Xi, Xi + 4096, nt > 0, info, Hs2, -1, -1, 0, nullptr, (unsigned*)(Hs2 + 7 * 4096));
+                launch_panel_step(s, A, ld, 0, N, nt, Xi, Xi + 4096, nt > 0, info, Hs2, -1, -1, 0, nullptr, (gpe_epoch_t*)(Hs2 + 7 * 4096));
                 hipEventRecord(e1, s);
                 CHK(hipStreamSynchronize(s));
                 float ms;
