@@ -758,6 +758,23 @@ template <class Redo> int compute_finish(gpe_ctx* c, Redo redo)
     HIPCHK(c, wait_stream(c->stream));
     HIPCHK(c, hipGetLastError());
     drain_phases(c);
+    if (c->hInfo[2] != 0) {
+        // a wave of a panel step gave up waiting for a head tile (potrf.hip) — not a reachable state with workgroups
+        // dispatched in index order; the bounded poll is a backstop, as for the sweeps.  The factor is unusable: run the
+        // whole evaluation again, from K on, with every workgroup deriving the head tiles itself.
+        c->hInfo[0] = c->hInfo[1] = c->hInfo[2] = 0;
+        c->panel_handover = false;
+        ++c->flow_retries;
+        const BatchLaunch saved = g_batch;
+        g_batch = BatchLaunch{};
+        const int e = compute_enqueue(c);
+        g_batch = saved;
+        if (e != GPE_OK)
+            return e;
+        HIPCHK(c, wait_stream(c->stream));
+        HIPCHK(c, hipGetLastError());
+        drain_phases(c);
+    }
     if (flow_failed(c)) {
         NoFlowScope off(c);
         redo();

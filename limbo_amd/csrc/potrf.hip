@@ -926,7 +926,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                                                        const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                        int do_next, int* __restrict__ info, double* __restrict__ Hs,
                                                        int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
-                                                       gpe_epoch_t* hflag, gpe_epoch_t epoch, const int bx)
+                                                       gpe_epoch_t* hflag, gpe_epoch_t epoch, int spin_limit, const int bx)
 {
     // one LDS array, carved: [Bx | T0 | T1 | Ld]; workgroup 0 re-carves it as [Ls | Ltb | invd]
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + 32 * XS];
@@ -1017,9 +1017,11 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
     // workgroup 0 INCLUDING the diagonal block).  A head workgroup publishes: its tile is in Hs, device-wide, then
     // hflag[b] = this launch's epoch (a value no earlier launch used: the words are never reset).  Consumers need only
     // lower-numbered head tiles and the heads wait for nobody but lower-numbered heads, so with workgroups dispatched in
-    // index order nobody can wait for a workgroup that is not running; the wait is bounded all the same and a workgroup that
-    // runs out of patience re-derives the tiles from A as before (A's head rows are intact until k_head_copy).
-    if (b < nt && hflag) {
+    // index order nobody can wait for a workgroup that is not running; the wait is bounded all the same (below).
+    const bool mute = spin_limit < 0; // test hook (GPE_HANDOVER_FAULT): nobody publishes, every consumer gives up at once
+    if (spin_limit < 0)
+        spin_limit = -spin_limit;
+    if (b < nt && hflag && !mute) {
         // The tile went out with device-scope (write-through) stores, the consumers read it and the flag with device-scope
         // loads: no release/acquire fence anywhere.  (An agent-scope release writes back the whole L2 of this XCD — every
         // dirty C tile of every workgroup on it: 7.5 k cycles when each wave issued one, 3 k for a single one, growing
@@ -1029,39 +1031,34 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
         if (threadIdx.x == 0)
             __hip_atomic_store(hflag + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    bool handed = true;
-    {
-        const int nneed = tmax < b ? tmax + 1 : tmax; // tiles t <= tmax, t != b  (b > tmax: all of 0..tmax; else all but b)
-        if (nneed > 0) {
-            if (threadIdx.x == 0) {
-                int ok = hflag != nullptr; // nullptr: no hand-over in this launch (GPE_PANEL_HANDOVER=0; tests): re-derive
-                for (int t = 0; t <= tmax && ok; ++t) {
-                    if (t == b)
-                        continue;
-                    int spins = 0;
-                    while (__hip_atomic_load(hflag + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-                        if (++spins > GPE_FLOW_SPIN_LIMIT) {
-                            ok = 0;
-                            break;
-                        }
-                }
-                sbad = ok; // (sbad is free until workgroup 0's factorisation, which has nneed == 0)
-            }
-            __syncthreads();
-            handed = sbad != 0;
-            __syncthreads();
-            if (threadIdx.x == 0)
-                sbad = 0;
+    // Every wave waits for a tile's word itself (all lanes read the same word: a wave-uniform spin) and then fetches its
+    // eighth of the tile: no broadcast of "it is there" through LDS, no barrier, and the three tiles' loads overlap.  (One
+    // thread polling the three words in turn + two barriers + the loads took 11 k cycles from "own L written" to "tiles in
+    // registers", tools/kbench_t.)  The poll is bounded; a wave that runs out of patience reports it (info[2] = 1) and the
+    // host runs the evaluation again without the hand-over (engine.hip, compute_finish) — its tile may be garbage by then.
+    const bool handed = hflag != nullptr; // nullptr: no hand-over in this launch (GPE_PANEL_HANDOVER=0): re-derive
+    gpe_epoch_t seen[PANEL_PRE];
 #pragma unroll
-            for (int t = 0; t < PANEL_PRE; ++t)
-                if (t <= tmax && t != b) {
-                    if (handed)
-                        head[t].load_coherent(Hs + (int64_t)t * (NB * NB));
-                    else
-                        head[t].load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
+    for (int t = 0; t < PANEL_PRE; ++t) // all words at once: a poll is a round trip to memory even when the word is set
+        seen[t] = (handed && t <= tmax && t != b) ? __hip_atomic_load(hflag + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+#pragma unroll
+    for (int t = 0; t < PANEL_PRE; ++t)
+        if (t <= tmax && t != b) {
+            if (handed) {
+                int spins = 0;
+                while (seen[t] != epoch) {
+                    if (++spins > spin_limit) {
+                        if (lane == 0)
+                            info[2] = 1;
+                        break;
+                    }
+                    seen[t] = __hip_atomic_load(hflag + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                head[t].load_coherent(Hs + (int64_t)t * (NB * NB));
+            }
+            else
+                head[t].load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
         }
-    }
 #else
     const bool handed = false;
 #endif
@@ -1075,6 +1072,8 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
         for (int it = 0; it < 8; ++it)
             cv[it] = (t == 0) ? c0v[it] : Cg[crc + (int64_t)(ccol + 2 * it) * lda];
         const double* Bop = T0;
+        if (t == 0)
+            PTS(10);
         if (t != b) { // head tile of another row block: recompute L_t = A_t X^T
             if (t == 0)
                 head[0].store(T1);
@@ -1084,8 +1083,16 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                 head[2].store(T1);
             else {
                 TileRegs late;
-                if (handed)
+                if (handed) {
+                    int spins = 0;
+                    while (__hip_atomic_load(hflag + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+                        if (++spins > spin_limit) {
+                            if (lane == 0)
+                                info[2] = 1;
+                            break;
+                        }
                     late.load_coherent(Hs + (int64_t)t * (NB * NB));
+                }
                 else
                     late.load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
                 late.store(T1);
@@ -1101,9 +1108,15 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
 #pragma unroll
             for (int n = 0; n < 4; ++n)
                 a2[m][n] = 0.0;
+        if (t == 0)
+            PTS(11);
         mm64<false>(T0, Bop, wm, wn, lane, a2);
+        if (t == 0)
+            PTS(12);
         double a2r[8];
         wave_tile_to_rows(a2, a2r, lane);
+        if (t == 0)
+            PTS(13);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const double v = cv[it] - a2r[it];
@@ -1113,7 +1126,11 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
             if (crow < nrows && !(b == 0 && do_next))
                 Cg[crow + (int64_t)(ccol + 2 * it) * lda] = v;
         }
+        if (t == 0)
+            PTS(14);
         __syncthreads(); // T1 is free again
+        if (t == 0)
+            PTS(15);
     }
 
     // 2b. the piece(s) of the next outer panel's first diagonal block that this workgroup can provide
@@ -1211,16 +1228,17 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ A, int6
                                                     const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                     int do_next, int* __restrict__ info, double* __restrict__ Hs,
                                                     int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
-                                                    gpe_epoch_t* hflag, gpe_epoch_t epoch)
+                                                    gpe_epoch_t* hflag, gpe_epoch_t epoch, int spin_limit)
 {
-    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch,
+    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch, spin_limit,
                     (int)blockIdx.x);
 }
 __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, int64_t lda, int64_t j0, int64_t M, int nt,
                                                       const double* __restrict__ Xt_cur, double* __restrict__ Xt_next,
                                                       int do_next, int* __restrict__ info, double* __restrict__ Hs,
                                                       int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
-                                                      gpe_epoch_t* hflag, gpe_epoch_t epoch, const BatchTab* __restrict__ bt)
+                                                      gpe_epoch_t* hflag, gpe_epoch_t epoch, int spin_limit,
+                                                      const BatchTab* __restrict__ bt)
 {
     const int G = bt->G, gp = (int)blockIdx.x % G;
     A = bt_rebase(bt, gp, A);
@@ -1230,7 +1248,7 @@ __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, in
     Hs = bt_rebase(bt, gp, Hs);
     Dacc = bt_rebase(bt, gp, Dacc);
     hflag = bt_rebase(bt, gp, hflag);
-    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch,
+    panel_step_body(A, lda, j0, M, nt, Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch, spin_limit,
                     (int)blockIdx.x / G);
 }
 
@@ -1374,6 +1392,8 @@ void dump_panel_timing()
            h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
     printf("k_panel_step last WG cycles: loads %lld | trsm %lld | writeL %lld | updates %lld | total %lld\n", h[33] - h[32],
            h[34] - h[33], h[35] - h[34], h[36] - h[35], h[36] - h[32]);
+    printf("  its first update (wave 0): wait + fetch head tiles %lld | tile -> LDS + barrier %lld | 64^3 product %lld | to row layout %lld | C -= , store %lld | barrier %lld\n",
+           h[42] - h[35], h[43] - h[42], h[44] - h[43], h[45] - h[44], h[46] - h[45], h[47] - h[46]);
 }
 #endif
 void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_t M, int nt, const double* Xt_cur,
@@ -1383,15 +1403,18 @@ void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_
     // a value no earlier launch of this process has used; 64 bits: never wraps (0 is what fresh flag words hold)
     static std::atomic<gpe_epoch_t> g_epoch{0};
     const gpe_epoch_t epoch = ++g_epoch;
+    // test hook: the consumers wait (briefly) for a value nobody writes, i.e. every hand-over of the launch "times out"
+    static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
+    const int spin_limit = fault ? -16 : GPE_FLOW_SPIN_LIMIT;
     const int64_t rows = M - (j0 + NB);
     if (rows <= 0)
         return;
     if (g_batch.bt)
         hipLaunchKernelGGL(k_panel_step_b, dim3((unsigned)((rows + NB - 1) / NB) * g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
-                           Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch, g_batch.bt);
+                           Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch, spin_limit, g_batch.bt);
     else
         hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, j0, M, nt, Xt_cur,
-                           Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch);
+                           Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch, spin_limit);
 }
 
 // head tiles of the fused steps of one outer panel -> their place in A.  Step f (f = 0..nf-1) of the

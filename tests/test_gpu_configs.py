@@ -348,6 +348,33 @@ def test_gpu_panel_head_tiles_handed_over_or_rederived_give_the_same_factor(engi
     assert np.array_equal(L0, L1), float(np.max(np.abs(L0 - L1)))
 
 
+def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib):
+    """GPE_HANDOVER_FAULT=1: no head workgroup publishes and every consumer gives up after a few polls, i.e. every fused
+    panel step of the first attempt reports a lost hand-over.  The host must notice (info word 2), run the evaluation again
+    from K on without the hand-over, count it in flow_retries(), and return the same log-likelihood as an undisturbed
+    process (child process: the switch is read once)."""
+    N = 1100
+    X, Y = synth.make_problem("c2", N=N)
+    om, _ = synth.obs_mean_data(Y)
+    h = new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(7), 0.01)
+    assert h.compute() == 0 and h.flow_retries() == 0
+    ll = h.log_lik()
+    h.close()
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from limbo_amd import _capi, synth\n"
+            "X, Y = synth.make_problem('c2', N=%d); om, _ = synth.obs_mean_data(Y)\n"
+            "h = _capi.Handle(_capi.load_engine()); h.set_data(X, om); h.set_kernel(0, np.zeros(7), 0.01)\n"
+            "assert h.compute() == 0\n"
+            "assert h.flow_retries() == 1, h.flow_retries()\n"
+            "assert h.compute() == 0 and h.flow_retries() == 1  # the handle stays without the hand-over\n"
+            "print('child ok %%.17g' %% h.log_lik())\n") % (str(ROOT), N)
+    env = dict(os.environ, GPE_HANDOVER_FAULT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert float(r.stdout.split("child ok")[1]) == ll
+
+
 @pytest.mark.parametrize("kind,D,P,lam", [(O.SE_ARD, 6, 1, 0), (O.MATERN52, 3, 2, 0), (O.SE_ARD, 4, 3, 1), (O.EXP, 2, 1, 0)])
 def test_gpu_small_path_vs_oracle(engine_lib, oracle_lib, kind, D, P, lam):
     """The one-launch small-N path (csrc/small.hip: add_sample and point queries below 256 samples) across every
