@@ -64,6 +64,9 @@ static __device__ __forceinline__ double rsq_newton(double p)
     return fma(y0, eh, y0);
 }
 
+#ifndef FLOWP_LDSMUL
+#define FLOWP_LDSMUL 1 // P's look-ahead multipliers of x0..x2 through LDS (1) or all by v_readlane (0)
+#endif
 // ---- P ---------------------------------------------------------------------------------------------------------------------
 template <int G>
 struct FlowP {
@@ -98,6 +101,11 @@ struct FlowP {
         const double y1 = rsq_newton(fma(-l10, l10, b11));
         const double l21 = fma(-l20, l10, b21) * y1, l31 = fma(-l30, l10, b31) * y1;
         const double x1 = fma(-x0, l10, c[1]) * y1;
+        double* dst = Ls + r * XS + c0;
+#if FLOWP_LDSMUL
+        dst[0] = x0; // out as soon as they exist: the multipliers of the look-ahead update come back through LDS (below)
+        dst[1] = x1;
+#endif
         if (fetch && seen < G + 1) { // rare: the hand-over was not there yet
             lds_await(&sy->hflag[(G + 1) & 1], G + 1);
             n[0] = h[0];
@@ -110,14 +118,33 @@ struct FlowP {
         const double y2 = rsq_newton(fma(-l21, l21, fma(-l20, l20, b22)));
         const double l32 = fma(-l31, l21, fma(-l30, l20, b32)) * y2;
         const double x2 = fma(-x1, l21, fma(-x0, l20, c[2])) * y2;
+#if FLOWP_LDSMUL
+        // The look-ahead update needs x_j[row c0+4+e] in every lane.  For x0, x1, x2 those twelve values come back from LDS
+        // (this wave's own writes, in order; wave-uniform reads: 8 instructions) while the chain computes y3 and x3 —
+        // 24 v_readlane + their s_nop less in the wave that bounds the block; only x3's four are v_readlane broadcasts.
+        dst[2] = x2;
+        double m0[4], m1[4], m2[4];
+        if (G < 15) {
+            const double* mrow = Ls + (c0 + 4) * XS + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m0[e] = mrow[e * XS + 0];
+                m1[e] = mrow[e * XS + 1];
+                m2[e] = mrow[e * XS + 2];
+            }
+        }
+#endif
         const double y3 = rsq_newton(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, b33))));
         const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, c[3]))) * y3;
         // publish: columns into Ls (rows above the diagonal carry garbage nobody reads), inverse pivots, then the counter
-        double* dst = Ls + r * XS + c0;
+#if FLOWP_LDSMUL
+        dst[3] = x3;
+#else
         dst[0] = x0;
         dst[1] = x1;
         dst[2] = x2;
         dst[3] = x3;
+#endif
         if (r == 0) {
             invd[c0 + 0] = y0;
             invd[c0 + 1] = y1;
@@ -126,6 +153,20 @@ struct FlowP {
             lds_post(&sy->prog, G + 1);
         }
         if (G < 15) {
+#if FLOWP_LDSMUL
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                n[e] = fma(-x0, m0[e], n[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                n[e] = fma(-x1, m1[e], n[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                n[e] = fma(-x2, m2[e], n[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                c[e] = fma(-x3, bcast_lane(x3, c0 + 4 + e), n[e]);
+#else
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 double v = n[e];
@@ -135,6 +176,7 @@ struct FlowP {
                 v = fma(-x3, bcast_lane(x3, c0 + 4 + e), v);
                 c[e] = v;
             }
+#endif
         }
         FTS(0, G);
     }
