@@ -46,6 +46,7 @@ for cnt in WRITE_SIZE FETCH_SIZE; do rocprofv3 --kernel-trace --pmc $cnt -d /tmp
 cd $root
 # in-kernel stamps: the diagonal block alone (data-flow form, and the barrier rounds it replaced), the four steps of an outer
 # panel (workgroup 0 / last workgroup), with and without the head-tile hand-over
+python tools/make_k64.py > /dev/null
 { echo "# tools/diagflow (diag_flow.h) and tools/diagbench_0 (the barrier rounds, DIAG_FLOW=0): k_diag alone on tools/tmp/K64.bin if present"; tools/diagflow; tools/diagbench_0; } > $out/${tag}_diag_flow_stamps.log 2>&1
 { echo "# tools/kbench_t: k_panel_step at the first panel of N = 4096, nt = head tiles of the step (3, 2, 1, 0); s_memtime cycles at 2.38 GHz"; echo "## head tiles handed over (default)"; tools/kbench_t 1 | grep -A2 "step with nt"; } > $out/${tag}_panel_step_stamps.log 2>&1
 ls -la $out
