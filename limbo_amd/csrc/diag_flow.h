@@ -24,9 +24,14 @@
 struct DiagSync {
     int prog;     // number of 4-column panels P has published into Ls (and their inverse pivots into invd)
     int hflag[2]; // hflag[g & 1] == g: H[g & 1] holds group g with the panels 0..g-2 applied
-    int pad;
+    int xprog;    // rounds the inversion wave has finished (8: X11 complete in Xw, 16: X22 too)
+    int wdone;    // W = L21 X11 is in Xw
+    int pad[3];
 };
 #define DIAG_H_DOUBLES (2 * NB * 4)
+// the inverse's LDS work area Xw: X11 | X22 | W = L21 X11, 32 x 32 each, row-major with stride XH
+#define XH 34
+#define DIAG_XW_DOUBLES (3 * 32 * XH)
 
 static __device__ __forceinline__ int lds_peek(const int* p)
 {
@@ -237,9 +242,10 @@ template <int BJ>
 struct FlowU<BJ, -1> {
     static __device__ __forceinline__ void run(double (&)[4][4], const double*, double*, DiagSync*, int) {}
 };
+static __device__ __forceinline__ void flow_x21(DiagSync* sy, const double* Xw, double* __restrict__ Xt, int u, int lane);
 template <int BJ>
-static __device__ __forceinline__ void flow_u_wave(const double* Ls, double* H,
-                                                   DiagSync* sy, int lane)
+static __device__ __forceinline__ void flow_u_wave(const double* Ls, double* H, DiagSync* sy, const double* Xw,
+                                                   double* __restrict__ Xt, int lane)
 {
     double acc[4][4];
 #pragma unroll
@@ -249,6 +255,7 @@ static __device__ __forceinline__ void flow_u_wave(const double* Ls, double* H,
             acc[bi][nq] = Ls[(16 * bi + 4 * ((lane >> 2) & 3) + (lane >> 4)) * XS + 16 * BJ + 4 * nq + (lane & 3)];
     __syncthreads(); // every wave has its part of the block in registers: P may start overwriting Ls with L
     FlowU<BJ, 13>::run(acc, Ls, H, sy, lane);
+    flow_x21(sy, Xw, Xt, BJ, lane);
 }
 
 // ---- X ---------------------------------------------------------------------------------------------------------------------
@@ -313,9 +320,9 @@ struct XFold { // rows i0 + 4 + XFOLD_CH CHK ..: q holds this chunk's multiplier
 template <int G>
 struct FlowX {
     static __device__ __forceinline__ void run(double (&S)[32], const double* Ls, const double* invd, double* __restrict__ Xt,
-                                               const DiagSync* sy, int c, int h)
+                                               DiagSync* sy, double* Xw, int c, int h)
     {
-        FlowX<G - 1>::run(S, Ls, invd, Xt, sy, c, h);
+        FlowX<G - 1>::run(S, Ls, invd, Xt, sy, Xw, c, h);
         constexpr int hb = G >> 3, i0 = 4 * (G & 7), base = 32 * hb, nrow = 28 - i0;
         if (G == 8) { // second half-block: start again from the identity
 #pragma unroll
@@ -346,16 +353,99 @@ struct FlowX {
             Xt[base + c + NB * (base + i0 + 1)] = x1;
             Xt[base + c + NB * (base + i0 + 2)] = x2;
             Xt[base + c + NB * (base + i0 + 3)] = x3;
+            double* xh = Xw + hb * (32 * XH) + i0 * XH + c; // and into LDS, for the off-diagonal quarter (flow_x21)
+            xh[0] = x0;
+            xh[XH] = x1;
+            xh[2 * XH] = x2;
+            xh[3 * XH] = x3;
         }
         const double xa = h ? x2 : x0, xb = h ? x3 : x1;
         XFold<G, 0>::run(S, q, lbase, xa, xb);
+        if ((G & 7) == 7 && c == 0 && h == 0)
+            lds_post(&sy->xprog, G + 1); // a half-block of X is complete in Xw
         FTS(5, G);
     }
 };
 template <>
 struct FlowX<-1> {
-    static __device__ __forceinline__ void run(double (&)[32], const double*, const double*, double*, const DiagSync*, int, int) {}
+    static __device__ __forceinline__ void run(double (&)[32], const double*, const double*, double*, DiagSync*, double*, int, int) {}
 };
+
+// ---- the off-diagonal quarter X21 = -X22 (L21 X11) -------------------------------------------------------------------------
+// Round 1 left it to a kernel of its own after the factorisation (k_xinv_complete) because the panel steps can do with the
+// two diagonal quarters (three small products, six barriers: trsm_tile_half).  With all of X the solve against L11 is ONE
+// product (trsm_tile_full, potrf.hip).  Here: W = L21 X11 by the eighth wave while the second half of the block is still being
+// factored, X21 = -X22 W by the four update waves once X22 is complete — 32 matrix-core instructions each, ~1 k cycles behind
+// the inversion wave.  mfma4 layouts as in mm16 / st16 (potrf.hip).
+static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* sy, double* Xw, int lane)
+{
+    lds_await(&sy->xprog, 8);
+    const double* X11 = Xw;
+    double* W = Xw + 2 * (32 * XH);
+    const int kq = lane >> 4;
+    double acc[2][8];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            acc[sl][n] = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < 32; ks += 4) {
+        double a[2];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+            a[sl] = Ls[(32 + 16 * sl + (lane & 15)) * XS + ks + kq];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            if (4 * n > ks + 3)
+                continue; // X11 is lower triangular: its rows ks .. ks+3 are zero from column ks+4 on
+            const double b = X11[(ks + kq) * XH + 4 * n + (lane & 3)];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+                acc[sl][n] = mfma4(a[sl], b, acc[sl][n]);
+        }
+    }
+    const int row = 4 * ((lane >> 2) & 3) + (lane >> 4), col = lane & 3;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            W[(16 * sl + row) * XH + 4 * n + col] = acc[sl][n];
+    if (lane == 0)
+        lds_post(&sy->wdone, 1);
+}
+// update wave u: columns 8u .. 8u+7 of X21, all 32 rows
+static __device__ __forceinline__ void flow_x21(DiagSync* sy, const double* Xw, double* __restrict__ Xt, int u, int lane)
+{
+    lds_await(&sy->wdone, 1);
+    lds_await(&sy->xprog, 16);
+    const double* X22 = Xw + 32 * XH;
+    const double* W = Xw + 2 * (32 * XH);
+    const int kq = lane >> 4;
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+    for (int ks = 0; ks < 32; ks += 4) {
+        double b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            b[j] = W[(ks + kq) * XH + 4 * (2 * u + j) + (lane & 3)];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (16 * sl + 15 < ks)
+                continue; // X22 is lower triangular
+            const double a = -X22[(16 * sl + (lane & 15)) * XH + ks + kq];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[sl][j] = mfma4(a, b[j], acc[sl][j]);
+        }
+    }
+    const int row = 4 * ((lane >> 2) & 3) + (lane >> 4), col = lane & 3;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) // Xt[col + 64 row] = X[row][col]
+            Xt[4 * (2 * u + j) + col + NB * (32 + 16 * sl + row)] = acc[sl][j];
+}
 
 // ---- S ---------------------------------------------------------------------------------------------------------------------
 template <int G>
@@ -386,8 +476,8 @@ struct FlowS<-1> {
 };
 
 // Factor the 64 x 64 block held in Ls (Ls[row * XS + col], lower triangle meaningful) and invert its two 32 x 32 diagonal
-// half-blocks: L -> Ad (global, lower triangle) and Ls, X11^T / X22^T -> the diagonal quarters of Xt.  Call with >= 7 waves,
-// all of them, after Ls is complete and `sy` was cleared by diag_flow_init and a barrier; waves >= 7 just leave.  There is NO
+// blocks: L -> Ad (global, lower triangle) and Ls, X^T = L^-T -> Xt (all of it but the zero quarter).  Call with >= 8 waves,
+// all of them, after Ls is complete and `sy` was cleared by diag_flow_init and a barrier; waves >= 8 just leave.  There is NO
 // barrier at the end: a caller that re-uses the LDS afterwards has to synchronise itself.
 static __device__ __forceinline__ void diag_flow_init(DiagSync* sy)
 {
@@ -395,21 +485,28 @@ static __device__ __forceinline__ void diag_flow_init(DiagSync* sy)
         sy->prog = 0;
         sy->hflag[0] = -1;
         sy->hflag[1] = -1;
+        sy->xprog = 0;
+        sy->wdone = 0;
     }
 }
 static __device__ __forceinline__ void diag_flow(double* Ls, double* H, double* invd,
                                                  DiagSync* sy, double* __restrict__ Ad, int64_t lda,
                                                  double* __restrict__ Xt, int* __restrict__ info, int64_t goff, int wave,
-                                                 int lane)
+                                                 int lane, double* Xw)
 {
-    if (wave >= 7)
+    if (wave >= 8)
         return; // s_barrier only counts the waves that are still alive
+    if (wave == 7) {
+        __syncthreads();
+        flow_w_wave(Ls, sy, Xw, lane);
+        return;
+    }
     if (wave >= 1 && wave <= 4) {
         switch (wave) {
-        case 1: flow_u_wave<0>(Ls, H, sy, lane); break;
-        case 2: flow_u_wave<1>(Ls, H, sy, lane); break;
-        case 3: flow_u_wave<2>(Ls, H, sy, lane); break;
-        default: flow_u_wave<3>(Ls, H, sy, lane); break;
+        case 1: flow_u_wave<0>(Ls, H, sy, Xw, Xt, lane); break;
+        case 2: flow_u_wave<1>(Ls, H, sy, Xw, Xt, lane); break;
+        case 3: flow_u_wave<2>(Ls, H, sy, Xw, Xt, lane); break;
+        default: flow_u_wave<3>(Ls, H, sy, Xw, Xt, lane); break;
         }
         return;
     }
@@ -430,7 +527,7 @@ static __device__ __forceinline__ void diag_flow(double* Ls, double* H, double* 
 #pragma unroll
         for (int k = 0; k < 32; ++k)
             S[k] = (lane < 32 && k == lane) ? 1.0 : 0.0;
-        FlowX<15>::run(S, Ls, invd, Xt, sy, lane & 31, lane >> 5);
+        FlowX<15>::run(S, Ls, invd, Xt, sy, Xw, lane & 31, lane >> 5);
         return;
     }
     int bad = 0;

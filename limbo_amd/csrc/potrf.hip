@@ -493,8 +493,11 @@ static __device__ __forceinline__ void xpipe32_wave(const double* __restrict__ L
 #define DIAG_FLOW 1 // 1: the data-flow form of the block factorisation (diag_flow.h); 0: the barrier rounds above
 #endif
 #include "diag_flow.h"
+#ifndef TRSM_FULL
+#define TRSM_FULL (DIAG_FLOW) // the panel steps solve against L11 with all of its inverse (one product); 0: half-block form
+#endif
 #if DIAG_FLOW
-#define DIAG_THREADS 448
+#define DIAG_THREADS 512
 #else
 #define DIAG_THREADS 320
 #endif
@@ -600,9 +603,9 @@ static __device__ __forceinline__ void store_Xt(const double* __restrict__ Xs, d
         Xt[e] = Xs[(e >> 6) * XS + (e & 63)];
 }
 
-// Half-inverse form used by the fused panel steps: L11 in place, X11^T and X22^T (the inverses of the
-// two 32 x 32 diagonal half-blocks) into the diagonal quarters of Xt; the quarter X21 is completed
-// later by k_xinv_complete, the quarter above the diagonal stays zero.  Waves 0-3 factor, wave 4
+// The block the fused panel steps start from: L11 in place and X^T = L11^-T into Xt (the quarter above the
+// diagonal stays zero).  DIAG_FLOW = 0 (the barrier rounds): only the inverses of the two 32 x 32 diagonal
+// half-blocks, the quarter X21 is completed later by k_xinv_complete.  Waves 0-3 factor, wave 4
 // runs the inversion pipeline.  Full 64 x 64 blocks only.
 static __device__ __forceinline__ void diag_body(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
                                                  int* __restrict__ info, int64_t goff)
@@ -613,6 +616,7 @@ static __device__ __forceinline__ void diag_body(double* __restrict__ A, int64_t
     const int r = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #if DIAG_FLOW
     __shared__ DiagSync sy;
+    __shared__ __attribute__((aligned(16))) double Xw[DIAG_XW_DOUBLES];
     static_assert(DIAG_H_DOUBLES <= DIAG_LTB, "H fits where the round buffers were");
     TS(0);
     for (int e = threadIdx.x; e < NB * NB; e += DIAG_THREADS)
@@ -620,7 +624,7 @@ static __device__ __forceinline__ void diag_body(double* __restrict__ A, int64_t
     diag_flow_init(&sy);
     __syncthreads();
     TS(1);
-    diag_flow(Ls, Ltb, invd, &sy, A, lda, Xt, info, goff, w, r);
+    diag_flow(Ls, Ltb, invd, &sy, A, lda, Xt, info, goff, w, r, Xw);
     TS(2);
     return;
 #endif
@@ -818,6 +822,7 @@ static __device__ __forceinline__ void mm64(const double* __restrict__ Aop, cons
     mmk<BKM, NB, 4>(Aop, 0, Bop, 0, wm, wn, lane, acc);
 }
 
+#if !TRSM_FULL
 // T (64 x 64 tile, [kk = col][i = row], stride PS) <- T L11^-T with the half-block form of the inverse:
 //   Y1 = T[:, 0:32] X11^T ;  Y2 = (T[:, 32:64] - Y1 L21^T) X22^T          (L11 = [[L1, 0], [L21, L2]])
 // Bx[c * XS + k] = X[c][k] (diagonal quarters valid), Ld[c * XS + k] = L21[c][k].  512 threads, in
@@ -860,6 +865,34 @@ static __device__ __forceinline__ void trsm_tile_half(double* __restrict__ T, co
 #pragma unroll
         for (int n = 0; n < 2; ++n)
             T[(32 + wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
+    __syncthreads();
+}
+
+#endif
+// The same solve with ALL of X = L11^-1 (lower triangular; diag_flow.h leaves the off-diagonal quarter too): ONE product,
+// Y[i][c] = sum_{k <= c} T[i][k] X[c][k], two barriers instead of six.  A wave's 16 columns need k < wn + 16 only.
+static __device__ __forceinline__ void trsm_tile_full(double* __restrict__ T, const double* __restrict__ Bx, int lane, int wave)
+{
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+    double y[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            y[m][n] = 0.0;
+    switch (wave >> 1) {
+    case 0: mmk<true, 16, 4>(T, 0, Bx, 0, wm, wn, lane, y); break;
+    case 1: mmk<true, 32, 4>(T, 0, Bx, 0, wm, wn, lane, y); break;
+    case 2: mmk<true, 48, 4>(T, 0, Bx, 0, wm, wn, lane, y); break;
+    default: mmk<true, 64, 4>(T, 0, Bx, 0, wm, wn, lane, y); break;
+    }
+    __syncthreads(); // every wave has read what it needs of T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            T[(wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y[m][n];
     __syncthreads();
 }
 
@@ -934,7 +967,9 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
     double* Bx = lds;
     double* T0 = lds + NB * XS;
     double* T1 = T0 + NB * PS;
+#if !TRSM_FULL
     double* Ld = T1 + NB * PS; // L21 of the current diagonal block, Ld[c * XS + k] = L[32 + c][k]
+#endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
     const int b = bx;
@@ -959,22 +994,26 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
         if (t <= tmax && t != b)
             head[t].load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
 #endif
+#if !TRSM_FULL
     double ldv[2]; // L21 of the diagonal block at (j0, j0): rows 32..63, columns 0..31
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = threadIdx.x + 512 * q; // e = c + 32 k  (c = row of L21, contiguous in memory)
         ldv[q] = A[j0 + 32 + (e & 31) + (j0 + (e >> 5)) * lda];
     }
+#endif
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int e = threadIdx.x + 512 * q;
         Bx[(e >> 6) * XS + (e & 63)] = xv[q]; // Bx[c][k] = X[c][k]
     }
+#if !TRSM_FULL
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = threadIdx.x + 512 * q;
         Ld[(e & 31) * XS + (e >> 5)] = ldv[q];
     }
+#endif
     own.store(T0);
     // the C tile of the first update (for workgroup 0: the next diagonal block) is fetched now, under
     // the triangular solve, instead of at the top of the update loop
@@ -992,7 +1031,11 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
     PTS(1);
 
     // 1. L_b = A_b L11^-T  (half-block form of the inverse, in place in T0)
+#if TRSM_FULL
+    trsm_tile_full(T0, Bx, lane, wave);
+#else
     trsm_tile_half(T0, Bx, Ld, lane, wave);
+#endif
     PTS(2);
     {
         // Row blocks b < nt are the "head" tiles other workgroups re-derive from A while this one
@@ -1098,8 +1141,13 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                 late.store(T1);
             }
             __syncthreads();
-            if (!handed)
+            if (!handed) {
+#if TRSM_FULL
+                trsm_tile_full(T1, Bx, lane, wave);
+#else
                 trsm_tile_half(T1, Bx, Ld, lane, wave);
+#endif
+            }
             Bop = T1;
         }
         double a2[2][4];
@@ -1179,7 +1227,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
         diag_flow_init(sy);
         __syncthreads();
         PTS(5);
-        diag_flow(Ls, Ltb, invd, sy, A + r0 + r0 * lda, lda, Xt_next, info, r0, wave, lane);
+        diag_flow(Ls, Ltb, invd, sy, A + r0 + r0 * lda, lda, Xt_next, info, r0, wave, lane, invd + NB + 8);
         PTS(6);
         return;
     }
@@ -1273,7 +1321,8 @@ __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restric
         return;
     }
     // ---- the diagonal workgroup ----
-    static_assert(NB * XS + DIAG_LTB + NB <= 2 * NB * PS, "[Ls | Ltb | invd] is carved out of the two operand tiles");
+    static_assert(NB * XS + DIAG_LTB + NB + 8 + DIAG_XW_DOUBLES <= 2 * NB * PS,
+                  "[Ls | Ltb | invd | sync | Xw] is carved out of the two operand tiles");
     double* T0 = lds;
     double* T1 = lds + NB * PS;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1320,7 +1369,7 @@ __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restric
         DiagSync* sy = reinterpret_cast<DiagSync*>(invd + NB);
         diag_flow_init(sy);
         __syncthreads();
-        diag_flow(Ls, Ltb, invd, sy, A + pe + pe * lda, lda, Xt_next, info, pe, wave, lane);
+        diag_flow(Ls, Ltb, invd, sy, A + pe + pe * lda, lda, Xt_next, info, pe, wave, lane, invd + NB + 8);
         return;
     }
 #endif
@@ -1471,6 +1520,9 @@ __global__ __launch_bounds__(256) void k_xinv_complete(const double* __restrict_
 }
 void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b0, int64_t nblocks, double* Xt_all)
 {
+#if DIAG_FLOW
+    return; // the data-flow block factorisation leaves all of X (diag_flow.h: flow_w_wave, flow_x21)
+#endif
     if (nblocks > 0)
         hipLaunchKernelGGL(k_xinv_complete, dim3((unsigned)nblocks, 1, g_batch.G), dim3(256), 0, s, L, ldl, b0, Xt_all, g_batch.bt);
 }

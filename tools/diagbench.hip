@@ -74,6 +74,17 @@ int main()
                     xe = fmax(xe, er);
                 }
         printf("max |X_hh L_hh - I| = %.2e\n", xe);
+#if DIAG_FLOW
+        double xf = 0.0; // the data-flow form also leaves the off-diagonal quarter: all of X L = I
+        for (int i = 0; i < 64; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double sum = 0.0;
+                for (int k = j; k <= i; ++k)
+                    sum += X[k + 64 * i] * L[k + j * ld];
+                xf = fmax(xf, fabs(sum - (i == j ? 1.0 : 0.0)));
+            }
+        printf("max |X L - I| (all 64 x 64) = %.2e\n", xf);
+#endif
     }
 #if DIAG_FLOW
     {
