@@ -489,7 +489,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 }
                 hipStreamWaitEvent(c->stream2, ev(3 * kp), 0); // the bulk update starts now and shares the chip
                                                                // with panel kp + 1 only
-                if (nf > 0)
+                if (nf > 0 && !c->panel_handover) // (with the hand-over the head tiles were written in place too)
                     launch_head_copy(c->stream2, A, ld, p0, nt0, nf, Hbase);
                 nf = 0;
                 if (c->fuse_panel && c->xinv_done == p0 / NB && pw % NB == 0) { // this panel's block inverses:
@@ -516,13 +516,13 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                     hipStreamWaitEvent(s, c->la_events[la_last], 0);
                     la_pending = false;
                 }
-                if (nf > 0)
+                if (nf > 0 && !c->panel_handover)
                     launch_head_copy(s, A, ld, p0, nt0, nf, Hbase);
                 nf = 0;
                 upd(s, pe, N, pe);
             }
         }
-        if (nf > 0) { // last panel: no trailing update
+        if (nf > 0 && !c->panel_handover) { // last panel: no trailing update
             PhaseScope ps(c, GPE_PH_POTRF_PANEL, 0.0);
             launch_head_copy(s, A, ld, p0, nt0, nf, Hbase);
             nf = 0;

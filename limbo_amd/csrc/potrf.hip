@@ -1046,8 +1046,13 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
         for (int q = 0; q < 8; ++q) {
             const int col = kk0 + 8 * q;
             const double v = T0[col * PS + i];
-            if (b < nt) // write-through: other XCDs read this tile during this launch (PANEL_HANDOVER)
+            if (b < nt) { // write-through: other XCDs read this tile during this launch (PANEL_HANDOVER)
                 __hip_atomic_store(Hs + (int64_t)b * (NB * NB) + i + NB * col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // with the hand-over nobody re-derives anything from A's head rows: L goes into place as well and the
+                // panel needs no k_head_copy behind it (a launch in front of every look-ahead update)
+                if (hflag)
+                    A[R0 + i + (j0 + col) * lda] = v;
+            }
             else if (i < nrows)
                 A[R0 + i + (j0 + col) * lda] = v;
         }
