@@ -54,7 +54,10 @@ struct gpe_ctx {
     bool fuse_diag = true;      // next diagonal block factored inside the next-panel update launch (k_upd_fused)
     bool lookahead = true;             // GPE_LOOKAHEAD=0 disables
     int bulk_wgs = 192;                // physical workgroups of a look-ahead bulk update (GPE_BULK_WGS)
-    int64_t bulk_free_tiles = 384;     // ... unless it has at least this many 128 x 128 tiles (GPE_BULK_FREE_TILES): N > 4096
+    int near_wgs = 0;                  // workgroups of the "near" part of a look-ahead update (0: unrestricted — it is what the
+                                       // next panel's update waits for; -1: bulk_wgs; GPE_NEAR_WGS)
+    int64_t bulk_free_tiles = 250;     // ... unless it has at least this many 128 x 128 tiles (GPE_BULK_FREE_TILES): the first
+                                       // three far updates at N = 4096 (re-tuned once stream2 carried nothing else: 554 -> 561/s)
     std::mutex mu;
     int64_t N = 0, cap = 0, ld = 0;
     int D = 0, P = 0;
@@ -497,7 +500,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                     c->xinv_done = pe / NB;
                 }
                 const int64_t pe3 = std::min<int64_t>(pe2 + nbo, N);
-                upd(c->stream2, pe2, pe3, pe2, c->bulk_wgs, nullptr, 64); // near: what panel kp + 1's update needs
+                upd(c->stream2, pe2, pe3, pe2, c->near_wgs >= 0 ? c->near_wgs : c->bulk_wgs, nullptr, 64); // near: what panel kp + 1's update needs
                 hipEventRecord(ev(3 * kp + 1), c->stream2);
                 if (pe3 < N) {
                     // 1 looping workgroup per CU on bulk_wgs CUs leaves 256 - bulk_wgs CUs to the panel.  When the update
@@ -1147,6 +1150,8 @@ int gpe_create(int device_id, gpe_handle* out)
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
     if (const char* f = getenv("GPE_BULK_WGS"))
         c->bulk_wgs = atoi(f);
+    if (const char* f = getenv("GPE_NEAR_WGS"))
+        c->near_wgs = atoi(f);
     if (const char* f = getenv("GPE_PANEL_HANDOVER"))
         c->panel_handover = atoi(f) != 0;
     if (const char* f = getenv("GPE_BULK_FREE_TILES"))
