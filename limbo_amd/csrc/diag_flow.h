@@ -380,6 +380,10 @@ struct FlowX<-1> {
 static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* sy, double* Xw, int lane)
 {
     lds_await(&sy->xprog, 8);
+    // ... and not before panel 10 is out: this wave shares its SIMD with update wave U2, which hands groups 8..11 to P in
+    // rounds 6..9 — started at round 8 its matrix-core instructions delayed those hand-overs and P with them (round 10:
+    // 1.6 k cycles instead of 1.0 k, r02_diag_flow_stamps.log of that build).  Three rounds are enough for W.
+    lds_await(&sy->prog, 11);
     const double* X11 = Xw;
     double* W = Xw + 2 * (32 * XH);
     const int kq = lane >> 4;
