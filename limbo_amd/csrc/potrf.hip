@@ -961,8 +961,9 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                                                        int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
                                                        gpe_epoch_t* hflag, gpe_epoch_t epoch, int spin_limit, const int bx)
 {
-    // one LDS array, carved: [Bx | T0 | T1 | Ld]; workgroup 0 re-carves it as [Ls | Ltb | invd]
-    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + 32 * XS];
+    // one LDS array, carved: [Bx | T0 | T1 (| Ld: half-block form only)]; workgroup 0 re-carves it as [Ls | Ltb | invd | sync | Xw]
+    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + (TRSM_FULL ? 0 : 32 * XS)];
+    static_assert(NB * XS + DIAG_LTB + NB + 8 + DIAG_XW_DOUBLES <= NB * XS + 2 * NB * PS, "workgroup 0's carve fits");
     __shared__ int sbad;
     double* Bx = lds;
     double* T0 = lds + NB * XS;
