@@ -265,216 +265,13 @@ struct XPipe32<-1> {
     static __device__ __forceinline__ void run(double (&)[32], const double*, const double*, double*, int) {}
 };
 
-// ---- 8-column rounds (round 2) -----------------------------------------------------------------------------------------
-// The 4-column rounds above spend ~1.9 k cycles per round, and not on work: publish through LDS, barrier, read back,
-// broadcast, scale.  Here a round is EIGHT columns: half as many barriers and publishes, and inside
-// the owner wave a shorter chain per column — the pivot and the not-yet-scaled multipliers of the later panel columns
-// (the entries of column c at lanes c0+c+1 .. c0+7) are broadcast together, in one burst of v_readlanes, as soon as
-// column c is final, and every lane scales them itself (mul + fma each, redundant but off the chain): the chain per
-// column is  broadcast -> rsq -> mul -> fma -> [scale of the next column's multiplier: mul, fma] -> fma,  with no second
-// broadcast hop.  Wave w owns the column groups g = w and w + 4 (columns 8 g .. 8 g + 7): thread (r, w) holds, as
-// a[q][e], i = 4 q + e: column DIAG_COL(q, e, w) = 32 (i >> 3) + 8 w + (i & 7).
-static __device__ __forceinline__ void rank8_update(double (&a)[4][4], const double* __restrict__ Lt, int r, int w, int gmin)
-{
-    double m[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        m[j] = Lt[r * 8 + j];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (4 * h + w < gmin)
-            continue; // wave-uniform
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double* lc = Lt + (32 * h + 8 * w + k) * 8; // wave-uniform address: LDS broadcast
-            double v = a[2 * h + (k >> 2)][k & 3];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v = fma(-m[j], lc[j], v);
-            a[2 * h + (k >> 2)][k & 3] = v;
-        }
-    }
-}
+// (Round 2 also built 8-column rounds here — half the barriers and publishes, optionally with a 1/p update chain — and
+// measured them neutral, profiles/r02_diag_rounds.log; the data-flow form in diag_flow.h replaced that line of attack and
+// the code was removed.)
 
-template <int G>
-struct DiagRound8 {
-    static __device__ __forceinline__ void run(double (&a)[4][4], double* __restrict__ Ltb, double* __restrict__ invd,
-                                               int* __restrict__ sbad, int r, int w, double* __restrict__ Ls)
-    {
-        DiagRound8<G - 1>::run(a, Ltb, invd, sbad, r, w, Ls);
-        constexpr int h = G >> 2, own = G & 3, c0 = 8 * G;
-        double* Lt = Ltb + (G & 3) * (NB * 8);
-        const double* Lp = Ltb + ((G + 3) & 3) * (NB * 8);  // round G-1
-        const double* Lpp = Ltb + ((G + 2) & 3) * (NB * 8); // round G-2
-        if (w == own) {
-            double x[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                x[k] = a[2 * h + (k >> 2)][k & 3];
-            if (G > 0) { // critical: round G-1's update on this group's eight columns only
-                double m[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    m[j] = Lp[r * 8 + j];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double* lc = Lp + (c0 + k) * 8;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        x[k] = fma(-m[j], lc[j], x[k]);
-                }
-            }
-            double l[8], y[8], piv[8];
-#if DIAG8 == 2
-            // Shortest chain between two pivots (every dependent fp64 op is ~30 cycles here): the update of a later
-            // column needs l_c[row] l_c[k] = x_c[row] x_c[k] / p, i.e. 1/p, not 1/sqrt(p):
-            //   r0 = v_rcp_f64(p) (seed), e = 2 - p r0 (one Newton step folded into the update), w0 = x_c r0,
-            //   x_k -= (w0 mu_k) e.
-            // The next pivot's column is updated first and its broadcast issued at once; the other columns' updates (one
-            // fma each, against the raw broadcast values) and the scaling of the finished column by 1/sqrt(p) fill the
-            // shadow of that broadcast.
-            double p = bcast_lane(x[0], c0);
-            double mu[8];
-#pragma unroll
-            for (int k = 1; k < 8; ++k)
-                mu[k] = bcast_lane(x[0], c0 + k);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const double r0 = __builtin_amdgcn_rcp(p);
-                const double e = fma(-p, r0, 2.0);
-                const double w0 = x[c] * r0;
-                double pn = 0.0, mun[8];
-                if (c < 7) {
-                    const double t = w0 * mu[c + 1];
-                    x[c + 1] = fma(-t, e, x[c + 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    pn = bcast_lane(x[c + 1], c0 + c + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const double w = w0 * e;
-#pragma unroll
-                for (int k = c + 2; k < 8; ++k)
-                    x[k] = fma(-w, mu[k], x[k]);
-                if (c < 7) {
-#pragma unroll
-                    for (int k = c + 2; k < 8; ++k)
-                        mun[k] = bcast_lane(x[c + 1], c0 + k);
-                }
-                { // off the chain: this column's entries of L and 1 / L_cc
-                    const RsqScale sc(p);
-                    l[c] = sc.scale(x[c]);
-                    y[c] = sc.inv(p);
-                    piv[c] = p;
-                }
-                p = pn;
-#pragma unroll
-                for (int k = c + 2; k < 8; ++k)
-                    mu[k] = mun[k];
-            }
-#else
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                // column c of the panel is final: its pivot and its entries at the rows of the later panel columns, one burst
-                const double p = bcast_lane(x[c], c0 + c);
-                double mu[8];
-#pragma unroll
-                for (int k = c + 1; k < 8; ++k)
-                    mu[k] = bcast_lane(x[c], c0 + k);
-                const RsqScale sc(p);
-                l[c] = sc.scale(x[c]);
-#pragma unroll
-                for (int k = c + 1; k < 8; ++k)
-                    x[k] = fma(-l[c], sc.scale(mu[k]), x[k]); // k = c + 1 first: the next pivot's column
-                y[c] = sc.inv(p);
-                piv[c] = p;
-            }
-#endif
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                a[2 * h + (k >> 2)][k & 3] = l[k];
-                Lt[r * 8 + k] = l[k];
-                if (Ls) // the finished columns, for the inversion pipeline
-                    Ls[r * XS + c0 + k] = l[k];
-            }
-            if (r == 0) {
-                int bad = 0;
-#pragma unroll
-                for (int k = 7; k >= 0; --k) {
-                    invd[c0 + k] = y[k];
-                    if (!(piv[k] > 0.0))
-                        bad = c0 + k + 1; // first non-positive pivot (the reference never checks LLT::info(), gp.hpp:565)
-                }
-                if (bad != 0 && *sbad == 0)
-                    *sbad = bad;
-            }
-        }
-        else {
-            if (G > 1 && w == ((G - 1) & 3)) // last round's owner catches up on round G-2
-                rank8_update(a, Lpp, r, w, G);
-            if (G > 0)
-                rank8_update(a, Lp, r, w, G);
-        }
-        ARR(G, w);
-        __syncthreads();
-        if (G < 8)
-            TS(10 + G);
-    }
-};
-template <>
-struct DiagRound8<-1> {
-    static __device__ __forceinline__ void run(double (&)[4][4], double*, double*, int*, int, int, double*) {}
-};
-
-// the inversion pipeline of XPipe32 for 8-column rounds: eight rows of X per round
-template <int G>
-struct XPipe8 {
-    static __device__ __forceinline__ void run(double (&S)[32], const double* __restrict__ Ls,
-                                               const double* __restrict__ invd, double* __restrict__ Xt, int c)
-    {
-        XPipe8<G - 1>::run(S, Ls, invd, Xt, c);
-        ARR(G, 4);
-        __syncthreads(); // = the barrier that ends round G: columns 8G..8G+7 of L and their pivots are final
-        constexpr int hb = G >> 2, i0 = 8 * (G & 3), base = 32 * hb;
-        if ((c >> 5) == hb) {
-            const double* Lb = Ls + base * XS + base; // this half-block of L
-            double x[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                double t = S[i0 + i];
-#pragma unroll
-                for (int j = 0; j < i; ++j)
-                    t = fma(-Lb[(i0 + i) * XS + i0 + j], x[j], t);
-                x[i] = t * invd[base + i0 + i];
-                Xt[c + NB * (base + i0 + i)] = x[i]; // row base+i0+i of X is final: Xt[col + 64 row] = X[row][col]
-            }
-#pragma unroll
-            for (int i = i0 + 8; i < 32; ++i) { // fold the eight new rows into every later row of the half-block
-                double v = S[i];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v = fma(-Lb[i * XS + i0 + j], x[j], v);
-                S[i] = v;
-            }
-        }
-    }
-};
-template <>
-struct XPipe8<-1> {
-    static __device__ __forceinline__ void run(double (&)[32], const double*, const double*, double*, int) {}
-};
-
-#ifndef DIAG8
-#define DIAG8 0 // 0: the 4-column rounds of round 1 (default); 1: 8-column rounds; 2: 8-column rounds, 1/p update chain — both measured neutral (profiles/r02_diag_rounds.log)
-#endif
-#if DIAG8 != 0
-#define DIAG_COL(q, e, w) (32 * ((4 * (q) + (e)) >> 3) + 8 * (w) + ((4 * (q) + (e)) & 7))
-#define DIAG_LTB (4 * NB * 8)
-#define DIAG_RUN(a, Ltb, invd, sbad, r, w, Ls) DiagRound8<7>::run(a, Ltb, invd, sbad, r, w, Ls)
-#else
 #define DIAG_COL(q, e, w) (16 * (q) + 4 * (w) + (e))
 #define DIAG_LTB (4 * NB * 4)
 #define DIAG_RUN(a, Ltb, invd, sbad, r, w, Ls) DiagRound<15>::run(a, Ltb, invd, sbad, r, w, Ls)
-#endif
 static __device__ __forceinline__ void xpipe32_wave(const double* __restrict__ Ls, const double* __restrict__ invd,
                                                     double* __restrict__ Xt, int c)
 {
@@ -482,11 +279,7 @@ static __device__ __forceinline__ void xpipe32_wave(const double* __restrict__ L
 #pragma unroll
     for (int k = 0; k < 32; ++k)
         S[k] = (k == (c & 31)) ? 1.0 : 0.0;
-#if DIAG8 != 0
-    XPipe8<7>::run(S, Ls, invd, Xt, c);
-#else
     XPipe32<15>::run(S, Ls, invd, Xt, c);
-#endif
 }
 
 #ifndef DIAG_FLOW

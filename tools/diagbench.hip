@@ -1,5 +1,5 @@
 // diagbench.hip — the 64 x 64 diagonal-block kernel (k_diag) alone: average launch time and the in-kernel round stamps.
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -DDIAG_TIMING [-DDIAG8=0] tools/diagbench.hip -o tools/diagbench_[48]
+// build: make -C tools diagflow diagbench_0   (the data-flow form / the barrier rounds, -DDIAG_FLOW=0)
 #include "../limbo_amd/csrc/potrf.hip"
 #include <vector>
 thread_local BatchLaunch g_batch;
@@ -101,10 +101,10 @@ int main()
         return 0;
     }
 #endif
-    printf("DIAG8=%d: k_diag %.2f us per launch (events, incl. launch gap), max |L L^T - K| = %.2e\n", DIAG8, 1e3 * tot / reps, err);
+    printf("barrier rounds: k_diag %.2f us per launch (events, incl. launch gap), max |L L^T - K| = %.2e\n", 1e3 * tot / reps, err);
     printf("  cycles (clock64 = s_memtime): load %lld | rounds total %lld | store %lld | per round:", (h[1] - h[0]),
            (h[2] - h[1]), (h[3] - h[2]));
-    const int nr = DIAG8 != 0 ? 8 : 16;
+    const int nr = 16;
     for (int g = 0; g < nr; ++g)
         printf(" %lld", (h[10 + g] - (g ? h[9 + g] : h[1])));
     printf("\n");
