@@ -14,8 +14,12 @@
 //                  update of a 16 x 16 block is four matrix-core instructions and five per-lane LDS reads.  After applying
 //                  panel t a wave hands group t+2 (now updated through t) to P through the buffer H[(t+2)&1] + `hflag`.
 //   wave 5      X  the inversion pipeline of round 1 (XPipe32: the two 32 x 32 half-block inverses by forward substitution, one
-//                  round behind), following `prog` instead of the barriers.
+//                  round behind) on all 64 lanes, following `prog` instead of the barriers.
 //   wave 6      S  stores the finished columns of L to global memory and checks the pivots — none of that is in P.
+//   wave 7      W  W = L21 X11 once X11 is complete; the update waves then finish the inverse, X21 = -X22 W, when X22 is:
+//                  all of X = L11^-1 leaves the kernel and the panel steps solve against L11 with one product.
+// A lost hardware assumption would show as wrong numbers, not as a hang: every wait is for a counter another wave of the
+// same workgroup is certain to advance (P waits only for the update waves' hand-overs, they only for P).
 // Synchronisation is by counters in LDS: a publisher issues its data writes, then the counter write (LDS operations of one
 // wave execute in order); a consumer reads the counter, then the data.  No s_barrier inside the rounds: P never stalls on a
 // slower consumer, X and S may lag by several rounds and only have to finish shortly after P does.
