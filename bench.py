@@ -36,6 +36,164 @@ FP64_MFMA_PEAK_TF = 78.6  # 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz; v_mfma_f64_
 N_C2, D_C2 = 4096, 6
 
 
+def bo_inner_loop(lib, _capi, O, device):
+    """The BO inner loop of src/benchmarks/limbo/bench.cpp:66-84 / bayes_opt/boptimizer.hpp:148-161 through the C-ABI of
+    `lib` (the HIP engine; in the cpu_baseline leg the oracle, for the same-box figure)."""
+    n0, n1 = 10, 200
+    rng5 = np.random.default_rng(5)
+    X5 = rng5.uniform(0, 1, size=(n1, D_C2))
+    Y5 = O.hartmann6(X5)[:, None]
+    oms = [np.asfortranarray(O.obs_mean_data(Y5[: k + 1])[0]) for k in range(n1)]
+    xs = [np.ascontiguousarray(X5[k]) for k in range(n1)]
+    best_add = 1e30
+    h5 = None
+    for _ in range(5):
+        if h5 is not None:
+            h5.close()
+        h5 = _capi.Handle(lib, device)
+        h5.set_kernel(O.SE_ARD, np.zeros(D_C2 + 1), 0.01)
+        h5.set_data(X5[:n0], oms[n0 - 1])
+        h5.compute()
+        t0 = time.perf_counter()
+        for k in range(n0, n1):
+            h5.add_sample(xs[k], oms[k])
+        best_add = min(best_add, time.perf_counter() - t0)
+    pts = [np.ascontiguousarray(p_[None, :]) for p_ in rng5.uniform(0, 1, size=(350, D_C2))]
+    for p_ in pts[:50]:
+        h5.query_batch(p_)
+    best_q = 1e30
+    for i0 in (50, 150, 250):
+        t0 = time.perf_counter()
+        for p_ in pts[i0: i0 + 100]:
+            h5.query_batch(p_)
+        best_q = min(best_q, time.perf_counter() - t0)
+    Xb = rng5.uniform(0, 1, size=(20000, D_C2))
+    h5.query_batch(Xb[:256])
+    t0 = time.perf_counter()
+    h5.query_batch(Xb)
+    dtb = time.perf_counter() - t0
+    ll = h5.log_lik()
+    h5.close()
+    return {"add_sample_per_s": (n1 - n0) / best_add, "add_sample_us": 1e6 * best_add / (n1 - n0), "one_point_query_us": 1e6 * best_q / 100,
+            "batched_query_points_per_s_n200": 20000 / dtb, "log_lik": ll}
+
+
+def extras(eng, _capi, O, local_rank, steps):
+    """Secondary objects of the bench line, N=1 only, outside the headline's timed region (driver-run versions of what
+    bench_extra.py measures): BASELINE configs[1] as written (the gradient objective of one KernelLFOpt iteration),
+    configs[2] (N=16384 factorisation + 100k batched queries), configs[3] on one GPU (64 GPs), configs[4] (BO inner loop)."""
+    import torch
+
+    out = {}
+    PEAK = FP64_MFMA_PEAK_TF * 1e12
+
+    # ---- configs[1] as written: one KernelLFOptimization::operator() (kernel_lf_opt.hpp:77-92) = set theta ->
+    # recompute -> log-lik -> K^-1 -> gradient, on resident buffers
+    X, Y = O.make_problem("c2", N=N_C2)
+    om, _ = O.obs_mean_data(Y)
+    h = _capi.Handle(eng, local_rank)
+    h.set_data(X, om)
+    th = np.zeros(D_C2 + 1)
+    h.hp_objective(O.SE_ARD, th, 0.01, optimize_noise=False, want_grad=True)
+    n = max(5, steps // 2)
+    per = []
+    for i in range(n):
+        t0 = time.perf_counter()
+        ll, g, info = h.hp_objective(O.SE_ARD, th + 1e-3 * (i + 1), 0.01, optimize_noise=False, want_grad=True)
+        per.append(time.perf_counter() - t0)
+    assert info == 0 and np.all(np.isfinite(g))
+    dt = float(np.sum(per))
+    fl = float(N_C2) ** 3 / 3.0 + 2.0 * float(N_C2) ** 3 / 3.0  # factorisation + K^-1 = L^-T L^-1 (triangular products)
+    h.set_profiling(True)
+    h.reset_phase_ms()
+    h.hp_objective(O.SE_ARD, th, 0.01, optimize_noise=False, want_grad=True)
+    ph = h.get_phase_ms()
+    h.set_profiling(False)
+    out["hp_objective"] = {
+        "workload": f"configs[1] as written: SquaredExpARD N={N_C2} D={D_C2} + one KernelLFOpt objective evaluation "
+                    "(gpe_hp_objective: new theta -> K -> L -> alpha -> log-lik -> K^-1 -> d log-lik / d theta), resident buffers",
+        "value": n / dt, "unit": "objective evaluations/s", "ms_per_evaluation": 1e3 * dt / n, "median_ms": 1e3 * float(np.median(per)),
+        "roofline": {"bound": "mfma", "achieved": fl * n / dt / 1e12, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": fl * n / dt / PEAK, "algorithmic_flops": fl,
+                     "note": "N^3/3 (Cholesky) + 2 N^3/3 (K^-1 from L, triangular) per evaluation; the O(N^2 D) build and pair sums not counted"},
+        "phases_ms_profiled": {k: v["ms"] for k, v in ph.items() if v["launches"]},
+        "log_lik": ll, "grad_norm": float(np.linalg.norm(g)),
+    }
+    h.close()
+
+    # ---- configs[2]: N=16384, D=12, Matern-5/2: compute()+log_lik, its trailing updates alone, 100k batched queries
+    N3, D3, M3 = 16384, 12, 100000
+    X3, Y3 = O.make_problem("c3")
+    om3, _ = O.obs_mean_data(Y3)
+    h = _capi.Handle(eng, local_rank)
+    h.set_data(X3, om3)
+    h.set_kernel(O.MATERN52, np.zeros(2), 0.01)
+    h.compute()
+    best = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        info3 = h.compute()
+        ll3 = h.log_lik()
+        best = min(best, time.perf_counter() - t0)
+    fl3 = float(N3) ** 3 / 3.0 + 2.0 * float(N3) * N3
+    h.set_profiling(True)
+    h.reset_phase_ms()
+    h.compute()
+    ph3 = h.get_phase_ms()["potrf_update"]
+    h.set_profiling(False)
+    Xq3 = np.random.default_rng(3).uniform(0, 1, size=(M3, D3))
+    h.query_batch(Xq3[:512])
+    bq = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        kta3, var3 = h.query_batch(Xq3)
+        bq = min(bq, time.perf_counter() - t0)
+    assert info3 == 0 and np.isfinite(ll3) and np.all(np.isfinite(var3))
+    out["config3"] = {
+        "workload": f"configs[2]: Matern5/2 GP, N={N3}, D={D3}, fp64: compute()+log_lik (best of 3), then mu/sigma^2 for {M3} query "
+                    "points through gpe_query_batch (best of 2, host to host incl. the PCIe copies of the points and results)",
+        "compute_loglik_ms": 1e3 * best, "factorisation_tflops": fl3 / best / 1e12, "factorisation_frac_of_fp64_peak": fl3 / best / PEAK,
+        "trailing_update": {"tflops": ph3["flops"] / (ph3["ms"] * 1e-3) / 1e12, "frac": ph3["flops"] / (ph3["ms"] * 1e-3) / PEAK,
+                            "launches": ph3["launches"], "note": "every launch alone, HIP events on the handle's stream (as `roofline`)"},
+        "query_points_per_s": M3 / bq, "query_s": bq, "query_tflops": 1.0 * M3 * N3 * N3 / bq / 1e12,
+        "query_frac_of_fp64_peak": 1.0 * M3 * N3 * N3 / bq / PEAK, "log_lik": ll3,
+    }
+    h.close()
+    torch.cuda.empty_cache()
+
+    # ---- configs[3] on ONE GPU: all 64 GPs of N=2048 through one batched launch sequence
+    G4, N4 = 64, 2048
+    X4, Y4 = O.make_problem("c4", N=N4)
+    rng4 = np.random.default_rng(4)
+    hs = []
+    for g_ in range(G4):
+        om4, _ = O.obs_mean_data(Y4 * rng4.uniform(0.5, 1.5) + 0.1 * np.sin(3.0 * X4[:, g_ % 6: g_ % 6 + 1] + g_))
+        hh = _capi.Handle(eng, local_rank)
+        hh.set_data(X4, om4)
+        hh.set_kernel(O.SE_ARD, rng4.uniform(-1e-2, 1e-2, size=D_C2 + 1), 0.01)
+        hs.append(hh)
+    _capi.batch_compute(hs)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        st4 = _capi.batch_compute(hs)
+        ll4 = _capi.batch_log_lik(hs)
+    dt4 = time.perf_counter() - t0
+    assert all(s_ == 0 for s_ in st4) and np.all(np.isfinite(ll4))
+    fl4 = float(N4) ** 3 / 3.0 + 2.0 * float(N4) * N4
+    out["config4_g64"] = {"workload": f"configs[3] on one GPU: {G4} independent SquaredExpARD GPs, N={N4}, D={D_C2}, compute()+log_lik each, "
+                                      "one gpe_batch_compute", "value": G4 * reps / dt4, "unit": "evaluations/s",
+                          "ms_per_batch": 1e3 * dt4 / reps, "tflops": G4 * reps * fl4 / dt4 / 1e12, "frac_of_fp64_peak": G4 * reps * fl4 / dt4 / PEAK}
+    for hh in hs:
+        hh.close()
+
+    # ---- configs[4]: the BO inner loop (benchmarks/limbo/bench.cpp:66-84): add_sample 10 -> 200, one-point queries at n = 200
+    out["config5"] = dict(bo_inner_loop(eng, _capi, O, local_rank),
+                          workload="configs[4] regime: SquaredExpARD D=6, noise 0.01, add_sample() n = 10 -> 200 (best of 5 loops), one-point "
+                                   "mu+sigma^2 at n = 200 (best of 3 blocks of 100), host to host through ctypes; fp64 throughout (bf16: DESIGN §10)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,6 +203,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="profiling runs: only the N=4096 evaluation loop (no H2D variant, no config 4)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (hp_objective, config3, config4_g64, config5)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1: nccl (= RCCL over xGMI, the default) or gloo (CPU tensors for the two "
+                         "collectives; lets several ranks share one visible GPU: tests/test_gpu_configs.py)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -55,13 +217,22 @@ def main():
     import torch
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # ranks may outnumber the visible GPUs only with --dist-backend gloo (the one-GPU rehearsal of the multi-rank path)
+    n_vis = torch.cuda.device_count()
+    if local_rank >= n_vis:
+        assert args.dist_backend == "gloo", f"rank {rank}: LOCAL_RANK {local_rank} but {n_vis} visible GPU(s)"
+        local_rank %= n_vis
     torch.cuda.set_device(local_rank)
     dist = None
+    coll_dev = f"cuda:{local_rank}" if args.dist_backend == "nccl" else "cpu"  # where the collectives' tensors live
     if world > 1:
         import torch.distributed as dist_
 
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from limbo_amd import _capi
     from limbo_amd import synth as O  # synthetic-problem generator (pure numpy)
@@ -93,21 +264,30 @@ def main():
     sync()
     t0 = time.perf_counter()
     ll = 0.0
+    stamps = [t0]
     for _ in range(args.steps):
-        info, ll = step()
+        info, ll = step()  # returns with the result on the host: every step ends synchronised
+        stamps.append(time.perf_counter())
     # arg-max over the restarts: all-gather of (log_lik, theta) -- the only collective
     from limbo_amd import parallel as PAR
 
-    best_ll, best_theta, best_rank = PAR.argmax_over_ranks([ll], [theta], dist, device=f"cuda:{local_rank}")
+    best_ll, best_theta, best_rank = PAR.argmax_over_ranks([ll], [theta], dist, device=coll_dev)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert info == 0 and np.isfinite(ll), (info, ll)
     evals = world * args.steps
     value = evals / dt
+    # spread of the K timed steps (this rank's host clock; each step ends with its result on the host): a scheduler
+    # hiccup inside the timed region shows as max >> median instead of silently moving `value`
+    per = np.diff(np.asarray(stamps)) * 1e3
+    blocks = [float(np.sum(b)) / len(b) for b in np.array_split(per, min(5, len(per))) if len(b)]
+    step_stats = {"median_ms": float(np.median(per)), "min_ms": float(per.min()), "max_ms": float(per.max()),
+                  "p90_ms": float(np.percentile(per, 90)), "block_ms_per_step": blocks,
+                  "value_from_median_step": world * 1e3 / float(np.median(per))}
 
     value_incl_h2d, config4 = None, None
     if not args.headline_only:
@@ -121,7 +301,7 @@ def main():
         sync()
         dt_h2d = time.perf_counter() - t0
         if dist is not None:
-            tmax = torch.tensor([dt_h2d], dtype=torch.float64, device=f"cuda:{local_rank}")
+            tmax = torch.tensor([dt_h2d], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_h2d = float(tmax.item())
         value_incl_h2d = world * n_h2d / dt_h2d
@@ -148,11 +328,11 @@ def main():
         for _ in range(reps4):
             st4 = _capi.batch_compute(hs4)
             ll4 = _capi.batch_log_lik(hs4)
-        best4 = PAR.argmax_over_ranks(list(ll4), th4, dist, device=f"cuda:{local_rank}")
+        best4 = PAR.argmax_over_ranks(list(ll4), th4, dist, device=coll_dev)
         sync()
         dt4 = time.perf_counter() - t0
         if dist is not None:
-            tmax = torch.tensor([dt4], dtype=torch.float64, device=f"cuda:{local_rank}")
+            tmax = torch.tensor([dt4], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt4 = float(tmax.item())
         assert all(s4 == 0 for s4 in st4) and np.all(np.isfinite(ll4))
@@ -175,11 +355,13 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic (Hartmann6 + noise on U[0,1]^6, numpy default_rng(20260927))",
+        "data": "synthetic (Hartmann6 + noise on U[0,1]^6, numpy default_rng(20260925 + config index = 20260927 — SURVEY §8(d) names mt19937_64 with the same seed rule; numpy's generator is what the committed goldens use), theta0 = 0",
         "config": {"workload": f"configs[1]: SquaredExpARD GP, N={N}, D={D_C2}, P=1, fp64, theta0=0, noise=0.01; "
                                "step = compute()+compute_log_lik(), X resident in HBM",
                    "parallelism": f"{world} independent GP restart(s), 1 per GPU, final RCCL all-gather arg-max"},
         "log_lik": ll,
+        "argmax": {"best_log_lik": best_ll, "owner_rank": best_rank},
+        "step_time_spread": step_stats,
         "value_incl_h2d": value_incl_h2d,
         "value_incl_h2d_note": "same step with gpe_set_data (X: 196 KB, obs_mean: 32 KB, host -> HBM) inside the timed region",
         "config4": config4,
@@ -204,7 +386,7 @@ def main():
         # HBM traffic of the dominant launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md): profiles/, not live
         traffic = None
-        pmc = next((q for q in (ROOT / "profiles" / "r02_pmc_trailing_update.json", ROOT / "profiles" / "r01_pmc_trailing_update.json") if q.exists()), ROOT / "none")
+        pmc = next((q for q in (ROOT / "profiles" / "r03_pmc_trailing_update.json", ROOT / "profiles" / "r02_pmc_trailing_update.json") if q.exists()), ROOT / "none")
         if pmc.exists() and N == N_C2:
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch_corrected")
         out["roofline"] = {
@@ -258,6 +440,9 @@ def main():
                 hr.close()
         out["concurrent_evaluations_per_s"] = conc
 
+    if rank == 0 and world == 1 and not args.no_extras and not args.headline_only and N == N_C2:
+        out.update(extras(eng, _capi, O, local_rank, args.steps))
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU side-by-side: the oracle (C restatement of the reference's path, 1 thread = the
         # reference's default: one GP::compute is single-threaded) on a bounded sample.
@@ -288,6 +473,8 @@ def main():
             ac = sl.cho_solve((Lc, True), om, check_finite=False)
             ll_all = -0.5 * float((om * ac).sum()) - float(np.log(np.diag(Lc)).sum()) - 0.5 * N * np.log(2 * np.pi)
             best_all = min(best_all, time.perf_counter() - t0)
+        if "config5" in out:  # the same BO inner loop through the oracle on one core of this box
+            out["config5"]["cpu_oracle_1_core"] = bo_inner_loop(orc, _capi, O, 0)
         out["cpu_baseline_all_cores"] = {"value": 1.0 / best_all, "unit": "evaluations/s", "cores": os.cpu_count(), "kind": "port",
                                          "sample": f"best of 3 compute()+log_lik at N={N}: numpy kernel build + LAPACK dpotrf/dpotrs (scipy/OpenBLAS) "
                                                    "on all host cores", "log_lik": ll_all}

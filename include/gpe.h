@@ -188,6 +188,9 @@ int gpe_get_phase_ms(gpe_handle h, double* ms, int64_t* launches, double* flops,
 int gpe_reset_phase_ms(gpe_handle h);
 /* one-launch sweeps that had to be re-run block by block after a hand-off timeout (never expected; tests) */
 int gpe_flow_retries(gpe_handle h, int64_t* n);
+/* evaluations run a second time because a panel step's head-tile hand-over timed out (never expected; counted in
+ * gpe_flow_retries as well).  The hand-over is switched off for the 16 evaluations that follow and re-armed after. */
+int gpe_handover_reruns(gpe_handle h, int64_t* n);
 /* calls (add_sample, point queries) served by the one-launch small-N path (csrc/small.hip; GPE_SMALL=0 disables it) */
 int gpe_small_calls(gpe_handle h, int64_t* n);
 /* fp64 MFMA peak micro-benchmark (v_mfma_f64_4x4x4_4b, the instruction the GEMM kernels issue), TFLOP/s */

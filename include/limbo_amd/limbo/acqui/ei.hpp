@@ -2,6 +2,9 @@
 // (contract: src/limbo/acqui/ei.hpp:77-120: returns 0 when sigma < 1e-10 or there is no sample;
 // f+ = best predicted mean over the training samples, cached per nb_samples) plus batch().
 // The f+ scan, N calls of model.mu() in the reference (ei.hpp:100-103), is one query_batch here.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_ACQUI_EI_HPP
 #define LIMBO_ACQUI_EI_HPP
 #include <algorithm>

@@ -1,5 +1,8 @@
 // limbo/acqui/gp_ucb.hpp — GP-UCB: mu + kappa sigma, kappa = sqrt(2 log(n^(D/2+2) pi^2 / (3 delta)))
 // (contract: src/limbo/acqui/gp_ucb.hpp:83-107) plus batch() over GP::query_batch.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_ACQUI_GP_UCB_HPP
 #define LIMBO_ACQUI_GP_UCB_HPP
 #include <cmath>

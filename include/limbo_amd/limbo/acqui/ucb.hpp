@@ -1,6 +1,9 @@
 // limbo/acqui/ucb.hpp — UCB(x) = mu(x) + alpha sqrt(sigma^2(x))   (contract: src/limbo/acqui/ucb.hpp:71-95)
 // plus batch(): the same value for M points through one GP::query_batch — row N1 of SURVEY.md §8f:
 // the acquisition optimiser is the caller that turns per-point query() into the device batch.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_ACQUI_UCB_HPP
 #define LIMBO_ACQUI_UCB_HPP
 #include <cmath>

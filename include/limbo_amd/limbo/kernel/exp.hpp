@@ -1,5 +1,8 @@
 // limbo/kernel/exp.hpp — isotropic squared exponential  k = sigma_f^2 exp(-|x-y|^2 / (2 l^2))
 // hyper-parameters (log-space): [log l, log sigma_f]   (contract: src/limbo/kernel/exp.hpp:73-122)
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_KERNEL_EXP_HPP
 #define LIMBO_KERNEL_EXP_HPP
 #include <limbo/kernel/kernel.hpp>

@@ -4,6 +4,9 @@
 // acquisition functions may call directly, and they are the fallback for kernels the engine has
 // no device code for.  `limbo_amd::device_kernel<K>` (bottom of each kernel header) tells the GP
 // which engine kind evaluates the same function on the MI355X.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_KERNEL_KERNEL_HPP
 #define LIMBO_KERNEL_KERNEL_HPP
 

@@ -2,6 +2,9 @@
 //   k(x, y) = sigma_f^2 (1 + sqrt5 d/l + 5 d^2 / (3 l^2)) exp(-sqrt5 d/l),  d = |x - y|
 // hyper-parameters (log-space): [log l, log sigma_f]
 // (policy contract and formulas: src/limbo/kernel/matern_five_halves.hpp:83-139).
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_KERNEL_MATERN_FIVE_HALVES_HPP
 #define LIMBO_KERNEL_MATERN_FIVE_HALVES_HPP
 

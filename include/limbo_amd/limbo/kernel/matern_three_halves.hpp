@@ -1,6 +1,9 @@
 // limbo/kernel/matern_three_halves.hpp — isotropic Matern 3/2
 //   k = sigma_f^2 (1 + sqrt3 d/l) exp(-sqrt3 d/l);  hyper-parameters [log l, log sigma_f]
 // (contract: src/limbo/kernel/matern_three_halves.hpp:80-132)
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_KERNEL_MATERN_THREE_HALVES_HPP
 #define LIMBO_KERNEL_MATERN_THREE_HALVES_HPP
 #include <limbo/kernel/kernel.hpp>

@@ -6,6 +6,9 @@
 // the parameter count): (x-y)^T M (x-y) is a sum of squares over the D inputs scaled by 1/ell and the k
 // projections Lambda^T x, which the engine keeps as k extra rows of its sample matrix.  Engine limits:
 // k <= D and D + D k + 1 <= 64 parameters (gpe_compute returns GPE_ERR_ARG beyond them).
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_KERNEL_SQUARED_EXP_ARD_HPP
 #define LIMBO_KERNEL_SQUARED_EXP_ARD_HPP
 

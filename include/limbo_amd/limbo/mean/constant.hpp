@@ -1,4 +1,7 @@
 // limbo/mean/constant.hpp — a fixed constant mean (src/limbo/mean/constant.hpp:52-83)
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MEAN_CONSTANT_HPP
 #define LIMBO_MEAN_CONSTANT_HPP
 #include <limbo/mean/mean.hpp>

@@ -1,4 +1,7 @@
 // limbo/mean/data.hpp — constant mean equal to the mean of the observations (src/limbo/mean/data.hpp:55-64)
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MEAN_DATA_HPP
 #define LIMBO_MEAN_DATA_HPP
 #include <limbo/mean/mean.hpp>

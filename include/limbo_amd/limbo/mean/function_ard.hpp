@@ -3,6 +3,9 @@
 //     m'(x) = T [m(x); 1],   T: dim_out x (dim_out + 1), initialised to [I | 0] (:64-66);
 // h_params = [T row-major | inner mean's h_params] (:74-92).  Written with element loops only, so it
 // compiles against Eigen and against the minimal eigen_shim alike.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MEAN_FUNCTION_ARD_HPP
 #define LIMBO_MEAN_FUNCTION_ARD_HPP
 #include <limbo/mean/mean.hpp>

@@ -1,6 +1,9 @@
 // limbo/mean/mean.hpp — base of the mean functors (contract: src/limbo/mean/mean.hpp:61-77).
 // Mean functors receive the GP itself and are evaluated on the HOST (gp.hpp:537-548): only
 // obs_mean = Y - m(X) crosses to the device.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MEAN_MEAN_HPP
 #define LIMBO_MEAN_MEAN_HPP
 #include <Eigen/Core>

@@ -1,4 +1,7 @@
 // limbo/mean/null_function.hpp — zero mean (src/limbo/mean/null_function.hpp:52-66)
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MEAN_NULL_FUNCTION_HPP
 #define LIMBO_MEAN_NULL_FUNCTION_HPP
 #include <limbo/mean/mean.hpp>

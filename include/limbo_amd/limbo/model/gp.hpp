@@ -20,6 +20,9 @@
 //
 // Additions (not in the reference): query_batch() — the batched acquisition path of SURVEY.md
 // §8 row a13/N1 — and last_status().
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MODEL_GP_HPP
 #define LIMBO_MODEL_GP_HPP
 

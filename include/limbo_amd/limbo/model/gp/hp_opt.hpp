@@ -1,5 +1,8 @@
 // limbo/model/gp/hp_opt.hpp — base of the hyper-parameter optimisation policies
 // (contract: src/limbo/model/gp/hp_opt.hpp:58-73: default/copy constructible, warns if never used)
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MODEL_GP_HP_OPT_HPP
 #define LIMBO_MODEL_GP_HP_OPT_HPP
 #include <iostream>

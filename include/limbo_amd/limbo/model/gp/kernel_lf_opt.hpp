@@ -6,6 +6,9 @@
 // new theta": each host thread that calls the objective keeps ONE private device clone of the
 // original GP for the lifetime of the optimisation and re-runs build -> factor -> solve on it.
 // The original GP is untouched until the optimiser returns, exactly as in the reference.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MODEL_GP_KERNEL_LF_OPT_HPP
 #define LIMBO_MODEL_GP_KERNEL_LF_OPT_HPP
 #include <map>

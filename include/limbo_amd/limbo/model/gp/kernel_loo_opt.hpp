@@ -2,6 +2,9 @@
 // hyper-parameters (contract: src/limbo/model/gp/kernel_loo_opt.hpp:55-97).
 // As in kernel_lf_opt.hpp here: one persistent device clone per calling host thread instead of the
 // reference's deep copy per evaluation (kernel_loo_opt.hpp:79).
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MODEL_GP_KERNEL_LOO_OPT_HPP
 #define LIMBO_MODEL_GP_KERNEL_LOO_OPT_HPP
 #include <map>

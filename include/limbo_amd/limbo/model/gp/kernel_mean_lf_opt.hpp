@@ -2,6 +2,9 @@
 // the mean hyper-parameters (contract: src/limbo/model/gp/kernel_mean_lf_opt.hpp:55-113).
 // Parameter vector = [kernel h_params | mean h_params] (:67-69).  One persistent device clone per
 // calling host thread instead of the reference's deep copy per evaluation (:92).
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MODEL_GP_KERNEL_MEAN_LF_OPT_HPP
 #define LIMBO_MODEL_GP_KERNEL_MEAN_LF_OPT_HPP
 #include <map>

@@ -2,6 +2,9 @@
 // hyper-parameters only (contract: src/limbo/model/gp/mean_lf_opt.hpp:55-100).
 // K and L do not change during this optimisation: an evaluation is recompute(true, false), i.e. new
 // obs_mean -> two triangular sweeps on the device (gpe_update_alpha); the factor stays in HBM.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MODEL_GP_MEAN_LF_OPT_HPP
 #define LIMBO_MODEL_GP_MEAN_LF_OPT_HPP
 #include <map>

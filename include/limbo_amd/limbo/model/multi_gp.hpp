@@ -3,6 +3,9 @@
 // (tools::par::loop at :124,172,191,210,226,263); here every output GP owns a device handle and a
 // HIP stream, so the same loop makes their kernels overlap on one MI355X (BASELINE config 4 within
 // a GPU; across GPUs the outputs are sharded by limbo_amd/parallel.py).
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MODEL_MULTI_GP_HPP
 #define LIMBO_MODEL_MULTI_GP_HPP
 #include <cassert>

@@ -1,6 +1,9 @@
 // limbo/model/multi_gp/parallel_lf_opt.hpp — fit the hyper-parameters of every output GP of a
 // MultiGP, all at once (contract: src/limbo/model/multi_gp/parallel_lf_opt.hpp:56-70).  Each output
 // GP is an independent device GP on its own stream: the fits overlap on the MI355X.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MODEL_MULTI_GP_PARALLEL_LF_OPT_HPP
 #define LIMBO_MODEL_MULTI_GP_PARALLEL_LF_OPT_HPP
 #include <limbo/model/gp/hp_opt.hpp>

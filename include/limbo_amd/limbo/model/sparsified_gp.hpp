@@ -6,6 +6,9 @@
 // (_sparsify/_get_most_dense_point, :124-183: N - max_points removals, each a partial sort of every
 // row of an N x N distance matrix) runs on the device: gpe_sparsify (limbo_amd/csrc/sparsify.hip)
 // keeps the distance matrix in HBM and re-scans only the rows a removal invalidates.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_MODEL_SPARSIFIED_GP_HPP
 #define LIMBO_MODEL_SPARSIFIED_GP_HPP
 #include <stdexcept>

@@ -12,6 +12,9 @@
 //   BatchGridSearch   : the exact grid and tie-breaking of opt::GridSearch, one batch.
 //   BatchRandomSearch : `points` uniform samples, then `refine_rounds` rounds of `points` samples in
 //                       a box shrinking around the incumbent; every round is one batch.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_OPT_BATCH_SEARCH_HPP
 #define LIMBO_OPT_BATCH_SEARCH_HPP
 #include <algorithm>

@@ -2,6 +2,9 @@
 // (contract: src/limbo/opt/optimizer.hpp:61-96).  The reference spells the optional gradient
 // boost::optional<Eigen::VectorXd>; boost is used when present, otherwise an equivalent minimal
 // optional with the same accessors (is_initialized(), get(), operator bool).
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_AMD_OPT_OPTIMIZER_HPP
 #define LIMBO_AMD_OPT_OPTIMIZER_HPP
 // With limbo's own tree on the include path BEHIND this directory, this file steps aside: limbo's

@@ -4,6 +4,9 @@
 // GP (model/gp/kernel_lf_opt.hpp) clone it once per thread, so the restarts are independent GPs
 // on independent HIP streams and their kernels interleave on the MI355X — the latency-bound
 // factorisation of one restart leaves most CUs idle for the others.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_OPT_PARALLEL_REPEATER_HPP
 #define LIMBO_OPT_PARALLEL_REPEATER_HPP
 #include <future>

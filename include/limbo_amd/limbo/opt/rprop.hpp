@@ -2,6 +2,9 @@
 // (contract and constants: src/limbo/opt/rprop.hpp:82-145: delta0 0.1, delta in [1e-6, 50],
 // eta- 0.5, eta+ 1.2; maximises f; returns the best point SEEN, not the last).
 // Host code by design: it drives <= dim(theta) scalars; every f(theta) is one device evaluation.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_AMD_OPT_RPROP_HPP
 #define LIMBO_AMD_OPT_RPROP_HPP
 // With limbo's own tree on the include path BEHIND this directory, this file steps aside: limbo's

@@ -1,6 +1,9 @@
 // limbo/serialize/binary_archive.hpp — one ".bin" file per object: rows, cols as Eigen::Index
 // (8 bytes each) followed by the column-major doubles; a list is an `int` count followed by its
 // items — the on-disk format of src/limbo/serialize/binary_archive.hpp:63-170.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_SERIALIZE_BINARY_ARCHIVE_HPP
 #define LIMBO_SERIALIZE_BINARY_ARCHIVE_HPP
 #include <cassert>

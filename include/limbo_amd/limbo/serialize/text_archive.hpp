@@ -2,6 +2,9 @@
 // matrix row (or one vector of a list) per line, full precision: the on-disk format of
 // src/limbo/serialize/text_archive.hpp:63-151, so directories written by stock limbo load here and
 // vice versa (row SURVEY.md §8f N3).  std::filesystem instead of boost::filesystem.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_SERIALIZE_TEXT_ARCHIVE_HPP
 #define LIMBO_SERIALIZE_TEXT_ARCHIVE_HPP
 #include <cassert>

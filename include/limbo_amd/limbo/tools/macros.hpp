@@ -3,6 +3,9 @@
 // `Params` struct is written against (reference: src/limbo/tools/macros.hpp:53-110), so they are
 // kept verbatim-compatible: BO_PARAM(T, name, v) yields `static constexpr T name()`, BO_DYN_PARAM
 // a runtime-settable static, and so on.  New MI355X knobs live in limbo::defaults::gpu below.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_AMD_TOOLS_MACROS_HPP
 #define LIMBO_AMD_TOOLS_MACROS_HPP
 // With limbo's own tree on the include path BEHIND this directory, this file steps aside: limbo's

@@ -1,4 +1,7 @@
 // limbo/tools/math.hpp — scalar helpers used by the optimisers (reference: src/limbo/tools/math.hpp)
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_AMD_TOOLS_MATH_HPP
 #define LIMBO_AMD_TOOLS_MATH_HPP
 // With limbo's own tree on the include path BEHIND this directory, this file steps aside: limbo's

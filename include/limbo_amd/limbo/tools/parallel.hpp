@@ -2,6 +2,9 @@
 // (contract: src/limbo/tools/parallel.hpp:116-229, TBB or serial there).  Here a task is normally
 // "drive one device GP": host threads only issue launches on independent HIP streams, so plain
 // std::thread workers are enough — the parallelism that matters happens on the MI355X.
+// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
+// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
+// file named above.  The implementation behind the interface is this project's own.
 #ifndef LIMBO_TOOLS_PARALLEL_HPP
 #define LIMBO_TOOLS_PARALLEL_HPP
 #include <algorithm>

@@ -91,6 +91,7 @@ def _sig(lib, prefix):
             "get_phase_ms": [_vp, _dp, C.POINTER(_i64), _dp, C.c_int],
             "reset_phase_ms": [_vp],
             "flow_retries": [_vp, C.POINTER(_i64)],
+            "handover_reruns": [_vp, C.POINTER(_i64)],
             "small_calls": [_vp, C.POINTER(_i64)],
             "mfma_f64_peak": [C.c_int, _dp],
             "hbm_stream_peak": [C.c_int, _dp],
@@ -189,6 +190,11 @@ class Handle:
     def flow_retries(self) -> int:
         n = _i64()
         self._chk(self.lib.fn("flow_retries")(self._h, C.byref(n)), "flow_retries")
+        return n.value
+
+    def handover_reruns(self) -> int:
+        n = _i64()
+        self._chk(self.lib.fn("handover_reruns")(self._h, C.byref(n)), "handover_reruns")
         return n.value
 
     def small_calls(self) -> int:

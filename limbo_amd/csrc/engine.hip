@@ -22,7 +22,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <chrono>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -72,6 +74,9 @@ struct gpe_ctx {
     size_t query_bytes = 0;
     double* dHead = nullptr; // scratch tiles of the fused panel steps (k_panel_step)
     bool panel_handover = true; // head tiles of a panel step change hands (potrf.hip); GPE_PANEL_HANDOVER=0: re-derived
+    bool panel_handover_cfg = true; // what the caller / environment chose: a hand-over timeout switches panel_handover off
+    int handover_off_left = 0;      // ... for this many evaluations only, then it is re-armed (one hiccup is not forever)
+    int64_t handover_reruns = 0;    // evaluations re-run after a hand-over timeout (gpe_handover_reruns)
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     int64_t grad_partial_cap = 0;
     int* dInfo = nullptr; // = hInfo: pinned host memory the kernels write directly (no copy-back, no device memset)
@@ -142,6 +147,35 @@ hipEvent_t get_event(gpe_ctx* c)
     return e;
 }
 
+// roctx ranges around every phase (tracing), so that a rocprofv3 --marker-trace timeline carries the phase
+// names.  Off unless GPE_ROCTX=1; libroctx64 is looked up at run time (no link-time dependency of the product on it).
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("GPE_ROCTX");
+        if (!e || atoi(e) == 0)
+            return;
+        void* h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h)
+            h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h)
+            return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop)
+            push = nullptr, pop = nullptr;
+    }
+};
+const Roctx& roctx()
+{
+    static const Roctx r;
+    return r;
+}
+const char* const kPhaseNames[GPE_PH_COUNT] = {"gpe:kernel_build", "gpe:potrf_panel", "gpe:potrf_update", "gpe:solve",
+                                               "gpe:loglik",       "gpe:inv",         "gpe:grad",         "gpe:query"};
+
 struct PhaseScope {
     gpe_ctx* c;
     int phase;
@@ -149,6 +183,8 @@ struct PhaseScope {
     hipEvent_t e0 = nullptr;
     PhaseScope(gpe_ctx* c_, int ph, double fl = 0.0) : c(c_), phase(ph), flops(fl)
     {
+        if (roctx().push)
+            roctx().push(kPhaseNames[ph]);
         if (c->prof) {
             e0 = get_event(c);
             hipEventRecord(e0, c->stream);
@@ -156,6 +192,8 @@ struct PhaseScope {
     }
     ~PhaseScope()
     {
+        if (roctx().pop)
+            roctx().pop();
         if (c->prof) {
             hipEvent_t e1 = get_event(c);
             hipEventRecord(e1, c->stream);
@@ -675,6 +713,8 @@ int compute_enqueue(gpe_ctx* c)
     hipStream_t s = c->stream;
     digest_kernel(c);
     c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
+    if (c->handover_off_left > 0 && --c->handover_off_left == 0)
+        c->panel_handover = c->panel_handover_cfg; // re-armed after a run of clean evaluations without it
     if (c->host_K) {
         if (!c->dKhost)
             return GPE_ERR_STATE;
@@ -705,9 +745,19 @@ int compute_enqueue(gpe_ctx* c)
 
 // Host wait for the stream.  A blocking hipStreamSynchronize costs a sleep/wake-up of the calling thread
 // (tens of microseconds between back-to-back evaluations of a few milliseconds each); poll for up to
-// 20 ms first, then block.
+// 20 ms first, then block.  Polling is for the few: with more than four threads waiting at once (restarts under
+// par::max, eight handles in flight) the pollers contend inside the runtime and burn a core each — 930 -> 831
+// evaluations/s going from 4 to 8 in flight — so the fifth waiter onwards blocks straight away.
+static std::atomic<int> g_pollers{0};
 static hipError_t wait_stream(hipStream_t s)
 {
+    struct Count {
+        int n;
+        Count() : n(g_pollers.fetch_add(1, std::memory_order_relaxed)) {}
+        ~Count() { g_pollers.fetch_sub(1, std::memory_order_relaxed); }
+    } me;
+    if (me.n >= 4)
+        return hipStreamSynchronize(s);
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         for (int i = 0; i < 64; ++i) {
@@ -767,7 +817,9 @@ template <class Redo> int compute_finish(gpe_ctx* c, Redo redo)
         // whole evaluation again, from K on, with every workgroup deriving the head tiles itself.
         c->hInfo[0] = c->hInfo[1] = c->hInfo[2] = 0;
         c->panel_handover = false;
+        c->handover_off_left = 16 + 1; // this re-run and the next 16 evaluations re-derive the tiles, then hand over again
         ++c->flow_retries;
+        ++c->handover_reruns;
         const BatchLaunch saved = g_batch;
         g_batch = BatchLaunch{};
         const int e = compute_enqueue(c);
@@ -1154,6 +1206,7 @@ int gpe_create(int device_id, gpe_handle* out)
         c->near_wgs = atoi(f);
     if (const char* f = getenv("GPE_PANEL_HANDOVER"))
         c->panel_handover = atoi(f) != 0;
+    c->panel_handover_cfg = c->panel_handover;
     if (const char* f = getenv("GPE_BULK_FREE_TILES"))
         c->bulk_free_tiles = atoll(f);
     if (const char* f = getenv("GPE_FUSE_DIAG"))
@@ -1348,11 +1401,15 @@ int gpe_update_alpha(gpe_handle c, const double* obs_mean)
         a.seq = c->hSmallSeq;
         a.seq_val = ++c->small_seq;
         a.n = (int)c->N;
-        launch_small_alpha(c->stream, a, c->P);
+        {
+            PhaseScope ps(c, GPE_PH_SOLVE, 2.0 * (double)c->N * c->N * c->P);
+            launch_small_alpha(c->stream, a, c->P);
+        }
         c->al_prefilled = false;
         c->ll_partials = 0;
         ++c->small_calls;
         int rc = small_wait(c, 1, a.seq_val);
+        drain_phases(c);
         if (rc)
             return rc;
         c->hScal[0] = c->hSmall[0];
@@ -1436,7 +1493,10 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         a.seq = c->hSmallSeq;
         a.seq_val = ++c->small_seq;
         a.n = (int)n;
-        launch_small_add(s, a, P, c->kp, lam_params(c), x);
+        {
+            PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)n * n + 2.0 * (double)n * n * P);
+            launch_small_add(s, a, P, c->kp, lam_params(c), x);
+        }
         c->N = n + 1;
         c->have_L = true;
         c->inv_ok = false; // gp.hpp:602
@@ -1444,6 +1504,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         c->ll_partials = 0;
         ++c->small_calls;
         int rc = small_wait(c, 1, a.seq_val);
+        drain_phases(c);
         if (rc)
             return rc;
         c->hScal[0] = c->hSmall[0]; // sum log L_ii
@@ -1652,9 +1713,13 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
         q.seq_val = ++c->small_seq;
         q.want_kta = kta ? 1 : 0;
         q.want_var = var ? 1 : 0;
-        launch_small_query(s, q, c->kp, lam_params(c));
+        {
+            PhaseScope ps(c, GPE_PH_QUERY, (double)N * N * M);
+            launch_small_query(s, q, c->kp, lam_params(c));
+        }
         ++c->small_calls;
         int rc = small_wait(c, (int)M, q.seq_val);
+        drain_phases(c);
         if (rc)
             return rc;
         if (kta)
@@ -1991,6 +2056,14 @@ int gpe_flow_retries(gpe_handle c, int64_t* n)
     return GPE_OK;
 }
 
+int gpe_handover_reruns(gpe_handle c, int64_t* n)
+{
+    if (!c || !n)
+        return GPE_ERR_ARG;
+    *n = c->handover_reruns;
+    return GPE_OK;
+}
+
 int gpe_small_calls(gpe_handle c, int64_t* n)
 {
     if (!c || !n)
@@ -2084,15 +2157,43 @@ static bool batch_compatible(const gpe_ctx* a, const gpe_ctx* b)
 // gpe_compute on Gc <= GPE_BT_MAXG compatible handles as ONE launch sequence (gridDim.z = Gc): the chain of small
 // latency-bound kernels of one factorisation does not fill the chip, Gc of them in lock-step do.  The handles' mutexes
 // are held by the caller.
-static int batch_enqueue_fused(gpe_ctx** cs, int Gc, int slot)
+// Device copies of the batch tables: a pool per device behind a mutex.  (They were thread_local once: every host
+// thread that ever batched — par::loop spawns fresh ones per call on a multi-GPU node — leaked 41 KB of device memory.)
+static std::mutex g_tab_mu;
+static std::vector<BatchTab*> g_tab_pool[16];
+static BatchTab* acquire_tab(int device)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_tab_mu);
+        auto& pool = g_tab_pool[device];
+        if (!pool.empty()) {
+            BatchTab* t = pool.back();
+            pool.pop_back();
+            return t;
+        }
+    }
+    BatchTab* t = nullptr;
+    return hipMalloc(&t, sizeof(BatchTab)) == hipSuccess ? t : nullptr;
+}
+static void release_tab(int device, BatchTab* t)
+{
+    if (!t)
+        return;
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    g_tab_pool[device].push_back(t);
+}
+
+static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out)
 {
     gpe_ctx* c0 = cs[0];
     DevGuard g(c0);
-    static thread_local BatchTab* dtab[16][4] = {{nullptr}}; // device tables, kept: one per device and concurrent sub-batch
-    if (c0->device >= 16 || slot >= 4)
+    *tab_out = nullptr;
+    if (c0->device >= 16)
         return GPE_ERR_UNSUPPORTED;
-    if (!dtab[c0->device][slot])
-        HIPCHK(c0, hipMalloc(&dtab[c0->device][slot], sizeof(BatchTab)));
+    BatchTab* dtab = acquire_tab(c0->device); // held until the batch has finished (batch_finish_fused's caller releases it)
+    if (!dtab)
+        return GPE_ERR_NOMEM;
+    *tab_out = dtab;
     std::vector<BatchTab> tabv(1);
     BatchTab& t = tabv[0];
     memset(&t, 0, sizeof(t));
@@ -2119,11 +2220,11 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, int slot)
         t.base0[k] = t.base[k][0];
         t.size[k] = sz[k];
     }
-    HIPCHK(c0, hipMemcpyAsync(dtab[c0->device][slot], &t, sizeof(BatchTab), hipMemcpyHostToDevice, c0->stream));
+    HIPCHK(c0, hipMemcpyAsync(dtab, &t, sizeof(BatchTab), hipMemcpyHostToDevice, c0->stream));
     HIPCHK(c0, hipStreamSynchronize(c0->stream)); // `t` is pageable: the copy must have left it before it goes out of scope
     const bool la = c0->lookahead;
     c0->lookahead = false; // the batch fills the chip: one stream, no look-ahead split
-    g_batch.bt = dtab[c0->device][slot];
+    g_batch.bt = dtab;
     g_batch.G = Gc;
     int e = compute_enqueue(c0);
     g_batch = BatchLaunch{};
@@ -2167,8 +2268,14 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
             fused = hs[q] != c; // the same handle twice cannot be stepped in parallel
     }
     if (fused) {
-        for (int g = 0; g < G; ++g)
-            hs[g]->mu.lock();
+        // every handle's mutex, taken in one canonical order (by address) whatever order the caller listed them in — two
+        // threads batching overlapping sets cannot deadlock — and released by RAII on every way out
+        std::vector<gpe_ctx*> order(hs, hs + G);
+        std::sort(order.begin(), order.end());
+        std::vector<std::unique_lock<std::mutex>> locks;
+        locks.reserve(G);
+        for (gpe_ctx* c : order)
+            locks.emplace_back(c->mu);
         int worst = GPE_OK;
         // Sub-batches of <= GPE_BT_MAXG GPs, up to four in flight on their own streams: while one sub-batch is in its
         // panel steps (latency-bound workgroups, one per CU) another one's matrix-core updates fill the chip.
@@ -2186,9 +2293,10 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
                 g0 += counts[nw];
             }
             int en[4];
+            BatchTab* tabs[4] = {nullptr, nullptr, nullptr, nullptr};
             for (int w = 0; w < nw; ++w) {
                 if (counts[w] >= 2)
-                    en[w] = batch_enqueue_fused(hs + starts[w], counts[w], w);
+                    en[w] = batch_enqueue_fused(hs + starts[w], counts[w], &tabs[w]);
                 else {
                     DevGuard dg(hs[starts[w]]);
                     en[w] = compute_enqueue(hs[starts[w]]);
@@ -2199,12 +2307,21 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
                     for (int q = 0; q < counts[w]; ++q)
                         rc[starts[w] + q] = en[w];
                     worst = en[w];
+                    if (tabs[w]) { // whatever was enqueued before the failure may still read the table
+                        DevGuard dg(hs[starts[w]]);
+                        hipStreamSynchronize(hs[starts[w]]->stream);
+                        release_tab(hs[starts[w]]->device, tabs[w]);
+                    }
                     continue;
                 }
                 if (counts[w] >= 2) {
                     int e = batch_finish_fused(hs + starts[w], counts[w], rc.data() + starts[w]);
-                    if (e < 0)
+                    if (e < 0) {
                         worst = e;
+                        DevGuard dg(hs[starts[w]]);
+                        hipStreamSynchronize(hs[starts[w]]->stream);
+                    }
+                    release_tab(hs[starts[w]]->device, tabs[w]); // the stream is idle: nothing reads the table any more
                 }
                 else {
                     DevGuard dg(hs[starts[w]]);
@@ -2213,7 +2330,6 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
             }
         }
         for (int g = 0; g < G; ++g) {
-            hs[g]->mu.unlock();
             if (status)
                 status[g] = rc[g];
             if (rc[g] < 0)
@@ -2223,14 +2339,30 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
     }
     // enqueue everything first (each GP on its own stream), then collect: kernels of different
     // GPs overlap on the device — the TBB par::loop of multi_gp.hpp:124-126, on one GPU.
+    std::vector<gpe_ctx*> order;
+    for (int g = 0; g < G; ++g)
+        if (hs[g])
+            order.push_back(hs[g]);
+    std::sort(order.begin(), order.end());
+    order.erase(std::unique(order.begin(), order.end()), order.end()); // a handle listed twice is locked once
+    std::vector<std::unique_lock<std::mutex>> locks;
+    locks.reserve(order.size());
+    for (gpe_ctx* c : order)
+        locks.emplace_back(c->mu);
+    std::vector<char> first(G, 0); // first occurrence of a handle: the one that is enqueued (a second one would race it)
     for (int g = 0; g < G; ++g) {
         gpe_ctx* c = hs[g];
         if (!c) {
             rc[g] = GPE_ERR_ARG;
             continue;
         }
+        first[g] = 1;
+        for (int q = 0; q < g; ++q)
+            if (hs[q] == c)
+                first[g] = 0;
+        if (!first[g])
+            continue;
         hipSetDevice(c->device);
-        c->mu.lock();
         rc[g] = compute_enqueue(c);
     }
     int worst = GPE_OK;
@@ -2238,10 +2370,17 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
         gpe_ctx* c = hs[g];
         if (!c)
             continue;
-        hipSetDevice(c->device);
-        if (rc[g] == GPE_OK)
-            rc[g] = compute_finish(c);
-        c->mu.unlock();
+        if (first[g]) {
+            hipSetDevice(c->device);
+            if (rc[g] == GPE_OK)
+                rc[g] = compute_finish(c);
+        }
+        else
+            for (int q = 0; q < g; ++q)
+                if (hs[q] == c) {
+                    rc[g] = rc[q];
+                    break;
+                }
         if (status)
             status[g] = rc[g];
         if (rc[g] < 0)

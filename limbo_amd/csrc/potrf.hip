@@ -896,6 +896,9 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                     }
                     seen[t] = __hip_atomic_load(hflag + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                // the tile's loads may not be moved above the poll by the compiler (the hardware returns a wave's
+                // loads in order; relaxed atomics alone do not order them in the language): a zero-cost fence
+                asm volatile("" ::: "memory");
                 head[t].load_coherent(Hs + (int64_t)t * (NB * NB));
             }
             else
@@ -933,6 +936,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                                 info[2] = 1;
                             break;
                         }
+                    asm volatile("" ::: "memory"); // as above: the tile's loads stay behind the poll
                     late.load_coherent(Hs + (int64_t)t * (NB * NB));
                 }
                 else

@@ -51,13 +51,33 @@ def test_engine_is_independent_of_the_oracle():
 
     blob = _capi.ENGINE_SO.read_bytes()
     assert b"liboracle" not in blob and b"orc_compute" not in blob
-    src = "".join(p.read_text() for p in (ROOT / "limbo_amd").rglob("*") if p.suffix in (".hip", ".h", ".hpp"))
-    assert "oracle" not in src.lower().replace("oracle/", "")  or "orc_" not in src
+    # no product source — device code, C-ABI header, drop-in headers, Python package — imports, includes, links, dlopens or
+    # spawns anything under oracle/ (comments may name the oracle: they are stripped first)
+    import re
+
+    offenders = []
+    files = [p for root in (ROOT / "limbo_amd", ROOT / "include") for p in root.rglob("*")
+             if p.is_file() and (p.suffix in (".hip", ".h", ".hpp", ".py", ".cpp", ".c") or p.name == "Makefile")]
+    assert len(files) > 30
+    for p in files:
+        text = p.read_text()
+        if p.suffix == ".py":
+            text = re.sub(r'"""[\s\S]*?"""', "", text)
+            text = re.sub(r"#[^\n]*", "", text)
+        else:
+            text = re.sub(r"/\*[\s\S]*?\*/", "", text)
+            text = re.sub(r"//[^\n]*", "", text)
+            text = re.sub(r"^\s*#(?!include)[^\n]*", "", text, flags=re.M) if p.name == "Makefile" else text
+        for pat in (r"\borc_\w+", r"liboracle", r"gp_oracle", r"np_oracle", r"from\s+oracle\b", r"import\s+oracle\b",
+                    r"oracle/", r"libref\.so", r"_ref/"):
+            if re.search(pat, text):
+                offenders.append((str(p.relative_to(ROOT)), pat))
+    assert not offenders, offenders
 
 
 def test_oracle_mirrors_the_abi(oracle_lib):
     skip = {"gpe_get_stream", "gpe_set_profiling", "gpe_get_phase_ms", "gpe_reset_phase_ms", "gpe_mfma_f64_peak",
-            "gpe_hbm_stream_peak", "gpe_flow_retries", "gpe_small_calls"}
+            "gpe_hbm_stream_peak", "gpe_flow_retries", "gpe_small_calls", "gpe_handover_reruns"}
     for s in declared_symbols():
         if s in skip:
             continue
