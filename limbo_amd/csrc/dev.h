@@ -183,6 +183,9 @@ struct GemmArgs {
     int total;     // set by launch_gemm_sub: logical workgroups (glds kernel)
     int grid_limit; // > 0: at most this many physical workgroups (they loop) — leaves CUs to another stream
     int tile;      // 0: pick by problem size; 128 / 64 / 32: force the 128x128 / 64x64 / 32x64 tile
+    int rhs_rows;  // the LAST rhs_rows of the m rows of C / A are right-hand-side rows (engine.hip): the direct-to-LDS
+                   // kernels update them with plain FMAs instead of a tile row (gemm_glds64.h: gemm_rhs_rows); inside those
+                   // kernels m counts the main rows only
     void* stop_event; // host side only: hipEvent_t completed by this launch (null: none)
     const BatchTab* bt; // batched launch (gridDim.z GPs): set by the launch wrapper, null otherwise
 };

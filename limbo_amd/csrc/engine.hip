@@ -475,6 +475,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 g.gcol0 = c0;
                 g.grid_limit = grid_limit;
                 g.stop_event = stop;
+                g.rhs_rows = (int)(M - N); // the appended obs_mean rows: FMAs inside the direct-to-LDS kernels, not a tile row
                 if (grid_limit > 0)
                     g.tile = tile ? tile : 128; // the direct-to-LDS kernels are the ones that honour grid_limit
                 PhaseScope ps(c, GPE_PH_POTRF_UPDATE, gemm_flops(g));

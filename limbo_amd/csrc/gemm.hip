@@ -363,6 +363,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g_)
 
     const int tiles_m = (int)((g.m + TM - 1) / TM);
     const int tiles_n = (int)((g.n + TN - 1) / TN);
+    if (g.rhs_rows > 0) // the right-hand-side rows under the matrix: this workgroup's n / G columns of them (gemm_glds64.h)
+        gemm_rhs_rows<64 * NWV>(g, g.rhs_rows, (int)gridDim.x, lds);
     // g.total logical workgroups; a launch with fewer physical ones (gridDim.x < g.total: the
     // look-ahead update, which must leave CUs free for the panel on the other stream) loops.
     for (int lwg = blockIdx.x; lwg < g.total; lwg += gridDim.x) {
@@ -621,6 +623,9 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
         variant = e ? atoi(e) : 2;
     }
     const bool two_per_cu = variant == 2 ? (g.grid_limit <= 0 && (int64_t)g.total * g_batch.G > 256) : variant == 1;
+    // (ONE workgroup of 16 waves per CU — 2 x 8 waves of 64 x 16, or 4 x 4 of 32 x 32: four waves per SIMD from one barrier
+    // group — was measured too: a lone 128 x 128 x 256 tile takes 47.9 us against 47.3 with 8 waves, 4 x 4 is 15 % slower.
+    // What reaches 97 % of the matrix-core peak in the k loop is two INDEPENDENT barrier groups per CU: profiles/r03_sk_study.md)
     if (two_per_cu)
         launch_k(k_gemm_glds<128, 128, 2, 4, 16, 2, 4, 2>, k_gemm_glds<128, 128, 2, 4, 16, 2, 4, 2, true>, dim3((unsigned)tiles), dim3(512), s, g);
     else
@@ -644,11 +649,12 @@ static int64_t live_tiles(const GemmArgs& g, int TM, int TN)
     return cnt;
 }
 
-void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
+static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds64, int force, int deep32);
+void launch_gemm_sub(hipStream_t s, const GemmArgs& g0)
 {
-    if (g.m <= 0 || g.n <= 0)
+    if (g0.m <= 0 || g0.n <= 0)
         return;
-    if (g.k <= 0 && !g.overwrite)
+    if (g0.k <= 0 && !g0.overwrite)
         return;
     static int use_glds64 = -1;
     if (use_glds64 < 0) {
@@ -665,6 +671,37 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
         const char* e = getenv("GPE_GEMM_DEEP32");
         deep32 = e ? atoi(e) : 0;
     }
+    if (g0.rhs_rows > 0) {
+        // Right-hand-side rows as FMAs inside the kernel (gemm_glds64.h) instead of a row of tiles: the FMAs cost every
+        // workgroup ~4 us before its first tile, the tile row costs n / 128 extra workgroups — which only matters when
+        // they push the launch over a round of the chip (tools/updbench: the fifth update of N = 4096 has 253 + 22
+        // tiles for 256 CUs, 77.5 -> 52.4 us; every other launch of that factorisation is 3-5 us slower with the FMAs).
+        // So: FMAs exactly when dropping the row brings the tile count down to a whole round.
+        GemmArgs q = g0;
+        q.m = g0.m - g0.rhs_rows;
+        q.rhs_rows = 0; // (for the tile counts below)
+        static const int rhs_fma = getenv("GPE_RHS_FMA") ? atoi(getenv("GPE_RHS_FMA")) : 1; // 0: never, 2: always
+        bool fma = false;
+        if (rhs_fma && q.m > 0 && !q.overwrite && glds_ok(q) && g_batch.G == 1 && g0.grid_limit <= 0) {
+            auto crosses = [&](int T, int64_t round) { return live_tiles(q, T, T) <= round && live_tiles(g0, T, T) > round; };
+            fma = rhs_fma == 2 || crosses(128, 256) || (live_tiles(g0, 128, 128) < 200 && (crosses(64, 512) || crosses(64, 256)));
+        }
+        if (fma) {
+            q.rhs_rows = g0.rhs_rows;
+            launch_gemm_sub_impl(s, q, use_glds64, force, deep32);
+        }
+        else {
+            q = g0;
+            q.rhs_rows = 0;
+            launch_gemm_sub_impl(s, q, use_glds64, force, deep32);
+        }
+        return;
+    }
+    launch_gemm_sub_impl(s, g0, use_glds64, force, deep32);
+}
+
+static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds64, int force, int deep32)
+{
     int tile = g.tile ? g.tile : force;
     if (tile != 128 && tile != 64 && tile != 32) {
         // measured at k = 256 (tools/kbench): one 128 x 128 glds workgroup per CU runs at the
@@ -679,6 +716,17 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g)
             tile = 64;
         else
             tile = 32;
+    }
+    if (g.rhs_rows > 0) {
+        // right-hand-side rows are FMAs inside the direct-to-LDS kernels only; any other kernel takes them as ordinary rows
+        const bool direct = glds_ok(g) && (tile == 128 || (tile == 64 && !g.ktri && use_glds64));
+        if (!direct) {
+            GemmArgs q = g;
+            q.m += q.rhs_rows;
+            q.rhs_rows = 0;
+            launch_gemm_sub_impl(s, q, use_glds64, force, deep32);
+            return;
+        }
     }
     if (tile == 128 && glds_ok(g))
         launch_glds128(s, g);

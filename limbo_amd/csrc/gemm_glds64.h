@@ -26,6 +26,75 @@ static __host__ __device__ __forceinline__ int first_live_tile(const GemmArgs& g
     return (int)(t < tiles_m ? t : tiles_m);
 }
 
+// ---- right-hand-side rows ------------------------------------------------------------------------------------
+// The rows appended under the matrix (engine.hip: z = L^-1 obs_mean rides in the factorisation) are not tiles: as a tile
+// row they cost every trailing update n / 128 extra workgroups with ONE live row each (30 of 495 in the first update of
+// N = 4096; 22 of 275 in the fifth, which they push over 256 CUs into a second round: 78 us instead of 50).  Instead
+// every workgroup of the launch updates its n / G columns of those rows with plain FMAs before its first tile:
+//   C[m + p, c] -= sum_kk A[m + p, kk] B[c, kk],   g.m = the main rows, G = workgroups of the launch.
+// 16 columns at a time, thread = (column tid & 15, k-group tid >> 4); every thread has 4 loads of B and 16 of the rows in
+// flight together, then the NT / 16 k-groups are added in order through LDS (red: 4 x NT / 16 x 16 doubles): bitwise
+// reproducible.  Four rows per pass.
+template <int NT>
+static __device__ __forceinline__ void gemm_rhs_rows(const GemmArgs& g, int rhs_rows, int G, double* red)
+{
+    constexpr int KG = NT / 16;
+    const int tid = threadIdx.x, cl = tid & 15, kg = tid >> 4, b = blockIdx.x;
+    const int nc = (int)((g.n + G - 1) / G);
+    const int64_t c_lo = (int64_t)b * nc;
+    int64_t c_hi = c_lo + nc;
+    c_hi = c_hi < g.n ? c_hi : g.n;
+    const int kper = (int)((g.k + KG - 1) / KG);
+    const int kk0 = kg * kper;
+    int kk1 = kk0 + kper;
+    kk1 = kk1 < (int)g.k ? kk1 : (int)g.k;
+    for (int64_t cb = c_lo; cb < c_hi; cb += 16) {
+        const int64_t c = cb + cl;
+        const int64_t cc = c < c_hi ? c : c_hi - 1;
+        for (int p0 = 0; p0 < rhs_rows; p0 += 4) {
+            const int pn = rhs_rows - p0 < 4 ? rhs_rows - p0 : 4;
+            // the finishing threads (tid < 16 pn: row tid >> 4, column tid & 15) fetch their C element now
+            const int pf = kg < pn ? kg : pn - 1;
+            double* Cp = g.C + (g.m + p0 + pf) + cc * g.ldc;
+            const double cold = *Cp;
+            double a4[4] = {0.0, 0.0, 0.0, 0.0};
+            const double* Bc = g.B + cc;
+            const double* Ar = g.A + g.m + p0;
+            for (int kb = kk0; kb < kk1; kb += 4) {
+                double bv[4], zv[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kc = kb + u < kk1 ? kb + u : kk1 - 1;
+                    bv[u] = Bc[(int64_t)kc * g.ldb];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) // rows beyond pn repeat the last one: summed, never stored
+                        zv[p][u] = Ar[(p < pn ? p : pn - 1) + (int64_t)kc * g.lda];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double keep = kb + u < kk1 ? 1.0 : 0.0;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        a4[p] += zv[p][u] * (bv[u] * keep);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                red[(p * KG + kg) * 16 + cl] = a4[p];
+            __syncthreads();
+            if (tid < 16 * pn) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int q = 0; q < KG; ++q)
+                    sacc += red[(kg * KG + q) * 16 + cl];
+                if (c < c_hi)
+                    *Cp = cold - sacc;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- C tile traffic in the lane = row layout ---------------------------------------------------------
 // The accumulator of v_mfma_f64_4x4x4 puts lane l on row 4*((l>>2)&3) + (l>>4), column l&3 of a 16 x 4
 // fragment: one global load/store of a fragment touches 4 columns x 16 rows, adjacent lanes sit in
@@ -148,6 +217,8 @@ static __device__ __forceinline__ void gemm_glds64_body(const GemmArgs& g, doubl
     const int tiles_n = (int)((g.n + TN - 1) / TN);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (g.rhs_rows > 0 && !skip00) // (the fused next-panel update keeps its right-hand-side rows as a tile row)
+        gemm_rhs_rows<64 * NWV>(g, g.rhs_rows, n_wg, lds);
     for (int lwg = first_wg; lwg < g.total; lwg += n_wg) {
         int wg = lwg;
         {
