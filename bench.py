@@ -121,6 +121,51 @@ def extras(eng, _capi, O, local_rank, steps):
     }
     h.close()
 
+    # ---- the same objective for G restarts in lock-step (opt/parallel_repeater.hpp:84-105 as the drop-in runs it:
+    # opt/batched_rprop.hpp -> gpe_batch_hp_objective, one launch sequence with gridDim.z = restart), against the
+    # restarts as host threads with one launch chain each (rounds 1-2)
+    import threading
+
+    def batched(G, N, reps):
+        Xb, Yb = O.make_problem("c2" if N == N_C2 else "c4", N=N)
+        omb, _ = O.obs_mean_data(Yb)
+        rngb = np.random.default_rng(77)
+        hs = []
+        for _ in range(G):
+            hb = _capi.Handle(eng, local_rank)
+            hb.set_data(Xb, omb)
+            hs.append(hb)
+        th = rngb.uniform(-1e-2, 1e-2, size=(G, D_C2 + 1))
+        _capi.batch_hp_objective(hs, O.SE_ARD, th, 0.01, want_grad=True)
+        t0 = time.perf_counter()
+        for r in range(reps):
+            lk, gr, st = _capi.batch_hp_objective(hs, O.SE_ARD, th + 1e-3 * (r + 1), 0.01, want_grad=True)
+        dtb = time.perf_counter() - t0
+        assert all(s_ == 0 for s_ in st) and np.all(np.isfinite(gr))
+        # the same restarts as host threads (one handle, one launch chain each)
+        def worker(hb, row):
+            for r in range(reps):
+                hb.hp_objective(O.SE_ARD, th[row] + 1e-3 * (r + 1), 0.01, want_grad=True)
+        ths = [threading.Thread(target=worker, args=(hb, i)) for i, hb in enumerate(hs)]
+        t0 = time.perf_counter()
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        dtt = time.perf_counter() - t0
+        for hb in hs:
+            hb.close()
+        flb = float(N) ** 3
+        return {"restarts": G, "N": N, "value": G * reps / dtb, "unit": "objective evaluations/s", "ms_per_batch": 1e3 * dtb / reps,
+                "tflops": G * reps * flb / dtb / 1e12, "frac_of_fp64_peak": G * reps * flb / dtb / PEAK,
+                "threads_one_chain_each_per_s": G * reps / dtt}
+
+    out["batched_hp_objective"] = {
+        "workload": "G hyper-parameter restarts of configs[1] / configs[3] in lock-step: every member's K -> L -> alpha -> log-lik -> "
+                    "K^-1 -> gradient by ONE launch sequence (gpe_batch_hp_objective); flops = N^3 per member and evaluation",
+        "c2_10_restarts": batched(10, N_C2, 4), "c4_64_restarts": batched(64, 2048, 3)}
+    torch.cuda.empty_cache()
+
     # ---- configs[2]: N=16384, D=12, Matern-5/2: compute()+log_lik, its trailing updates alone, 100k batched queries
     N3, D3, M3 = 16384, 12, 100000
     X3, Y3 = O.make_problem("c3")

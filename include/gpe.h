@@ -165,6 +165,14 @@ int gpe_get_K(gpe_handle h, double* K, int64_t ld);          /* rebuilds K; for 
  * interleaved on the device instead of being serialised. */
 int gpe_batch_compute(gpe_handle* hs, int G, int* status);
 int gpe_batch_log_lik(gpe_handle* hs, int G, double* out);
+/* model/gp/kernel_lf_opt.hpp:77-92 KernelLFOptimization::operator() for G GPs at once: the restarts of
+ * opt::ParallelRepeater (opt/parallel_repeater.hpp:84-105) stepped in lock-step, or the per-output fits of
+ * multi_gp::ParallelLFOpt (model/multi_gp/parallel_lf_opt.hpp:64-67).  Member g: log_theta[g n_theta .. (g+1) n_theta),
+ * noise[g] -> lik[g], grad[g n_grad .. (g+1) n_grad) with n_grad = n_theta + (optimize_noise ? 1 : 0), status[g]
+ * (0 or the 1-based first non-positive pivot).  Handles of one shape on one device are stepped by ONE launch sequence
+ * (kernel build, factorisation, alpha, K^-1 and the gradient pair sum, gridDim.z = member); others one by one. */
+int gpe_batch_hp_objective(gpe_handle* hs, int G, int kind, const double* log_theta, int n_theta, const double* noise,
+                           int optimize_noise, int want_grad, double* lik, double* grad, int* status);
 
 /* ---- instrumentation ----------------------------------------------------- */
 /* HIP stream the handle launches on (hipStream_t as void*) */

@@ -716,6 +716,71 @@ namespace limbo {
                 });
             }
 
+            /// Addition: one KernelLFOptimization evaluation (kernel_lf_opt.hpp:77-92: recompute(false), log-lik and, with
+            /// want_grad, its gradient) of EVERY GP in `gps`, each with the hyper-parameters its kernel functor currently
+            /// holds — the restarts of opt::ParallelRepeater or the outputs of multi_gp::ParallelLFOpt in lock-step.  GPs
+            /// on the same device go through ONE gpe_batch_hp_objective (one launch sequence when they agree in shape).
+            static void hp_objectives_batched(const std::vector<GP*>& gps, bool want_grad, std::vector<double>& liks,
+                                              std::vector<Eigen::VectorXd>& grads)
+            {
+                const size_t G = gps.size();
+                liks.assign(G, 0.0);
+                grads.assign(G, Eigen::VectorXd());
+                if (G == 0)
+                    return;
+                constexpr int kind = limbo_amd::device_kernel<KernelFunction>::kind;
+                if (kind == limbo_amd::KIND_HOST_K) { // functor-built K: one by one (the factorisations still run on the device)
+                    limbo::tools::par::loop(0, G, [&](size_t i) {
+                        gps[i]->recompute(false);
+                        liks[i] = gps[i]->compute_log_lik();
+                        if (want_grad)
+                            grads[i] = gps[i]->compute_kernel_grad_log_lik();
+                    });
+                    return;
+                }
+                const bool on = Params::kernel::optimize_noise();
+                std::vector<int> devs;
+                for (GP* g : gps) {
+                    if (!g->_data_on_device)
+                        g->_push_data();
+                    if (std::find(devs.begin(), devs.end(), g->device()) == devs.end())
+                        devs.push_back(g->device());
+                }
+                limbo::tools::par::loop(0, devs.size(), [&](size_t di) { // one host thread per device
+                    std::vector<size_t> mine;
+                    std::vector<gpe_handle> hs;
+                    for (size_t i = 0; i < G; ++i)
+                        if (gps[i]->device() == devs[di]) {
+                            mine.push_back(i);
+                            hs.push_back(gps[i]->_eng.get());
+                        }
+                    const int T = gps[mine[0]]->_kernel_function.h_params_size();
+                    const int nk = T - (on ? 1 : 0);
+                    std::vector<double> th((size_t)nk * mine.size()), nz(mine.size()), lk(mine.size()), gr((size_t)T * mine.size());
+                    for (size_t q = 0; q < mine.size(); ++q) {
+                        const Eigen::VectorXd hp = gps[mine[q]]->_kernel_function.h_params();
+                        for (int t = 0; t < nk; ++t)
+                            th[q * nk + t] = hp(t);
+                        nz[q] = gps[mine[q]]->_kernel_function.noise();
+                    }
+                    std::vector<int> st(mine.size(), 0);
+                    const int rc = gpe_batch_hp_objective(hs.data(), (int)hs.size(), kind, th.data(), nk, nz.data(), on ? 1 : 0,
+                                                          want_grad ? 1 : 0, lk.data(), want_grad ? gr.data() : nullptr, st.data());
+                    for (size_t q = 0; q < mine.size(); ++q) {
+                        GP* g = gps[mine[q]];
+                        g->_commit_full_kernel(g->_eng.check(st[q] < 0 ? st[q] : (rc < 0 ? rc : st[q]), "gpe_batch_hp_objective"));
+                        g->_log_lik = lk[q];
+                        liks[mine[q]] = lk[q];
+                        if (want_grad) {
+                            g->_inv_kernel_updated = true; // the device computed and cached K^-1 (gp.hpp:289-291)
+                            grads[mine[q]] = Eigen::VectorXd::Zero(T);
+                            for (int t = 0; t < T; ++t)
+                                grads[mine[q]](t) = gr[q * T + t];
+                        }
+                    }
+                });
+            }
+
         protected:
 
             /// gp.hpp:573-603

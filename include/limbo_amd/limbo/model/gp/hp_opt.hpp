@@ -95,6 +95,7 @@ namespace limbo {
                 HPOpt() : _called(false) {}
                 HPOpt(const HPOpt&) : _called(true) {} // copies never warn
                 HPOpt& operator=(const HPOpt&) { return *this; }
+                void mark_called() { _called = true; } // (addition: a policy object used only through a static batched path)
                 ~HPOpt()
                 {
                     if (!_called)

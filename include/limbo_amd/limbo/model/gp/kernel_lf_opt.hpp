@@ -16,6 +16,8 @@
 #include <mutex>
 #include <thread>
 #include <limbo/model/gp/hp_opt.hpp>
+#include <limbo/opt/batched_rprop.hpp>
+#include <limbo/tools/parallel.hpp>
 namespace limbo {
     namespace model {
         namespace gp {
@@ -32,6 +34,45 @@ namespace limbo {
                     gp.kernel_function().set_h_params(params);
                     gp.recompute(false);
                     gp.compute_log_lik();
+                }
+
+                /// Addition: the fits of several GPs (the outputs of a MultiGP: multi_gp/parallel_lf_opt.hpp:64-67) in
+                /// lock-step — with Rprop as the optimiser, iteration i of every fit is one batched device evaluation.
+                /// Each fit works on a private clone and touches its GP only at the end, as operator() does.
+                template <typename GP>
+                static bool fit_many(std::vector<GP>& gps)
+                {
+                    if (!opt::is_rprop<Optimizer>::value || !opt::batch_restarts_enabled() || gps.size() < 2)
+                        return false;
+                    std::vector<std::unique_ptr<GP>> clones;
+                    std::vector<GP*> ptrs;
+                    std::vector<Eigen::VectorXd> inits;
+                    for (auto& g : gps) {
+                        clones.emplace_back(new GP(g));
+                        ptrs.push_back(clones.back().get());
+                        inits.push_back(g.kernel_function().h_params());
+                    }
+                    auto fb = [&](const std::vector<Eigen::VectorXd>& xs, bool gr) {
+                        for (size_t i = 0; i < xs.size(); ++i)
+                            ptrs[i]->kernel_function().set_h_params(xs[i]);
+                        std::vector<double> liks;
+                        std::vector<Eigen::VectorXd> grads;
+                        GP::hp_objectives_batched(ptrs, gr, liks, grads);
+                        std::vector<opt::eval_t> out;
+                        for (size_t i = 0; i < xs.size(); ++i)
+                            out.push_back(gr ? opt::eval_t{liks[i], opt::eval_t::second_type(grads[i])} : opt::no_grad(liks[i]));
+                        return out;
+                    };
+                    auto res = opt::rprop_lockstep<Params>(fb, inits, false);
+                    std::vector<GP*> orig;
+                    for (size_t i = 0; i < gps.size(); ++i) {
+                        gps[i].kernel_function().set_h_params(res[i].first);
+                        orig.push_back(&gps[i]);
+                    }
+                    std::vector<double> liks; // recompute(false) + compute_log_lik() of operator(), batched
+                    std::vector<Eigen::VectorXd> none;
+                    GP::hp_objectives_batched(orig, false, liks, none);
+                    return true;
                 }
 
             protected:
@@ -51,9 +92,44 @@ namespace limbo {
                         return {lik, opt::eval_t::second_type(gp.compute_kernel_grad_log_lik())};
                     }
 
+                    /// Addition: the objective at params.size() points at once — one private device clone of the original
+                    /// GP per point (kept for the lifetime of the optimisation, dealt over the visible devices), all
+                    /// evaluated by one batched launch sequence per device (GP::hp_objectives_batched).  What lets
+                    /// opt::ParallelRepeater step its restarts in lock-step.
+                    std::vector<opt::eval_t> eval_batch(const std::vector<Eigen::VectorXd>& params, bool compute_grad) const
+                    {
+                        std::lock_guard<std::mutex> lk(_batch_mu);
+                        while (_batch.size() < params.size())
+                            _batch.emplace_back(new GP(_original_gp, limbo_amd::deal_device<Params>(_batch.size(), _original_gp.device())));
+                        std::vector<GP*> gps;
+                        for (size_t i = 0; i < params.size(); ++i) {
+                            _batch[i]->kernel_function().set_h_params(params[i]);
+                            gps.push_back(_batch[i].get());
+                        }
+                        std::vector<double> liks;
+                        std::vector<Eigen::VectorXd> grads;
+                        GP::hp_objectives_batched(gps, compute_grad, liks, grads);
+                        std::vector<opt::eval_t> out;
+                        for (size_t i = 0; i < params.size(); ++i)
+                            out.push_back(compute_grad ? opt::eval_t{liks[i], opt::eval_t::second_type(grads[i])} : opt::no_grad(liks[i]));
+                        return out;
+                    }
+
+                    /// devices the lock-step clones were put on (instrumentation / tests)
+                    std::vector<int> batch_devices() const
+                    {
+                        std::lock_guard<std::mutex> lk(_batch_mu);
+                        std::vector<int> d;
+                        for (auto& g : _batch)
+                            d.push_back(g->device());
+                        return d;
+                    }
+
                 protected:
                     const GP& _original_gp;
                     limbo_amd::WorkerClones<Params, GP> _workers;
+                    mutable std::mutex _batch_mu;
+                    mutable std::vector<std::unique_ptr<GP>> _batch;
                 };
             };
         } // namespace gp

@@ -13,6 +13,7 @@
 #include <limits>
 #include <random>
 #include <vector>
+#include <limbo/opt/batched_rprop.hpp>
 #include <limbo/opt/optimizer.hpp>
 #include <limbo/tools/macros.hpp>
 namespace limbo {
@@ -35,6 +36,32 @@ namespace limbo {
                 std::vector<unsigned> seeds(repeats);
                 for (auto& s : seeds)
                     s = rd();
+                if constexpr (has_eval_batch<F>::value && is_rprop<Optimizer>::value) {
+                    // The objective can evaluate many points at once (a device GP per restart: kernel_lf_opt.hpp) and the
+                    // local optimiser is Rprop: the restarts advance in lock-step, iteration i of all of them being ONE
+                    // batched device evaluation (gpe_batch_hp_objective) instead of `repeats` launch chains racing each
+                    // other.  Same perturbed starts, same Rprop iterates per restart, same arg-max.
+                    if (batch_restarts_enabled()) {
+                        std::vector<Eigen::VectorXd> starts;
+                        for (int i = 0; i < repeats; ++i) {
+                            std::mt19937_64 g(seeds[i]);
+                            std::uniform_real_distribution<double> u(-eps, eps);
+                            Eigen::VectorXd start = init;
+                            for (int j = 0; j < (int)start.size(); ++j)
+                                start(j) += u(g);
+                            starts.push_back(start);
+                        }
+                        auto res = rprop_lockstep<Params>([&](const std::vector<Eigen::VectorXd>& xs, bool gr) { return f.eval_batch(xs, gr); }, starts, bounded);
+                        Eigen::VectorXd best = init;
+                        double best_val = -std::numeric_limits<float>::max();
+                        for (auto& r : res)
+                            if (r.second > best_val) { // (the value at the returned point: what opt::eval(f, v) would recompute)
+                                best_val = r.second;
+                                best = r.first;
+                            }
+                        return best;
+                    }
+                }
                 auto body = [&](int i) {
                     std::mt19937_64 g(seeds[i]);
                     std::uniform_real_distribution<double> u(-eps, eps);

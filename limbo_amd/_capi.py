@@ -71,6 +71,7 @@ def _sig(lib, prefix):
         "get_K": [_vp, _dp, _i64],
         "batch_compute": [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int)],
         "batch_log_lik": [C.POINTER(_vp), C.c_int, _dp],
+        "batch_hp_objective": [C.POINTER(_vp), C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.POINTER(C.c_int)],
         "synchronize": [_vp],
     }
     for name, args in S.items():
@@ -399,6 +400,29 @@ def batch_log_lik(handles):
     if rc < 0:
         raise EngineError(f"batch_log_lik failed: {rc}")
     return out
+
+
+def batch_hp_objective(handles, kind, thetas, noises, optimize_noise=False, want_grad=True):
+    """gpe_batch_hp_objective: thetas (G x n_theta), noises (G,) -> (lik (G,), grad (G x n_grad) or None, status list)."""
+    lib = handles[0].lib
+    G = len(handles)
+    kind = KERNEL_NAMES.get(kind, kind)
+    th = _c(np.asarray(thetas, dtype=np.float64).reshape(G, -1))
+    nz = _c(np.broadcast_to(np.asarray(noises, dtype=np.float64), (G,)).copy())
+    n_theta = th.shape[1]
+    n_grad = n_theta + (1 if optimize_noise else 0)
+    arr = (_vp * G)(*[h._h for h in handles])
+    lik = np.zeros(G)
+    grad = np.zeros((G, n_grad))
+    st = (C.c_int * G)()
+    rc = lib.fn("batch_hp_objective")(arr, G, int(kind), _d(th), n_theta, _d(nz), int(optimize_noise), int(want_grad), _d(lik),
+                                      _d(grad) if want_grad else None, st)
+    if rc < 0:
+        raise EngineError(f"batch_hp_objective failed: {rc}")
+    for h in handles:
+        h.n_theta = n_theta
+        h.kind = kind
+    return lik, (grad if want_grad else None), list(st)
 
 
 def device_count(lib) -> int:

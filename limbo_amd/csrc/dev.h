@@ -35,7 +35,7 @@ static __device__ __forceinline__ d4_t mfma_f64(double a, double b, d4_t c)
 // Every GP has its own buffers, allocated separately.  The launch sequence is built once, from GP 0's pointers, with
 // gridDim.z = G; workgroup z translates each pointer argument from GP 0's buffer into GP z's buffer of the same class
 // (wave-uniform: a handful of scalar compares per pointer).  The per-GP kernel parameters travel in the same table.
-#define GPE_BT_CLS 10
+#define GPE_BT_CLS 12
 #define GPE_BT_MAXG 64
 struct BatchTab {
     int G;
@@ -242,6 +242,8 @@ void launch_set_identity(hipStream_t s, double* A, int64_t lda, int64_t n);
 // OutT (optional): the same blocks transposed
 void launch_inv_panels(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
                        int64_t ldo, double* OutT, int64_t ldt);
+// A[0 : rows, 0 : cols] = 0 (column-major, lda) — a kernel, not hipMemsetAsync: it takes part in batched launches
+void launch_zero2d(hipStream_t s, double* A, int64_t lda, int64_t rows, int64_t cols);
 void launch_zero_upper(hipStream_t s, double* A, int64_t lda, int64_t n);
 void launch_symmetrize_from_lower(hipStream_t s, double* A, int64_t lda, int64_t n);
 void launch_copy2d(hipStream_t s, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols);

@@ -916,7 +916,7 @@ int ensure_inv(gpe_ctx* c)
         const int64_t nbo = c->nbo;
         {
             PhaseScope ps(c, GPE_PH_INV, 0.0);
-            hipMemsetAsync(c->dKinv, 0, sizeof(double) * (size_t)(ld * N), s);
+            launch_zero2d(s, c->dKinv, ld, N, N); // (a kernel: it takes part in batched launches, dev.h)
             launch_inv_panels(s, c->dA, ld, N, (int)nbo, c->dXinv, c->dKinv, ld, c->dLinv, ld);
         }
         for (int64_t o0 = 0; o0 < N; o0 += nbo) {
@@ -1052,6 +1052,21 @@ static int loo_weights(gpe_ctx* c)
     return GPE_OK;
 }
 
+// scratch of the pair-sum kernel (grad.hip) + the T outputs behind it
+static int ensure_grad_partial(gpe_ctx* c, int n_grad)
+{
+    const int64_t need = grad_partial_size(c->N, n_grad) + GPE_MAX_THETA + 8;
+    if (need > c->grad_partial_cap) {
+        if (c->dGradPartial)
+            hipFree(c->dGradPartial);
+        c->dGradPartial = nullptr;
+        c->grad_partial_cap = 0;
+        HIPCHK(c, hipMalloc(&c->dGradPartial, sizeof(double) * (size_t)need));
+        c->grad_partial_cap = need;
+    }
+    return GPE_OK;
+}
+
 int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise, bool loo = false)
 {
     if (c->host_K)
@@ -1066,13 +1081,10 @@ int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise, bool loo = false)
         if (rc)
             return rc;
     }
-    int64_t need = grad_partial_size(c->N, n_grad) + GPE_MAX_THETA + 8;
-    if (need > c->grad_partial_cap) {
-        if (c->dGradPartial)
-            hipFree(c->dGradPartial);
-        HIPCHK(c, hipMalloc(&c->dGradPartial, sizeof(double) * (size_t)need));
-        c->grad_partial_cap = need;
-    }
+    rc = ensure_grad_partial(c, n_grad);
+    if (rc)
+        return rc;
+    const int64_t need = grad_partial_size(c->N, n_grad) + GPE_MAX_THETA + 8;
     double* dgrad = c->dGradPartial + (need - GPE_MAX_THETA - 8);
     {
         PhaseScope ps(c, GPE_PH_GRAD, 0.0);
@@ -2184,11 +2196,32 @@ static void release_tab(int device, BatchTab* t)
     g_tab_pool[device].push_back(t);
 }
 
-static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out)
+// what a batched evaluation is to produce besides compute(): K^-1 and d log-lik / d theta of every member
+// (kernel_lf_opt.hpp:77-92 for G restarts at once)
+struct BatchWant {
+    bool grad = false;
+    int n_grad = 0, optimize_noise = 0;
+    double* grad_out = nullptr; // host, Gc x n_grad
+};
+
+static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const BatchWant* want = nullptr)
 {
     gpe_ctx* c0 = cs[0];
     DevGuard g(c0);
     *tab_out = nullptr;
+    if (want && want->grad) { // every member needs the same three buffers before the table is built
+        for (int q = 0; q < Gc; ++q) {
+            gpe_ctx* c = cs[q];
+            const size_t mat = sizeof(double) * (size_t)(c->ld * c->cap);
+            if (!c->dLinv)
+                HIPCHK(c, hipMalloc(&c->dLinv, mat));
+            if (!c->dKinv)
+                HIPCHK(c, hipMalloc(&c->dKinv, mat));
+            int rc = ensure_grad_partial(c, want->n_grad);
+            if (rc)
+                return rc;
+        }
+    }
     if (c0->device >= 16)
         return GPE_ERR_UNSUPPORTED;
     BatchTab* dtab = acquire_tab(c0->device); // held until the batch has finished (batch_finish_fused's caller releases it)
@@ -2206,7 +2239,7 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out)
         c->hInfo[0] = c->hInfo[1] = 0;
         const char* b[GPE_BT_CLS] = {(const char*)c->dA, (const char*)c->dXt, (const char*)c->dOm, (const char*)c->dAl,
                                      (const char*)c->dXinv, (const char*)c->dHead, (const char*)c->hInfo, (const char*)c->hScal,
-                                     nullptr, nullptr};
+                                     (const char*)c->dLinv, (const char*)c->dKinv, (const char*)c->dGradPartial, nullptr};
         for (int k = 0; k < GPE_BT_CLS; ++k)
             t.base[k][q] = b[k];
         t.kp[q] = c->kp;
@@ -2216,7 +2249,8 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out)
     const unsigned long long sz[GPE_BT_CLS] = {(unsigned long long)(dbl * c0->ld * c0->cap), (unsigned long long)(dbl * c0->ld * xt_rows(c0->D)),
                                                (unsigned long long)(dbl * c0->ld * c0->P), (unsigned long long)(dbl * c0->ld * c0->P),
                                                (unsigned long long)(dbl * (c0->cap / NB) * NB * NB), (unsigned long long)(dbl * GPE_HEAD_TILES * NB * NB), 64, 8192,
-                                               0, 0};
+                                               (unsigned long long)(c0->dLinv ? dbl * c0->ld * c0->cap : 0), (unsigned long long)(c0->dKinv ? dbl * c0->ld * c0->cap : 0),
+                                               (unsigned long long)(c0->dGradPartial ? dbl * c0->grad_partial_cap : 0), 0};
     for (int k = 0; k < GPE_BT_CLS; ++k) {
         t.base0[k] = t.base[k][0];
         t.size[k] = sz[k];
@@ -2228,12 +2262,23 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out)
     g_batch.bt = dtab;
     g_batch.G = Gc;
     int e = compute_enqueue(c0);
+    if (e == GPE_OK && want && want->grad) {
+        // K^-1 (gp.hpp:254-264) and the gradient pair sum (gp.hpp:285-311) of every member, same launch sequence
+        e = grad_enqueue(c0, want->n_grad, want->optimize_noise);
+        if (e == GPE_OK && want->grad_out) {
+            const int64_t off = c0->dGrad - c0->dGradPartial;
+            for (int q = 0; q < Gc && e == GPE_OK; ++q)
+                if (hipMemcpyAsync(want->grad_out + (size_t)q * want->n_grad, cs[q]->dGradPartial + off, sizeof(double) * want->n_grad,
+                                   hipMemcpyDeviceToHost, c0->stream) != hipSuccess)
+                    e = GPE_ERR_HIP;
+        }
+    }
     g_batch = BatchLaunch{};
     c0->lookahead = la;
     return e;
 }
 
-static int batch_finish_fused(gpe_ctx** cs, int Gc, int* rc)
+static int batch_finish_fused(gpe_ctx** cs, int Gc, int* rc, const BatchWant* want = nullptr)
 {
     gpe_ctx* c0 = cs[0];
     DevGuard g(c0);
@@ -2249,12 +2294,24 @@ static int batch_finish_fused(gpe_ctx** cs, int Gc, int* rc)
         c->xinv_done = 0;
         // the usual finish on the handle's own (idle) stream: sums the per-block partials; a sweep that gave up
         // (never expected) is re-run block by block for that GP alone
+        const int64_t retries = c->flow_retries;
         rc[q] = compute_finish(c);
+        if (want && want->grad) {
+            c->inv_ok = true; // gp.hpp:263
+            if (c->flow_retries != retries && rc[q] >= 0 && want->grad_out) {
+                // (never expected) this member's sweep or factorisation was re-run on its own after the batch: its
+                // K^-1 / gradient came from the first attempt — once more, alone
+                c->inv_ok = false;
+                int e = grad_fetch(c, want->grad_out + (size_t)q * want->n_grad, want->n_grad, want->optimize_noise, false);
+                if (e < 0)
+                    rc[q] = e;
+            }
+        }
     }
     return GPE_OK;
 }
 
-int gpe_batch_compute(gpe_handle* hs, int G, int* status)
+static int batch_compute_impl(gpe_handle* hs, int G, int* status, const BatchWant* want)
 {
     if (!hs || G < 0)
         return GPE_ERR_ARG;
@@ -2264,7 +2321,8 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
     for (int g = 0; g < G && fused; ++g) {
         gpe_ctx* c = hs[g];
         fused = c && c->N > 0 && batch_compatible(hs[0], c) && lam_columns(c->kind, c->n_theta, c->D) == 0
-            && c->flow_solve && (c->N + NB - 1) / NB <= 256;
+            && c->flow_solve && (c->N + NB - 1) / NB <= 256
+            && (!(want && want->grad) || (c->nbo % 128 == 0 && c->nbo <= 256)); // (K^-1: the one-launch panel inverses)
         for (int q = 0; q < g && fused; ++q)
             fused = hs[q] != c; // the same handle twice cannot be stepped in parallel
     }
@@ -2295,9 +2353,15 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
             }
             int en[4];
             BatchTab* tabs[4] = {nullptr, nullptr, nullptr, nullptr};
+            BatchWant wsub[4];
             for (int w = 0; w < nw; ++w) {
+                if (want) {
+                    wsub[w] = *want;
+                    if (want->grad_out)
+                        wsub[w].grad_out = want->grad_out + (size_t)starts[w] * want->n_grad;
+                }
                 if (counts[w] >= 2)
-                    en[w] = batch_enqueue_fused(hs + starts[w], counts[w], &tabs[w]);
+                    en[w] = batch_enqueue_fused(hs + starts[w], counts[w], &tabs[w], want ? &wsub[w] : nullptr);
                 else {
                     DevGuard dg(hs[starts[w]]);
                     en[w] = compute_enqueue(hs[starts[w]]);
@@ -2316,7 +2380,7 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
                     continue;
                 }
                 if (counts[w] >= 2) {
-                    int e = batch_finish_fused(hs + starts[w], counts[w], rc.data() + starts[w]);
+                    int e = batch_finish_fused(hs + starts[w], counts[w], rc.data() + starts[w], want ? &wsub[w] : nullptr);
                     if (e < 0) {
                         worst = e;
                         DevGuard dg(hs[starts[w]]);
@@ -2325,8 +2389,14 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
                     release_tab(hs[starts[w]]->device, tabs[w]); // the stream is idle: nothing reads the table any more
                 }
                 else {
-                    DevGuard dg(hs[starts[w]]);
-                    rc[starts[w]] = compute_finish(hs[starts[w]]);
+                    gpe_ctx* c1 = hs[starts[w]];
+                    DevGuard dg(c1);
+                    rc[starts[w]] = compute_finish(c1);
+                    if (want && want->grad && rc[starts[w]] >= 0 && want->grad_out) { // a sub-batch of one: on its own
+                        int e = grad_fetch(c1, wsub[w].grad_out, want->n_grad, want->optimize_noise, false);
+                        if (e < 0)
+                            rc[starts[w]] = e;
+                    }
                 }
             }
         }
@@ -2375,6 +2445,11 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
             hipSetDevice(c->device);
             if (rc[g] == GPE_OK)
                 rc[g] = compute_finish(c);
+            if (want && want->grad && rc[g] >= 0 && want->grad_out) {
+                int e = grad_fetch(c, want->grad_out + (size_t)g * want->n_grad, want->n_grad, want->optimize_noise, false);
+                if (e < 0)
+                    rc[g] = e;
+            }
         }
         else
             for (int q = 0; q < g; ++q)
@@ -2386,6 +2461,49 @@ int gpe_batch_compute(gpe_handle* hs, int G, int* status)
             status[g] = rc[g];
         if (rc[g] < 0)
             worst = rc[g];
+    }
+    return worst;
+}
+
+int gpe_batch_compute(gpe_handle* hs, int G, int* status) { return batch_compute_impl(hs, G, status, nullptr); }
+
+// KernelLFOptimization::operator() (kernel_lf_opt.hpp:77-92) for G clones at once — the restarts of
+// opt::ParallelRepeater (parallel_repeater.hpp:84-105), the outputs of multi_gp::ParallelLFOpt (parallel_lf_opt.hpp:64-67):
+// member g gets log_theta[g n_theta ..] and noise[g]; K -> L -> alpha -> log-lik -> K^-1 -> gradient of ALL members is one
+// launch sequence (gridDim.z = member) when the handles agree in shape, per-member chains otherwise.
+int gpe_batch_hp_objective(gpe_handle* hs, int G, int kind, const double* log_theta, int n_theta, const double* noise,
+                           int optimize_noise, int want_grad, double* lik, double* grad, int* status)
+{
+    if (!hs || G < 0 || !log_theta || !noise || !lik || (want_grad && !grad))
+        return GPE_ERR_ARG;
+    for (int g = 0; g < G; ++g) {
+        if (!hs[g])
+            return GPE_ERR_ARG;
+        int rc = gpe_set_kernel(hs[g], kind, log_theta + (size_t)g * n_theta, n_theta, noise[g]); // kernel_lf_opt.hpp:80
+        if (rc)
+            return rc;
+        if (want_grad && hs[g]->host_K)
+            return GPE_ERR_UNSUPPORTED;
+        if (lam_columns(kind, n_theta, hs[g]->D) < 0) {
+            hs[g]->err = "set_kernel: wrong number of hyper-parameters for this kernel/dimension";
+            return GPE_ERR_ARG;
+        }
+    }
+    BatchWant want;
+    want.grad = want_grad != 0;
+    want.optimize_noise = optimize_noise;
+    want.n_grad = n_theta + (optimize_noise ? 1 : 0);
+    want.grad_out = grad;
+    std::vector<int> st(G, 0);
+    int worst = batch_compute_impl(hs, G, st.data(), &want); // :82 recompute(false) (+ :89 the gradient)
+    for (int g = 0; g < G; ++g) {
+        if (status)
+            status[g] = st[g];
+        if (st[g] >= 0) {
+            int rc = gpe_log_lik(hs[g], lik + g); // :84
+            if (rc < 0)
+                worst = rc;
+        }
     }
     return worst;
 }

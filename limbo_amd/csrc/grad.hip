@@ -26,13 +26,22 @@
 // LAM = true : the Din entries of column `lam_col` of Lambda (squared_exp_ard.hpp:118-121):
 //              g = -((x1-x2)^T Lambda_col) (x1-x2) k;  n_theta = Din, optimize_noise = 0.
 template <int DMAX, bool LAM>
-__global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp,
+__global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp_,
                                                     const double* __restrict__ Kinv, int64_t ldk,
                                                     const double* __restrict__ alpha, int64_t lda,
                                                     const double* __restrict__ uvec, int P, double kinv_scale,
                                                     int n_theta, int optimize_noise, int lam_col,
-                                                    double* __restrict__ partial)
+                                                    double* __restrict__ partial, const BatchTab* bt)
 {
+    if (bt) { // batched launch (gridDim.z GPs, dev.h): this GP's buffers and kernel parameters
+        const int z = (int)blockIdx.z;
+        Xt = bt_rebase(bt, z, Xt);
+        Kinv = bt_rebase(bt, z, Kinv);
+        alpha = bt_rebase(bt, z, alpha);
+        uvec = bt_rebase(bt, z, uvec);
+        partial = bt_rebase(bt, z, partial);
+    }
+    const KParams& kp = bt ? bt->kp[blockIdx.z] : kp_;
     // weight of pair (i, j):  w = 1/2 sum_p (u_ip alpha_jp + alpha_ip u_jp) - Kinv[i, j]
     // (uvec == alpha for the log-likelihood gradient: w = sum_p alpha_ip alpha_jp - K^-1_ij)
     extern __shared__ __attribute__((aligned(16))) double smem[]; // xj[D][64] | aj[P][64] | uj[P][64] | red[4][T]
@@ -178,8 +187,10 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
 // (with Lambda columns the parameter vector is [ell | Lambda columns | sigma_f | (noise)])
 __global__ __launch_bounds__(256) void k_grad_final(const double* __restrict__ partial, int64_t nblk, int T,
                                                     double* __restrict__ grad_, int accumulate, int out_off,
-                                                    int tail_from, int tail_to)
+                                                    int tail_from, int tail_to, const BatchTab* bt)
 {
+    BT_REBASE(bt, partial);
+    BT_REBASE(bt, grad_);
     __shared__ double sh[4];
     const int t = blockIdx.x;
     double* grad = grad_ + ((t >= tail_from) ? tail_to - tail_from : out_off);
@@ -239,11 +250,11 @@ static void launch_grad_chunk(hipStream_t s, const double* Xt, int64_t ldx, int6
     const int64_t nt = (N + TILE - 1) / TILE;
     const int64_t nblk = nt * (nt + 1) / 2;
     const int D = kp.D;
-    dim3 grid((unsigned)nblk), block(256);
+    dim3 grid((unsigned)nblk, 1, (unsigned)g_batch.G), block(256);
 #define LG(DM, LAM)                                                                                              \
     hipLaunchKernelGGL((k_grad_tiles<DM, LAM>), grid, block,                                                     \
                        (size_t)(D * TILE + 2 * GPE_MAX_P * TILE + 4 * (DM + 2)) * sizeof(double), s, Xt, ldx, N, \
-                       kp, Kinv, ldk, alpha, lda, uvec, P, kinv_scale, n_theta, optimize_noise, lam_col, partial)
+                       kp, Kinv, ldk, alpha, lda, uvec, P, kinv_scale, n_theta, optimize_noise, lam_col, partial, g_batch.bt)
 #define LGD(LAM)      \
     if (D <= 4)       \
         LG(4, LAM);   \
@@ -263,8 +274,8 @@ static void launch_grad_chunk(hipStream_t s, const double* Xt, int64_t ldx, int6
     }
 #undef LGD
 #undef LG
-    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)T), dim3(256), 0, s, partial, nblk, T, grad, accumulate, out_off,
-                       tail_from, tail_to);
+    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)T, 1, (unsigned)g_batch.G), dim3(256), 0, s, partial, nblk, T, grad, accumulate,
+                       out_off, tail_from, tail_to, g_batch.bt);
 }
 
 // ---- leave-one-out helpers (gp.hpp:339-402) -------------------------------------------------------

@@ -45,8 +45,12 @@ static __device__ __forceinline__ void strip_mm(const double* __restrict__ As, c
 // Xt_all: Xt[k + 64 c] = (L_bb^-1)[c][k] per 64-block b, identity-padded.
 __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L, int64_t ld, int64_t N, int nbo,
                                                     const double* __restrict__ Xt_all, double* __restrict__ Out,
-                                                    int64_t ldo, double* __restrict__ OutT, int64_t ldt)
+                                                    int64_t ldo, double* __restrict__ OutT, int64_t ldt, const BatchTab* bt)
 {
+    BT_REBASE(bt, L); // batched launch (gridDim.z GPs, dev.h): this GP's buffers
+    BT_REBASE(bt, Xt_all);
+    BT_REBASE(bt, Out);
+    BT_REBASE(bt, OutT);
     __shared__ double Ys[4][NB * SW]; // the strip's result tiles, Ys[i - s][kk][col]
     __shared__ double Ss[NB * SW];    // sum_k L_ik Y_ks, as the right-hand operand of X_i
     __shared__ double As[NB * AST];   // left operand, k-major: As[kk][row]
@@ -147,6 +151,21 @@ void launch_inv_panels(hipStream_t s, const double* L, int64_t ld, int64_t N, in
     if (N <= 0)
         return;
     const unsigned np = (unsigned)((N + nbo - 1) / nbo);
-    hipLaunchKernelGGL(k_inv_panels, dim3((unsigned)(nbo / SW), np), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, ldo,
-                       OutT, ldt);
+    hipLaunchKernelGGL(k_inv_panels, dim3((unsigned)(nbo / SW), np, (unsigned)g_batch.G), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, ldo,
+                       OutT, ldt, g_batch.bt);
+}
+
+__global__ void k_zero2d(double* __restrict__ A, int64_t lda, int64_t rows, int64_t cols, const BatchTab* bt)
+{
+    BT_REBASE(bt, A);
+    const int64_t c = blockIdx.y;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x)
+        A[r + c * lda] = 0.0;
+}
+void launch_zero2d(hipStream_t s, double* A, int64_t lda, int64_t rows, int64_t cols)
+{
+    if (rows <= 0 || cols <= 0)
+        return;
+    const unsigned gx = (unsigned)((rows + 1023) / 1024 > 8 ? 8 : (rows + 1023) / 1024);
+    hipLaunchKernelGGL(k_zero2d, dim3(gx, (unsigned)cols, (unsigned)g_batch.G), dim3(256), 0, s, A, lda, rows, cols, g_batch.bt);
 }

@@ -1005,6 +1005,25 @@ int orc_batch_log_lik(orc_handle* hs, int G, double* out)
     return 0;
 }
 
+/* KernelLFOptimization::operator() (src/limbo/model/gp/kernel_lf_opt.hpp:77-92) for G GPs: the reference runs the
+ * restarts / outputs as independent tasks (opt/parallel_repeater.hpp:84-105, model/multi_gp/parallel_lf_opt.hpp:64-67):
+ * here, one after the other */
+int orc_batch_hp_objective(orc_handle* hs, int G, int kind, const double* th, int n_theta, const double* noise,
+    int optimize_noise, int want_grad, double* lik, double* grad, int* status)
+{
+    int worst = 0;
+    const int n_grad = n_theta + (optimize_noise ? 1 : 0);
+    for (int g = 0; g < G; ++g) {
+        int rc = orc_hp_objective(hs[g], kind, th + (size_t)g * n_theta, n_theta, noise[g], optimize_noise, want_grad,
+            lik + g, want_grad ? grad + (size_t)g * n_grad : 0);
+        if (status)
+            status[g] = rc;
+        if (rc < 0)
+            worst = rc;
+    }
+    return worst;
+}
+
 int orc_synchronize(orc_handle c)
 {
     (void)c;

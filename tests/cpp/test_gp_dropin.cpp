@@ -908,6 +908,63 @@ CASE(test_sparse_gp_accuracy)
 }
 
 // independent GPs / restarts spread over the devices of the node from the C++ drop-in itself —
+
+// Restarts / outputs in lock-step (opt/batched_rprop.hpp, gpe_batch_hp_objective): the same iterates as limbo's
+// sequential Rprop (opt/rprop.hpp:82-145) run per restart (opt/parallel_repeater.hpp:84-105) or per output
+// (model/multi_gp/parallel_lf_opt.hpp:64-67)
+CASE(test_lockstep_restarts)
+{
+    using Opt_t = model::gp::KernelLFOpt<Params, opt::ParallelRepeater<Params, opt::Rprop<Params>>>;
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>, Opt_t>;
+    std::vector<VectorXd> X, Y;
+    make_problem(150, 3, 1, X, Y);
+    GP_t gp;
+    gp.compute(X, Y);
+    Opt_t::KernelLFOptimization<GP_t> objective(gp);
+    const VectorXd h0 = gp.kernel_function().h_params();
+    std::vector<VectorXd> starts;
+    for (int i = 0; i < 5; ++i)
+        starts.push_back(h0 + 0.05 * rand_vec((int)h0.size(), -1, 1));
+    // one batched evaluation == the per-point objective
+    const std::vector<opt::eval_t> eb = objective.eval_batch(starts, true);
+    for (size_t i = 0; i < starts.size(); ++i) {
+        const opt::eval_t e1 = objective(starts[i], true);
+        CHECK(std::abs(opt::fun(eb[i]) - opt::fun(e1)) <= 1e-10 * std::abs(opt::fun(e1)));
+        CHECK((opt::grad(eb[i]) - opt::grad(e1)).norm() <= 1e-7 * opt::grad(e1).norm());
+    }
+    // lock-step Rprop == sequential Rprop from the same starts
+    auto res = opt::rprop_lockstep<Params>([&](const std::vector<VectorXd>& xs, bool g) { return objective.eval_batch(xs, g); }, starts, false);
+    for (size_t i = 0; i < starts.size(); ++i) {
+        const VectorXd seq = opt::Rprop<Params>()(objective, starts[i], false);
+        const double fseq = opt::eval(objective, seq);
+        CHECK(std::abs(res[i].second - fseq) <= 1e-7 * std::max(1.0, std::abs(fseq)));
+        CHECK((res[i].first - seq).norm() <= 1e-5 * std::max(1.0, seq.norm()));
+    }
+    // the restarts of a fit through the policy, both ways: never below the start
+    const double ll0 = gp.compute_log_lik();
+    gp.optimize_hyperparams();
+    CHECK(gp.get_log_lik() >= ll0 - 1e-9);
+    // MultiGP: per-output fits in lock-step == per-output fits on host threads
+    using Multi_t = model::MultiGP<Params, model::GP, kernel::SquaredExpARD<Params>, mean::Data<Params>, model::multi_gp::ParallelLFOpt<Params, model::gp::KernelLFOpt<Params>>>;
+    std::vector<VectorXd> X3, Y3;
+    make_problem(90, 2, 3, X3, Y3);
+    Multi_t a, b;
+    a.compute(X3, Y3);
+    b.compute(X3, Y3);
+    a.optimize_hyperparams(); // lock-step (default)
+    setenv("LIMBO_AMD_BATCH_RESTARTS", "0", 1);
+    b.optimize_hyperparams(); // one host thread and launch chain per output
+    unsetenv("LIMBO_AMD_BATCH_RESTARTS");
+    for (int p = 0; p < 3; ++p) {
+        const VectorXd ha = a.gp_models()[p].kernel_function().h_params(), hb = b.gp_models()[p].kernel_function().h_params();
+        CHECK((ha - hb).norm() <= 1e-5 * std::max(1.0, hb.norm()));
+        const double la = a.gp_models()[p].get_log_lik(), lb = b.gp_models()[p].get_log_lik();
+        CHECK(std::abs(la - lb) <= 1e-7 * std::max(1.0, std::abs(lb)));
+        const VectorXd q = rand_vec(2, 0, 1);
+        CHECK(std::abs(a.gp_models()[p].mu(q)(0) - b.gp_models()[p].mu(q)(0)) <= 1e-6);
+    }
+}
+
 // tools::par::loop over MultiGP members (multi_gp.hpp:124-126), tools::par::max under opt::ParallelRepeater
 // (parallel_repeater.hpp:84-105).  With one visible device everything stays on it; GPE_VIRTUAL_DEVICES=n (the
 // pytest wrapper runs the whole binary again with 4) deals n logical devices over the physical ones, so the
@@ -984,7 +1041,8 @@ CASE(test_multi_device_placement)
         Opt_t::KernelLFOptimization<GPo_t> objective(g2);
         opt::ParallelRepeater<Params, opt::Rprop<Params>> rep;
         const VectorXd best = rep(objective, g2.kernel_function().h_params(), false);
-        const std::vector<int> devs = objective._workers.devices();
+        // (lock-step restarts: one clone per restart, opt/batched_rprop.hpp; LIMBO_AMD_BATCH_RESTARTS=0: one per thread)
+        const std::vector<int> devs = opt::batch_restarts_enabled() ? objective.batch_devices() : objective._workers.devices();
         CHECK((int)devs.size() == Params::opt_parallelrepeater::repeats());
         std::vector<int> count(ndev, 0);
         for (int d : devs) {
@@ -1004,6 +1062,8 @@ CASE(test_multi_device_placement)
         opt::ParallelRepeater<ParamsPinned, opt::Rprop<ParamsPinned>> repp;
         repp(objp, g3.kernel_function().h_params(), false);
         for (int d : objp._workers.devices())
+            CHECK(d == 0);
+        for (int d : objp.batch_devices())
             CHECK(d == 0);
     }
     // an exception inside a par::loop body reaches the caller (as out of tbb::parallel_for)
@@ -1059,6 +1119,7 @@ int main()
     test_batch_search_run();
     test_sparse_gp_accuracy_run();
     test_multi_device_placement_run();
+    test_lockstep_restarts_run();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%d checks, %d failed cases, %.1f s\n", g_checks, g_failed, s);
     return g_failed;

@@ -636,3 +636,46 @@ def test_gpu_bench_two_ranks_on_one_gpu():
     assert out["config4"]["gps_total"] == 16 and out["config4"]["value"] > 0
     assert out["argmax"]["owner_rank"] in (0, 1) and np.isfinite(out["argmax"]["best_log_lik"])
     assert "roofline" in out and "cpu_baseline" not in out  # rank 0 at N = 1 only
+
+
+@pytest.mark.parametrize("N,G,kind,on,P", [(2048, 8, O.SE_ARD, False, 1), (700, 5, O.MATERN52, True, 2), (1100, 18, O.SE_ARD, True, 1),
+                                            (300, 3, O.SE_ARD, False, 1)])
+def test_gpu_batch_hp_objective_vs_single_and_oracle(engine_lib, oracle_lib, N, G, kind, on, P):
+    """gpe_batch_hp_objective — G restarts of KernelLFOptimization::operator() (kernel_lf_opt.hpp:77-92,
+    parallel_repeater.hpp:84-105) stepped by one launch sequence: every member's (log-lik, gradient) equals the
+    single-handle gpe_hp_objective to rounding and the oracle's to the usual tolerances; K^-1 of a member equals the oracle's;
+    the batch is bitwise reproducible; a second, different batch on the same handles works (resident buffers)."""
+    rng = np.random.default_rng(N + G)
+    D = 6 if kind == O.SE_ARD else 3
+    X = rng.uniform(0, 1, size=(N, D))
+    Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) + 0.05 * rng.normal(size=N) for p in range(P)], axis=1)
+    om, _ = O.obs_mean_data(Y)
+    nt = D + 1 if kind == O.SE_ARD else 2
+    hs = []
+    for g in range(G):
+        h = _capi.Handle(engine_lib)
+        h.set_data(X, om * (1.0 + 0.1 * g))
+        hs.append(h)
+    single = _capi.Handle(engine_lib)
+    orc = _capi.Handle(oracle_lib)
+    for rnd in range(2):
+        th = rng.uniform(-0.4, 0.3, size=(G, nt))
+        nz = 0.01 * np.exp(rng.uniform(-0.5, 0.5, size=G))
+        lik, grad, st = _capi.batch_hp_objective(hs, kind, th, nz, optimize_noise=on, want_grad=True)
+        lik2, grad2, st2 = _capi.batch_hp_objective(hs, kind, th, nz, optimize_noise=on, want_grad=True)
+        assert all(s == 0 for s in st) and np.array_equal(lik, lik2) and np.array_equal(grad, grad2)
+        for g in sorted(set([0, G // 2, G - 1])):
+            single.set_data(X, om * (1.0 + 0.1 * g))
+            l1, g1, info = single.hp_objective(kind, th[g], nz[g], optimize_noise=on, want_grad=True)
+            assert info == 0 and abs(lik[g] - l1) <= 1e-11 * abs(l1) and relerr_norm(grad[g], g1) < 1e-9
+            if N <= 1100:
+                orc.set_data(X, om * (1.0 + 0.1 * g))
+                lo, go, _ = orc.hp_objective(kind, th[g], nz[g], optimize_noise=on, want_grad=True)
+                assert abs(lik[g] - lo) <= PC.TOL_LL * abs(lo) and relerr_norm(grad[g], go) < PC.TOL_GRAD
+                assert relerr_norm(hs[g].get_Kinv(), orc.get_Kinv()) < 1e-8
+        # the value-only form
+        lik3, none, st3 = _capi.batch_hp_objective(hs, kind, th, nz, optimize_noise=on, want_grad=False)
+        assert none is None and np.array_equal(lik3, lik)
+    assert all(h.flow_retries() == 0 for h in hs)
+    for h in hs + [single, orc]:
+        h.close()
