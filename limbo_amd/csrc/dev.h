@@ -235,6 +235,12 @@ void launch_col_var(hipStream_t s, const double* Z, int64_t ldz, int64_t N, int6
 // kta[m, p] = sum_i Ks[i, m] alpha[i, p]
 void launch_kta(hipStream_t s, const double* Ks, int64_t ldk, int64_t N, int64_t M, const double* alpha, int64_t lda,
                 int P, double* kta, int64_t ldo);
+// the same two for the transposed layout of the batched query path (points contiguous, Zt[m + i ldz]); partial: scratch of
+// nseg x (P or 1) x ldp doubles, the segments are added in order (bitwise reproducible)
+void launch_row_var_t(hipStream_t s, const double* Zt, int64_t ldz, int64_t N, int64_t M, const double* kvv, double* var,
+                      double* partial, int64_t ldp, int nseg);
+void launch_kta_t(hipStream_t s, const double* Kst, int64_t ldk, int64_t N, int64_t M, const double* alpha, int64_t lda, int P,
+                  double* kta, int64_t ldo, double* partial, int64_t ldp, int nseg);
 // misc
 void launch_set_identity(hipStream_t s, double* A, int64_t lda, int64_t n);
 // inv.hip: Out[o0:o0+pw, o0:o0+pw] = inv(L[o0:o0+pw, o0:o0+pw]) (full square) for every outer panel of nbo <= 256

@@ -41,7 +41,8 @@ static __device__ __forceinline__ void strip_mm(const double* __restrict__ As, c
 }
 
 // Out[o0 : o0+pw, o0 : o0+pw] = inv(L[o0 : o0+pw, o0 : o0+pw]) for every outer panel (blockIdx.y), full square
-// (zeros above the diagonal); OutT (optional): the same blocks transposed.
+// (zeros above the diagonal); OutT (optional): the same blocks transposed.  ldo == 0: the blocks alone, one after the
+// other (what the batched query path multiplies by: engine.hip, query_impl).
 // Xt_all: Xt[k + 64 c] = (L_bb^-1)[c][k] per 64-block b, identity-padded.
 __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L, int64_t ld, int64_t N, int nbo,
                                                     const double* __restrict__ Xt_all, double* __restrict__ Out,
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = o0 + (int64_t)i * NB + 4 * ty + r;
                 if (row < N && col < N) {
-                    Out[row + col * ldo] = v[r][c];
+                    if (ldo == 0) // compact form: panel p's block alone, column-major nbo x nbo, at Out + p nbo^2
+                        Out[(row - o0) + (col - o0) * (int64_t)nbo + (int64_t)blockIdx.y * nbo * nbo] = v[r][c];
+                    else
+                        Out[row + col * ldo] = v[r][c];
                     if (OutT)
                         OutT[col + row * ldt] = v[r][c];
                 }

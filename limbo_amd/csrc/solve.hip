@@ -741,6 +741,76 @@ void launch_kta(hipStream_t s, const double* Ks, int64_t ldk, int64_t N, int64_t
     hipLaunchKernelGGL(k_kta, dim3(grid), dim3(256), 0, s, Ks, ldk, N, M, alpha, lda, P, kta, ldo);
 }
 
+// ---- the same two reductions for the TRANSPOSED layout of the batched query path (points contiguous: Zt[m + i ldz]) ----
+// partial[(seg * nout + q) * ldp + m] = sum over i in segment seg of  Zt[m, i]^2          (A == nullptr, nout = 1)
+//                                                                   or  Zt[m, i] A[i, q]   (A: N x nout, lda)
+// thread = point (coalesced along m), the N columns cut into gridDim.y segments; k_rows_finish adds the segments in order.
+template <int NQ>
+__global__ __launch_bounds__(256) void k_rows_partial_t(const double* __restrict__ Zt, int64_t ldz, int64_t N, int64_t M,
+                                                        const double* __restrict__ A, int64_t lda, int nout,
+                                                        double* __restrict__ partial, int64_t ldp)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t seg = blockIdx.y, nseg = gridDim.y;
+    const int64_t len = (N + nseg - 1) / nseg, i0 = seg * len, i1 = i0 + len < N ? i0 + len : N;
+    const int64_t mc = m < M ? m : M - 1;
+    for (int q0 = 0; q0 < nout; q0 += NQ) {
+        double acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            acc[q] = 0.0;
+        for (int64_t i = i0; i < i1; ++i) {
+            const double v = Zt[mc + i * ldz];
+            if (A) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    acc[q] = fma(v, A[i + (int64_t)(q0 + q < nout ? q0 + q : nout - 1) * lda], acc[q]);
+            }
+            else
+                acc[0] = fma(v, v, acc[0]);
+        }
+        if (m < M)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q0 + q < nout)
+                    partial[(seg * nout + q0 + q) * ldp + m] = acc[q];
+    }
+}
+// out[m + q ldo] = (base ? base[m] - sum : sum) of the nseg partials, in order
+__global__ void k_rows_finish_t(const double* __restrict__ partial, int64_t ldp, int nseg, int nout, int64_t M,
+                                const double* __restrict__ base, double* __restrict__ out, int64_t ldo)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;
+    if (m >= M)
+        return;
+    double s = 0.0;
+    for (int seg = 0; seg < nseg; ++seg)
+        s += partial[((int64_t)seg * nout + q) * ldp + m];
+    out[m + (int64_t)q * ldo] = base ? base[m] - s : s;
+}
+// var[m] = kvv[m] - sum_i Zt[m, i]^2   (gp.hpp:621);  partial: nseg x ldp doubles of scratch (ldp >= M)
+void launch_row_var_t(hipStream_t s, const double* Zt, int64_t ldz, int64_t N, int64_t M, const double* kvv, double* var,
+                      double* partial, int64_t ldp, int nseg)
+{
+    if (M <= 0)
+        return;
+    hipLaunchKernelGGL((k_rows_partial_t<1>), dim3((unsigned)((M + 255) / 256), (unsigned)nseg), dim3(256), 0, s, Zt, ldz, N, M,
+                       (const double*)nullptr, (int64_t)0, 1, partial, ldp);
+    hipLaunchKernelGGL(k_rows_finish_t, dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, s, partial, ldp, nseg, 1, M, kvv, var, M);
+}
+// kta[m + p ldo] = sum_i Kst[m, i] alpha[i, p]   (gp.hpp:615);  partial: nseg x P x ldp doubles
+void launch_kta_t(hipStream_t s, const double* Kst, int64_t ldk, int64_t N, int64_t M, const double* alpha, int64_t lda, int P,
+                  double* kta, int64_t ldo, double* partial, int64_t ldp, int nseg)
+{
+    if (M <= 0 || P <= 0)
+        return;
+    hipLaunchKernelGGL((k_rows_partial_t<4>), dim3((unsigned)((M + 255) / 256), (unsigned)nseg), dim3(256), 0, s, Kst, ldk, N, M, alpha,
+                       lda, P, partial, ldp);
+    hipLaunchKernelGGL(k_rows_finish_t, dim3((unsigned)((M + 255) / 256), (unsigned)P), dim3(256), 0, s, partial, ldp, nseg, P, M,
+                       (const double*)nullptr, kta, ldo);
+}
+
 // ---------------------------------------------------------------------------------------
 // small utilities
 // ---------------------------------------------------------------------------------------

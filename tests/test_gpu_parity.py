@@ -249,7 +249,10 @@ def test_gpu_c3_full_size_properties(engine_lib):
     Xq = rng.uniform(0, 1, size=(4096, D))
     k1, v1 = h.query_batch(Xq)
     k2, v2 = h.query_batch(Xq[:1000])
-    assert np.array_equal(k1[:1000], k2) and np.array_equal(v1[:1000], v2)
+    k3, v3 = h.query_batch(Xq)
+    assert np.array_equal(k1, k3) and np.array_equal(v1, v3)  # bitwise reproducible from call to call
+    # a different batch size may pick other matrix-core tile shapes for the solve (another summation order): equal to rounding
+    assert np.array_equal(k1[:1000], k2) and relerr(v1[:1000], v2) < 1e-10
     assert np.all(np.isfinite(v1)) and np.all(v1 > -1e-9)
     h.close()
 
