@@ -94,6 +94,7 @@ def _sig(lib, prefix):
             "flow_retries": [_vp, C.POINTER(_i64)],
             "handover_reruns": [_vp, C.POINTER(_i64)],
             "small_calls": [_vp, C.POINTER(_i64)],
+            "server_calls": [_vp, C.POINTER(_i64)],
             "mfma_f64_peak": [C.c_int, _dp],
             "hbm_stream_peak": [C.c_int, _dp],
         }
@@ -196,6 +197,11 @@ class Handle:
     def handover_reruns(self) -> int:
         n = _i64()
         self._chk(self.lib.fn("handover_reruns")(self._h, C.byref(n)), "handover_reruns")
+        return n.value
+
+    def server_calls(self) -> int:
+        n = _i64()
+        self._chk(self.lib.fn("server_calls")(self._h, C.byref(n)), "server_calls")
         return n.value
 
     def small_calls(self) -> int:

@@ -315,6 +315,23 @@ struct SmallAlphaArgs {
     unsigned long long seq_val;
     int n;
 };
+// the persistent form of the three (small.hip, k_small_server): requests through a pinned, coherent mailbox
+#define GPE_SMALL_OP_ADD 1
+#define GPE_SMALL_OP_QUERY 2
+#define GPE_SMALL_OP_ALPHA 3
+#define GPE_SMALL_OP_EXIT 0xFF
+struct SmallMailbox {
+    unsigned long long req_seq; // host: raised AFTER the request below is complete
+    unsigned long long state;   // 1: a server is (being) launched / running; 0: it has left (written by the server)
+    int op, P;
+    SmallAddArgs add;
+    SmallQueryArgs qry;
+    SmallAlphaArgs alp;
+    KParams kp;
+    LamParams lp;
+    double x[GPE_MAX_THETA];
+};
+void launch_small_server(hipStream_t s, SmallMailbox* mb, unsigned long long seen0, long long idle_ticks);
 int small_max_n();
 void launch_small_alpha(hipStream_t s, const SmallAlphaArgs& g, int P);
 void launch_small_add(hipStream_t s, const SmallAddArgs& g, int P, const KParams& kp, const LamParams& lp, const double* x);

@@ -34,6 +34,8 @@ thread_local BatchLaunch g_batch; // dev.h: what this thread's launch wrappers a
 #define NB 64
 // pinned staging of the small path: results in [0, 256), inputs (obs_mean: (n + 1) x P <= 257 x 3; query points: 8 x 64) from 256 on
 #define SMALL_STAGE_DOUBLES (256 + 1024)
+#define SMALL_MAIL_BYTES 4096
+static_assert(sizeof(SmallMailbox) <= SMALL_MAIL_BYTES, "mailbox fits its slot of the pinned block");
 
 namespace {
 
@@ -94,6 +96,15 @@ struct gpe_ctx {
     unsigned long long small_seq = 0;
     bool small_path = true;              // GPE_SMALL=0 disables
     int64_t small_calls = 0;             // calls served by the small path (instrumentation / tests)
+    // the persistent form of the small path (small.hip, k_small_server): after a run of small calls on this handle the next
+    // ones are requests to ONE resident workgroup instead of launches
+    SmallMailbox* hMail = nullptr;       // pinned, coherent (inside hPinned)
+    bool server_ok = true;               // GPE_SMALL_SERVER=0 disables
+    bool server_on = false;              // a server kernel was launched on `stream` and has not been joined
+    unsigned long long mail_seq = 0;     // sequence number of the last request
+    int small_streak = 0;                // consecutive small calls (any other call resets it)
+    int64_t server_calls = 0;            // calls served by the resident workgroup (instrumentation / tests)
+    long long server_idle_ticks = 100000; // it leaves after this many 100 MHz ticks without a request (1 ms)
     int64_t flow_retries = 0; // sweeps re-run block by block after a hand-off timeout (never expected; see flow_failed)
     bool flow_solve = true; // one data-flow launch for the backward sweep (GPE_FLOW_SOLVE=0: per-block launches)
     bool fuse_panel = true; // k_panel_step instead of the three-launch panel step (GPE_FUSE_PANEL=0 disables)
@@ -851,15 +862,20 @@ int compute_finish(gpe_ctx* c)
 // The small kernels write their results and then a sequence word straight into pinned host memory: spin on the
 // word(s) instead of synchronising the stream (an event round trip costs more than the kernel).  Falls back to a
 // stream synchronisation after 50 ms (a fault, or a debugger).
-static int small_wait(gpe_ctx* c, int nwords, unsigned long long want)
+static void server_start(gpe_ctx* c, unsigned long long seen0);
+static int small_wait(gpe_ctx* c, int nwords, unsigned long long want, bool served = false)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
+    for (unsigned spin = 0;; ++spin) {
         bool all = true;
         for (int i = 0; i < nwords; ++i)
             all = all && (__atomic_load_n(c->hSmallSeq + i, __ATOMIC_ACQUIRE) == want);
         if (all)
             return GPE_OK;
+        // a request to the resident workgroup that crossed its leaving (idle timeout): it says so in the mailbox and the
+        // request is still there — start another one for it
+        if (served && (spin & 31) == 31 && __atomic_load_n(&c->hMail->state, __ATOMIC_ACQUIRE) == 0)
+            server_start(c, c->mail_seq - 1);
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, hipGetLastError());
@@ -1116,6 +1132,46 @@ struct DevGuard {
     explicit DevGuard(gpe_ctx* c) { hipSetDevice(c->device); }
 };
 
+// ---- the resident workgroup of the small path (small.hip: k_small_server) --------------------------------------
+// All of this runs under the handle's mutex.  Any call that is not a small call joins the server first (server_stop): it
+// owns the handle's stream, and it holds nothing the other paths could not find in HBM.
+static void server_start(gpe_ctx* c, unsigned long long seen0)
+{
+    if (c->server_on)
+        hipStreamSynchronize(c->stream); // the previous one said it was leaving: let it
+    __atomic_store_n(&c->hMail->state, 1ull, __ATOMIC_RELEASE);
+    launch_small_server(c->stream, c->hMail, seen0, c->server_idle_ticks);
+    c->server_on = true;
+}
+static void server_stop(gpe_ctx* c)
+{
+    c->small_streak = 0;
+    if (!c->server_on)
+        return;
+    c->hMail->op = GPE_SMALL_OP_EXIT;
+    __atomic_store_n(&c->hMail->req_seq, ++c->mail_seq, __ATOMIC_RELEASE);
+    hipStreamSynchronize(c->stream); // (returns at once when it had already left by itself)
+    c->server_on = false;
+}
+// the request in c->hMail is complete: hand it over (starting a server if none is there)
+static void server_submit(gpe_ctx* c, int op, int P)
+{
+    SmallMailbox* mb = c->hMail;
+    mb->op = op;
+    mb->P = P;
+    const unsigned long long seq = ++c->mail_seq;
+    __atomic_store_n(&mb->req_seq, seq, __ATOMIC_RELEASE);
+    if (!c->server_on || __atomic_load_n(&mb->state, __ATOMIC_ACQUIRE) == 0)
+        server_start(c, seq - 1);
+    ++c->server_calls;
+}
+// a small call: through the resident workgroup?  (after a run of them; one output; not while profiling)
+static bool server_wanted(gpe_ctx* c, int P)
+{
+    ++c->small_streak;
+    return c->server_ok && !c->prof && P == 1 && c->small_streak > 3;
+}
+
 // what survives a handle: see gpe_create
 struct HandleShell {
     hipStream_t stream, stream2;
@@ -1192,7 +1248,7 @@ int gpe_create(int device_id, gpe_handle* out)
             || hipMalloc(&c->dScal, 8192 + sizeof(double) * GPE_HEAD_TILES * NB * NB) != hipSuccess
             // the hand-over flag words start from zero, in the order of the stream the panel steps run on
             || hipMemsetAsync(c->dScal + 1024 + 65 * NB * NB, 0, sizeof(double) * NB * NB, c->stream) != hipSuccess
-            || hipHostMalloc(&c->hPinned, 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)) {
+            || hipHostMalloc(&c->hPinned, 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES + SMALL_MAIL_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)) {
         delete c;
         return GPE_ERR_HIP;
     }
@@ -1201,7 +1257,13 @@ int gpe_create(int device_id, gpe_handle* out)
     c->hSmallSeq = (unsigned long long*)(c->hPinned + 64);
     c->hScal = (double*)(c->hPinned + 128);
     c->hSmall = c->hScal + 1024;
+    c->hMail = (SmallMailbox*)(c->hPinned + 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES);
     memset(c->hPinned, 0, 128);
+    memset(c->hMail, 0, sizeof(SmallMailbox));
+    if (const char* f = getenv("GPE_SMALL_SERVER"))
+        c->server_ok = atoi(f) != 0;
+    if (const char* f = getenv("GPE_SMALL_SERVER_IDLE_US"))
+        c->server_idle_ticks = std::max<long long>(1000, atoll(f) * 100);
     if (const char* f = getenv("GPE_SMALL"))
         c->small_path = atoi(f) != 0;
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
@@ -1239,6 +1301,7 @@ int gpe_destroy(gpe_handle c)
     if (!c)
         return GPE_ERR_ARG;
     DevGuard g(c);
+    server_stop(c);
     hipStreamSynchronize(c->stream);
     drain_phases(c);
     for (auto e : c->pool)
@@ -1274,6 +1337,7 @@ int gpe_set_data(gpe_handle c, const double* X, int64_t N, int D, const double* 
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     if (N > c->cap || D != c->D || P != c->P || !c->dA) {
         int rc = alloc_dev(c, N, D, P);
         if (rc)
@@ -1313,6 +1377,7 @@ int gpe_set_data_device(gpe_handle c, const double* dX, int64_t N, int D, const 
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     if (N > c->cap || D != c->D || P != c->P || !c->dA) {
         int rc = alloc_dev(c, N, D, P);
         if (rc)
@@ -1349,6 +1414,10 @@ int gpe_set_K_host(gpe_handle c, const double* K, int64_t ldk)
     if (!c || !K || c->N <= 0 || ldk < c->N)
         return GPE_ERR_ARG;
     DevGuard g(c);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        server_stop(c);
+    }
     if (!c->dKhost)
         HIPCHK(c, hipMalloc(&c->dKhost, sizeof(double) * (size_t)(c->ld * c->cap)));
     HIPCHK(c, hipMemcpy2D(c->dKhost, sizeof(double) * c->ld, K, sizeof(double) * ldk, sizeof(double) * c->N, c->N,
@@ -1364,6 +1433,7 @@ int gpe_compute(gpe_handle c)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     if (!c->host_K) {
         if (lam_columns(c->kind, c->n_theta, c->D) < 0) {
             c->err = "set_kernel: wrong number of hyper-parameters for this kernel/dimension";
@@ -1406,14 +1476,21 @@ int gpe_update_alpha(gpe_handle c, const double* obs_mean)
         a.seq = c->hSmallSeq;
         a.seq_val = ++c->small_seq;
         a.n = (int)c->N;
-        {
+        const bool served = server_wanted(c, c->P);
+        if (served) { // a request to the resident workgroup (small.hip, k_small_server) instead of a launch
+            c->hMail->alp = a;
+            server_submit(c, GPE_SMALL_OP_ALPHA, c->P);
+        }
+        else {
+            server_stop(c);
+            c->small_streak = 1;
             PhaseScope ps(c, GPE_PH_SOLVE, 2.0 * (double)c->N * c->N * c->P);
             launch_small_alpha(c->stream, a, c->P);
         }
         c->al_prefilled = false;
         c->ll_partials = 0;
         ++c->small_calls;
-        int rc = small_wait(c, 1, a.seq_val);
+        int rc = small_wait(c, 1, a.seq_val, served);
         drain_phases(c);
         if (rc)
             return rc;
@@ -1422,6 +1499,7 @@ int gpe_update_alpha(gpe_handle c, const double* obs_mean)
         c->ll_ok = true;
         return GPE_OK;
     }
+    server_stop(c);
     if (obs_mean)
         HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * c->ld, obs_mean, sizeof(double) * c->N,
                                    sizeof(double) * c->N, c->P, hipMemcpyHostToDevice, c->stream));
@@ -1455,6 +1533,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     if (c->N == 0) { // gp.hpp:128-137
         if (D > GPE_MAX_THETA - 2)
             return GPE_ERR_ARG;
+        server_stop(c);
         int rc = alloc_dev(c, 256, D, P);
         if (rc)
             return rc;
@@ -1466,6 +1545,8 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
             return GPE_ERR_ARG;
         if (!c->have_L)
             return GPE_ERR_STATE;
+        if (c->N + 1 > c->cap)
+            server_stop(c); // the buffers are about to move
         int rc = grow_dev(c, c->N + 1);
         if (rc)
             return rc;
@@ -1498,7 +1579,19 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         a.seq = c->hSmallSeq;
         a.seq_val = ++c->small_seq;
         a.n = (int)n;
-        {
+        const bool served = server_wanted(c, P);
+        if (served) { // a request to the resident workgroup instead of a launch
+            SmallMailbox* mb = c->hMail;
+            mb->add = a;
+            mb->kp = c->kp;
+            mb->lp = lam_params(c);
+            for (int d = 0; d < GPE_MAX_THETA; ++d)
+                mb->x[d] = d < c->kp.Din ? x[d] : 0.0;
+            server_submit(c, GPE_SMALL_OP_ADD, P);
+        }
+        else {
+            server_stop(c);
+            c->small_streak = 1;
             PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)n * n + 2.0 * (double)n * n * P);
             launch_small_add(s, a, P, c->kp, lam_params(c), x);
         }
@@ -1508,7 +1601,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         c->al_prefilled = false;
         c->ll_partials = 0;
         ++c->small_calls;
-        int rc = small_wait(c, 1, a.seq_val);
+        int rc = small_wait(c, 1, a.seq_val, served);
         drain_phases(c);
         if (rc)
             return rc;
@@ -1517,6 +1610,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         c->ll_ok = true;
         return *c->hInfo;
     }
+    server_stop(c);
     // new sample -> column n of Xt (staged through dY)
     HIPCHK(c, hipMemcpyAsync(c->dY, x, sizeof(double) * D, hipMemcpyHostToDevice, s));
     launch_transpose_x(s, c->dY, 1, D, c->dXt, ld, n);
@@ -1564,6 +1658,7 @@ int gpe_log_lik(gpe_handle c, double* out)
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->ll_ok) {
+        server_stop(c);
         enqueue_loglik_terms(c);
         int rc = compute_finish(c);
         if (rc < 0)
@@ -1582,6 +1677,7 @@ int gpe_compute_inv_kernel(gpe_handle c)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = ensure_inv(c);
     if (rc)
         return rc;
@@ -1620,6 +1716,7 @@ int gpe_log_lik_grad(gpe_handle c, double* grad, int n_grad, int optimize_noise)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     digest_kernel(c);
     return grad_fetch(c, grad, n_grad, optimize_noise, false);
 }
@@ -1633,6 +1730,7 @@ int gpe_log_loo_cv(gpe_handle c, double* out)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = ensure_inv(c);
     if (rc)
         return rc;
@@ -1660,6 +1758,7 @@ int gpe_log_loo_cv_grad(gpe_handle c, double* grad, int n_grad, int optimize_noi
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     digest_kernel(c);
     return grad_fetch(c, grad, n_grad, optimize_noise, true);
 }
@@ -1833,12 +1932,22 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
         q.seq_val = ++c->small_seq;
         q.want_kta = kta ? 1 : 0;
         q.want_var = var ? 1 : 0;
-        {
+        const bool served = server_wanted(c, 1); // (any number of outputs: the body loops over them)
+        if (served) { // a request to the resident workgroup instead of a launch
+            SmallMailbox* mb = c->hMail;
+            mb->qry = q;
+            mb->kp = c->kp;
+            mb->lp = lam_params(c);
+            server_submit(c, GPE_SMALL_OP_QUERY, P);
+        }
+        else {
+            server_stop(c);
+            c->small_streak = 1;
             PhaseScope ps(c, GPE_PH_QUERY, (double)N * N * M);
             launch_small_query(s, q, c->kp, lam_params(c));
         }
         ++c->small_calls;
-        int rc = small_wait(c, (int)M, q.seq_val);
+        int rc = small_wait(c, (int)M, q.seq_val, served);
         drain_phases(c);
         if (rc)
             return rc;
@@ -1851,6 +1960,7 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
     // a handful of points (the per-point calls of an acquisition functor, gp.hpp:159-191): the forward
     // substitution runs as ONE data-flow launch (k_trsv_fwd_flow, <= GPE_MAX_P right-hand sides) instead of a
     // blocked matrix solve, whose dependent matrix-core launches are all launch floor there
+    server_stop(c);
     static const bool sweep_ok0 = !(getenv("GPE_QUERY_SWEEP") && atoi(getenv("GPE_QUERY_SWEEP")) == 0);
     static const bool transposed_ok = !(getenv("GPE_QUERY_T") && atoi(getenv("GPE_QUERY_T")) == 0);
     const bool few0 = sweep_ok0 && c->flow_solve && M <= GPE_MAX_P && (N + NB - 1) / NB <= 256;
@@ -1973,6 +2083,7 @@ int gpe_query_batch_cross(gpe_handle c, const double* Ks, int64_t M, double* kta
         return GPE_OK;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = query_impl(c, nullptr, Ks, M, kta, zz);
     if (rc == GPE_OK && zz)
         for (int64_t m = 0; m < M; ++m)
@@ -1986,6 +2097,7 @@ int gpe_set_obs_mean(gpe_handle c, const double* obs_mean)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * c->ld, obs_mean, sizeof(double) * c->N, sizeof(double) * c->N,
                                c->P, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2009,6 +2121,7 @@ int gpe_get_L(gpe_handle c, double* L, int64_t ldh)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     const int64_t N = c->N;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(L, sizeof(double) * ldh, c->dA, sizeof(double) * c->ld, sizeof(double) * N, N,
@@ -2024,6 +2137,7 @@ int gpe_set_L(gpe_handle c, const double* L, int64_t ldh)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     HIPCHK(c, hipMemcpy2D(c->dA, sizeof(double) * c->ld, L, sizeof(double) * ldh, sizeof(double) * c->N, c->N,
                           hipMemcpyHostToDevice));
     launch_diag_inv(c->stream, c->dA, c->ld, c->N, 0, (c->N + NB - 1) / NB, c->dXinv);
@@ -2048,6 +2162,7 @@ int gpe_get_alpha(gpe_handle c, double* a)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(a, sizeof(double) * c->N, c->dAl, sizeof(double) * c->ld, sizeof(double) * c->N, c->P,
                           hipMemcpyDeviceToHost));
@@ -2060,6 +2175,7 @@ int gpe_set_alpha(gpe_handle c, const double* a)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     HIPCHK(c, hipMemcpy2D(c->dAl, sizeof(double) * c->ld, a, sizeof(double) * c->N, sizeof(double) * c->N, c->P,
                           hipMemcpyHostToDevice));
     c->ll_ok = false;
@@ -2072,6 +2188,7 @@ int gpe_get_Kinv(gpe_handle c, double* Kinv, int64_t ldh)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = ensure_inv(c);
     if (rc)
         return rc;
@@ -2096,6 +2213,7 @@ int gpe_get_loo_weights(gpe_handle c, double* W, int64_t ldh)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = ensure_inv(c);
     if (rc)
         return rc;
@@ -2138,6 +2256,7 @@ int gpe_get_K(gpe_handle c, double* K, int64_t ldh)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
+    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     const int64_t N = c->N;
     if (c->host_K) {
         if (!c->dKhost)
@@ -2192,6 +2311,14 @@ int gpe_handover_reruns(gpe_handle c, int64_t* n)
     return GPE_OK;
 }
 
+int gpe_server_calls(gpe_handle c, int64_t* n)
+{
+    if (!c || !n)
+        return GPE_ERR_ARG;
+    *n = c->server_calls;
+    return GPE_OK;
+}
+
 int gpe_small_calls(gpe_handle c, int64_t* n)
 {
     if (!c || !n)
@@ -2213,6 +2340,7 @@ int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out)
     std::lock_guard<std::mutex> lk(src->mu);
     {
         DevGuard gs(src);
+        server_stop(src);
         hipStreamSynchronize(src->stream);
     }
     DevGuard g(c);
@@ -2448,8 +2576,11 @@ static int batch_compute_impl(gpe_handle* hs, int G, int* status, const BatchWan
         std::sort(order.begin(), order.end());
         std::vector<std::unique_lock<std::mutex>> locks;
         locks.reserve(G);
-        for (gpe_ctx* c : order)
+        for (gpe_ctx* c : order) {
             locks.emplace_back(c->mu);
+            DevGuard dg(c);
+            server_stop(c);
+        }
         int worst = GPE_OK;
         // Sub-batches of <= GPE_BT_MAXG GPs, up to four in flight on their own streams: while one sub-batch is in its
         // panel steps (latency-bound workgroups, one per CU) another one's matrix-core updates fill the chip.
@@ -2533,8 +2664,11 @@ static int batch_compute_impl(gpe_handle* hs, int G, int* status, const BatchWan
     order.erase(std::unique(order.begin(), order.end()), order.end()); // a handle listed twice is locked once
     std::vector<std::unique_lock<std::mutex>> locks;
     locks.reserve(order.size());
-    for (gpe_ctx* c : order)
+    for (gpe_ctx* c : order) {
         locks.emplace_back(c->mu);
+        DevGuard dg(c);
+        server_stop(c);
+    }
     std::vector<char> first(G, 0); // first occurrence of a handle: the one that is enqueued (a second one would race it)
     for (int g = 0; g < G; ++g) {
         gpe_ctx* c = hs[g];
@@ -2648,6 +2782,10 @@ int gpe_synchronize(gpe_handle c)
     if (!c)
         return GPE_ERR_ARG;
     DevGuard g(c);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        server_stop(c);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GPE_OK;
 }

@@ -229,15 +229,18 @@ struct SmallX {
     double v[GPE_MAX_THETA];
 };
 
+// The bodies of the three calls.  As kernels of their own (one launch per call) and, for a run of calls on one GP, as
+// requests served by ONE persistent workgroup (k_small_server below): then the factor's tiles T and the block inverses
+// S.Xs stay where they are between requests (`reload` = false).
 template <int P>
-__global__ __launch_bounds__(SM_T) void k_small_add(SmallAddArgs g, KParams kp, LamParams lp, SmallX xnew)
+static __device__ __forceinline__ void small_add_body(const SmallAddArgs& g, const KParams& kp, const LamParams& lp,
+                                                      const double* xnew, SmallLds& S, double (&T)[SM_NT], bool reload)
 {
-    __shared__ SmallLds S;
     const int tid = threadIdx.x;
     const int n = g.n;
     SmallCtx c{g.A, g.ld, g.Xinv, n};
-    double T[SM_NT];
-    load_tiles(c, T, S);
+    if (reload)
+        load_tiles(c, T, S);
     // old diagonal (log-likelihood term), this thread's sample, obs_mean from pinned host memory
     const int ic = tid < n ? tid : 0;
     const double ldiag = (tid < n) ? g.A[ic + (int64_t)ic * g.ld] : 1.0;
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(SM_T) void k_small_add(SmallAddArgs g, KParams kp, 
     for (int p = 0; p < P; ++p)
         om_i[p] = (tid <= n) ? g.om_host[tid + (int64_t)p * (n + 1)] : 0.0;
     if (tid < kp.Din)
-        S.x[tid] = xnew.v[tid];
+        S.x[tid] = xnew[tid];
     if (tid == n) {
 #pragma unroll
         for (int p = 0; p < P; ++p)
@@ -352,17 +355,23 @@ __global__ __launch_bounds__(SM_T) void k_small_add(SmallAddArgs g, KParams kp, 
         __hip_atomic_store(g.seq, g.seq_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+template <int P>
+__global__ __launch_bounds__(SM_T) void k_small_add(SmallAddArgs g, KParams kp, LamParams lp, SmallX xnew)
+{
+    __shared__ SmallLds S;
+    double T[SM_NT];
+    small_add_body<P>(g, kp, lp, xnew.v, S, T, true);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // one workgroup per query point: k* -> k*^T alpha (gp.hpp:615) -> z = L^-1 k* (:620) -> k(v,v) - z.z (:621)
-__global__ __launch_bounds__(SM_T) void k_small_query(SmallQueryArgs g, KParams kp, LamParams lp)
+static __device__ __forceinline__ void small_query_body(const SmallQueryArgs& g, const KParams& kp, const LamParams& lp, int m,
+                                                        SmallLds& S, double (&T)[SM_NT], bool reload)
 {
-    __shared__ SmallLds S;
-    const int tid = threadIdx.x, m = blockIdx.x;
+    const int tid = threadIdx.x;
     const int n = g.n;
     SmallCtx c{g.L, g.ld, g.Xinv, n};
-    double T[SM_NT];
-    if (g.want_var)
+    if (g.want_var && reload)
         load_tiles(c, T, S);
     if (tid < g.D)
         S.x[tid] = g.xq_host[(int64_t)m * g.D + tid];
@@ -406,20 +415,25 @@ __global__ __launch_bounds__(SM_T) void k_small_query(SmallQueryArgs g, KParams 
         __hip_atomic_store(g.seq + m, g.seq_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+__global__ __launch_bounds__(SM_T) void k_small_query(SmallQueryArgs g, KParams kp, LamParams lp)
+{
+    __shared__ SmallLds S;
+    double T[SM_NT];
+    small_query_body(g, kp, lp, (int)blockIdx.x, S, T, true);
+}
 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // recompute(., false) / _compute_alpha (gp.hpp:241-252, :605-611) below 256 samples: new obs_mean, same factor.
 // alpha = L^-T L^-1 obs_mean and the two log-likelihood sums, one launch, obs_mean read from pinned host memory.
 template <int P>
-__global__ __launch_bounds__(SM_T) void k_small_alpha(SmallAlphaArgs g)
+static __device__ __forceinline__ void small_alpha_body(const SmallAlphaArgs& g, SmallLds& S, double (&T)[SM_NT], bool reload)
 {
-    __shared__ SmallLds S;
     const int tid = threadIdx.x;
     const int n = g.n;
     SmallCtx c{g.L, g.ld, g.Xinv, n};
-    double T[SM_NT];
-    load_tiles(c, T, S);
+    if (reload)
+        load_tiles(c, T, S);
     const int ic = tid < n ? tid : 0;
     const double ldiag = (tid < n) ? g.L[ic + (int64_t)ic * g.ld] : 1.0;
     double om_i[P];
@@ -459,8 +473,135 @@ __global__ __launch_bounds__(SM_T) void k_small_alpha(SmallAlphaArgs g)
     }
 }
 
+template <int P>
+__global__ __launch_bounds__(SM_T) void k_small_alpha(SmallAlphaArgs g)
+{
+    __shared__ SmallLds S;
+    double T[SM_NT];
+    small_alpha_body<P>(g, S, T, true);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The BO inner loop as REQUESTS to one persistent workgroup (bayes_opt/boptimizer.hpp:148-161: one add_sample, then
+// thousands of query() calls per iteration, all on one GP of <= 256 samples).  A launch per call costs ~12 us before the
+// first instruction runs; here the host writes the request into a pinned, coherent mailbox and raises its sequence word,
+// the workgroup — resident on one CU, the factor's tiles in its registers and the block inverses in its LDS — polls the
+// word over PCIe, copies the request into LDS (one 8-byte load per thread), runs the body and writes the results and the
+// completion word straight back to pinned memory, as the one-launch kernels do.  It leaves by itself after `idle_ticks`
+// (100 MHz ticks) without a request — a device-wide synchronisation elsewhere in the process (hipFree, hipDeviceSynchronize)
+// waits for it — and on request (op 0xFF: any other call on the handle); it tells the host through mb->state.
+// a wave-uniform struct read from LDS, moved into scalar registers word by word (as a kernel argument would be: left in
+// vector registers the pointers and sizes of a request cost the server ~100 VGPRs and it spilled)
+template <class T>
+static __device__ __forceinline__ T to_sgprs(const T& v)
+{
+    static_assert(sizeof(T) % 4 == 0, "dwords");
+    T out;
+    const int* src = (const int*)&v;
+    int* dst = (int*)&out;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i)
+        dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+    return out;
+}
+
+__global__ __launch_bounds__(SM_T) void k_small_server(SmallMailbox* mb, unsigned long long seen0, long long idle_ticks)
+{
+    __shared__ SmallLds S;
+    __shared__ __attribute__((aligned(16))) SmallMailbox R; // the request being served
+    __shared__ unsigned long long s_seq;
+    __shared__ int s_leave;
+    const int tid = threadIdx.x;
+    unsigned long long seen = seen0;
+    // it also leaves after 5 idle periods of service, busy or not: work submitted before that — above all a device-wide
+    // synchronisation in another thread (hipFree waits for every stream) — is never starved by a caller that keeps it busy
+    const long long t_born = wall_clock64(), life_ticks = 5 * idle_ticks;
+    // (Keeping the factor's tiles in registers BETWEEN requests was tried: with the three bodies in one function the
+    // register file does not hold them — 256 VGPRs and 344 bytes of scratch — so every request loads them as the
+    // one-launch kernels do: 320 KB from L2, ~2 us.)
+    for (;;) {
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            unsigned long long q;
+            for (;;) {
+                q = __hip_atomic_load(&mb->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (q != seen)
+                    break;
+                if (wall_clock64() - t0 > idle_ticks) {
+                    q = ~0ull;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_seq = q;
+        }
+        __syncthreads();
+        const unsigned long long q = s_seq;
+        if (q == ~0ull) { // idle: leave (the host relaunches on its next request)
+            if (tid == 0) {
+                __hip_atomic_store(&mb->state, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+            }
+            return;
+        }
+        { // the request, word by word
+            constexpr int NW = (int)(sizeof(SmallMailbox) / 8);
+            static_assert(sizeof(SmallMailbox) % 8 == 0 && NW <= 2 * SM_T, "mailbox size");
+            const unsigned long long* src = (const unsigned long long*)mb;
+            unsigned long long* dst = (unsigned long long*)&R;
+            for (int w = tid; w < NW; w += SM_T)
+                dst[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        const int op = __builtin_amdgcn_readfirstlane(R.op);
+        if (op == GPE_SMALL_OP_EXIT) {
+            if (tid == 0) {
+                __hip_atomic_store(&mb->state, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+            }
+            return;
+        }
+        {
+            // T is defined afresh in every round: left undefined on some path it becomes loop-carried and pins its 96
+            // registers across the whole loop (256 VGPRs + scratch spills otherwise)
+            double T[SM_NT];
+#pragma unroll
+            for (int i = 0; i < SM_NT; ++i)
+                T[i] = 0.0;
+            if (op == GPE_SMALL_OP_ADD)
+                small_add_body<1>(to_sgprs(R.add), R.kp, R.lp, R.x, S, T, true); // (one output: the host sends nothing else this way)
+            else if (op == GPE_SMALL_OP_QUERY) {
+                const SmallQueryArgs gq = to_sgprs(R.qry);
+                for (int m = 0; m < gq.M; ++m) {
+                    small_query_body(gq, R.kp, R.lp, m, S, T, true);
+                    __syncthreads();
+                }
+            }
+            else if (op == GPE_SMALL_OP_ALPHA)
+                small_alpha_body<1>(to_sgprs(R.alp), S, T, true);
+        }
+        seen = q;
+        __syncthreads();
+        if (tid == 0) // (thread 0's reading of the clock decides for everybody, through LDS)
+            s_leave = wall_clock64() - t_born > life_ticks ? 1 : 0;
+        __syncthreads();
+        if (s_leave == 1) {
+            if (tid == 0) {
+                __hip_atomic_store(&mb->state, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+            }
+            return;
+        }
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 int small_max_n() { return SM_NBLK * NB; }
+
+void launch_small_server(hipStream_t s, SmallMailbox* mb, unsigned long long seen0, long long idle_ticks)
+{
+    hipLaunchKernelGGL(k_small_server, dim3(1), dim3(SM_T), 0, s, mb, seen0, idle_ticks);
+}
 
 void launch_small_add(hipStream_t s, const SmallAddArgs& g, int P, const KParams& kp, const LamParams& lp, const double* x)
 {

@@ -679,3 +679,61 @@ def test_gpu_batch_hp_objective_vs_single_and_oracle(engine_lib, oracle_lib, N, 
     assert all(h.flow_retries() == 0 for h in hs)
     for h in hs + [single, orc]:
         h.close()
+
+
+def test_gpu_small_path_resident_workgroup(engine_lib, oracle_lib):
+    """The BO inner loop (bayes_opt/boptimizer.hpp:148-161: add_sample, then many query() calls) as REQUESTS to one resident
+    workgroup (csrc/small.hip: k_small_server) instead of launches: bitwise the results of the one-launch kernels (same
+    bodies), through every transition — the run of small calls that brings it up, another call on the handle that joins it
+    (get_L, compute), its idle timeout, capacity growth at 256 -> 257 samples (general path) — and the oracle's numbers."""
+    import time
+
+    rng = np.random.default_rng(55)
+    n0, n1, D = 8, 270, 4
+    X = rng.uniform(0, 1, size=(n1, D))
+    Y = np.cos(3.0 * X.sum(axis=1))[:, None] + 0.05 * rng.normal(size=(n1, 1))
+    th, noise = rng.uniform(-0.3, 0.3, size=D + 1), 0.01
+    pts = rng.uniform(0, 1, size=(n1, 3, D))
+
+    def run(server):
+        os.environ["GPE_SMALL_SERVER"] = "1" if server else "0"  # read when a handle is created
+        try:
+            h = _capi.Handle(engine_lib)
+        finally:
+            del os.environ["GPE_SMALL_SERVER"]
+        h.set_kernel(O.SE_ARD, th, noise)
+        h.set_data(X[:n0], synth.obs_mean_data(Y[:n0])[0])
+        assert h.compute() == 0
+        out = []
+        for n in range(n0, n1):
+            assert h.add_sample(X[n], synth.obs_mean_data(Y[: n + 1])[0]) == 0
+            out.append(h.log_lik())
+            for q in range(3):
+                k, v = h.query_batch(pts[n, q: q + 1])
+                out += [k[0, 0], v[0]]
+            if n % 40 == 17:
+                out.append(float(np.sum(h.get_L())))  # another call on the handle: joins the resident workgroup
+            if n % 50 == 33:
+                time.sleep(0.004)  # longer than its idle time: it leaves by itself, the next request restarts it
+            if n % 60 == 41:
+                h.update_alpha(synth.obs_mean_data(Y[: n + 1])[0] * 1.5)
+                out.append(h.log_lik())
+                h.update_alpha(synth.obs_mean_data(Y[: n + 1])[0])
+            if n == 100:
+                k8, v8 = h.query_batch(pts[n0: n0 + 8, 0])  # eight points in one request
+                out += list(k8[:, 0]) + list(v8)
+        served, small = h.server_calls(), h.small_calls()
+        al = h.get_alpha()
+        h.close()
+        return np.array(out), al, served, small
+
+    a, al_a, served_a, small_a = run(True)
+    b, al_b, served_b, small_b = run(False)
+    assert served_b == 0 and served_a > 0.8 * small_a and small_a == small_b
+    assert np.array_equal(a, b) and np.array_equal(al_a, al_b)
+    o = _capi.Handle(oracle_lib)
+    o.set_kernel(O.SE_ARD, th, noise)
+    o.set_data(X, synth.obs_mean_data(Y)[0])
+    o.compute()
+    assert relerr_norm(al_a, o.get_alpha()) < 1e-7
+    o.close()
