@@ -203,9 +203,12 @@ int gpe_handover_reruns(gpe_handle h, int64_t* n);
 int gpe_small_calls(gpe_handle h, int64_t* n);
 /* ... of which served by the RESIDENT workgroup of the small path: after a run of small calls on a handle the next ones are
  * requests written into a pinned mailbox that one persistent workgroup polls (csrc/small.hip: k_small_server) instead of
- * kernel launches; it leaves on any other call on the handle or after 1 ms without a request
- * (GPE_SMALL_SERVER=0 disables it, GPE_SMALL_SERVER_IDLE_US sets the idle time) */
+ * kernel launches; it leaves on any other call on the handle or after 1 ms without a request.  OFF by default
+ * (GPE_SMALL_SERVER=1 enables it, GPE_SMALL_SERVER_IDLE_US sets the idle time): measured 2 us slower per call than a
+ * launch — the body, not the launch, is what a small call costs */
 int gpe_server_calls(gpe_handle h, int64_t* n);
+/* microseconds the resident workgroup spent on its last request: us[0] copying it out of the mailbox, us[1] in the body */
+int gpe_server_last_us(gpe_handle h, double* us);
 /* fp64 MFMA peak micro-benchmark (v_mfma_f64_4x4x4_4b, the instruction the GEMM kernels issue), TFLOP/s */
 int gpe_mfma_f64_peak(int device_id, double* tflops);
 /* HBM write-stream micro-benchmark, GB/s */

@@ -95,6 +95,7 @@ def _sig(lib, prefix):
             "handover_reruns": [_vp, C.POINTER(_i64)],
             "small_calls": [_vp, C.POINTER(_i64)],
             "server_calls": [_vp, C.POINTER(_i64)],
+            "server_last_us": [_vp, _dp],
             "mfma_f64_peak": [C.c_int, _dp],
             "hbm_stream_peak": [C.c_int, _dp],
         }
@@ -203,6 +204,11 @@ class Handle:
         n = _i64()
         self._chk(self.lib.fn("server_calls")(self._h, C.byref(n)), "server_calls")
         return n.value
+
+    def server_last_us(self):
+        us = np.zeros(2)
+        self._chk(self.lib.fn("server_last_us")(self._h, _d(us)), "server_last_us")
+        return us
 
     def small_calls(self) -> int:
         n = _i64()

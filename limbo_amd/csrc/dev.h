@@ -330,6 +330,8 @@ struct SmallMailbox {
     KParams kp;
     LamParams lp;
     double x[GPE_MAX_THETA];
+    // instrumentation, written by the server (100 MHz ticks of the last request): seen -> request copied -> body done
+    long long t_seen, t_copied, t_done;
 };
 void launch_small_server(hipStream_t s, SmallMailbox* mb, unsigned long long seen0, long long idle_ticks);
 int small_max_n();

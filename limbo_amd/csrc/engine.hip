@@ -99,7 +99,10 @@ struct gpe_ctx {
     // the persistent form of the small path (small.hip, k_small_server): after a run of small calls on this handle the next
     // ones are requests to ONE resident workgroup instead of launches
     SmallMailbox* hMail = nullptr;       // pinned, coherent (inside hPinned)
-    bool server_ok = true;               // GPE_SMALL_SERVER=0 disables
+    bool server_ok = false;              // GPE_SMALL_SERVER=1 enables.  OFF by default: measured (tools/srvlat.py ->
+                                         // profiles/r03_small_server_latency.log) it is 2 us SLOWER per call than a launch — the
+                                         // workgroup spends 1.9 us copying the request out of the mailbox and 10 (n = 50) .. 17.5 us
+                                         // (n = 200) in the body, a launch costs only ~7 us of the 18 .. 25 us of a call
     bool server_on = false;              // a server kernel was launched on `stream` and has not been joined
     unsigned long long mail_seq = 0;     // sequence number of the last request
     int small_streak = 0;                // consecutive small calls (any other call resets it)
@@ -1143,15 +1146,20 @@ static void server_start(gpe_ctx* c, unsigned long long seen0)
     launch_small_server(c->stream, c->hMail, seen0, c->server_idle_ticks);
     c->server_on = true;
 }
-static void server_stop(gpe_ctx* c)
+static void server_join(gpe_ctx* c)
 {
-    c->small_streak = 0;
     if (!c->server_on)
         return;
     c->hMail->op = GPE_SMALL_OP_EXIT;
     __atomic_store_n(&c->hMail->req_seq, ++c->mail_seq, __ATOMIC_RELEASE);
     hipStreamSynchronize(c->stream); // (returns at once when it had already left by itself)
     c->server_on = false;
+}
+// any call that is not a small call: join it, and the run of small calls starts over
+static void server_stop(gpe_ctx* c)
+{
+    c->small_streak = 0;
+    server_join(c);
 }
 // the request in c->hMail is complete: hand it over (starting a server if none is there)
 static void server_submit(gpe_ctx* c, int op, int P)
@@ -1482,8 +1490,7 @@ int gpe_update_alpha(gpe_handle c, const double* obs_mean)
             server_submit(c, GPE_SMALL_OP_ALPHA, c->P);
         }
         else {
-            server_stop(c);
-            c->small_streak = 1;
+            server_join(c);
             PhaseScope ps(c, GPE_PH_SOLVE, 2.0 * (double)c->N * c->N * c->P);
             launch_small_alpha(c->stream, a, c->P);
         }
@@ -1590,8 +1597,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
             server_submit(c, GPE_SMALL_OP_ADD, P);
         }
         else {
-            server_stop(c);
-            c->small_streak = 1;
+            server_join(c);
             PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)n * n + 2.0 * (double)n * n * P);
             launch_small_add(s, a, P, c->kp, lam_params(c), x);
         }
@@ -1941,8 +1947,7 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
             server_submit(c, GPE_SMALL_OP_QUERY, P);
         }
         else {
-            server_stop(c);
-            c->small_streak = 1;
+            server_join(c);
             PhaseScope ps(c, GPE_PH_QUERY, (double)N * N * M);
             launch_small_query(s, q, c->kp, lam_params(c));
         }
@@ -2316,6 +2321,15 @@ int gpe_server_calls(gpe_handle c, int64_t* n)
     if (!c || !n)
         return GPE_ERR_ARG;
     *n = c->server_calls;
+    return GPE_OK;
+}
+// microseconds the resident workgroup spent on its last request: [0] copying it out of the mailbox, [1] in the body
+int gpe_server_last_us(gpe_handle c, double* us)
+{
+    if (!c || !us || !c->hMail)
+        return GPE_ERR_ARG;
+    us[0] = 0.01 * (double)(c->hMail->t_copied - c->hMail->t_seen);
+    us[1] = 0.01 * (double)(c->hMail->t_done - c->hMail->t_copied);
     return GPE_OK;
 }
 

@@ -537,6 +537,7 @@ __global__ __launch_bounds__(SM_T) void k_small_server(SmallMailbox* mb, unsigne
         }
         __syncthreads();
         const unsigned long long q = s_seq;
+        const long long t_seen = wall_clock64();
         if (q == ~0ull) { // idle: leave (the host relaunches on its next request)
             if (tid == 0) {
                 __hip_atomic_store(&mb->state, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(SM_T) void k_small_server(SmallMailbox* mb, unsigne
         }
         __syncthreads();
         const int op = __builtin_amdgcn_readfirstlane(R.op);
+        const long long t_copied = wall_clock64();
         if (op == GPE_SMALL_OP_EXIT) {
             if (tid == 0) {
                 __hip_atomic_store(&mb->state, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -582,6 +584,11 @@ __global__ __launch_bounds__(SM_T) void k_small_server(SmallMailbox* mb, unsigne
         }
         seen = q;
         __syncthreads();
+        if (tid == 0) {
+            mb->t_seen = t_seen;
+            mb->t_copied = t_copied;
+            mb->t_done = wall_clock64();
+        }
         if (tid == 0) // (thread 0's reading of the clock decides for everybody, through LDS)
             s_leave = wall_clock64() - t_born > life_ticks ? 1 : 0;
         __syncthreads();
