@@ -178,7 +178,7 @@ struct GemmArgs {
     int64_t m, n, k;
     int tri; int64_t grow0, gcol0;
     int ktri;
-    int overwrite; // 1: C = +A*B^T (no read of C), 0: C -= A*B^T
+    int overwrite; // 0: C -= A*B^T; 1: C = +A*B^T (no read of C); 2: C += A*B^T
     int fold_len;  // set by launch_gemm_sub (tri): live tiles per folded tile-column pair
     int total;     // set by launch_gemm_sub: logical workgroups (glds kernel)
     int grid_limit; // > 0: at most this many physical workgroups (they loop) — leaves CUs to another stream

@@ -80,6 +80,8 @@ struct gpe_ctx {
     int handover_off_left = 0;      // ... for this many evaluations only, then it is re-armed (one hiccup is not forever)
     int64_t handover_reruns = 0;    // evaluations re-run after a hand-over timeout (gpe_handover_reruns)
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
+    double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
+    size_t xp_cap = 0;
     int64_t grad_partial_cap = 0;
     int* dInfo = nullptr; // = hInfo: pinned host memory the kernels write directly (no copy-back, no device memset)
     double* dScal = nullptr; // [0] sum log L_ii, [1] trace(om^T alpha), [2] knn scratch, [8 .. 8 + 2 nblk) per-block partials
@@ -258,6 +260,10 @@ void free_dev(gpe_ctx* c)
         hipFree(c->dQuery);
     c->dQuery = nullptr;
     c->query_bytes = 0;
+    if (c->dXp)
+        hipFree(c->dXp);
+    c->dXp = nullptr;
+    c->xp_cap = 0;
     c->grad_partial_cap = 0;
     c->cap = c->ld = 0;
 }
@@ -925,10 +931,57 @@ int ensure_inv(gpe_ctx* c)
         //   AccT[0:oe, p+1..] -= U[0:oe, p] L[p+1.., p]^T
         //   K^-1 = U U^T                                              (one launch)
         const int64_t nbo = c->nbo;
+        const int64_t npan = (N + nbo - 1) / nbo;
+        // Round 3: K^-1 = sum_p U[:, p] U[:, p]^T is accumulated panel by panel on the SECOND stream while the main stream
+        // is still building the later panels of U — that chain is a string of small dependent launches that leaves most
+        // of the chip idle, and panel p's rank-k update only needs U's panel p.  (As a replacement for the one-launch
+        // product the 16 accumulating launches were slower, 761 against 704 us: they re-read C; underneath the chain they
+        // are free.)  The X_p now live in a compact side buffer, so the K^-1 buffer's diagonal blocks are free from the start.
+        // Batched launches, profiling runs and GPE_INV_OVERLAP=0 keep everything on one stream, product last, as before.
+        static const bool overlap_ok = !(getenv("GPE_INV_OVERLAP") && atoi(getenv("GPE_INV_OVERLAP")) == 0);
+        const bool overlap = overlap_ok && !g_batch.bt && !c->prof && c->stop_events && npan >= 4;
+        if (overlap && (int64_t)c->xp_cap < npan * nbo * nbo) {
+            if (c->dXp)
+                hipFree(c->dXp);
+            c->dXp = nullptr;
+            c->xp_cap = 0;
+            HIPCHK(c, hipMalloc(&c->dXp, sizeof(double) * (size_t)(npan * nbo * nbo)));
+            c->xp_cap = (size_t)(npan * nbo * nbo);
+        }
+        auto ev = [&](size_t i) {
+            while (c->la_events.size() <= i) {
+                hipEvent_t e;
+                hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                c->la_events.push_back(e);
+            }
+            return c->la_events[i];
+        };
         {
             PhaseScope ps(c, GPE_PH_INV, 0.0);
             launch_zero2d(s, c->dKinv, ld, N, N); // (a kernel: it takes part in batched launches, dev.h)
-            launch_inv_panels(s, c->dA, ld, N, (int)nbo, c->dXinv, c->dKinv, ld, c->dLinv, ld);
+            if (overlap)
+                launch_inv_panels(s, c->dA, ld, N, (int)nbo, c->dXinv, c->dXp, 0, c->dLinv, ld); // X_p compact, X_p^T -> U's diagonal blocks
+            else
+                launch_inv_panels(s, c->dA, ld, N, (int)nbo, c->dXinv, c->dKinv, ld, c->dLinv, ld);
+        }
+        auto rank_update = [&](hipStream_t st, int64_t o0, int64_t pw) { // K^-1[0:oe, 0:oe] += U[0:oe, p] U[0:oe, p]^T, lower triangle
+            GemmArgs g{};
+            g.C = c->dKinv;
+            g.ldc = ld;
+            g.A = c->dLinv + o0 * ld;
+            g.lda = ld;
+            g.B = c->dLinv + o0 * ld;
+            g.ldb = ld;
+            g.m = g.n = o0 + pw;
+            g.k = pw;
+            g.tri = 1;
+            g.overwrite = 2;
+            launch_gemm_sub(st, g);
+        };
+        if (overlap) {
+            hipEventRecord(ev(0), s); // zeroed K^-1 buffer, block inverses: panel 0 of U is complete
+            hipStreamWaitEvent(c->stream2, ev(0), 0);
+            rank_update(c->stream2, 0, std::min<int64_t>(nbo, N));
         }
         for (int64_t o0 = 0; o0 < N; o0 += nbo) {
             const int64_t pw = std::min<int64_t>(nbo, N - o0), oe = o0 + pw;
@@ -938,14 +991,20 @@ int ensure_inv(gpe_ctx* c)
                 g.ldc = ld;
                 g.A = c->dKinv + o0 * ld;
                 g.lda = ld;
-                g.B = c->dKinv + o0 + o0 * ld;
-                g.ldb = ld;
+                g.B = overlap ? c->dXp + (o0 / nbo) * (nbo * nbo) : c->dKinv + o0 + o0 * ld;
+                g.ldb = overlap ? nbo : ld;
                 g.m = o0;
                 g.n = pw;
                 g.k = pw;
                 g.overwrite = 1;
+                if (overlap)
+                    g.stop_event = ev((size_t)(o0 / nbo)); // this launch's own completion: panel p of U is final
                 PhaseScope ps(c, GPE_PH_INV, gemm_flops(g));
                 launch_gemm_sub(s, g);
+                if (overlap) {
+                    hipStreamWaitEvent(c->stream2, ev((size_t)(o0 / nbo)), 0);
+                    rank_update(c->stream2, o0, pw);
+                }
             }
             if (oe < N) {
                 GemmArgs g{};
@@ -962,10 +1021,13 @@ int ensure_inv(gpe_ctx* c)
                 launch_gemm_sub(s, g);
             }
         }
-        {
+        if (overlap) {
+            hipEventRecord(ev((size_t)npan), c->stream2);
+            hipStreamWaitEvent(s, ev((size_t)npan), 0);
+        }
+        else {
             // K^-1 = U U^T (gp.hpp:261) in one launch, lower triangle, k from the tile diagonal on (U is upper
-            // triangular).  (Panel by panel with the LDS-direct kernel and a C += epilogue — 16 launches, C re-read
-            // 15 times — was measured too: 761 us against 704 us for this one.)
+            // triangular).
             GemmArgs g{};
             g.C = c->dKinv;
             g.ldc = ld;

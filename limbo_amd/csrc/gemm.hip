@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g_)
     const bool live = rlim > 0 && clim > 0; // a ragged tile can leave a wave without any output
     constexpr bool CPRE = (NBUF == 1); // small one-shot tiles: fetch C together with the operands
     double cv[WT::NIT];
-    if (CPRE && live && !g.overwrite)
+    if (CPRE && live && g.overwrite != 1)
         WT::load(cv, Cw, g.ldc, rlim, clim, lane);
 
     SA sa;
@@ -280,14 +280,14 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g_)
     }
 
     static_assert(4 * WT::SCRATCH <= NBUF * (SA::ELEMS + SB::ELEMS), "transposition scratch must fit in the operand stages");
-    if (!CPRE && live && !g.overwrite)
+    if (!CPRE && live && g.overwrite != 1)
         WT::load(cv, Cw, g.ldc, rlim, clim, lane);
     // the operand stages are dead (the double-buffered k loop ends with a barrier, the one-shot form
     // needs one here): each wave takes a private slice of them as its transposition scratch
     if (NBUF == 1)
         __syncthreads();
     if (live)
-        WT::store(acc, cv, &lds[0][0] + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+        WT::store(acc, cv, &lds[0][0] + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite, lane);
 }
 
 // Launch with the dispatch's own completion signal as an event when the caller asked for one
@@ -495,12 +495,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g_)
         if (rlim > 0 && clim > 0) {
             // the k loop ended with a barrier: the stages are free, each wave uses a private slice
             if constexpr (EPC > 0)
-                WT::template rmw_chunked<EPC>(acc, lds + wave * SCR, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+                WT::template rmw_chunked<EPC>(acc, lds + wave * SCR, Cw, g.ldc, rlim, clim, g.overwrite, lane);
             else {
                 double cv[WT::NIT];
-                if (!g.overwrite)
+                if (g.overwrite != 1)
                     WT::load(cv, Cw, g.ldc, rlim, clim, lane);
-                WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+                WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite, lane);
             }
         }
     }

@@ -120,11 +120,13 @@ struct WaveTileC {
             cv[it] = Cw[(int64_t)(col < clim ? col : clim - 1) * ldc + rr];
         }
     }
-    // C = cv - acc (or C = acc when overwrite)
+    // C = cv - acc (mode 0), C = acc (mode 1: overwrite), C = cv + acc (mode 2: accumulate)
     static __device__ __forceinline__ void store(const double (&acc)[RA][RB], const double (&cv)[NIT], double* __restrict__ W,
-                                                 double* __restrict__ Cw, int64_t ldc, int rlim, int clim, bool overwrite,
+                                                 double* __restrict__ Cw, int64_t ldc, int rlim, int clim, int mode,
                                                  int lane)
     {
+        const bool overwrite = mode == 1;
+        const double sgn = mode == 2 ? 1.0 : -1.0; // fma(-1, t, cv) == cv - t exactly
         const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
 #pragma unroll
         for (int n = 0; n < RB; ++n)
@@ -139,14 +141,14 @@ struct WaveTileC {
         if (rlim == R && clim == CN) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
-                Cw[(int64_t)(it * CPI + cl) * ldc + row] = overwrite ? t[it] : cv[it] - t[it];
+                Cw[(int64_t)(it * CPI + cl) * ldc + row] = overwrite ? t[it] : fma(sgn, t[it], cv[it]);
         }
         else {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int col = it * CPI + cl;
                 if (row < rlim && col < clim)
-                    Cw[(int64_t)col * ldc + row] = overwrite ? t[it] : cv[it] - t[it];
+                    Cw[(int64_t)col * ldc + row] = overwrite ? t[it] : fma(sgn, t[it], cv[it]);
             }
         }
     }
@@ -155,8 +157,10 @@ struct WaveTileC {
     template <int NCH>
     static __device__ __forceinline__ void rmw_chunked(const double (&acc)[RA][RB], double* __restrict__ W,
                                                        double* __restrict__ Cw, int64_t ldc, int rlim, int clim,
-                                                       bool overwrite, int lane)
+                                                       int mode, int lane)
     {
+        const bool overwrite = mode == 1;
+        const double sgn = mode == 2 ? 1.0 : -1.0;
         static_assert(RB % NCH == 0 && (4 * RB / NCH) % CPI == 0, "chunking");
         constexpr int RBC = RB / NCH, CNC = 4 * RBC, NITC = CNC / CPI;
         const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
@@ -184,7 +188,7 @@ struct WaveTileC {
             for (int it = 0; it < NITC; ++it) {
                 const int col = ch * CNC + it * CPI + cl;
                 if (row < rlim && col < clim)
-                    Cw[(int64_t)col * ldc + row] = overwrite ? t[it] : cv[it] - t[it];
+                    Cw[(int64_t)col * ldc + row] = overwrite ? t[it] : fma(sgn, t[it], cv[it]);
             }
         }
     }
@@ -340,9 +344,9 @@ static __device__ __forceinline__ void gemm_glds64_body(const GemmArgs& g, doubl
             const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
             if (rlim > 0 && clim > 0) {
                 double cv[WT::NIT];
-                if (!g.overwrite)
+                if (g.overwrite != 1)
                     WT::load(cv, Cw, g.ldc, rlim, clim, lane);
-                WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+                WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite, lane);
             }
         }
         GTS64_(18);

@@ -333,12 +333,12 @@ __global__ __launch_bounds__(512, MINB) void k_gemm_sk(SkParams P)
             const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
             if (rlim > 0 && clim > 0) {
                 if constexpr (EPC > 0)
-                    WT::template rmw_chunked<EPC>(acc, lds + wave * SCR, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+                    WT::template rmw_chunked<EPC>(acc, lds + wave * SCR, Cw, g.ldc, rlim, clim, g.overwrite, lane);
                 else {
                     double cv[WT::NIT];
-                    if (!g.overwrite)
+                    if (g.overwrite != 1)
                         WT::load(cv, Cw, g.ldc, rlim, clim, lane);
-                    WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite != 0, lane);
+                    WT::store(acc, cv, lds + wave * WT::SCRATCH, Cw, g.ldc, rlim, clim, g.overwrite, lane);
                 }
             }
         }
