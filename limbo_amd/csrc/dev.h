@@ -248,6 +248,8 @@ void launch_set_identity(hipStream_t s, double* A, int64_t lda, int64_t n);
 // OutT (optional): the same blocks transposed
 void launch_inv_panels(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
                        int64_t ldo, double* OutT, int64_t ldt);
+void launch_inv_panel_one(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
+                          double* OutT, int64_t ldt, int panel);
 // A[0 : rows, 0 : cols] = 0 (column-major, lda) — a kernel, not hipMemsetAsync: it takes part in batched launches
 void launch_zero2d(hipStream_t s, double* A, int64_t lda, int64_t rows, int64_t cols);
 void launch_zero_upper(hipStream_t s, double* A, int64_t lda, int64_t n);

@@ -82,6 +82,16 @@ struct gpe_ctx {
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     size_t xp_cap = 0;
+    // K^-1 BEHIND the factorisation (gpe_hp_objective with a gradient): panel p of U = L^-T needs only L's panels <= p, so
+    // its chain (and the rank-k accumulation of K^-1) runs on a third, low-priority stream as the panels become final
+    hipStream_t stream3 = nullptr;
+    std::vector<hipEvent_t> inv_events;
+    bool inv_follow_req = false; // set by gpe_hp_objective for the compute() that follows
+    bool inv_follow = false;     // this factorisation feeds the chain (potrf_blocked)
+    int inv_limit = 96;          // workgroups per chain launch while the factorisation runs (GPE_INV_FOLLOW_WGS)
+    int64_t inv_next = 0;        // next panel of the chain to enqueue
+    bool inv_followed = false;   // the chain of the current factor is enqueued: ensure_inv only has to wait for it
+    bool inv_pending = false;    // ... and nobody has waited for it yet
     int64_t grad_partial_cap = 0;
     int* dInfo = nullptr; // = hInfo: pinned host memory the kernels write directly (no copy-back, no device memset)
     double* dScal = nullptr; // [0] sum log L_ii, [1] trace(om^T alpha), [2] knn scratch, [8 .. 8 + 2 nblk) per-block partials
@@ -249,6 +259,11 @@ int lam_columns(int kind, int n_theta, int D)
 
 void free_dev(gpe_ctx* c)
 {
+    if (c->stream3 && c->inv_pending) { // a K^-1 chain nobody waited for still owns these buffers
+        hipStreamSynchronize(c->stream3);
+        c->inv_pending = false;
+    }
+    c->inv_followed = false;
     double** ps[] = {&c->dXt, &c->dA, &c->dOm, &c->dAl, &c->dW, &c->dY, &c->dLinv, &c->dKinv, &c->dKhost,
                      &c->dGradPartial, &c->dXinv, &c->dLooS, &c->dLooV};
     for (auto p : ps) {
@@ -326,7 +341,7 @@ int grow_dev(gpe_ctx* c, int64_t need)
     c->dY = nY;
     c->dXinv = nXi;
     c->dLinv = c->dKinv = c->dLooS = c->dLooV = nullptr;
-    c->inv_ok = false;
+    c->inv_ok = c->inv_followed = false;
     c->cap = ncap;
     c->ld = nld;
     return GPE_OK;
@@ -374,6 +389,83 @@ void project_lambda(gpe_ctx* c, hipStream_t s, double* Xt, int64_t ld, int64_t c
     launch_lambda_rows(s, Xt, ld, col0, n, lp);
 }
 
+
+// ---- K^-1 behind the factorisation -----------------------------------------------------------------------------
+// One panel of the transposed inversion (see ensure_inv): X_p, U[0:o0, p] = AccT[0:o0, p] X_p^T,
+// AccT[0:oe, p+1 ..] -= U[0:oe, p] L[p+1 .., p]^T, K^-1[0:oe, 0:oe] += U[0:oe, p] U[0:oe, p]^T.  `limit` > 0: at most that
+// many workgroups per launch (the factorisation is still running).
+static void inv_chain_panel(gpe_ctx* c, hipStream_t st, int64_t p, int limit)
+{
+    const int64_t N = c->N, ld = c->ld, nbo = c->nbo;
+    const int64_t o0 = p * nbo, pw = std::min<int64_t>(nbo, N - o0), oe = o0 + pw;
+    launch_inv_panel_one(st, c->dA, ld, N, (int)nbo, c->dXinv, c->dXp, c->dLinv, ld, (int)p);
+    if (o0 > 0) {
+        GemmArgs g{};
+        g.C = c->dLinv + o0 * ld;
+        g.ldc = ld;
+        g.A = c->dKinv + o0 * ld;
+        g.lda = ld;
+        g.B = c->dXp + p * (nbo * nbo);
+        g.ldb = nbo;
+        g.m = o0;
+        g.n = pw;
+        g.k = pw;
+        g.overwrite = 1;
+        g.grid_limit = limit;
+        if (limit > 0)
+            g.tile = 64;
+        launch_gemm_sub(st, g);
+    }
+    if (oe < N) {
+        GemmArgs g{};
+        g.C = c->dKinv + oe * ld;
+        g.ldc = ld;
+        g.A = c->dLinv + o0 * ld;
+        g.lda = ld;
+        g.B = c->dA + oe + o0 * ld;
+        g.ldb = ld;
+        g.m = oe;
+        g.n = N - oe;
+        g.k = pw;
+        g.grid_limit = limit;
+        if (limit > 0)
+            g.tile = 128;
+        launch_gemm_sub(st, g);
+    }
+    {
+        GemmArgs g{};
+        g.C = c->dKinv;
+        g.ldc = ld;
+        g.A = c->dLinv + o0 * ld;
+        g.lda = ld;
+        g.B = c->dLinv + o0 * ld;
+        g.ldb = ld;
+        g.m = g.n = oe;
+        g.k = pw;
+        g.tri = 1;
+        g.overwrite = 2;
+        g.grid_limit = limit;
+        if (limit > 0)
+            g.tile = 128;
+        launch_gemm_sub(st, g);
+    }
+}
+static hipEvent_t inv_event(gpe_ctx* c, size_t i)
+{
+    while (c->inv_events.size() <= i) {
+        hipEvent_t e;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        c->inv_events.push_back(e);
+    }
+    return c->inv_events[i];
+}
+// panels inv_next .. upto of the chain, after `ready` (a point of the main stream at which they are final)
+static void inv_follow_upto(gpe_ctx* c, int64_t upto, hipEvent_t ready, int limit)
+{
+    hipStreamWaitEvent(c->stream3, ready, 0);
+    for (; c->inv_next <= upto; ++c->inv_next)
+        inv_chain_panel(c, c->stream3, c->inv_next, limit);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky, two levels (replaces Eigen::LLT at gp.hpp:565):
@@ -551,6 +643,8 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 }
                 hipStreamWaitEvent(c->stream2, ev(3 * kp), 0); // the bulk update starts now and shares the chip
                                                                // with panel kp + 1 only
+                if (c->inv_follow) // panel kp of L is final: its piece of the K^-1 chain, on the third stream
+                    inv_follow_upto(c, (int64_t)kp, ev(3 * kp), c->inv_limit);
                 if (nf > 0 && !c->panel_handover) // (with the hand-over the head tiles were written in place too)
                     launch_head_copy(c->stream2, A, ld, p0, nt0, nf, Hbase);
                 nf = 0;
@@ -756,7 +850,65 @@ int compute_enqueue(gpe_ctx* c)
         launch_cols_to_rows(s, c->dOm, c->ld, c->N, c->P, c->dA + c->N, c->ld, flow ? c->dAl : nullptr);
         c->al_prefilled = flow;
     }
+    // K^-1 behind the factorisation (gpe_hp_objective with a gradient; not in batched launches or profiling runs)
+    if (c->inv_pending) { // an earlier chain nobody waited for (an error path): it must not write under this evaluation
+        hipStreamSynchronize(c->stream3);
+        c->inv_pending = false;
+    }
+    c->inv_followed = false;
+    // OFF unless GPE_INV_FOLLOW=1: measured (bench.py hp_objective, N = 4096) the chain behind the factorisation LOSES —
+    // 3.38 ms with the chain after the factorisation (its product overlapped, ensure_inv), 3.51 ms following it unrestricted,
+    // 4.1 / 4.9 / 7.0 ms with its launches held to 160 / 96 / 48 workgroups: the chain's matrix-core workgroups take CUs and
+    // LDS from the panel steps, whose chain is the critical path, and a workgroup-limited launch is long enough to become one
+    static const bool follow_ok = getenv("GPE_INV_FOLLOW") && atoi(getenv("GPE_INV_FOLLOW")) != 0;
+    const int64_t npan = (c->N + c->nbo - 1) / c->nbo;
+    bool follow = c->inv_follow_req && follow_ok && !g_batch.bt && !c->prof && c->lookahead && c->stop_events && c->fuse_panel
+        && c->panel_handover // (otherwise the panel's head tiles reach A later, on the second stream)
+        && c->nbo % 128 == 0 && c->nbo <= 256 && npan >= 6 && c->N % c->nbo == 0;
+    c->inv_follow_req = false;
+    if (follow) {
+        const size_t mat = sizeof(double) * (size_t)(c->ld * c->cap);
+        if (!c->dLinv && hipMalloc(&c->dLinv, mat) != hipSuccess)
+            follow = false;
+        if (follow && !c->dKinv && hipMalloc(&c->dKinv, mat) != hipSuccess)
+            follow = false;
+        if (follow && (int64_t)c->xp_cap < npan * c->nbo * c->nbo) {
+            if (c->dXp)
+                hipFree(c->dXp);
+            c->dXp = nullptr;
+            c->xp_cap = 0;
+            if (hipMalloc(&c->dXp, sizeof(double) * (size_t)(npan * c->nbo * c->nbo)) == hipSuccess)
+                c->xp_cap = (size_t)(npan * c->nbo * c->nbo);
+            else
+                follow = false;
+        }
+        if (follow && !c->stream3) {
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi); // lo: the LEAST urgent
+            if (hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, lo) != hipSuccess)
+                follow = false;
+            if (const char* f = getenv("GPE_INV_FOLLOW_WGS"))
+                c->inv_limit = atoi(f);
+        }
+    }
+    if (follow) {
+        hipEventRecord(inv_event(c, 0), s); // everything of this handle that touched the K^-1 buffers is behind this point
+        hipStreamWaitEvent(c->stream3, inv_event(c, 0), 0);
+        launch_zero2d(c->stream3, c->dKinv, c->ld, c->N, c->N);
+        c->inv_follow = true;
+        c->inv_next = 0;
+        c->inv_pending = true;
+    }
     potrf_blocked(c, c->dA, c->N, c->N + c->P);
+    if (follow) {
+        // the panels the look-ahead schedule has no event for (the last two), and whatever else is left: after the whole
+        // factorisation, unrestricted
+        c->inv_follow = false;
+        hipEventRecord(inv_event(c, 1), s);
+        inv_follow_upto(c, npan - 1, inv_event(c, 1), 0);
+        hipEventRecord(inv_event(c, 2), c->stream3);
+        c->inv_followed = true;
+    }
     c->have_L = true;
     c->inv_ok = false; // gp.hpp:570
     solve_alpha_from_z(c);
@@ -914,6 +1066,13 @@ int ensure_inv(gpe_ctx* c)
         return GPE_OK;
     if (!c->have_L)
         return GPE_ERR_STATE;
+    if (c->inv_followed) { // the chain ran behind the factorisation (compute_enqueue): wait for its end, that is all
+        hipStreamWaitEvent(c->stream, inv_event(c, 2), 0);
+        c->inv_followed = false;
+        c->inv_pending = false;
+        c->inv_ok = true; // gp.hpp:263
+        return GPE_OK;
+    }
     hipStream_t s = c->stream;
     const int64_t N = c->N, ld = c->ld;
     if (!c->dLinv)
@@ -1379,6 +1538,12 @@ int gpe_destroy(gpe_handle c)
     free_dev(c);
     for (auto e : c->la_events)
         hipEventDestroy(e);
+    for (auto e : c->inv_events)
+        hipEventDestroy(e);
+    if (c->stream3) {
+        hipStreamSynchronize(c->stream3);
+        hipStreamDestroy(c->stream3);
+    }
     hipStreamSynchronize(c->stream2);
     bool kept = false;
     if (c->device < 16) {
@@ -1429,7 +1594,7 @@ int gpe_set_data(gpe_handle c, const double* X, int64_t N, int D, const double* 
     c->N = N;
     c->D = D;
     c->P = P;
-    c->have_L = c->inv_ok = c->ll_ok = false;
+    c->have_L = c->inv_ok = c->ll_ok = c->inv_followed = false;
     c->host_K = (c->kind == GPE_KERNEL_HOST_K);
     // stage X through the (not yet used) matrix buffer, then transpose to SoA on the device
     double* tmp = c->dA;
@@ -1456,7 +1621,7 @@ int gpe_set_data_device(gpe_handle c, const double* dX, int64_t N, int D, const 
     c->N = N;
     c->D = D;
     c->P = P;
-    c->have_L = c->inv_ok = c->ll_ok = false;
+    c->have_L = c->inv_ok = c->ll_ok = c->inv_followed = false;
     c->host_K = (c->kind == GPE_KERNEL_HOST_K);
     launch_transpose_x(c->stream, dX, N, D, c->dXt, c->ld, 0);
     launch_copy2d(c->stream, dOm, N, c->dOm, c->ld, N, P);
@@ -1665,7 +1830,8 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         }
         c->N = n + 1;
         c->have_L = true;
-        c->inv_ok = false; // gp.hpp:602
+        c->inv_ok = c->inv_followed = false; // gp.hpp:602
+        c->inv_followed = false;
         c->al_prefilled = false;
         c->ll_partials = 0;
         ++c->small_calls;
@@ -1706,7 +1872,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     new_row();
     c->N = n + 1;
     c->have_L = true;
-    c->inv_ok = false; // gp.hpp:602
+    c->inv_ok = c->inv_followed = false; // gp.hpp:602
     solve_alpha(c);    // gp.hpp:599
     enqueue_loglik_terms(c);
     return compute_finish(c, [c, new_row] {
@@ -1839,6 +2005,7 @@ int gpe_hp_objective(gpe_handle c, int kind, const double* th, int n_theta, doub
     int rc = gpe_set_kernel(c, kind, th, n_theta, noise); // kernel_lf_opt.hpp:80
     if (rc)
         return rc;
+    c->inv_follow_req = want_grad != 0 && !c->host_K; // K^-1 behind the factorisation (compute_enqueue)
     int info = gpe_compute(c); // :82 recompute(false)
     if (info < 0)
         return info;
@@ -2216,7 +2383,7 @@ int gpe_set_L(gpe_handle c, const double* L, int64_t ldh)
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_L = true;
-    c->inv_ok = false;
+    c->inv_ok = c->inv_followed = false;
     c->ll_ok = false;
     return GPE_OK;
 }
@@ -2607,7 +2774,7 @@ static int batch_finish_fused(gpe_ctx** cs, int Gc, int* rc, const BatchWant* wa
     for (int q = 0; q < Gc; ++q) {
         gpe_ctx* c = cs[q];
         c->have_L = true;
-        c->inv_ok = false;
+        c->inv_ok = c->inv_followed = false;
         c->al_prefilled = false;
         c->ll_partials = c0->flow_solve && nblk <= 256 ? (int)nblk : 0;
         c->xinv_done = 0;
@@ -2620,7 +2787,7 @@ static int batch_finish_fused(gpe_ctx** cs, int Gc, int* rc, const BatchWant* wa
             if (c->flow_retries != retries && rc[q] >= 0 && want->grad_out) {
                 // (never expected) this member's sweep or factorisation was re-run on its own after the batch: its
                 // K^-1 / gradient came from the first attempt — once more, alone
-                c->inv_ok = false;
+                c->inv_ok = c->inv_followed = false;
                 int e = grad_fetch(c, want->grad_out + (size_t)q * want->n_grad, want->n_grad, want->optimize_noise, false);
                 if (e < 0)
                     rc[q] = e;

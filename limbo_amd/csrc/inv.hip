@@ -46,7 +46,8 @@ static __device__ __forceinline__ void strip_mm(const double* __restrict__ As, c
 // Xt_all: Xt[k + 64 c] = (L_bb^-1)[c][k] per 64-block b, identity-padded.
 __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L, int64_t ld, int64_t N, int nbo,
                                                     const double* __restrict__ Xt_all, double* __restrict__ Out,
-                                                    int64_t ldo, double* __restrict__ OutT, int64_t ldt, const BatchTab* bt)
+                                                    int64_t ldo, double* __restrict__ OutT, int64_t ldt, const BatchTab* bt,
+                                                    int panel0)
 {
     BT_REBASE(bt, L); // batched launch (gridDim.z GPs, dev.h): this GP's buffers
     BT_REBASE(bt, Xt_all);
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L
     __shared__ double Ys[4][NB * SW]; // the strip's result tiles, Ys[i - s][kk][col]
     __shared__ double Ss[NB * SW];    // sum_k L_ik Y_ks, as the right-hand operand of X_i
     __shared__ double As[NB * AST];   // left operand, k-major: As[kk][row]
-    const int64_t o0 = (int64_t)blockIdx.y * nbo;
+    const int64_t pidx = (int64_t)blockIdx.y + panel0; // (panel0: one panel at a time, behind the factorisation: engine.hip)
+    const int64_t o0 = pidx * nbo;
     const int pw = (int)((N - o0 < nbo) ? N - o0 : nbo);
     const int c0 = blockIdx.x * SW; // first column of the strip inside the panel
     if (c0 >= pw)
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L
                 const int64_t row = o0 + (int64_t)i * NB + 4 * ty + r;
                 if (row < N && col < N) {
                     if (ldo == 0) // compact form: panel p's block alone, column-major nbo x nbo, at Out + p nbo^2
-                        Out[(row - o0) + (col - o0) * (int64_t)nbo + (int64_t)blockIdx.y * nbo * nbo] = v[r][c];
+                        Out[(row - o0) + (col - o0) * (int64_t)nbo + pidx * nbo * nbo] = v[r][c];
                     else
                         Out[row + col * ldo] = v[r][c];
                     if (OutT)
@@ -156,7 +158,14 @@ void launch_inv_panels(hipStream_t s, const double* L, int64_t ld, int64_t N, in
         return;
     const unsigned np = (unsigned)((N + nbo - 1) / nbo);
     hipLaunchKernelGGL(k_inv_panels, dim3((unsigned)(nbo / SW), np, (unsigned)g_batch.G), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, ldo,
-                       OutT, ldt, g_batch.bt);
+                       OutT, ldt, g_batch.bt, 0);
+}
+// the same for ONE panel (compact output only makes sense here: ldo == 0)
+void launch_inv_panel_one(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
+                          double* OutT, int64_t ldt, int panel)
+{
+    hipLaunchKernelGGL(k_inv_panels, dim3((unsigned)(nbo / SW), 1, 1), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, (int64_t)0, OutT, ldt,
+                       (const BatchTab*)nullptr, panel);
 }
 
 __global__ void k_zero2d(double* __restrict__ A, int64_t lda, int64_t rows, int64_t cols, const BatchTab* bt)
