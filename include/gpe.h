@@ -209,6 +209,13 @@ int gpe_small_calls(gpe_handle h, int64_t* n);
 int gpe_server_calls(gpe_handle h, int64_t* n);
 /* microseconds the resident workgroup spent on its last request: us[0] copying it out of the mailbox, us[1] in the body */
 int gpe_server_last_us(gpe_handle h, double* us);
+/* Launch trace of the PRODUCTION schedule: while on, every kernel launch of the library carries its own start and stop
+ * event (hipExtLaunchKernelGGL, the dispatch's own timestamps: no marker packets, no profiler) — rocprofv3's kernel trace
+ * cannot show the fused next-panel update, it delays dispatches that carry a completion event by ~100 us.  gpe_trace(1/0)
+ * switches it (and clears the records; GPE_TRACE=1 starts a process with it on); gpe_trace_dump writes one line per launch:
+ * start us, end us, stream index, kernel, grid, block (times from the first recorded launch's start). */
+int gpe_trace(int on);
+int gpe_trace_dump(const char* path);
 /* fp64 MFMA peak micro-benchmark (v_mfma_f64_4x4x4_4b, the instruction the GEMM kernels issue), TFLOP/s */
 int gpe_mfma_f64_peak(int device_id, double* tflops);
 /* HBM write-stream micro-benchmark, GB/s */

@@ -97,6 +97,8 @@ def _sig(lib, prefix):
             "server_calls": [_vp, C.POINTER(_i64)],
             "server_last_us": [_vp, _dp],
             "mfma_f64_peak": [C.c_int, _dp],
+            "trace": [C.c_int],
+            "trace_dump": [C.c_char_p],
             "hbm_stream_peak": [C.c_int, _dp],
         }
         for name, args in G.items():

@@ -2,6 +2,7 @@
 // gfx950 (MI355X, CDNA4) only: wave = 64 lanes, v_mfma_f64_16x16x4_f64, 160 KiB LDS/CU.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #define GPE_MAX_THETA 64
@@ -113,6 +114,38 @@ static __device__ __forceinline__ int64_t flow_block_of(int64_t nblk, bool backw
 }
 unsigned flow_grid(int64_t nblk); // 8 nblk (XCD-local chains) or nblk (GPE_FLOW_XCD=0)
 #define GPE_FLOW_GRID(nblk) flow_grid(nblk)
+
+// ---- launch tracing (GPE_TRACE=1 / gpe_trace(1)) ------------------------------------------------------------------
+// rocprofv3's kernel trace delays every dispatch that carries its own completion event by ~100 us, so the PRODUCTION
+// schedule of the factorisation (look-ahead on two streams, the fused next-panel update + diagonal block) cannot be traced
+// with it.  With tracing on, every launch of the library carries a start and a stop event of its own instead
+// (hipExtLaunchKernelGGL: the dispatch packet's own timestamps, no marker packets, the mechanism the look-ahead already
+// uses for ordering), and gpe_trace_dump() writes (kernel, stream, start, end) relative to the first launch.
+bool gpe_trace_on();
+hipEvent_t gpe_trace_event();
+void gpe_trace_add(const char* name, hipStream_t s, hipEvent_t e0, hipEvent_t e1, dim3 grid, dim3 block);
+#define GPE_LAUNCH_NAMED(name, kern, grid, block, shmem, stream, ...)                                      \
+    do {                                                                                                   \
+        if (gpe_trace_on()) {                                                                              \
+            hipEvent_t e0_ = gpe_trace_event(), e1_ = gpe_trace_event();                                   \
+            hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, e0_, e1_, 0, __VA_ARGS__);             \
+            gpe_trace_add(name, stream, e0_, e1_, grid, block);                                            \
+        }                                                                                                  \
+        else                                                                                               \
+            hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);                             \
+    } while (0)
+#define GPE_LAUNCH(kern, grid, block, shmem, stream, ...) GPE_LAUNCH_NAMED(#kern, kern, grid, block, shmem, stream, __VA_ARGS__)
+// the same for a launch that signals `stop` (an event of the caller's: the look-ahead's ordering) through its dispatch
+#define GPE_LAUNCH_STOP(name, kern, grid, block, shmem, stream, stop, ...)                                 \
+    do {                                                                                                   \
+        if (gpe_trace_on()) {                                                                              \
+            hipEvent_t e0_ = gpe_trace_event();                                                            \
+            hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, e0_, stop, 0, __VA_ARGS__);            \
+            gpe_trace_add(name, stream, e0_, stop, grid, block);                                           \
+        }                                                                                                  \
+        else                                                                                               \
+            hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, nullptr, stop, 0, __VA_ARGS__);        \
+    } while (0)
 
 // ---- kernel-matrix build (kbuild.hip) ----------------------------------------------
 // Xt: SoA, D x ldx (sample index contiguous).  Writes the LOWER triangle (incl. diagonal,

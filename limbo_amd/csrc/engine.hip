@@ -24,12 +24,55 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <map>
 #include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
 
 thread_local BatchLaunch g_batch; // dev.h: what this thread's launch wrappers add to every launch
+
+// ---- launch tracing (dev.h: GPE_LAUNCH) --------------------------------------------------------------------------
+namespace {
+struct TraceRec {
+    const char* name;
+    hipStream_t stream;
+    hipEvent_t e0, e1;
+    unsigned gx, gy, gz, bx;
+    bool own_stop; // e1 came from the trace pool (not the look-ahead's)
+};
+std::mutex g_trace_mu;
+std::vector<TraceRec> g_trace;
+std::vector<hipEvent_t> g_trace_pool;
+std::atomic<int> g_trace_state{-1}; // -1: not looked at yet (GPE_TRACE), 0 off, 1 on
+} // namespace
+bool gpe_trace_on()
+{
+    int st = g_trace_state.load(std::memory_order_relaxed);
+    if (st < 0) {
+        const char* e = getenv("GPE_TRACE");
+        st = e && atoi(e) != 0 ? 1 : 0;
+        g_trace_state.store(st);
+    }
+    return st == 1;
+}
+hipEvent_t gpe_trace_event()
+{
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    if (!g_trace_pool.empty()) {
+        hipEvent_t e = g_trace_pool.back();
+        g_trace_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+void gpe_trace_add(const char* name, hipStream_t s, hipEvent_t e0, hipEvent_t e1, dim3 grid, dim3 block)
+{
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    g_trace.push_back(TraceRec{name, s, e0, e1, grid.x, grid.y, grid.z, block.x, false});
+}
 
 #define NB 64
 // pinned staging of the small path: results in [0, 256), inputs (obs_mean: (n + 1) x P <= 257 x 3; query points: 8 x 64) from 256 on
@@ -1854,7 +1897,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
     // k(x_i, x_new) for i = 0..n (gp.hpp:583-586), no noise yet
     launch_build_Ks(s, c->dXt, ld, n + 1, c->dXt + n, ld, 1, c->kp, c->dW, ld);
-    hipLaunchKernelGGL(k_knn, dim3(1), dim3(1), 0, s, c->dW, n, c->kp.diag_add, c->dScal + 2);
+    GPE_LAUNCH(k_knn, dim3(1), dim3(1), 0, s, c->dW, n, c->kp.diag_add, c->dScal + 2);
     auto new_row = [c, s, n, ld] {
         PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)n * n);
         if (n > 0) {
@@ -1863,7 +1906,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
                 launch_trsv_fwd_flow(s, c->dA, ld, n, c->dXinv, c->dW, ld, c->dY, ld, 1, c->dInfo + 1);
             else
                 launch_trsv_sweep(s, c->dA, ld, n, c->dXinv, c->dW, c->dY, ld, 1, 0);
-            hipLaunchKernelGGL(k_vec_to_row, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->dY, c->dA + n, ld,
+            GPE_LAUNCH(k_vec_to_row, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->dY, c->dA + n, ld,
                                n);
         }
         launch_append_diag(s, c->dA + n, ld, n, c->dScal + 2, c->dInfo); // gp.hpp:596-597
@@ -3064,6 +3107,42 @@ int gpe_reset_phase_ms(gpe_handle c)
         c->ph_ms[i] = c->ph_flops[i] = 0.0;
         c->ph_launches[i] = 0;
     }
+    return GPE_OK;
+}
+
+// launch tracing: on / off (clears what was recorded), and the records so far as text:
+//   <start us> <end us> <stream index> <kernel> grid=<x,y,z> block=<x>      (times from the first recorded launch's start)
+int gpe_trace(int on)
+{
+    (void)gpe_trace_on();
+    hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    for (auto& r : g_trace)
+        g_trace_pool.push_back(r.e0); // (stop events may be the look-ahead's: only the start events go back to the pool)
+    g_trace.clear();
+    g_trace_state.store(on ? 1 : 0);
+    return GPE_OK;
+}
+int gpe_trace_dump(const char* path)
+{
+    if (!path)
+        return GPE_ERR_ARG;
+    hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    FILE* f = fopen(path, "w");
+    if (!f)
+        return GPE_ERR_ARG;
+    std::map<hipStream_t, int> sid;
+    hipEvent_t ref = g_trace.empty() ? nullptr : g_trace[0].e0;
+    for (auto& r : g_trace) {
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, ref, r.e0) != hipSuccess || hipEventElapsedTime(&b, ref, r.e1) != hipSuccess)
+            continue;
+        if (!sid.count(r.stream))
+            sid[r.stream] = (int)sid.size();
+        fprintf(f, "%10.2f %10.2f %d %s grid=%u,%u,%u block=%u\n", 1e3 * a, 1e3 * b, sid[r.stream], r.name, r.gx, r.gy, r.gz, r.bx);
+    }
+    fclose(f);
     return GPE_OK;
 }
 

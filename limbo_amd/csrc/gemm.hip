@@ -294,17 +294,19 @@ __global__ __launch_bounds__(256) void k_gemm4(GemmArgs g_)
 // (GemmArgs::stop_event): a separate hipEventRecord is a marker packet of its own on the stream and
 // costs ~6 us on a dependent chain (rocprofv3 timeline of the factorisation).
 template <typename K>
-static void launch_k(K kern_single, K kern_batched, dim3 grid, dim3 block, hipStream_t s, const GemmArgs& g0)
+static void launch_k_named(const char* name, K kern_single, K kern_batched, dim3 grid, dim3 block, hipStream_t s, const GemmArgs& g0)
 {
     GemmArgs g = g0;
     g.bt = g_batch.bt; // batched launch: gridDim.z GPs, pointers rebased per GP in the kernel (dev.h)
     grid.z = (unsigned)g_batch.G;
     K kern = g.bt ? kern_batched : kern_single;
     if (g.stop_event)
-        hipExtLaunchKernelGGL(kern, grid, block, 0, s, nullptr, (hipEvent_t)g.stop_event, 0, g);
+        GPE_LAUNCH_STOP(name, kern, grid, block, 0, s, (hipEvent_t)g.stop_event, g);
     else
-        hipLaunchKernelGGL(kern, grid, block, 0, s, g);
+        GPE_LAUNCH_NAMED(name, kern, grid, block, 0, s, g);
 }
+// (the kernel's name for the launch trace: the first argument as written)
+#define launch_k(ks, ...) launch_k_named(#ks, ks, __VA_ARGS__)
 template <int TM, int TN, int BKT, int NBUF>
 static void launch_tile(hipStream_t s, const GemmArgs& g0)
 {

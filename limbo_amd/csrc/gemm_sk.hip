@@ -437,9 +437,9 @@ void launch_gemm_sk_ex(hipStream_t s, const GemmArgs& g0, int rhs_rows, void* ws
     const dim3 grid((unsigned)P.G), block(512);
     auto go = [&](auto kern) {
         if (g0.stop_event)
-            hipExtLaunchKernelGGL(kern, grid, block, 0, s, nullptr, (hipEvent_t)g0.stop_event, 0, P);
+            GPE_LAUNCH_STOP("k_gemm_sk", kern, grid, block, 0, s, (hipEvent_t)g0.stop_event, P);
         else
-            hipLaunchKernelGGL(kern, grid, block, 0, s, P);
+            GPE_LAUNCH_NAMED("k_gemm_sk", kern, grid, block, 0, s, P);
     };
     if (variant == 1)
         go(k_gemm_sk<32, 2, 0, 1>);

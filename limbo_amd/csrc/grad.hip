@@ -252,7 +252,7 @@ static void launch_grad_chunk(hipStream_t s, const double* Xt, int64_t ldx, int6
     const int D = kp.D;
     dim3 grid((unsigned)nblk, 1, (unsigned)g_batch.G), block(256);
 #define LG(DM, LAM)                                                                                              \
-    hipLaunchKernelGGL((k_grad_tiles<DM, LAM>), grid, block,                                                     \
+    GPE_LAUNCH((k_grad_tiles<DM, LAM>), grid, block,                                                     \
                        (size_t)(D * TILE + 2 * GPE_MAX_P * TILE + 4 * (DM + 2)) * sizeof(double), s, Xt, ldx, N, \
                        kp, Kinv, ldk, alpha, lda, uvec, P, kinv_scale, n_theta, optimize_noise, lam_col, partial, g_batch.bt)
 #define LGD(LAM)      \
@@ -274,7 +274,7 @@ static void launch_grad_chunk(hipStream_t s, const double* Xt, int64_t ldx, int6
     }
 #undef LGD
 #undef LG
-    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)T, 1, (unsigned)g_batch.G), dim3(256), 0, s, partial, nblk, T, grad, accumulate,
+    GPE_LAUNCH(k_grad_final, dim3((unsigned)T, 1, (unsigned)g_batch.G), dim3(256), 0, s, partial, nblk, T, grad, accumulate,
                        out_off, tail_from, tail_to, g_batch.bt);
 }
 
@@ -357,17 +357,17 @@ __global__ void k_scale_vec(double* __restrict__ g, int n, double f)
 void launch_loo_prep(hipStream_t s, const double* Kinv, int64_t ldk, int64_t N, const double* alpha, int64_t lda, int P,
                      double* v, double* sc, double* val, double* out)
 {
-    hipLaunchKernelGGL(k_loo_prep, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Kinv, ldk, N, alpha, lda, P, v,
+    GPE_LAUNCH(k_loo_prep, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Kinv, ldk, N, alpha, lda, P, v,
                        sc, val);
-    hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(256), 0, s, val, N, out);
+    GPE_LAUNCH(k_sum_fixed, dim3(1), dim3(256), 0, s, val, N, out);
 }
 void launch_sym_colscale(hipStream_t s, const double* Kl, int64_t ldk, int64_t N, const double* sc, double* S,
                          int64_t lds_)
 {
     const unsigned nt = (unsigned)((N + TILE - 1) / TILE);
-    hipLaunchKernelGGL(k_sym_colscale, dim3(nt, nt), dim3(256), 0, s, Kl, ldk, N, sc, S, lds_);
+    GPE_LAUNCH(k_sym_colscale, dim3(nt, nt), dim3(256), 0, s, Kl, ldk, N, sc, S, lds_);
 }
 void launch_scale_vec(hipStream_t s, double* g, int n, double f)
 {
-    hipLaunchKernelGGL(k_scale_vec, dim3(1), dim3(64), 0, s, g, n, f);
+    GPE_LAUNCH(k_scale_vec, dim3(1), dim3(64), 0, s, g, n, f);
 }

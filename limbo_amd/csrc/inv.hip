@@ -157,14 +157,14 @@ void launch_inv_panels(hipStream_t s, const double* L, int64_t ld, int64_t N, in
     if (N <= 0)
         return;
     const unsigned np = (unsigned)((N + nbo - 1) / nbo);
-    hipLaunchKernelGGL(k_inv_panels, dim3((unsigned)(nbo / SW), np, (unsigned)g_batch.G), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, ldo,
+    GPE_LAUNCH(k_inv_panels, dim3((unsigned)(nbo / SW), np, (unsigned)g_batch.G), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, ldo,
                        OutT, ldt, g_batch.bt, 0);
 }
 // the same for ONE panel (compact output only makes sense here: ldo == 0)
 void launch_inv_panel_one(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
                           double* OutT, int64_t ldt, int panel)
 {
-    hipLaunchKernelGGL(k_inv_panels, dim3((unsigned)(nbo / SW), 1, 1), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, (int64_t)0, OutT, ldt,
+    GPE_LAUNCH(k_inv_panels, dim3((unsigned)(nbo / SW), 1, 1), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, (int64_t)0, OutT, ldt,
                        (const BatchTab*)nullptr, panel);
 }
 
@@ -180,5 +180,5 @@ void launch_zero2d(hipStream_t s, double* A, int64_t lda, int64_t rows, int64_t 
     if (rows <= 0 || cols <= 0)
         return;
     const unsigned gx = (unsigned)((rows + 1023) / 1024 > 8 ? 8 : (rows + 1023) / 1024);
-    hipLaunchKernelGGL(k_zero2d, dim3(gx, (unsigned)cols, (unsigned)g_batch.G), dim3(256), 0, s, A, lda, rows, cols, g_batch.bt);
+    GPE_LAUNCH(k_zero2d, dim3(gx, (unsigned)cols, (unsigned)g_batch.G), dim3(256), 0, s, A, lda, rows, cols, g_batch.bt);
 }

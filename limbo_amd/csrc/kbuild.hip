@@ -30,7 +30,7 @@ void launch_transpose_x(hipStream_t s, const double* Xrm, int64_t n, int D, doub
     int64_t tot = n * D;
     if (tot <= 0)
         return;
-    hipLaunchKernelGGL(k_transpose_x, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xrm, n, D, Xt, ld, col0);
+    GPE_LAUNCH(k_transpose_x, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xrm, n, D, Xt, ld, col0);
 }
 
 __global__ void k_lambda_rows(double* __restrict__ Xt, int64_t ld, int64_t col0, int64_t n, LamParams lp)
@@ -50,7 +50,7 @@ void launch_lambda_rows(hipStream_t s, double* Xt, int64_t ld, int64_t col0, int
 {
     if (n <= 0 || lp.k <= 0)
         return;
-    hipLaunchKernelGGL(k_lambda_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Xt, ld, col0, n, lp);
+    GPE_LAUNCH(k_lambda_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Xt, ld, col0, n, lp);
 }
 
 // MODE 0: lower triangle of the symmetric training matrix (+diag_add on i==j)
@@ -158,9 +158,9 @@ static void launch_build(hipStream_t s, const double* Xt, int64_t ldx, int64_t N
 #define LB(DM)                                                                                                                  \
     do {                                                                                                                        \
         if (bt)                                                                                                                 \
-            hipLaunchKernelGGL((k_build<DM, MODE, true>), grid, dim3(256), sh, s, Xt, ldx, N, Qt, ldq, M, kp, A, lda, bt);      \
+            GPE_LAUNCH((k_build<DM, MODE, true>), grid, dim3(256), sh, s, Xt, ldx, N, Qt, ldq, M, kp, A, lda, bt);      \
         else                                                                                                                    \
-            hipLaunchKernelGGL((k_build<DM, MODE, false>), grid, dim3(256), sh, s, Xt, ldx, N, Qt, ldq, M, kp, A, lda, bt);     \
+            GPE_LAUNCH((k_build<DM, MODE, false>), grid, dim3(256), sh, s, Xt, ldx, N, Qt, ldq, M, kp, A, lda, bt);     \
     } while (0)
     if (D <= 4)
         LB(4);
@@ -287,9 +287,9 @@ static void launch_build_lower_kind(hipStream_t s, const double* Xt, int64_t ldx
 #define LBL(DM)                                                                                                   \
     do {                                                                                                          \
         if (bt)                                                                                                   \
-            hipLaunchKernelGGL((k_build_lower<KIND, DM, true>), grid, dim3(256), 0, s, Xt, ldx, N, kp, A, lda, bt);  \
+            GPE_LAUNCH((k_build_lower<KIND, DM, true>), grid, dim3(256), 0, s, Xt, ldx, N, kp, A, lda, bt);  \
         else                                                                                                      \
-            hipLaunchKernelGGL((k_build_lower<KIND, DM, false>), grid, dim3(256), 0, s, Xt, ldx, N, kp, A, lda, bt); \
+            GPE_LAUNCH((k_build_lower<KIND, DM, false>), grid, dim3(256), 0, s, Xt, ldx, N, kp, A, lda, bt); \
     } while (0)
     if (kp.D <= 4)
         LBL(4);
@@ -408,9 +408,9 @@ static void launch_build_wide_kind(hipStream_t s, const double* Xt, int64_t ldx,
 #define LBW(DM)                                                                                                     \
     do {                                                                                                            \
         if (bt)                                                                                                     \
-            hipLaunchKernelGGL((k_build_wide<KIND, DM, true>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt);  \
+            GPE_LAUNCH((k_build_wide<KIND, DM, true>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt);  \
         else                                                                                                        \
-            hipLaunchKernelGGL((k_build_wide<KIND, DM, false>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt); \
+            GPE_LAUNCH((k_build_wide<KIND, DM, false>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt); \
     } while (0)
     if (kp.D <= 4)
         LBW(4);
@@ -480,5 +480,5 @@ void launch_kvv(hipStream_t s, const double* Qt, int64_t ldq, int64_t M, const K
     (void)ldq;
     if (M <= 0)
         return;
-    hipLaunchKernelGGL(k_kvv, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, kp, kvv);
+    GPE_LAUNCH(k_kvv, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, kp, kvv);
 }

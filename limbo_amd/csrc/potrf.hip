@@ -559,12 +559,12 @@ void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int*
     if (half_form && jb == NB)
     {
         if (g_batch.bt)
-            hipLaunchKernelGGL(k_diag_b, dim3(1, 1, g_batch.G), dim3(DIAG_THREADS), 0, s, A, lda, Xt, info, goff, g_batch.bt);
+            GPE_LAUNCH(k_diag_b, dim3(1, 1, g_batch.G), dim3(DIAG_THREADS), 0, s, A, lda, Xt, info, goff, g_batch.bt);
         else
-            hipLaunchKernelGGL(k_diag, dim3(1), dim3(DIAG_THREADS), 0, s, A, lda, Xt, info, goff);
+            GPE_LAUNCH(k_diag, dim3(1), dim3(DIAG_THREADS), 0, s, A, lda, Xt, info, goff);
     }
     else
-        hipLaunchKernelGGL(k_diag_full, dim3(1, 1, g_batch.G), dim3(256), 0, s, A, lda, jb, Xt, info, goff, g_batch.bt);
+        GPE_LAUNCH(k_diag_full, dim3(1, 1, g_batch.G), dim3(256), 0, s, A, lda, jb, Xt, info, goff, g_batch.bt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1229,10 +1229,9 @@ void launch_upd_fused(hipStream_t s, const GemmArgs& g0, double* A, int64_t lda,
     g.total = nsup * fold;
     const dim3 grid((unsigned)g.total + 1), block(512);
     if (g.stop_event)
-        hipExtLaunchKernelGGL(k_upd_fused, grid, block, 0, s, nullptr, (hipEvent_t)g.stop_event, 0, g, A, lda, p0, pe, Xt_next,
-                              info, Dacc);
+        GPE_LAUNCH_STOP("k_upd_fused", k_upd_fused, grid, block, 0, s, (hipEvent_t)g.stop_event, g, A, lda, p0, pe, Xt_next, info, Dacc);
     else
-        hipLaunchKernelGGL(k_upd_fused, grid, block, 0, s, g, A, lda, p0, pe, Xt_next, info, Dacc);
+        GPE_LAUNCH(k_upd_fused, grid, block, 0, s, g, A, lda, p0, pe, Xt_next, info, Dacc);
 }
 
 #ifdef DIAG_TIMING
@@ -1262,10 +1261,10 @@ void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_
     if (rows <= 0)
         return;
     if (g_batch.bt)
-        hipLaunchKernelGGL(k_panel_step_b, dim3((unsigned)((rows + NB - 1) / NB) * g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
+        GPE_LAUNCH(k_panel_step_b, dim3((unsigned)((rows + NB - 1) / NB) * g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
                            Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch, spin_limit, g_batch.bt);
     else
-        hipLaunchKernelGGL(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, j0, M, nt, Xt_cur,
+        GPE_LAUNCH(k_panel_step, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, j0, M, nt, Xt_cur,
                            Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch, spin_limit);
 }
 
@@ -1292,7 +1291,7 @@ void launch_head_copy(hipStream_t s, double* A, int64_t lda, int64_t p0, int nt0
     for (int f = 0; f < nf; ++f)
         tiles += nt0 - f;
     if (tiles > 0)
-        hipLaunchKernelGGL(k_head_copy, dim3((unsigned)tiles, 1, g_batch.G), dim3(256), 0, s, A, lda, p0, nt0, H, g_batch.bt);
+        GPE_LAUNCH(k_head_copy, dim3((unsigned)tiles, 1, g_batch.G), dim3(256), 0, s, A, lda, p0, nt0, H, g_batch.bt);
 }
 
 // Off-diagonal quarter of the block inverses left by the half-form kernels: for blocks b0..b0+n-1
@@ -1327,7 +1326,7 @@ void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b
     return; // the data-flow block factorisation leaves all of X (diag_flow.h: flow_w_wave, flow_x21)
 #endif
     if (nblocks > 0)
-        hipLaunchKernelGGL(k_xinv_complete, dim3((unsigned)nblocks, 1, g_batch.G), dim3(256), 0, s, L, ldl, b0, Xt_all, g_batch.bt);
+        GPE_LAUNCH(k_xinv_complete, dim3((unsigned)nblocks, 1, g_batch.G), dim3(256), 0, s, L, ldl, b0, Xt_all, g_batch.bt);
 }
 
 // inverses of the diagonal blocks of an existing factor: block b at L[64 b, 64 b]
@@ -1363,5 +1362,5 @@ void launch_diag_inv(hipStream_t s, const double* L, int64_t ldl, int64_t N, int
 {
     if (nblocks <= 0)
         return;
-    hipLaunchKernelGGL(k_diag_inv, dim3((unsigned)nblocks), dim3(256), 0, s, L, ldl, N, b0, Xt_all);
+    GPE_LAUNCH(k_diag_inv, dim3((unsigned)nblocks), dim3(256), 0, s, L, ldl, N, b0, Xt_all);
 }

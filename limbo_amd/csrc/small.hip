@@ -607,7 +607,7 @@ int small_max_n() { return SM_NBLK * NB; }
 
 void launch_small_server(hipStream_t s, SmallMailbox* mb, unsigned long long seen0, long long idle_ticks)
 {
-    hipLaunchKernelGGL(k_small_server, dim3(1), dim3(SM_T), 0, s, mb, seen0, idle_ticks);
+    GPE_LAUNCH(k_small_server, dim3(1), dim3(SM_T), 0, s, mb, seen0, idle_ticks);
 }
 
 void launch_small_add(hipStream_t s, const SmallAddArgs& g, int P, const KParams& kp, const LamParams& lp, const double* x)
@@ -616,26 +616,26 @@ void launch_small_add(hipStream_t s, const SmallAddArgs& g, int P, const KParams
     for (int d = 0; d < GPE_MAX_THETA; ++d)
         xv.v[d] = d < kp.Din ? x[d] : 0.0;
     if (P == 1)
-        hipLaunchKernelGGL(k_small_add<1>, dim3(1), dim3(SM_T), 0, s, g, kp, lp, xv);
+        GPE_LAUNCH(k_small_add<1>, dim3(1), dim3(SM_T), 0, s, g, kp, lp, xv);
     else if (P == 2)
-        hipLaunchKernelGGL(k_small_add<2>, dim3(1), dim3(SM_T), 0, s, g, kp, lp, xv);
+        GPE_LAUNCH(k_small_add<2>, dim3(1), dim3(SM_T), 0, s, g, kp, lp, xv);
     else
-        hipLaunchKernelGGL(k_small_add<3>, dim3(1), dim3(SM_T), 0, s, g, kp, lp, xv);
+        GPE_LAUNCH(k_small_add<3>, dim3(1), dim3(SM_T), 0, s, g, kp, lp, xv);
 }
 
 void launch_small_query(hipStream_t s, const SmallQueryArgs& g, const KParams& kp, const LamParams& lp)
 {
-    hipLaunchKernelGGL(k_small_query, dim3((unsigned)g.M), dim3(SM_T), 0, s, g, kp, lp);
+    GPE_LAUNCH(k_small_query, dim3((unsigned)g.M), dim3(SM_T), 0, s, g, kp, lp);
 }
 
 void launch_small_alpha(hipStream_t s, const SmallAlphaArgs& g, int P)
 {
     if (P == 1)
-        hipLaunchKernelGGL(k_small_alpha<1>, dim3(1), dim3(SM_T), 0, s, g);
+        GPE_LAUNCH(k_small_alpha<1>, dim3(1), dim3(SM_T), 0, s, g);
     else if (P == 2)
-        hipLaunchKernelGGL(k_small_alpha<2>, dim3(1), dim3(SM_T), 0, s, g);
+        GPE_LAUNCH(k_small_alpha<2>, dim3(1), dim3(SM_T), 0, s, g);
     else if (P == 3)
-        hipLaunchKernelGGL(k_small_alpha<3>, dim3(1), dim3(SM_T), 0, s, g);
+        GPE_LAUNCH(k_small_alpha<3>, dim3(1), dim3(SM_T), 0, s, g);
     else
-        hipLaunchKernelGGL(k_small_alpha<4>, dim3(1), dim3(SM_T), 0, s, g);
+        GPE_LAUNCH(k_small_alpha<4>, dim3(1), dim3(SM_T), 0, s, g);
 }

@@ -156,7 +156,7 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, co
             unsigned grid = (unsigned)((rest + 255) / 256);
             if (grid == 0)
                 grid = 1;
-            hipLaunchKernelGGL(k_trsv_fwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, Xt_all + b * NB * NB, w,
+            GPE_LAUNCH(k_trsv_fwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, Xt_all + b * NB * NB, w,
                                out, ldw, P);
         }
     }
@@ -167,7 +167,7 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, co
             unsigned grid = (unsigned)((j0 + 63) / 64);
             if (grid == 0)
                 grid = 1;
-            hipLaunchKernelGGL(k_trsv_bwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, Xt_all + b * NB * NB, w,
+            GPE_LAUNCH(k_trsv_bwd_step, dim3(grid), dim3(256), 0, s, L, ld, N, j0, jb, Xt_all + b * NB * NB, w,
                                out, ldw, P);
         }
     }
@@ -450,10 +450,10 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
         if (pc == 1)
         {
             if (g_batch.bt)
-                hipLaunchKernelGGL(k_trsv_bwd_flow_b, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc,
+                GPE_LAUNCH(k_trsv_bwd_flow_b, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc,
                                    ysi, ysp, ac, ldw, 1, err, omc, ldom, part, acc, g_batch.bt);
             else
-                hipLaunchKernelGGL(k_trsv_bwd_flow, dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac,
+                GPE_LAUNCH(k_trsv_bwd_flow, dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac,
                                    ldw, 1, err, omc, ldom, part, acc);
         }
         else
@@ -600,7 +600,7 @@ void launch_trsv_fwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
         const double* bc = b + (int64_t)p0 * ldb;
         double* yc = y + (int64_t)p0 * ldy;
         if (pc == 1)
-            hipLaunchKernelGGL(k_trsv_fwd_flow, dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, bc, ldb, yc, ldy, 1,
+            GPE_LAUNCH(k_trsv_fwd_flow, dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, bc, ldb, yc, ldy, 1,
                                err);
         else
             launch_trsv_fwd_flow_mp(s, L, ld, N, Xt_all, bc, ldb, yc, ldy, pc, err);
@@ -637,13 +637,13 @@ void launch_cols_to_rows(hipStream_t s, const double* V, int64_t ldv, int64_t N,
                          double* sent)
 {
     if (N > 0 && P > 0)
-        hipLaunchKernelGGL(k_cols_to_rows, dim3((unsigned)((N + 255) / 256), 1, g_batch.G), dim3(256), 0, s, V, ldv, N, P, Arows, lda, sent,
+        GPE_LAUNCH(k_cols_to_rows, dim3((unsigned)((N + 255) / 256), 1, g_batch.G), dim3(256), 0, s, V, ldv, N, P, Arows, lda, sent,
                            g_batch.bt);
 }
 void launch_rows_to_cols(hipStream_t s, const double* Arows, int64_t lda, int64_t N, int P, double* V, int64_t ldv)
 {
     if (N > 0 && P > 0)
-        hipLaunchKernelGGL(k_rows_to_cols, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Arows, lda, N, P, V, ldv);
+        GPE_LAUNCH(k_rows_to_cols, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, Arows, lda, N, P, V, ldv);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void k_loglik_terms(const double* __restrict__
 void launch_loglik_terms(hipStream_t s, const double* L, int64_t ldl, int64_t N, const double* om, const double* alpha,
                          int64_t ldv, int P, double* out)
 {
-    hipLaunchKernelGGL(k_loglik_terms, dim3(1), dim3(256), 0, s, L, ldl, N, om, alpha, ldv, P, out);
+    GPE_LAUNCH(k_loglik_terms, dim3(1), dim3(256), 0, s, L, ldl, N, om, alpha, ldv, P, out);
 }
 
 // var[m] = kvv[m] - sum_i Z[i,m]^2   (gp.hpp:621)
@@ -710,7 +710,7 @@ void launch_col_var(hipStream_t s, const double* Z, int64_t ldz, int64_t N, int6
     if (M <= 0)
         return;
     unsigned grid = (unsigned)(M < 4096 ? M : 4096);
-    hipLaunchKernelGGL(k_col_var, dim3(grid), dim3(256), 0, s, Z, ldz, N, M, kvv, var);
+    GPE_LAUNCH(k_col_var, dim3(grid), dim3(256), 0, s, Z, ldz, N, M, kvv, var);
 }
 
 // kta[m, p] = sum_i Ks[i, m] alpha[i, p]   (gp.hpp:615)
@@ -738,7 +738,7 @@ void launch_kta(hipStream_t s, const double* Ks, int64_t ldk, int64_t N, int64_t
     if (M <= 0)
         return;
     unsigned grid = (unsigned)(M < 4096 ? M : 4096);
-    hipLaunchKernelGGL(k_kta, dim3(grid), dim3(256), 0, s, Ks, ldk, N, M, alpha, lda, P, kta, ldo);
+    GPE_LAUNCH(k_kta, dim3(grid), dim3(256), 0, s, Ks, ldk, N, M, alpha, lda, P, kta, ldo);
 }
 
 // ---- the same two reductions for the TRANSPOSED layout of the batched query path (points contiguous: Zt[m + i ldz]) ----
@@ -795,9 +795,9 @@ void launch_row_var_t(hipStream_t s, const double* Zt, int64_t ldz, int64_t N, i
 {
     if (M <= 0)
         return;
-    hipLaunchKernelGGL((k_rows_partial_t<1>), dim3((unsigned)((M + 255) / 256), (unsigned)nseg), dim3(256), 0, s, Zt, ldz, N, M,
+    GPE_LAUNCH((k_rows_partial_t<1>), dim3((unsigned)((M + 255) / 256), (unsigned)nseg), dim3(256), 0, s, Zt, ldz, N, M,
                        (const double*)nullptr, (int64_t)0, 1, partial, ldp);
-    hipLaunchKernelGGL(k_rows_finish_t, dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, s, partial, ldp, nseg, 1, M, kvv, var, M);
+    GPE_LAUNCH(k_rows_finish_t, dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, s, partial, ldp, nseg, 1, M, kvv, var, M);
 }
 // kta[m + p ldo] = sum_i Kst[m, i] alpha[i, p]   (gp.hpp:615);  partial: nseg x P x ldp doubles
 void launch_kta_t(hipStream_t s, const double* Kst, int64_t ldk, int64_t N, int64_t M, const double* alpha, int64_t lda, int P,
@@ -805,9 +805,9 @@ void launch_kta_t(hipStream_t s, const double* Kst, int64_t ldk, int64_t N, int6
 {
     if (M <= 0 || P <= 0)
         return;
-    hipLaunchKernelGGL((k_rows_partial_t<4>), dim3((unsigned)((M + 255) / 256), (unsigned)nseg), dim3(256), 0, s, Kst, ldk, N, M, alpha,
+    GPE_LAUNCH((k_rows_partial_t<4>), dim3((unsigned)((M + 255) / 256), (unsigned)nseg), dim3(256), 0, s, Kst, ldk, N, M, alpha,
                        lda, P, partial, ldp);
-    hipLaunchKernelGGL(k_rows_finish_t, dim3((unsigned)((M + 255) / 256), (unsigned)P), dim3(256), 0, s, partial, ldp, nseg, P, M,
+    GPE_LAUNCH(k_rows_finish_t, dim3((unsigned)((M + 255) / 256), (unsigned)P), dim3(256), 0, s, partial, ldp, nseg, P, M,
                        (const double*)nullptr, kta, ldo);
 }
 
@@ -825,7 +825,7 @@ void launch_set_identity(hipStream_t s, double* A, int64_t lda, int64_t n)
 {
     if (n <= 0)
         return;
-    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, A, lda, n);
+    GPE_LAUNCH(k_set_identity, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, A, lda, n);
 }
 
 __global__ void k_zero_upper(double* __restrict__ A, int64_t lda, int64_t n)
@@ -839,7 +839,7 @@ void launch_zero_upper(hipStream_t s, double* A, int64_t lda, int64_t n)
 {
     if (n <= 0)
         return;
-    hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, A, lda, n);
+    GPE_LAUNCH(k_zero_upper, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, A, lda, n);
 }
 
 // A[i][j] = A[j][i] for i < j (32x32 LDS-transposed tiles so both sides are coalesced)
@@ -867,7 +867,7 @@ void launch_symmetrize_from_lower(hipStream_t s, double* A, int64_t lda, int64_t
     if (n <= 0)
         return;
     unsigned t = (unsigned)((n + 31) / 32);
-    hipLaunchKernelGGL(k_symmetrize, dim3(t, t), dim3(256), 0, s, A, lda, n);
+    GPE_LAUNCH(k_symmetrize, dim3(t, t), dim3(256), 0, s, A, lda, n);
 }
 
 __global__ void k_copy2d(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd,
@@ -884,7 +884,7 @@ void launch_copy2d(hipStream_t s, const double* src, int64_t lds_, double* dst, 
     if (rows <= 0 || cols <= 0)
         return;
     unsigned gy = (unsigned)(cols < 65535 ? cols : 65535);
-    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((rows + 255) / 256), gy), dim3(256), 0, s, src, lds_, dst, ldd, rows,
+    GPE_LAUNCH(k_copy2d, dim3((unsigned)((rows + 255) / 256), gy), dim3(256), 0, s, src, lds_, dst, ldd, rows,
                        cols);
 }
 
@@ -908,5 +908,5 @@ __global__ __launch_bounds__(256) void k_append_diag(double* __restrict__ Lrow, 
 }
 void launch_append_diag(hipStream_t s, double* Lrow, int64_t ldl, int64_t n, const double* knn, int* info)
 {
-    hipLaunchKernelGGL(k_append_diag, dim3(1), dim3(256), 0, s, Lrow, ldl, n, knn, info);
+    GPE_LAUNCH(k_append_diag, dim3(1), dim3(256), 0, s, Lrow, ldl, n, knn, info);
 }

@@ -220,18 +220,18 @@ extern "C" int gpe_sparsify(int device_id, const double* X, int64_t N, int D, in
         SCHK(hipMemcpyAsync(dAlive, alive.data(), (size_t)N, hipMemcpyHostToDevice, s));
         SCHK(hipMemcpyAsync(dSt, &h, sizeof(h), hipMemcpyHostToDevice, s));
         const unsigned nt = (unsigned)((N + ST - 1) / ST);
-        hipLaunchKernelGGL(k_dist_matrix, dim3(nt, nt), dim3(256), sizeof(double) * 2 * ST * D, s, dX, N, D, dD, ld);
+        GPE_LAUNCH(k_dist_matrix, dim3(nt, nt), dim3(256), sizeof(double) * 2 * ST * D, s, dX, N, D, dD, ld);
         const dim3 rg((unsigned)((N + 3) / 4));
         for (int64_t it = 0; it < N - max_points; ++it) {
             if (D <= 8)
-                hipLaunchKernelGGL((k_row_density<8>), rg, dim3(256), 0, s, dD, ld, N, D, dAlive, dSt, dSum, dKth);
+                GPE_LAUNCH((k_row_density<8>), rg, dim3(256), 0, s, dD, ld, N, D, dAlive, dSt, dSum, dKth);
             else if (D <= 16)
-                hipLaunchKernelGGL((k_row_density<16>), rg, dim3(256), 0, s, dD, ld, N, D, dAlive, dSt, dSum, dKth);
+                GPE_LAUNCH((k_row_density<16>), rg, dim3(256), 0, s, dD, ld, N, D, dAlive, dSt, dSum, dKth);
             else if (D <= 32)
-                hipLaunchKernelGGL((k_row_density<32>), rg, dim3(256), 0, s, dD, ld, N, D, dAlive, dSt, dSum, dKth);
+                GPE_LAUNCH((k_row_density<32>), rg, dim3(256), 0, s, dD, ld, N, D, dAlive, dSt, dSum, dKth);
             else
-                hipLaunchKernelGGL((k_row_density<64>), rg, dim3(256), 0, s, dD, ld, N, D, dAlive, dSt, dSum, dKth);
-            hipLaunchKernelGGL(k_remove_densest, dim3(1), dim3(1024), 0, s, dSum, N, dAlive, dSt);
+                GPE_LAUNCH((k_row_density<64>), rg, dim3(256), 0, s, dD, ld, N, D, dAlive, dSt, dSum, dKth);
+            GPE_LAUNCH(k_remove_densest, dim3(1), dim3(1024), 0, s, dSum, N, dAlive, dSt);
         }
         SCHK(hipMemcpyAsync(alive.data(), dAlive, (size_t)N, hipMemcpyDeviceToHost, s));
         SCHK(hipStreamSynchronize(s));
