@@ -138,10 +138,11 @@ void gpe_trace_add(const char* name, hipStream_t s, hipEvent_t e0, hipEvent_t e1
 // the same for a launch that signals `stop` (an event of the caller's: the look-ahead's ordering) through its dispatch
 #define GPE_LAUNCH_STOP(name, kern, grid, block, shmem, stream, stop, ...)                                 \
     do {                                                                                                   \
-        if (gpe_trace_on()) {                                                                              \
-            hipEvent_t e0_ = gpe_trace_event();                                                            \
-            hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, e0_, stop, 0, __VA_ARGS__);            \
-            gpe_trace_add(name, stream, e0_, stop, grid, block);                                           \
+        if (gpe_trace_on()) { /* (the caller's event has no timestamps: own events + a marker packet for `stop`) */ \
+            hipEvent_t e0_ = gpe_trace_event(), e1_ = gpe_trace_event();                                   \
+            hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, e0_, e1_, 0, __VA_ARGS__);             \
+            hipEventRecord(stop, stream);                                                                  \
+            gpe_trace_add(name, stream, e0_, e1_, grid, block);                                            \
         }                                                                                                  \
         else                                                                                               \
             hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, nullptr, stop, 0, __VA_ARGS__);        \

@@ -3117,8 +3117,10 @@ int gpe_trace(int on)
     (void)gpe_trace_on();
     hipDeviceSynchronize();
     std::lock_guard<std::mutex> lk(g_trace_mu);
-    for (auto& r : g_trace)
-        g_trace_pool.push_back(r.e0); // (stop events may be the look-ahead's: only the start events go back to the pool)
+    for (auto& r : g_trace) {
+        g_trace_pool.push_back(r.e0);
+        g_trace_pool.push_back(r.e1);
+    }
     g_trace.clear();
     g_trace_state.store(on ? 1 : 0);
     return GPE_OK;
