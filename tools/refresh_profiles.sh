@@ -53,7 +53,7 @@ python tools/make_k64.py > /dev/null
 # stream-k study of the trailing update, the resident small-path workgroup
 python tools/trace_eval.py compute 4096 > $out/${tag}_production_timeline.txt 2> $out/trace.err
 python tools/trace_eval.py hp 4096 > $out/${tag}_production_timeline_hp_objective.txt 2>> $out/trace.err
-make -C tools updbench updbench_t > /dev/null 2>&1
+# (tools/updbench, tools/updbench_t: built where hipcc is, make -C tools updbench updbench_t; the binaries travel with the snapshot)
 { tools/updbench 4096 5; } > $out/${tag}_updbench_trailing_update.log 2>&1
 { tools/updbench_t 4096 2 | head -120; } > $out/${tag}_updbench_stream_k_stamps.log 2>&1
 python tools/srvlat.py > $out/${tag}_small_server_latency_raw.log 2>&1
