@@ -236,8 +236,12 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g);
 // the next-panel update g (as for launch_gemm_sub: C = A[pe:, pe:pe2], k = pe - p0, tri) and, in the same launch, the
 // update + factorisation + half-inversion of the next diagonal block A[pe:pe+64, pe:pe+64] (-> Xt_next)
 // (Dacc: sum of the pieces the panel steps already formed, subtracted as well; p0 == pe: no products here)
+// fold (j4 >= 0): the launch also does the panel's last 64-column step (columns j4 .. j4+63 = pe-64 .. pe-1): g.k covers the
+// panel's first columns only (p0 .. j4-1), L4 = A4 X3^T is formed per tile in LDS and written to the scratch panel L4s
+// ((M - pe) x 64, ld4) instead of A (potrf.hip: UpdFold)
 void launch_upd_fused(hipStream_t s, const GemmArgs& g, double* A, int64_t lda, int64_t p0, int64_t pe, double* Xt_next,
-                      int* info, const double* Dacc);
+                      int* info, const double* Dacc, int64_t j4 = -1, const double* X3 = nullptr, double* L4s = nullptr,
+                      int64_t ld4 = 0);
 double gemm_flops(const GemmArgs& g);
 
 // ---- vector solves, reductions (solve.hip) -----------------------------------------

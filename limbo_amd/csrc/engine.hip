@@ -123,6 +123,8 @@ struct gpe_ctx {
     int handover_off_left = 0;      // ... for this many evaluations only, then it is re-armed (one hiccup is not forever)
     int64_t handover_reruns = 0;    // evaluations re-run after a hand-over timeout (gpe_handover_reruns)
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
+    double* dL4 = nullptr;   // ld x 64: the last 64 columns of a panel's L while the fused next-panel update forms them (fold)
+    bool fold4 = true;       // the panel's last step inside the fused next-panel update (GPE_FOLD4=0: a launch of its own)
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     size_t xp_cap = 0;
     // K^-1 BEHIND the factorisation (gpe_hp_objective with a gradient): panel p of U = L^-T needs only L's panels <= p, so
@@ -308,7 +310,7 @@ void free_dev(gpe_ctx* c)
     }
     c->inv_followed = false;
     double** ps[] = {&c->dXt, &c->dA, &c->dOm, &c->dAl, &c->dW, &c->dY, &c->dLinv, &c->dKinv, &c->dKhost,
-                     &c->dGradPartial, &c->dXinv, &c->dLooS, &c->dLooV};
+                     &c->dGradPartial, &c->dXinv, &c->dLooS, &c->dLooV, &c->dL4};
     for (auto p : ps) {
         if (*p)
             hipFree(*p);
@@ -341,6 +343,7 @@ int alloc_dev(gpe_ctx* c, int64_t cap, int D, int P)
     HIPCHK(c, hipMalloc(&c->dW, sizeof(double) * (size_t)(ld * std::max(P, 1))));
     HIPCHK(c, hipMalloc(&c->dY, sizeof(double) * (size_t)(ld * std::max(P, 1))));
     HIPCHK(c, hipMalloc(&c->dXinv, sizeof(double) * (size_t)(cap / NB) * NB * NB));
+    HIPCHK(c, hipMalloc(&c->dL4, sizeof(double) * (size_t)(ld * NB)));
     HIPCHK(c, hipMemsetAsync(c->dXinv, 0, sizeof(double) * (size_t)(cap / NB) * NB * NB, c->stream));
     HIPCHK(c, hipMemsetAsync(c->dXt, 0, sizeof(double) * (size_t)(ld * xt_rows(D)), c->stream));
     return GPE_OK;
@@ -362,6 +365,10 @@ int grow_dev(gpe_ctx* c, int64_t need)
     HIPCHK(c, hipMalloc(&nAl, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nW, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nY, sizeof(double) * (size_t)(nld * P)));
+    if (c->dL4)
+        hipFree(c->dL4);
+    c->dL4 = nullptr;
+    HIPCHK(c, hipMalloc(&c->dL4, sizeof(double) * (size_t)(nld * NB)));
     HIPCHK(c, hipMalloc(&nXi, sizeof(double) * (size_t)(ncap / NB) * NB * NB));
     HIPCHK(c, hipMemsetAsync(nXi, 0, sizeof(double) * (size_t)(ncap / NB) * NB * NB, c->stream));
     HIPCHK(c, hipMemsetAsync(nXt, 0, sizeof(double) * (size_t)(nld * xt_rows(D)), c->stream));
@@ -542,6 +549,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
         const bool fuse_diag = c->lookahead && !c->prof && std::min<int64_t>(pe + nbo, N) < N && c->fuse_panel && c->fuse_diag
             && c->stop_events && pw == nbo && nbo % NB == 0 && nbo >= 2 * NB && ld % 2 == 0
             && std::min<int64_t>(nbo, N - pe) % NB == 0;
+        const bool fold_last = fuse_diag && c->fold4 && c->dL4 && nbo == 4 * NB && c->panel_handover && !g_batch.bt;
         for (int64_t j0 = p0; j0 < pe; j0 += NB) {
             const int jb = (int)std::min<int64_t>(NB, pe - j0);
             const int64_t r0 = j0 + jb;
@@ -554,6 +562,12 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 launch_diag(s, A + j0 + j0 * ld, ld, jb, Xt, c->dInfo, j0, fuse ? 1 : 0);
             }
             diag_done = false;
+            // the panel's last step (nothing left to update, no diagonal block to factor) rides in the fused next-panel
+            // update when that follows (potrf.hip: UpdFold)
+            if (fuse && fold_last && nt == 0 && j0 == pe - NB) {
+                diag_done = false;
+                continue;
+            }
             if (fuse) {
                 PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - r0) * NB * NB * (1 + nt));
                 if (nf == 0)
@@ -673,8 +687,14 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                     g.grow0 = pe;
                     g.gcol0 = pe;
                     g.stop_event = ev(3 * kp);
-                    launch_upd_fused(s, g, A, ld, pe, pe, c->dXinv + (pe / NB) * (NB * NB), c->dInfo,
-                                     c->dHead + 64 * NB * NB); // the steps summed the pieces: no products here
+                    if (fold_last) {
+                        g.k = pw - NB; // the panel's first three column blocks through the direct-to-LDS loop, the last from LDS
+                        launch_upd_fused(s, g, A, ld, pe, pe, c->dXinv + (pe / NB) * (NB * NB), c->dInfo, c->dHead + 64 * NB * NB,
+                                         pe - NB, c->dXinv + ((pe - NB) / NB) * (NB * NB), c->dL4, ld);
+                    }
+                    else
+                        launch_upd_fused(s, g, A, ld, pe, pe, c->dXinv + (pe / NB) * (NB * NB), c->dInfo,
+                                         c->dHead + 64 * NB * NB); // the steps summed the pieces: no products here
                     next_diag_done = true;
                 }
                 else if (c->stop_events)
@@ -695,6 +715,8 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                     launch_xinv_complete(c->stream2, A, ld, p0 / NB, pw / NB, c->dXinv); // off the critical path
                     c->xinv_done = pe / NB;
                 }
+                if (fuse_diag && fold_last) // the panel's last 64 columns of L, formed by the fused update: into place
+                    launch_copy2d(c->stream2, c->dL4, ld, A + pe + (pe - NB) * ld, ld, M - pe, NB);
                 const int64_t pe3 = std::min<int64_t>(pe2 + nbo, N);
                 upd(c->stream2, pe2, pe3, pe2, c->near_wgs >= 0 ? c->near_wgs : c->bulk_wgs, nullptr, 64); // near: what panel kp + 1's update needs
                 hipEventRecord(ev(3 * kp + 1), c->stream2);
@@ -1550,6 +1572,8 @@ int gpe_create(int device_id, gpe_handle* out)
         c->bulk_free_tiles = atoll(f);
     if (const char* f = getenv("GPE_FUSE_DIAG"))
         c->fuse_diag = atoi(f) != 0;
+    if (const char* f = getenv("GPE_FOLD4"))
+        c->fold4 = atoi(f) != 0;
     if (const char* f = getenv("GPE_STOP_EVENT"))
         c->stop_events = atoi(f) != 0;
     if (const char* f = getenv("GPE_LOOKAHEAD"))

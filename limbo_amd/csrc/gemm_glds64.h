@@ -205,9 +205,16 @@ struct WaveTileC {
 // conflict-free.
 // skip00: leave tile (0, 0) alone (the fused next-panel update: that tile is the next diagonal block, which the
 // extra workgroup of the same launch updates and factors — potrf.hip:k_upd_fused)
-template <int BKT, int NST, int NWV>
+// hooks of the body (potrf.hip: the next-panel update that also does the panel's last step): `pre` runs once the tile is
+// known, before the first operand stage is requested; `post` gets the accumulators after the k loop, before the epilogue
+struct Glds64NoHook {
+    __device__ __forceinline__ void pre(int, int, int64_t, int64_t, int, int) const {}
+    template <int RA_, int RB_>
+    __device__ __forceinline__ void post(double (&)[RA_][RB_], int, int) const {}
+};
+template <int BKT, int NST, int NWV, class HOOK = Glds64NoHook>
 static __device__ __forceinline__ void gemm_glds64_body(const GemmArgs& g, double* __restrict__ lds, int first_wg, int n_wg,
-                                                        bool skip00)
+                                                        bool skip00, const HOOK& hook = HOOK())
 {
     constexpr int TM = 64, TN = 64;
     static_assert(NWV == 4 || NWV == 8, "2 x 2 waves of 32 x 32 or 2 x 4 waves of 32 x 16");
@@ -269,6 +276,7 @@ static __device__ __forceinline__ void gemm_glds64_body(const GemmArgs& g, doubl
             rb = rb < mb ? rb : mb;
         }
         const int khalf = lane >> 5;
+        hook.pre(ti, tj, row0, col0, mr, nc);
         const double* pa = g.A + row0 + ra + (int64_t)(2 * wave + khalf) * g.lda;
         const double* pb = g.B + col0 + rb + (int64_t)(2 * wave + khalf) * g.ldb;
         // wave w moves pairs w, w + NWV, .. of each operand
@@ -336,6 +344,7 @@ static __device__ __forceinline__ void gemm_glds64_body(const GemmArgs& g, doubl
             __builtin_amdgcn_s_barrier(); // stage st may be refilled
         }
         GTS64_(17);
+        hook.post(acc, wm, wn);
 
         {
             using WT = WaveTileC<RA, RB>;

@@ -1112,15 +1112,84 @@ __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, in
 // k_diag used to follow the update as a launch of its own (13.6 us on the critical path of every
 // outer panel, with 255 CUs idle); here it runs underneath the update (~18 us).
 // ---------------------------------------------------------------------------------------------
+// Round 3 — `fold` (j4 >= 0): the launch also does the panel's LAST 64-column step.  That step (k_panel_step with nt = 0) only
+// solves L4 = A4 X3^T for the rows below the panel — 9.7 us of kernel plus a launch boundary on the critical path of every panel,
+// with nothing to update and no diagonal block to factor.  Here every tile workgroup forms the two L4 tiles it needs itself
+// (its row block's and its column block's: one 64^3 product each with X3 = inverse of the panel's last diagonal block, from
+// k_panel_step's third step), multiplies the first 192 columns of the panel through the direct-to-LDS loop as before and the
+// last 64 from those tiles in LDS.  The row block's L4 goes out to a scratch panel L4s (the workgroups of its tile column 0
+// write it): in place it would be read, as A4, by the workgroups of other tile rows of this same launch; the look-ahead
+// stream copies it into A in front of its updates.  The diagonal workgroup adds the L4 L4^T piece of ITS block itself.
+struct UpdFold {
+    const double* A; // the matrix (rows from pe on are the tile rows of this launch)
+    int64_t lda, pe, j4;
+    const double* X3; // Xt[k + 64 c] = (L33^-1)[c][k]
+    double* L4s;      // scratch panel, (M - pe) x 64, leading dimension ld4
+    int64_t ld4;
+    double* T1;       // LDS: this tile's row block of L4, [kk][i], stride PS
+    double* T2;       // LDS: its column block's
+    double* Bx;       // LDS (inside the operand stages, before they are requested): X3 as Bx[c * XS + k]
+    mutable bool same;
+    __device__ __forceinline__ void pre(int ti, int tj, int64_t row0, int64_t col0, int mr, int nc) const
+    {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        same = ti == tj;
+        TileRegs ta, tb;
+        ta.load(A + pe + row0 + j4 * lda, lda, mr);
+        if (!same)
+            tb.load(A + pe + col0 + j4 * lda, lda, nc);
+        double xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            xv[q] = X3[threadIdx.x + 512 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = threadIdx.x + 512 * q;
+            Bx[(e >> 6) * XS + (e & 63)] = xv[q]; // Bx[c][k] = X[c][k]
+        }
+        ta.store(T1);
+        if (!same)
+            tb.store(T2);
+        __syncthreads();
+        trsm_tile_full(T1, Bx, lane, wave);
+        if (!same)
+            trsm_tile_full(T2, Bx, lane, wave);
+        if (tj == 0) { // this row block's piece of the panel's last 64 columns of L
+            const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int col = kk0 + 8 * q;
+                if (i < mr)
+                    L4s[row0 + i + (int64_t)col * ld4] = T1[col * PS + i];
+            }
+        }
+        __syncthreads(); // Bx (inside the operand stages) is dead from here on
+    }
+    template <int RA_, int RB_>
+    __device__ __forceinline__ void post(double (&acc)[RA_][RB_], int wm, int wn) const
+    {
+        static_assert(RA_ == 2 && RB_ == 4, "the 8-wave 64 x 64 body");
+        mm64<false>(T1, same ? T1 : T2, wm, wn, threadIdx.x & 63, acc);
+    }
+};
+
 __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restrict__ A, int64_t lda, int64_t p0, int64_t pe,
                                                    double* __restrict__ Xt_next, int* __restrict__ info,
-                                                   const double* __restrict__ Dacc)
+                                                   const double* __restrict__ Dacc, int64_t j4, const double* __restrict__ X3,
+                                                   double* __restrict__ L4s, int64_t ld4)
 {
     constexpr int GEMM_LDS = 4 * Glds64Shape<16>::STAGE, DIAG_LDS = 2 * NB * PS;
-    __shared__ __attribute__((aligned(16))) double lds[GEMM_LDS > DIAG_LDS ? GEMM_LDS : DIAG_LDS];
+    static_assert(NB * XS <= GEMM_LDS, "X3 fits into the operand stages");
+    __shared__ __attribute__((aligned(16))) double lds[GEMM_LDS + 2 * NB * PS]; // [4 stages | T1 | T2] (T1, T2: fold only)
+    static_assert(GEMM_LDS + 2 * NB * PS >= DIAG_LDS, "the diagonal workgroup carves its tiles out of the same array");
     __shared__ int sbad;
     if (blockIdx.x + 1 < gridDim.x) {
-        gemm_glds64_body<16, 4, 8>(g, lds, (int)blockIdx.x, (int)gridDim.x - 1, true);
+        if (j4 >= 0) {
+            UpdFold h{A, lda, pe, j4, X3, L4s, ld4, lds + GEMM_LDS, lds + GEMM_LDS + NB * PS, lds, false};
+            gemm_glds64_body<16, 4, 8, UpdFold>(g, lds, (int)blockIdx.x, (int)gridDim.x - 1, true, h);
+        }
+        else
+            gemm_glds64_body<16, 4, 8>(g, lds, (int)blockIdx.x, (int)gridDim.x - 1, true);
         return;
     }
     // ---- the diagonal workgroup ----
@@ -1147,6 +1216,32 @@ __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restric
 #pragma unroll
         for (int n = 0; n < 4; ++n)
             acc[m][n] = 0.0;
+    if (j4 >= 0) { // fold: the piece of the panel's last step, L4 L4^T with L4 = A4 X3^T for this block's rows
+        TileRegs t4;
+        t4.load(A + pe + j4 * lda, lda, NB);
+        double xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            xv[q] = X3[threadIdx.x + 512 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = threadIdx.x + 512 * q;
+            T1[(e >> 6) * XS + (e & 63)] = xv[q]; // (T1 as Bx: 64 x XS <= 64 x PS)
+        }
+        t4.store(T0);
+        __syncthreads();
+        trsm_tile_full(T0, T1, lane, wave);
+        mm64<false>(T0, T0, wm, wn, lane, acc);
+        { // tile (0, 0) has no workgroup of its own: this block's rows of the panel's last 64 columns of L go out from here
+            const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int col = kk0 + 8 * q;
+                L4s[i + (int64_t)col * ld4] = T0[col * PS + i];
+            }
+        }
+        __syncthreads();
+    }
 #pragma unroll 1
     for (int c = 0; c < nkb; ++c) { // two tiles alternate: a wave that refills one has passed the barrier behind its last readers
         double* T = (c & 1) ? T1 : T0;
@@ -1211,7 +1306,7 @@ __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restric
 
 // g: the next-panel update as for launch_gemm_sub (tri, 64-multiple shapes checked by the caller)
 void launch_upd_fused(hipStream_t s, const GemmArgs& g0, double* A, int64_t lda, int64_t p0, int64_t pe, double* Xt_next,
-                      int* info, const double* Dacc)
+                      int* info, const double* Dacc, int64_t j4, const double* X3, double* L4s, int64_t ld4)
 {
     constexpr int TM = 64, TN = 64;
     GemmArgs g = g0;
@@ -1229,9 +1324,9 @@ void launch_upd_fused(hipStream_t s, const GemmArgs& g0, double* A, int64_t lda,
     g.total = nsup * fold;
     const dim3 grid((unsigned)g.total + 1), block(512);
     if (g.stop_event)
-        GPE_LAUNCH_STOP("k_upd_fused", k_upd_fused, grid, block, 0, s, (hipEvent_t)g.stop_event, g, A, lda, p0, pe, Xt_next, info, Dacc);
+        GPE_LAUNCH_STOP("k_upd_fused", k_upd_fused, grid, block, 0, s, (hipEvent_t)g.stop_event, g, A, lda, p0, pe, Xt_next, info, Dacc, j4, X3, L4s, ld4);
     else
-        GPE_LAUNCH(k_upd_fused, grid, block, 0, s, g, A, lda, p0, pe, Xt_next, info, Dacc);
+        GPE_LAUNCH(k_upd_fused, grid, block, 0, s, g, A, lda, p0, pe, Xt_next, info, Dacc, j4, X3, L4s, ld4);
 }
 
 #ifdef DIAG_TIMING
