@@ -341,11 +341,17 @@ def test_gpu_panel_head_tiles_handed_over_or_rederived_give_the_same_factor(engi
             "assert h.compute() == 0\n"
             "np.save(%r, np.tril(h.get_L()))\n"
             "print('child ok')\n") % (str(ROOT), N, str(f))
-    env = dict(os.environ, GPE_PANEL_HANDOVER="0")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
-    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    L0 = np.load(f)
-    assert np.array_equal(L0, L1), float(np.max(np.abs(L0 - L1)))
+    Ls = {}
+    for tag, extra in (("no_handover", {"GPE_PANEL_HANDOVER": "0"}), ("handover_unfolded", {"GPE_FOLD4": "0"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+        assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+        Ls[tag] = np.load(f)
+    # handed over or re-derived: the same products in the same order, bitwise the same factor
+    assert np.array_equal(Ls["no_handover"], Ls["handover_unfolded"]), float(np.max(np.abs(Ls["no_handover"] - Ls["handover_unfolded"])))
+    # the default folds the panel's last step into the fused next-panel update (potrf.hip: UpdFold): the last 64 columns of a
+    # panel enter that update from LDS tiles instead of through the direct-to-LDS loop — another grouping of the same sum
+    assert np.max(np.abs(Ls["no_handover"] - L1)) <= 1e-13 * np.max(np.abs(L1))
 
 
 def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib):
@@ -372,7 +378,8 @@ def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib):
     env = dict(os.environ, GPE_HANDOVER_FAULT="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    assert float(r.stdout.split("child ok")[1]) == ll
+    # the re-run factorises without the hand-over and hence without the folded last step (round 3): the same factor to rounding
+    assert abs(float(r.stdout.split("child ok")[1]) - ll) <= 1e-13 * abs(ll)
 
 
 @pytest.mark.parametrize("kind,D,P,lam", [(O.SE_ARD, 6, 1, 0), (O.MATERN52, 3, 2, 0), (O.SE_ARD, 4, 3, 1), (O.EXP, 2, 1, 0)])

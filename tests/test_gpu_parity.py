@@ -487,7 +487,7 @@ def _small_parity(engine_lib, oracle_lib, N=300, D=3, P=2, seed=0):
 
 
 @pytest.mark.parametrize("env", [{"GPE_FLOW_SOLVE": "0"}, {"GPE_LOOKAHEAD": "0"}, {"GPE_FUSE_PANEL": "0"},
-                                 {"GPE_FUSE_DIAG": "0", "GPE_STOP_EVENT": "0"}, {"GPE_NBO": "192"}],
+                                 {"GPE_FUSE_DIAG": "0", "GPE_STOP_EVENT": "0"}, {"GPE_NBO": "192"}, {"GPE_FOLD4": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_alternate_schedules(engine_lib, oracle_lib, monkeypatch, env):
     """The switches read when a handle is created select the schedules that also serve as fall-backs (per-block
@@ -498,19 +498,36 @@ def test_gpu_alternate_schedules(engine_lib, oracle_lib, monkeypatch, env):
     _small_parity(engine_lib, oracle_lib, N=520, seed=len(env))
 
 
-def test_gpu_process_wide_switches():
-    """GPE_QUERY_SWEEP / GPE_INV_PANELS are read once per process: run the same parity check in a child."""
+@pytest.mark.parametrize("env", [{"GPE_QUERY_SWEEP": "0", "GPE_INV_PANELS": "0"}, {"GPE_QUERY_T": "0", "GPE_INV_OVERLAP": "0"},
+                                 {"GPE_RHS_FMA": "2"}, {"GPE_RHS_FMA": "0", "GPE_INV_FOLLOW": "1"}, {"GPE_SMALL_SERVER": "1"}],
+                         ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
+def test_gpu_process_wide_switches(env):
+    """Switches that are read once per process (the blocked point-query solve, the in-panel substitution chain for K^-1; round 3:
+    the sample-contiguous batched queries, K^-1's product after its chain, right-hand-side rows always / never as FMAs,
+    the K^-1 chain behind the factorisation, the resident small-path workgroup): the same parity checks in a child, at a size
+    with seven outer panels (N = 1700: look-ahead, fused updates with the folded last step, ragged last panel) and, for the
+    hyper-parameter objective, through gpe_hp_objective."""
     import os
     import subprocess
     import sys
     code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
             "from limbo_amd import _capi\n"
             "from oracle import binding as OB\n"
             "from tests.test_gpu_parity import _small_parity\n"
-            "_small_parity(_capi.load_engine(), OB.load_oracle(), N=520, seed=7)\n"
+            "from tests.util import relerr_norm\n"
+            "eng, orc = _capi.load_engine(), OB.load_oracle()\n"
+            "_small_parity(eng, orc, N=520, seed=7)\n"
+            "_small_parity(eng, orc, N=1700, D=4, P=1, seed=8)\n"
+            "_small_parity(eng, orc, N=150, D=3, P=1, seed=9)\n"
+            "rng = np.random.default_rng(3); X = rng.uniform(0, 1, (1792, 5)); om = np.cos(X.sum(1))[:, None] - 0.1\n"
+            "res = []\n"
+            "for lib in (eng, orc):\n"
+            "    h = _capi.Handle(lib); h.set_data(X, om)\n"
+            "    res.append(h.hp_objective(0, rng.uniform(-0.2, 0.2, 6) * 0 + 0.1, 0.01, optimize_noise=True, want_grad=True)); h.close()\n"
+            "assert abs(res[0][0] - res[1][0]) <= 1e-10 * abs(res[1][0]) and relerr_norm(res[0][1], res[1][1]) < 1e-6\n"
             "print('child ok')\n") % str(ROOT)
-    env = dict(os.environ, GPE_QUERY_SWEEP="0", GPE_INV_PANELS="0")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
 
 
