@@ -36,6 +36,29 @@ struct DiagSync {
 // the inverse's LDS work area Xw: X11 | X22 | W = L21 X11, 32 x 32 each, row-major with stride XH
 #define XH 34
 #define DIAG_XW_DOUBLES (3 * 32 * XH)
+// X leaves with device-scope (write-through) stores: k_panel256's other workgroups read it DURING the launch, possibly behind
+// another XCD's L2 (potrf.hip); for the launches that hand X to the next launch it makes no difference
+#define DIAG_XT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// Optional early hand-over of the inverse to ANOTHER workgroup of the same launch (k_panel256's next factoring strip):
+//   f_early <- epoch once X11 (Xt) and L21 (L21s[c + 32 k] = L[32 + c][k]) are out and acknowledged — half-way through the block;
+//   f_x22   <- epoch once X22 (Xt) is — ~0.4 us before the update waves finish X21 and well before a barrier could say so.
+// With these the consumer solves in the half-block form (Y1 = T1 X11^T, T2 -= Y1 L21^T early; Y2 = T2 X22^T at the end) and
+// three quarters of its solve overlap with this factorisation.
+typedef unsigned long long diag_epoch_t;
+struct DiagEarly {
+    bool xearly, mute;     // xearly: raise f_early / f_x22; mute (test hook): raise no flag at all
+    double* L21s;
+    diag_epoch_t *f_early, *f_x22;
+    diag_epoch_t epoch;
+    // The last 32 columns of the caller's own 64 x 64 tile in LDS (Lt[col * lts + row], outside the factorisation's work area)
+    // leave under the factorisation too: write-through to Lh (ld 64), then f_head <- epoch (the first 32 went out earlier and are
+    // acknowledged).  The eighth wave has nothing to do until X11 is complete.
+    const double* Lt;
+    int lts;
+    double* Lh;
+    diag_epoch_t* f_head;
+};
 
 static __device__ __forceinline__ int lds_peek(const int* p)
 {
@@ -353,10 +376,10 @@ struct FlowX {
             q[i] = v2d_t{x0, x1}; // (defined for the asm operands)
         xfold_issue<i0 + 4, (nrow > XFOLD_CH ? XFOLD_CH : nrow)>(q, lbase);
         if (h == 0) { // rows base+i0 .. +3 of X are final: Xt[col + 64 row] = X[row][col]
-            Xt[base + c + NB * (base + i0 + 0)] = x0;
-            Xt[base + c + NB * (base + i0 + 1)] = x1;
-            Xt[base + c + NB * (base + i0 + 2)] = x2;
-            Xt[base + c + NB * (base + i0 + 3)] = x3;
+            DIAG_XT_STORE(Xt + base + c + NB * (base + i0 + 0), x0);
+            DIAG_XT_STORE(Xt + base + c + NB * (base + i0 + 1), x1);
+            DIAG_XT_STORE(Xt + base + c + NB * (base + i0 + 2), x2);
+            DIAG_XT_STORE(Xt + base + c + NB * (base + i0 + 3), x3);
             double* xh = Xw + hb * (32 * XH) + i0 * XH + c; // and into LDS, for the off-diagonal quarter (flow_x21)
             xh[0] = x0;
             xh[XH] = x1;
@@ -381,9 +404,42 @@ struct FlowX<-1> {
 // product (trsm_tile_full, potrf.hip).  Here: W = L21 X11 by the eighth wave while the second half of the block is still being
 // factored, X21 = -X22 W by the four update waves once X22 is complete — 32 matrix-core instructions each, ~1 k cycles behind
 // the inversion wave.  mfma4 layouts as in mm16 / st16 (potrf.hip).
-static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* sy, double* Xw, int lane)
+static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* sy, double* Xw, int lane,
+                                                   double* __restrict__ Xt, const DiagEarly* ea)
 {
+    if (ea && ea->Lt) { // (the copy into the matrix itself, which nobody reads during the launch, is the caller's business)
+        const double* Lt = ea->Lt;
+        double* Lh = ea->Lh;
+        const int lts = ea->lts;
+#pragma unroll
+        for (int c0 = NB / 2; c0 < NB; c0 += 16) { // 16 LDS reads in flight, then their 16 stores
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = Lt[(c0 + j) * lts + lane];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                DIAG_XT_STORE(Lh + lane + NB * (c0 + j), v[j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && !ea->mute)
+            __hip_atomic_store(ea->f_head, ea->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     lds_await(&sy->xprog, 8);
+    if (ea && ea->xearly) { // X11 is complete in Xw, L21 in Ls (prog >= 8: the inversion wave is one round behind P): both go out from here,
+              // this wave waits for ITS stores only and raises the flag (the inversion wave's own stores of X11 may still be
+              // on their way: the same values to the same addresses)
+        lds_await(&sy->prog, 8);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = lane + 64 * i, hi = e >> 5, lo = e & 31;
+            DIAG_XT_STORE(Xt + lo + NB * hi, Xw[hi * XH + lo]);          // Xt[col + 64 row] = X11[row][col]
+            DIAG_XT_STORE(ea->L21s + e, Ls[(32 + lo) * XS + hi]);        // L21s[c + 32 k] = L[32 + c][k]
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && !ea->mute)
+            __hip_atomic_store(ea->f_early, ea->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ... and not before panel 10 is out: this wave shares its SIMD with update wave U2, which hands groups 8..11 to P in
     // rounds 6..9 — started at round 8 its matrix-core instructions delayed those hand-overs and P with them (round 10:
     // 1.6 k cycles instead of 1.0 k, r02_diag_flow_stamps.log of that build).  Three rounds are enough for W.
@@ -452,7 +508,7 @@ static __device__ __forceinline__ void flow_x21(DiagSync* sy, const double* Xw, 
     for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
         for (int j = 0; j < 2; ++j) // Xt[col + 64 row] = X[row][col]
-            Xt[4 * (2 * u + j) + col + NB * (32 + 16 * sl + row)] = acc[sl][j];
+            DIAG_XT_STORE(Xt + 4 * (2 * u + j) + col + NB * (32 + 16 * sl + row), acc[sl][j]);
 }
 
 // ---- S ---------------------------------------------------------------------------------------------------------------------
@@ -500,13 +556,13 @@ static __device__ __forceinline__ void diag_flow_init(DiagSync* sy)
 static __device__ __forceinline__ void diag_flow(double* Ls, double* H, double* invd,
                                                  DiagSync* sy, double* __restrict__ Ad, int64_t lda,
                                                  double* __restrict__ Xt, int* __restrict__ info, int64_t goff, int wave,
-                                                 int lane, double* Xw)
+                                                 int lane, double* Xw, const DiagEarly* ea = nullptr)
 {
     if (wave >= 8)
         return; // s_barrier only counts the waves that are still alive
     if (wave == 7) {
         __syncthreads();
-        flow_w_wave(Ls, sy, Xw, lane);
+        flow_w_wave(Ls, sy, Xw, lane, Xt, ea);
         return;
     }
     if (wave >= 1 && wave <= 4) {
@@ -536,6 +592,11 @@ static __device__ __forceinline__ void diag_flow(double* Ls, double* H, double* 
         for (int k = 0; k < 32; ++k)
             S[k] = (lane < 32 && k == lane) ? 1.0 : 0.0;
         FlowX<15>::run(S, Ls, invd, Xt, sy, Xw, lane & 31, lane >> 5);
+        if (ea && ea->xearly) { // X22's last rows are this wave's last stores
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && !ea->mute)
+                __hip_atomic_store(ea->f_x22, ea->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     int bad = 0;

@@ -124,6 +124,7 @@ struct gpe_ctx {
     int64_t handover_reruns = 0;    // evaluations re-run after a hand-over timeout (gpe_handover_reruns)
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     double* dL4 = nullptr;   // ld x 64: the last 64 columns of a panel's L while the fused next-panel update forms them (fold)
+    bool panel256 = true;    // all steps of a 256-column outer panel in one data-flow launch (GPE_PANEL256=0: step by step)
     bool fold4 = true;       // the panel's last step inside the fused next-panel update (GPE_FOLD4=0: a launch of its own)
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     size_t xp_cap = 0;
@@ -549,8 +550,21 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
         const bool fuse_diag = c->lookahead && !c->prof && std::min<int64_t>(pe + nbo, N) < N && c->fuse_panel && c->fuse_diag
             && c->stop_events && pw == nbo && nbo % NB == 0 && nbo >= 2 * NB && ld % 2 == 0
             && std::min<int64_t>(nbo, N - pe) % NB == 0;
-        const bool fold_last = fuse_diag && c->fold4 && c->dL4 && nbo == 4 * NB && c->panel_handover && !g_batch.bt;
-        for (int64_t j0 = p0; j0 < pe; j0 += NB) {
+        // the whole panel in one launch (potrf.hip: k_panel256): full 256 columns, head tiles and block inverses handed over
+        // between its workgroups
+        const bool p256 = c->panel256 && c->fuse_panel && c->panel_handover && !g_batch.bt && nbo == 4 * NB && pw == nbo && pe <= M;
+        const bool fold_last = !p256 && fuse_diag && c->fold4 && c->dL4 && nbo == 4 * NB && c->panel_handover && !g_batch.bt;
+        if (p256) {
+            double* Xt = c->dXinv + (p0 / NB) * (NB * NB);
+            if (!diag_done) {
+                PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)NB * NB * NB);
+                launch_diag(s, A + p0 + p0 * ld, ld, NB, Xt, c->dInfo, p0, 1);
+            }
+            PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - p0 - NB) * NB * NB * 2.5 * 4);
+            launch_panel256(s, A, ld, p0, M, Xt, c->dInfo, Hbase, fuse_diag ? pe : -1, c->dHead + 64 * NB * NB,
+                            (gpe_epoch_t*)(c->dHead + 65 * NB * NB) + ((p0 / nbo) & 1) * 32);
+        }
+        for (int64_t j0 = p0; j0 < pe && !p256; j0 += NB) {
             const int jb = (int)std::min<int64_t>(NB, pe - j0);
             const int64_t r0 = j0 + jb;
             double* Xt = c->dXinv + (j0 / NB) * (NB * NB);
@@ -1574,6 +1588,8 @@ int gpe_create(int device_id, gpe_handle* out)
         c->fuse_diag = atoi(f) != 0;
     if (const char* f = getenv("GPE_FOLD4"))
         c->fold4 = atoi(f) != 0;
+    if (const char* f = getenv("GPE_PANEL256"))
+        c->panel256 = atoi(f) != 0;
     if (const char* f = getenv("GPE_STOP_EVENT"))
         c->stop_events = atoi(f) != 0;
     if (const char* f = getenv("GPE_LOOKAHEAD"))

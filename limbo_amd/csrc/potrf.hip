@@ -50,8 +50,11 @@ __device__ long long g_diag_ts[32];
 #ifdef DIAG_TIMING
 __device__ long long g_panel_ts[64];
 #define PTS(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_panel_ts[(blockIdx.x == 0 ? 0 : 32) + (i)] = clock64(); } while (0)
+__device__ long long g_p256_ts[5][32]; // k_panel256: strips 0..3 and the last one; [6 S + i] = stamp i of step S, [30] start, [31] end
+#define P2TS(i) do { if (threadIdx.x == 0 && (blockIdx.x < 4 || blockIdx.x == gridDim.x - 1)) g_p256_ts[blockIdx.x < 4 ? blockIdx.x : 4][(i)] = wall_clock64(); } while (0)
 #else
 #define PTS(i) do { } while (0)
+#define P2TS(i) do { } while (0)
 #endif
 #define XS 66 // LDS row stride (doubles) of the 64 x 64 work matrices: conflict-free MFMA operand reads
 
@@ -1104,6 +1107,449 @@ __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_panel256 (round 3) — ALL 64-column steps of a 256-column outer panel in ONE launch, as data flow between the
+// workgroups.  The step-by-step form pays, per step, a launch boundary plus the serial sequence
+//   [diagonal block | head tiles | everybody's solve | everybody's updates]
+// (21 + 20 + 19 us for the three steps of a panel at N = 4096 and ~3 us between launches), although the only true chain is
+//   X_s -> L(s, s) = A(s, s) X_s^T -> A(s, s+1) -= L L^T -> factor -> X_{s+1}                (~12 us per step).
+// Here workgroup b owns the 64-row strip R_b = rows p0 + 64 (b + 1) .. +63 of the panel for the whole launch and keeps its
+// (up to four) 64 x 64 tiles in REGISTERS between the steps: every tile is read once and written once, as L.
+//   step s (column block s of the panel), strips b >= s:
+//     wait for X_s (s = 0: the diagonal block at p0 was factored by the launch before; s > 0: flag word xs)  ->  L_bs = A_bs X_s^T
+//     strips b <= 2 publish L_bs (a "head tile": the rows of column block b + 1) through Hs + a flag word, as k_panel_step does
+//     A_bc -= L_bs L_{c-1,s}^T for the strip's remaining column blocks c = s+1 .. min(3, b+1)
+//     strip b = s now holds the finished diagonal block of column block s + 1: it factors it (diag_flow), X_{s+1} goes out
+//       with write-through stores, then the flag — and the strip is done.
+// A strip only ever waits for lower-numbered strips (X_s comes from strip s - 1 <= b - 1, head tiles from strips < b), so
+// with workgroups dispatched in index order nobody waits for a workgroup that is not running (dev.h, requirement (1));
+// the polls are bounded all the same and a timeout is reported exactly like k_panel_step's (info[2], the host re-runs).
+// dnext >= 0: the strip of rows dnext (the next panel's first diagonal block) also leaves sum_s L_bs L_bs^T in Dacc for
+// k_upd_fused.  Full 64-column blocks, nbo = 256 only; everything else goes the step-by-step way.
+// ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void p256_wait(const gpe_epoch_t* w, gpe_epoch_t epoch, int spin_limit, int* __restrict__ info, int lane)
+{
+    int spins = 0;
+    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+        if (++spins > spin_limit) {
+            if (lane == 0)
+                info[2] = 1;
+            break;
+        }
+    asm volatile("" ::: "memory"); // what the flag guards is loaded behind the poll (the hardware returns a wave's loads in order)
+}
+// flag words: fl[s - 1] = X_s is out (s = 1..3); fl[3 + h] = head tile h, h = P256_H(s, t) for strip t at step s (t = s..2);
+// fl[8 + s] = X11 and L21 of diagonal block s are out, fl[11 + s] = X22 is (s = 1..3; diag_flow.h: DiagEarly).  Hs: tiles 0..5
+// the head tiles, tile 5 + s the L21 quarter of diagonal block s.
+#define P256_H(s, t) ((s) == 0 ? (t) : ((s) == 1 ? 2 + (t) : 5))
+
+struct P256 {
+    double* A;
+    int64_t lda, p0, R0;
+    double* Xt;
+    int* info;
+    double* Hs;
+    gpe_epoch_t* fl;
+    gpe_epoch_t epoch;
+    int spin_limit, nrows;
+    bool mute, want_d;
+    double *Bx, *T0, *T1, *T2;
+};
+
+// The strip that factors next solves against the block inverse in the half-block form, in two phases: three quarters of its
+// solve and half of its one update run while the previous strip is still factoring (X11 and L21 of that block leave it half-way
+// through, diag_flow.h: DiagEarly); what is left behind the arrival of X22 is one 64 x 32 x 32 product and the other half of the
+// update.  T (64 x 64, [kk][i], stride PS) <- own L^-T; acc += (own L^-T)(own L^-T)^T over both halves of k.
+template <int S>
+static __device__ __forceinline__ void p256_chain_solve(const P256& x, double* __restrict__ T, double* __restrict__ Ld,
+                                                        const double (&own)[8], double (&a2)[2][4])
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16; // the 64 x 64 product's wave tile
+    const int hn = (wave >> 1) * 8;                        // the half-block products': column within the 32-column half
+    const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+    double* Bx = x.Bx;
+    const double* Xs = x.Xt + S * (NB * NB);
+    const double* L21s = x.Hs + (int64_t)(5 + S) * (NB * NB);
+    P2TS(6 * S + 0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        T[(ccol + 2 * it) * PS + crow] = own[it];
+    // ---- phase A: behind the early flag ----
+    p256_wait(x.fl + 8 + S, x.epoch, x.spin_limit, x.info, lane);
+    P2TS(6 * S + 1);
+    {
+        double xa[2], la[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = threadIdx.x + 512 * q; // e = k + 32 c
+            xa[q] = __hip_atomic_load(Xs + (e & 31) + NB * (e >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // X11[c][k]
+            la[q] = __hip_atomic_load(L21s + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // e = c + 32 k
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = threadIdx.x + 512 * q;
+            Bx[(e >> 5) * XS + (e & 31)] = xa[q];
+            Ld[(e & 31) * XS + (e >> 5)] = la[q]; // Ld[c][k] = L21[c][k]
+        }
+    }
+    __syncthreads();
+    double y1[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    mmk<true, 32, 2>(T, 0, Bx, 0, wm, hn, lane, y1); // Y1 = T1 X11^T
+    __syncthreads();                                 // all reads of T[:, 0:32] done
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            T[(hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y1[m][n];
+    __syncthreads();
+    double u[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    mmk<true, 32, 2>(T, 0, Ld, 0, wm, hn, lane, u); // Y1 L21^T
+    double t2[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            t2[m][n] = T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] - u[m][n];
+    __syncthreads(); // every wave has read its part of T[:, 32:64]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = t2[m][n];
+    { // columns 0..31 of the strip's L tile are final: its head-tile copy starts its way now (the flag follows the rest)
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = kk0 + 8 * q;
+            __hip_atomic_store(x.Hs + (int64_t)P256_H(S, S) * (NB * NB) + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    mmk<false, 32, 4>(T, 0, T, 0, wm, wn, lane, a2); // the update's first half: Y1 Y1^T (columns 0..31 of T are final)
+    P2TS(6 * S + 2);
+    // ---- phase B: X22 ----
+    p256_wait(x.fl + 11 + S, x.epoch, x.spin_limit, x.info, lane);
+    {
+        double xb[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = threadIdx.x + 512 * q; // e = k + 32 c
+            xb[q] = __hip_atomic_load(Xs + 32 + (e & 31) + NB * (32 + (e >> 5)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = threadIdx.x + 512 * q;
+            Bx[(32 + (e >> 5)) * XS + 32 + (e & 31)] = xb[q];
+        }
+    }
+    __syncthreads(); // X22 is in LDS (and T[:, 32:64] complete)
+    P2TS(6 * S + 3);
+    double y2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    mmk<true, 32, 2>(T, 32, Bx + 32 * XS + 32, 0, wm, hn, lane, y2); // Y2 = T2 X22^T
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
+    __syncthreads();
+    mmk<false, 32, 4>(T, 32, T, 32, wm, wn, lane, a2); // the update's second half
+}
+
+// One step of one strip.  ROLE = 0..2: the strip with that index (it factors the diagonal block of column block ROLE + 1 at the
+// end of step ROLE and is done); ROLE = 3: any strip below the panel's own 256 rows.  Everything about the role is a compile-
+// time constant, so that each role's code holds exactly the tiles it needs (the factorisation alone wants 192 VGPRs).
+template <int S, int ROLE>
+static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][8], double (&pr)[2][4])
+{
+    constexpr int CMAX = ROLE < 3 ? ROLE + 1 : 3; // last column block of the panel the strip has a tile in
+    constexpr bool HEAD = ROLE <= 2;              // other strips need this strip's tile of every step
+    constexpr bool CHAIN = ROLE == S && ROLE < 3; // the strip that factors next: everything it does is on the panel's critical path
+    if constexpr (ROLE >= S) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
+        const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
+        // the strip's L tile of this step: the factoring strip keeps it in T1, which its factorisation (re-carving [Bx | T0])
+        // leaves alone — the tile goes out to memory from there UNDER the factorisation (diag_flow.h: DiagEarly::Lt)
+        double* const TT = CHAIN ? x.T1 : x.T0;
+        if constexpr (CHAIN && S > 0) {
+            double a2c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            p256_chain_solve<S>(x, TT, x.T0, cv[S], a2c);
+            double a2r[8];
+            wave_tile_to_rows(a2c, a2r, lane);
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                cv[S + 1][it] -= a2r[it];
+            P2TS(6 * S + 5);
+        }
+        else {
+            // ---- X_S and this strip's tile of column block S into LDS ----
+            P2TS(6 * S + 0);
+            double xv[8];
+            const double* Xs = x.Xt + S * (NB * NB);
+            if constexpr (S > 0) {
+                p256_wait(x.fl + (S - 1), x.epoch, x.spin_limit, x.info, lane);
+                P2TS(6 * S + 1);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    xv[q] = __hip_atomic_load(Xs + threadIdx.x + 512 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    xv[q] = Xs[threadIdx.x + 512 * q];
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                TT[(ccol + 2 * it) * PS + crow] = cv[S][it];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = threadIdx.x + 512 * q;
+                x.Bx[(e >> 6) * XS + (e & 63)] = xv[q]; // Bx[c][k] = X[c][k]
+            }
+            __syncthreads();
+            P2TS(6 * S + 2);
+            trsm_tile_full(TT, x.Bx, lane, wave); // L_bS, ends with a barrier
+            P2TS(6 * S + 3);
+            {
+                const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+                double* Ag = x.A + x.R0 + (x.p0 + (int64_t)NB * S) * x.lda;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int col = kk0 + 8 * q;
+                    const double v = TT[col * PS + i];
+                    if constexpr (HEAD) // write-through: other XCDs read this tile during this launch
+                        __hip_atomic_store(x.Hs + (int64_t)P256_H(S, ROLE) * (NB * NB) + i + NB * col, v, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    if (i < x.nrows)
+                        Ag[i + (int64_t)col * x.lda] = v;
+                }
+            }
+            if constexpr (HEAD && !CHAIN) {
+                if (!x.mute) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's part of the tile is acknowledged
+                    __syncthreads();
+                    if (threadIdx.x == 0)
+                        __hip_atomic_store(x.fl + 3 + P256_H(S, ROLE), x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            else if (!HEAD && x.want_d) // this strip's piece of the next panel's first diagonal block
+                mm64<false>(TT, TT, wm, wn, lane, pr);
+            P2TS(6 * S + 4);
+            if constexpr (S < 3) {
+                // ---- updates of the strip's remaining column blocks c = S+1 .. CMAX with the tile of strip t = c - 1 ----
+                // Highest t first: the tile of strip t = S, the one that factors next, comes out last (under its factorisation).
+                // The tiles alternate between two LDS buffers: one barrier per update.
+                // The tile of strip t = S — the strip that factors next — is the last to come out; its flag is looked at between
+                // the other updates and its loads go out as soon as it is seen.
+                constexpr bool NEED_S = S != ROLE && S + 1 <= CMAX;
+                TileRegs hd[3];
+                gpe_epoch_t seen[3];
+#pragma unroll
+                for (int t = 2; t >= S; --t) // all flag words at once: a poll is a round trip to memory even when the word is set
+                    seen[t] = (t != ROLE && t + 1 <= CMAX)
+                        ? __hip_atomic_load(x.fl + 3 + P256_H(S, t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : x.epoch;
+#pragma unroll
+                for (int t = 2; t > S; --t)
+                    if (t != ROLE && t + 1 <= CMAX) {
+                        if (seen[t] != x.epoch)
+                            p256_wait(x.fl + 3 + P256_H(S, t), x.epoch, x.spin_limit, x.info, lane);
+                        asm volatile("" ::: "memory");
+                        hd[t].load_coherent(x.Hs + (int64_t)P256_H(S, t) * (NB * NB));
+                    }
+                bool got_s = false;
+                int nb = 0;
+#pragma unroll
+                for (int t = 2; t >= S; --t)
+                    if (t + 1 <= CMAX) {
+                        if constexpr (NEED_S) {
+                            if (t > S && !got_s) { // a look at the last tile's flag; not there: ask again for the next look
+                                if (seen[S] == x.epoch) {
+                                    asm volatile("" ::: "memory");
+                                    hd[S].load_coherent(x.Hs + (int64_t)P256_H(S, S) * (NB * NB));
+                                    got_s = true;
+                                }
+                                else
+                                    seen[S] = __hip_atomic_load(x.fl + 3 + P256_H(S, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            if (t == S && !got_s) {
+                                if (seen[S] != x.epoch)
+                                    p256_wait(x.fl + 3 + P256_H(S, S), x.epoch, x.spin_limit, x.info, lane);
+                                asm volatile("" ::: "memory");
+                                hd[S].load_coherent(x.Hs + (int64_t)P256_H(S, S) * (NB * NB));
+                            }
+                        }
+                        const double* Bop = TT;
+                        if (t != ROLE) {
+                            double* buf = (nb & 1) ? x.T2 : x.T1;
+                            ++nb;
+                            hd[t].store(buf);
+                            __syncthreads();
+                            Bop = buf;
+                        }
+                        double a2[2][4];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int n = 0; n < 4; ++n)
+                                a2[m][n] = 0.0;
+                        mm64<false>(TT, Bop, wm, wn, lane, a2);
+                        double a2r[8];
+                        wave_tile_to_rows(a2, a2r, lane);
+#pragma unroll
+                        for (int it = 0; it < 8; ++it)
+                            cv[t + 1][it] -= a2r[it];
+                    }
+                if constexpr (!CHAIN)
+                    __syncthreads(); // T0 and the buffers are free again
+            }
+            P2TS(6 * S + 5);
+        }
+        if constexpr (CHAIN) {
+            // ---- tile S + 1 is the finished diagonal block of column block S + 1 ----
+            // the strip's head-tile copy (S = 0: all of it, before its update; S > 0: the first 32 columns, since phase A of
+            // its solve) has been on its way for microseconds: this wait is free, and behind the barrier every wave's part
+            // is acknowledged
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // [Bx | T0] have no readers left
+            if (S == 0 && threadIdx.x == 0 && !x.mute)
+                __hip_atomic_store(x.fl + 3 + P256_H(S, ROLE), x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double* Ls = x.Bx; // [Ls | Ltb | invd | sync | Xw] re-carved over [Bx | T0], as in k_panel_step; T1 = this strip's L tile
+            double* Ltb = Ls + NB * XS;
+            double* invd = Ltb + DIAG_LTB;
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                Ls[crow * XS + ccol + 2 * it] = cv[S + 1][it];
+            DiagSync* sy = reinterpret_cast<DiagSync*>(invd + NB);
+            diag_flow_init(sy);
+            __syncthreads();
+            P2TS(26);
+            DiagEarly ea;
+            ea.xearly = S < 2; // the next strip factors too and solves in two phases
+            ea.L21s = x.Hs + (int64_t)(5 + S + 1) * (NB * NB);
+            ea.f_early = x.fl + 8 + S + 1;
+            ea.f_x22 = x.fl + 11 + S + 1;
+            ea.epoch = x.epoch;
+            ea.Lt = S > 0 ? TT : nullptr; // the tile's last 32 columns leave under the factorisation (eighth wave), then the flag
+            ea.lts = PS;
+            ea.Lh = x.Hs + (int64_t)P256_H(S, ROLE) * (NB * NB);
+            ea.f_head = x.fl + 3 + P256_H(S, ROLE);
+            ea.mute = x.mute;
+            diag_flow(Ls, Ltb, invd, sy, x.A + x.R0 + x.R0 * x.lda, x.lda, x.Xt + (S + 1) * (NB * NB), x.info, x.R0, wave, lane,
+                      invd + NB + 8, &ea);
+            P2TS(27);
+            if (!x.mute) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // X went out with write-through stores (DIAG_XT_STORE)
+                __syncthreads();
+                P2TS(28);
+                if (threadIdx.x == 0)
+                    __hip_atomic_store(x.fl + S, x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            P2TS(29);
+            if constexpr (S > 0) { // this strip's L tile of the step into the matrix: nobody reads it there before the launch ends
+                const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+                double* Ag = x.A + x.R0 + (x.p0 + (int64_t)NB * S) * x.lda;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int col = kk0 + 8 * q;
+                    Ag[i + (int64_t)col * x.lda] = TT[col * PS + i];
+                }
+            }
+        }
+    }
+}
+
+template <int ROLE>
+static __device__ __forceinline__ void p256_strip(const P256& x, double* __restrict__ Dacc)
+{
+    constexpr int CMAX = ROLE < 3 ? ROLE + 1 : 3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
+    // the strip's tiles, lane = row layout (wave_tile_to_rows): element it of a thread is row wm + (lane & 31), column
+    // wn + 2 it + (lane >> 5) of the 64 x 64 tile
+    const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
+    const int crc = crow < x.nrows ? crow : x.nrows - 1;
+    double cv[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            cv[c][it] = (c <= CMAX) ? x.A[x.R0 + crc + (x.p0 + (int64_t)NB * c + ccol + 2 * it) * x.lda] : 0.0;
+    double pr[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            pr[m][n] = 0.0;
+    p256_step<0, ROLE>(x, cv, pr);
+    p256_step<1, ROLE>(x, cv, pr);
+    p256_step<2, ROLE>(x, cv, pr);
+    p256_step<3, ROLE>(x, cv, pr);
+    if constexpr (ROLE == 3) {
+        if (x.want_d) {
+            double prr[8];
+            wave_tile_to_rows(pr, prr, lane);
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                Dacc[threadIdx.x + 512 * it] = prr[it];
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_panel256(double* __restrict__ A, int64_t lda, int64_t p0, int64_t M,
+                                                  double* __restrict__ Xt, int* __restrict__ info, double* __restrict__ Hs,
+                                                  int64_t dnext, double* __restrict__ Dacc, gpe_epoch_t* fl,
+                                                  gpe_epoch_t epoch, int spin_limit)
+{
+    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS]; // [Bx | T0 | T1 | T2]: 156,672 B
+    static_assert(NB * XS + DIAG_LTB + NB + 8 + DIAG_XW_DOUBLES <= NB * XS + NB * PS, "the factoring strips' carve fits into [Bx | T0]");
+    const int b = (int)blockIdx.x;
+    P256 x;
+    x.A = A;
+    x.lda = lda;
+    x.p0 = p0;
+    x.R0 = p0 + (int64_t)NB * (b + 1);
+    x.Xt = Xt;
+    x.info = info;
+    x.Hs = Hs;
+    x.fl = fl;
+    x.epoch = epoch;
+    x.mute = spin_limit < 0; // test hook (GPE_HANDOVER_FAULT): nobody publishes, every consumer gives up at once
+    x.spin_limit = spin_limit < 0 ? -spin_limit : spin_limit;
+    x.nrows = (int)((M - x.R0 < NB) ? M - x.R0 : NB);
+    x.want_d = dnext >= 0 && x.R0 == dnext;
+    x.Bx = lds;
+    x.T0 = lds + NB * XS;
+    x.T1 = x.T0 + NB * PS;
+    x.T2 = x.T1 + NB * PS;
+    P2TS(30);
+    switch (b) {
+    case 0: p256_strip<0>(x, Dacc); break;
+    case 1: p256_strip<1>(x, Dacc); break;
+    case 2: p256_strip<2>(x, Dacc); break;
+    default: p256_strip<3>(x, Dacc); break;
+    }
+    P2TS(31);
+}
+
+static std::atomic<gpe_epoch_t> g_handover_epoch{0}; // a value no earlier launch of this process has used; 64 bits: never wraps
+
+void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t M, double* Xt, int* info, double* Hs,
+                     int64_t dnext, double* Dacc, gpe_epoch_t* fl)
+{
+    const gpe_epoch_t epoch = ++g_handover_epoch;
+    static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
+    const int spin_limit = fault ? -16 : GPE_FLOW_SPIN_LIMIT;
+    const int64_t rows = M - (p0 + NB);
+    if (rows <= 0)
+        return;
+    GPE_LAUNCH(k_panel256, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, p0, M, Xt, info, Hs, dnext, Dacc, fl,
+               epoch, spin_limit);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_upd_fused — the next-panel update (rows >= pe of columns [pe, pe2), k = pe - p0) and, in the SAME
 // launch, the factorisation of the next diagonal block.  The update is the 64 x 64 direct-to-LDS GEMM
 // (gemm_glds64.h) on gridDim.x - 1 workgroups, which leave tile (0, 0) alone; the last workgroup forms
@@ -1330,6 +1776,32 @@ void launch_upd_fused(hipStream_t s, const GemmArgs& g0, double* A, int64_t lda,
 }
 
 #ifdef DIAG_TIMING
+void dump_p256_timing()
+{
+    long long h[5][32];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_p256_ts), sizeof(h));
+    const char* names[5] = {"strip 0", "strip 1", "strip 2", "strip 3", "last strip"};
+    long long t0 = h[0][30];
+    for (int r = 0; r < 5; ++r)
+        t0 = h[r][30] < t0 ? h[r][30] : t0;
+    // wall_clock64 (s_memrealtime): the 100 MHz constant clock, the same on every CU -> 10 ns units
+    printf("k_panel256 stamps (us after the first strip's start; per step: enter | X flag seen | X+tile in LDS | solved | L out/published | updates done)\n");
+    for (int r = 0; r < 5; ++r) {
+        printf("  %-10s start %6.2f :", names[r], (h[r][30] - t0) * 0.01);
+        const int smax = r < 3 ? r : 3;
+        for (int S = 0; S <= smax; ++S) {
+            printf(" [S%d", S);
+            for (int i = 0; i < 6; ++i)
+                if (!(S == 0 && i == 1))
+                    printf(" %6.2f", (h[r][6 * S + i] - t0) * 0.01);
+            printf("]");
+        }
+        if (r < 3)
+            printf(" diag start %6.2f wave 0 done %6.2f all acked %6.2f X out %6.2f", (h[r][26] - t0) * 0.01, (h[r][27] - t0) * 0.01,
+                   (h[r][28] - t0) * 0.01, (h[r][29] - t0) * 0.01);
+        printf(" end %6.2f\n", (h[r][31] - t0) * 0.01);
+    }
+}
 void dump_panel_timing()
 {
     long long h[64];
@@ -1346,9 +1818,8 @@ void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_
                        double* Xt_next, int do_next, int* info, double* Hs, int64_t dnext, int64_t dfirst, int dinit,
                        double* Dacc, gpe_epoch_t* hflag)
 {
-    // a value no earlier launch of this process has used; 64 bits: never wraps (0 is what fresh flag words hold)
-    static std::atomic<gpe_epoch_t> g_epoch{0};
-    const gpe_epoch_t epoch = ++g_epoch;
+    // a value no earlier launch of this process has used (0 is what fresh flag words hold)
+    const gpe_epoch_t epoch = ++g_handover_epoch;
     // test hook: the consumers wait (briefly) for a value nobody writes, i.e. every hand-over of the launch "times out"
     static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
     const int spin_limit = fault ? -16 : GPE_FLOW_SPIN_LIMIT;

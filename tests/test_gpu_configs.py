@@ -342,15 +342,19 @@ def test_gpu_panel_head_tiles_handed_over_or_rederived_give_the_same_factor(engi
             "np.save(%r, np.tril(h.get_L()))\n"
             "print('child ok')\n") % (str(ROOT), N, str(f))
     Ls = {}
-    for tag, extra in (("no_handover", {"GPE_PANEL_HANDOVER": "0"}), ("handover_unfolded", {"GPE_FOLD4": "0"})):
+    for tag, extra in (("no_handover", {"GPE_PANEL_HANDOVER": "0"}), ("handover_unfolded", {"GPE_FOLD4": "0", "GPE_PANEL256": "0"}),
+                       ("handover_folded", {"GPE_PANEL256": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
         assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
         Ls[tag] = np.load(f)
     # handed over or re-derived: the same products in the same order, bitwise the same factor
     assert np.array_equal(Ls["no_handover"], Ls["handover_unfolded"]), float(np.max(np.abs(Ls["no_handover"] - Ls["handover_unfolded"])))
-    # the default folds the panel's last step into the fused next-panel update (potrf.hip: UpdFold): the last 64 columns of a
-    # panel enter that update from LDS tiles instead of through the direct-to-LDS loop — another grouping of the same sum
+    # the step-by-step default (GPE_PANEL256=0) folds the panel's last step into the fused next-panel update (potrf.hip:
+    # UpdFold): the last 64 columns of a panel enter that update from LDS tiles instead of through the direct-to-LDS loop —
+    # another grouping of the same sum; the default (k_panel256: the whole panel as one data-flow launch) solves the factoring
+    # strips' tiles in the half-block form of the inverse and sums the next diagonal block's pieces in one accumulator
+    assert np.max(np.abs(Ls["no_handover"] - Ls["handover_folded"])) <= 1e-13 * np.max(np.abs(L1))
     assert np.max(np.abs(Ls["no_handover"] - L1)) <= 1e-13 * np.max(np.abs(L1))
 
 

@@ -2,6 +2,7 @@
 // `rocprofv3 --kernel-trace` and read the per-(kernel, grid) durations with tools/kstats.py.
 // build: make -C tools kbench   (links the engine's object files)
 #include "../limbo_amd/csrc/dev.h"
+#include "trace_stub.h"
 #include "../include/gpe.h"
 #include <cstdio>
 #include <cstdlib>
@@ -137,6 +138,32 @@ int main(int argc, char** argv)
             printf("step with nt = %d: %.2f us (events)\n", nt, 1e3 * best);
             dump_panel_timing();
         }
+    }
+#endif
+#ifdef DIAG_TIMING
+    { // all steps of the first outer panel in one launch (k_panel256)
+        static double* Hs3 = nullptr;
+        CHK(hipMalloc(&Hs3, sizeof(double) * 8 * 4096));
+        CHK(hipMemset(Hs3, 0, sizeof(double) * 8 * 4096));
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            launch_copy2d(s, A0, ld, A, ld, N, 320);
+            launch_diag(s, A, ld, 64, Xi, info, 0, 1);
+            CHK(hipStreamSynchronize(s));
+            hipEventRecord(e0, s);
+            launch_panel256(s, A, ld, 0, N, Xi, info, Hs3, 256, Hs3 + 6 * 4096, (gpe_epoch_t*)(Hs3 + 7 * 4096));
+            hipEventRecord(e1, s);
+            CHK(hipStreamSynchronize(s));
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            best = ms < best ? ms : best;
+        }
+        printf("k_panel256, first panel of N = 4096: %.2f us (events)\n", 1e3 * best);
+        extern void dump_p256_timing();
+        dump_p256_timing();
     }
 #endif
     printf("kbench done\n");

@@ -3,6 +3,7 @@
 // kernels of gemm.hip against the persistent stream-k kernel of gemm_sk.hip (variants / workgroup counts), with a
 // correctness check of every variant against the first.   build: make -C tools updbench
 #include "../limbo_amd/csrc/dev.h"
+#include "trace_stub.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
