@@ -103,8 +103,10 @@ struct gpe_ctx {
     int bulk_wgs = 192;                // physical workgroups of a look-ahead bulk update (GPE_BULK_WGS)
     int near_wgs = 0;                  // workgroups of the "near" part of a look-ahead update (0: unrestricted — it is what the
                                        // next panel's update waits for; -1: bulk_wgs; GPE_NEAR_WGS)
-    int64_t bulk_free_tiles = 250;     // ... unless it has at least this many 128 x 128 tiles (GPE_BULK_FREE_TILES): the first
-                                       // three far updates at N = 4096 (re-tuned once stream2 carried nothing else: 554 -> 561/s)
+    int64_t bulk_free_tiles = 0;       // ... unless it has at least this many 128 x 128 tiles (GPE_BULK_FREE_TILES).  250 (the
+                                       // first three far updates at N = 4096) while the panels ran step by step; with the
+                                       // one-launch panels (64 CUs for ~55 us) every far update is better off unrestricted:
+                                       // 640 -> 651/s at N = 4096 for 0..100, round 3
     std::mutex mu;
     int64_t N = 0, cap = 0, ld = 0;
     int D = 0, P = 0;
@@ -1414,8 +1416,27 @@ int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise, bool loo = false)
 // bulk update that owns all 256 CUs would simply delay the panel: the bulk update is launched with
 // `bulk_wgs` < 256 looping workgroups (gemm.hip, GemmArgs::grid_limit), the other CUs stay free for
 // the critical path.  (A CU mask on the stream was tried first and had no effect.)
+// GPE_STREAM_PRIO=1: the panel chain's stream gets the most urgent priority, the look-ahead stream the least
+static int stream_prio_mode()
+{
+    static const int m = getenv("GPE_STREAM_PRIO") ? atoi(getenv("GPE_STREAM_PRIO")) : 0;
+    return m;
+}
+hipError_t create_main_stream(hipStream_t* st)
+{
+    if (stream_prio_mode() == 0)
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+}
 hipError_t create_bulk_stream(hipStream_t* st)
 {
+    if (stream_prio_mode() != 0) {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        return hipStreamCreateWithPriority(st, hipStreamNonBlocking, lo);
+    }
     int keep = 4; // of every 4 CUs (GPE_BULK_CU_MASK=1..3 enables a mask; it had no measurable effect on MI355X/ROCm 7.2)
     if (const char* e = getenv("GPE_BULK_CU_MASK"))
         keep = atoi(e);
@@ -1549,7 +1570,7 @@ int gpe_create(int device_id, gpe_handle* out)
         }
     }
     if (!reused
-        && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || create_bulk_stream(&c->stream2) != hipSuccess
+        && (create_main_stream(&c->stream) != hipSuccess || create_bulk_stream(&c->stream2) != hipSuccess
             // one device block [dScal 8 KiB | dHead GPE_HEAD_TILES tiles] and one coherent (fine-grained) pinned block
             // [hInfo 64 B | hSmallSeq 64 B | hScal 8 KiB | hSmall]: the small path's host side reads the pinned words while
             // the stream is still busy
