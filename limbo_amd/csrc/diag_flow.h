@@ -51,13 +51,6 @@ struct DiagEarly {
     double* L21s;
     diag_epoch_t *f_early, *f_x22;
     diag_epoch_t epoch;
-    // The last 32 columns of the caller's own 64 x 64 tile in LDS (Lt[col * lts + row], outside the factorisation's work area)
-    // leave under the factorisation too: write-through to Lh (ld 64), then f_head <- epoch (the first 32 went out earlier and are
-    // acknowledged).  The eighth wave has nothing to do until X11 is complete.
-    const double* Lt;
-    int lts;
-    double* Lh;
-    diag_epoch_t* f_head;
 };
 
 static __device__ __forceinline__ int lds_peek(const int* p)
@@ -407,34 +400,23 @@ struct FlowX<-1> {
 static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* sy, double* Xw, int lane,
                                                    double* __restrict__ Xt, const DiagEarly* ea)
 {
-    if (ea && ea->Lt) { // (the copy into the matrix itself, which nobody reads during the launch, is the caller's business)
-        const double* Lt = ea->Lt;
-        double* Lh = ea->Lh;
-        const int lts = ea->lts;
-#pragma unroll
-        for (int c0 = NB / 2; c0 < NB; c0 += 16) { // 16 LDS reads in flight, then their 16 stores
-            double v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                v[j] = Lt[(c0 + j) * lts + lane];
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                DIAG_XT_STORE(Lh + lane + NB * (c0 + j), v[j]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0 && !ea->mute)
-            __hip_atomic_store(ea->f_head, ea->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     lds_await(&sy->xprog, 8);
     if (ea && ea->xearly) { // X11 is complete in Xw, L21 in Ls (prog >= 8: the inversion wave is one round behind P): both go out from here,
               // this wave waits for ITS stores only and raises the flag (the inversion wave's own stores of X11 may still be
               // on their way: the same values to the same addresses)
         lds_await(&sy->prog, 8);
+        double xv[16], lv[16]; // all LDS reads in flight, then the stores
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int e = lane + 64 * i, hi = e >> 5, lo = e & 31;
-            DIAG_XT_STORE(Xt + lo + NB * hi, Xw[hi * XH + lo]);          // Xt[col + 64 row] = X11[row][col]
-            DIAG_XT_STORE(ea->L21s + e, Ls[(32 + lo) * XS + hi]);        // L21s[c + 32 k] = L[32 + c][k]
+            xv[i] = Xw[hi * XH + lo];
+            lv[i] = Ls[(32 + lo) * XS + hi];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = lane + 64 * i, hi = e >> 5, lo = e & 31;
+            DIAG_XT_STORE(Xt + lo + NB * hi, xv[i]);   // Xt[col + 64 row] = X11[row][col]
+            DIAG_XT_STORE(ea->L21s + e, lv[i]);        // L21s[c + 32 k] = L[32 + c][k]
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0 && !ea->mute)

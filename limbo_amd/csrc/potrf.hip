@@ -1159,9 +1159,12 @@ struct P256 {
 // solve and half of its one update run while the previous strip is still factoring (X11 and L21 of that block leave it half-way
 // through, diag_flow.h: DiagEarly); what is left behind the arrival of X22 is one 64 x 32 x 32 product and the other half of the
 // update.  T (64 x 64, [kk][i], stride PS) <- own L^-T; acc += (own L^-T)(own L^-T)^T over both halves of k.
-template <int S>
-static __device__ __forceinline__ void p256_chain_solve(const P256& x, double* __restrict__ T, double* __restrict__ Ld,
-                                                        const double (&own)[8], double (&a2)[2][4])
+// Every strip solves this way from step 1 on (PUBHALF / acc_on: the factoring strip publishes the first half of its tile after
+// phase A and accumulates its update; the strip of the next panel's first diagonal block accumulates its piece of that block;
+// the others only solve): what a strip still has to do once the last rows of X are out is a quarter of the solve.
+template <int S, bool PUBHALF>
+static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __restrict__ T, double* __restrict__ Ld,
+                                                       const double (&own)[8], double (&a2)[2][4], const bool acc_on)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16; // the 64 x 64 product's wave tile
@@ -1217,7 +1220,7 @@ static __device__ __forceinline__ void p256_chain_solve(const P256& x, double* _
 #pragma unroll
         for (int n = 0; n < 2; ++n)
             T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = t2[m][n];
-    { // columns 0..31 of the strip's L tile are final: its head-tile copy starts its way now (the flag follows the rest)
+    if constexpr (PUBHALF) { // columns 0..31 of the strip's L tile are final: its head-tile copy starts its way now (the flag follows the rest)
         const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1226,7 +1229,8 @@ static __device__ __forceinline__ void p256_chain_solve(const P256& x, double* _
                                __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    mmk<false, 32, 4>(T, 0, T, 0, wm, wn, lane, a2); // the update's first half: Y1 Y1^T (columns 0..31 of T are final)
+    if (acc_on)
+        mmk<false, 32, 4>(T, 0, T, 0, wm, wn, lane, a2); // the product's first half: Y1 Y1^T (columns 0..31 of T are final)
     P2TS(6 * S + 2);
     // ---- phase B: X22 ----
     p256_wait(x.fl + 11 + S, x.epoch, x.spin_limit, x.info, lane);
@@ -1254,7 +1258,17 @@ static __device__ __forceinline__ void p256_chain_solve(const P256& x, double* _
         for (int n = 0; n < 2; ++n)
             T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
     __syncthreads();
-    mmk<false, 32, 4>(T, 32, T, 32, wm, wn, lane, a2); // the update's second half
+    if constexpr (PUBHALF) { // ... and the other 32 columns: the product below covers most of their way
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 4; q < 8; ++q) {
+            const int col = kk0 + 8 * q;
+            __hip_atomic_store(x.Hs + (int64_t)P256_H(S, S) * (NB * NB) + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (acc_on)
+        mmk<false, 32, 4>(T, 32, T, 32, wm, wn, lane, a2); // the product's second half
 }
 
 // One step of one strip.  ROLE = 0..2: the strip with that index (it factors the diagonal block of column block ROLE + 1 at the
@@ -1275,7 +1289,7 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
         double* const TT = CHAIN ? x.T1 : x.T0;
         if constexpr (CHAIN && S > 0) {
             double a2c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            p256_chain_solve<S>(x, TT, x.T0, cv[S], a2c);
+            p256_half_solve<S, true>(x, TT, x.T0, cv[S], a2c, true);
             double a2r[8];
             wave_tile_to_rows(a2c, a2r, lane);
 #pragma unroll
@@ -1284,34 +1298,29 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
             P2TS(6 * S + 5);
         }
         else {
-            // ---- X_S and this strip's tile of column block S into LDS ----
-            P2TS(6 * S + 0);
-            double xv[8];
-            const double* Xs = x.Xt + S * (NB * NB);
-            if constexpr (S > 0) {
-                p256_wait(x.fl + (S - 1), x.epoch, x.spin_limit, x.info, lane);
-                P2TS(6 * S + 1);
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    xv[q] = __hip_atomic_load(Xs + threadIdx.x + 512 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if constexpr (S > 0)
+                p256_half_solve<S, false>(x, TT, x.T2, cv[S], pr, !HEAD && x.want_d);
             else {
+                // ---- X_0 (from the launch before) and this strip's tile of column block 0 into LDS ----
+                P2TS(6 * S + 0);
+                double xv[8];
+                const double* Xs = x.Xt;
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     xv[q] = Xs[threadIdx.x + 512 * q];
-            }
 #pragma unroll
-            for (int it = 0; it < 8; ++it)
-                TT[(ccol + 2 * it) * PS + crow] = cv[S][it];
+                for (int it = 0; it < 8; ++it)
+                    TT[(ccol + 2 * it) * PS + crow] = cv[S][it];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = threadIdx.x + 512 * q;
-                x.Bx[(e >> 6) * XS + (e & 63)] = xv[q]; // Bx[c][k] = X[c][k]
+                for (int q = 0; q < 8; ++q) {
+                    const int e = threadIdx.x + 512 * q;
+                    x.Bx[(e >> 6) * XS + (e & 63)] = xv[q]; // Bx[c][k] = X[c][k]
+                }
+                __syncthreads();
+                P2TS(6 * S + 2);
+                trsm_tile_full(TT, x.Bx, lane, wave); // L_b0, ends with a barrier
+                P2TS(6 * S + 3);
             }
-            __syncthreads();
-            P2TS(6 * S + 2);
-            trsm_tile_full(TT, x.Bx, lane, wave); // L_bS, ends with a barrier
-            P2TS(6 * S + 3);
             {
                 const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
                 double* Ag = x.A + x.R0 + (x.p0 + (int64_t)NB * S) * x.lda;
@@ -1334,7 +1343,7 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
                         __hip_atomic_store(x.fl + 3 + P256_H(S, ROLE), x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            else if (!HEAD && x.want_d) // this strip's piece of the next panel's first diagonal block
+            else if (S == 0 && !HEAD && x.want_d) // this strip's piece of the next panel's first diagonal block (later steps: inside the solve)
                 mm64<false>(TT, TT, wm, wn, lane, pr);
             P2TS(6 * S + 4);
             if constexpr (S < 3) {
@@ -1409,12 +1418,12 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
         }
         if constexpr (CHAIN) {
             // ---- tile S + 1 is the finished diagonal block of column block S + 1 ----
-            // the strip's head-tile copy (S = 0: all of it, before its update; S > 0: the first 32 columns, since phase A of
-            // its solve) has been on its way for microseconds: this wait is free, and behind the barrier every wave's part
-            // is acknowledged
+            // the strip's head-tile copy (S = 0: all of it, before its update; S > 0: the first 32 columns since phase A of
+            // its solve, the rest since before the last product) has been on its way for a microsecond or more: this wait is
+            // (nearly) free, and behind the barrier every wave's part is acknowledged
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();   // [Bx | T0] have no readers left
-            if (S == 0 && threadIdx.x == 0 && !x.mute)
+            if (threadIdx.x == 0 && !x.mute)
                 __hip_atomic_store(x.fl + 3 + P256_H(S, ROLE), x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             double* Ls = x.Bx; // [Ls | Ltb | invd | sync | Xw] re-carved over [Bx | T0], as in k_panel_step; T1 = this strip's L tile
             double* Ltb = Ls + NB * XS;
@@ -1427,15 +1436,11 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
             __syncthreads();
             P2TS(26);
             DiagEarly ea;
-            ea.xearly = S < 2; // the next strip factors too and solves in two phases
+            ea.xearly = true; // every strip solves in two phases
             ea.L21s = x.Hs + (int64_t)(5 + S + 1) * (NB * NB);
             ea.f_early = x.fl + 8 + S + 1;
             ea.f_x22 = x.fl + 11 + S + 1;
             ea.epoch = x.epoch;
-            ea.Lt = S > 0 ? TT : nullptr; // the tile's last 32 columns leave under the factorisation (eighth wave), then the flag
-            ea.lts = PS;
-            ea.Lh = x.Hs + (int64_t)P256_H(S, ROLE) * (NB * NB);
-            ea.f_head = x.fl + 3 + P256_H(S, ROLE);
             ea.mute = x.mute;
             diag_flow(Ls, Ltb, invd, sy, x.A + x.R0 + x.R0 * x.lda, x.lda, x.Xt + (S + 1) * (NB * NB), x.info, x.R0, wave, lane,
                       invd + NB + 8, &ea);
