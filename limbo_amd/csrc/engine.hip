@@ -96,6 +96,9 @@ struct gpe_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead: bulk of a trailing update runs here, behind the next panel
     std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
+    std::vector<hipEvent_t> pl_events; // ... one per outer panel: the one-launch panel is complete (early release of the look-ahead stream)
+    int64_t early_bulk = 100;          // release the look-ahead stream at the END OF THE PANEL (not of the fused next-panel update)
+                                       // when the far update has at least this many 128 x 128 tiles (GPE_EARLY_BULK_TILES; -1: never)
     int64_t xinv_done = 0;      // diagonal blocks whose inverse is already complete (done per panel on stream2)
     bool stop_events = true;    // next-panel update signals through its own dispatch (hipExtLaunchKernel stop event)
     bool fuse_diag = true;      // next diagonal block factored inside the next-panel update launch (k_upd_fused)
@@ -556,6 +559,24 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
         // between its workgroups
         const bool p256 = c->panel256 && c->fuse_panel && c->panel_handover && !g_batch.bt && nbo == 4 * NB && pw == nbo && pe <= M;
         const bool fold_last = !p256 && fuse_diag && c->fold4 && c->dL4 && nbo == 4 * NB && c->panel_handover && !g_batch.bt;
+        // In the first panels of a large factorisation the look-ahead stream is the longer one (N = 4096, panel 1: near + far
+        // update 30 + 84 us against 54 + 18 us of chain) and the fused next-panel update, whose 155 KB workgroups need whole CUs,
+        // ends up queued behind the far update of the panel before: releasing the stream when the PANEL is complete — its
+        // updates need nothing from the fused update — starts every near/far pair one fused update earlier.
+        hipEvent_t p_done = nullptr;
+        if (p256 && fuse_diag && c->early_bulk >= 0) {
+            const int64_t pe2_ = std::min<int64_t>(pe + nbo, N), pe3_ = std::min<int64_t>(pe2_ + nbo, N);
+            const int64_t nt128 = (N - pe3_ + 127) / 128, far_tiles = nt128 * (nt128 + 1) / 2;
+            if (pe3_ < N && far_tiles >= c->early_bulk) {
+                const size_t kp = (size_t)(p0 / nbo);
+                while (c->pl_events.size() <= kp) {
+                    hipEvent_t e;
+                    hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                    c->pl_events.push_back(e);
+                }
+                p_done = c->pl_events[kp];
+            }
+        }
         if (p256) {
             double* Xt = c->dXinv + (p0 / NB) * (NB * NB);
             if (!diag_done) {
@@ -564,7 +585,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
             }
             PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - p0 - NB) * NB * NB * 2.5 * 4);
             launch_panel256(s, A, ld, p0, M, Xt, c->dInfo, Hbase, fuse_diag ? pe : -1, c->dHead + 64 * NB * NB,
-                            (gpe_epoch_t*)(c->dHead + 65 * NB * NB) + ((p0 / nbo) & 1) * 32);
+                            (gpe_epoch_t*)(c->dHead + 65 * NB * NB) + ((p0 / nbo) & 1) * 32, p_done);
         }
         for (int64_t j0 = p0; j0 < pe && !p256; j0 += NB) {
             const int jb = (int)std::min<int64_t>(NB, pe - j0);
@@ -720,8 +741,8 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                     upd(s, pe, pe2, pe);
                     hipEventRecord(ev(3 * kp), s);
                 }
-                hipStreamWaitEvent(c->stream2, ev(3 * kp), 0); // the bulk update starts now and shares the chip
-                                                               // with panel kp + 1 only
+                hipStreamWaitEvent(c->stream2, p_done ? p_done : ev(3 * kp), 0); // the bulk update starts now and shares the
+                                                               // chip with panel kp + 1 only (p_done: and with this update)
                 if (c->inv_follow) // panel kp of L is final: its piece of the K^-1 chain, on the third stream
                     inv_follow_upto(c, (int64_t)kp, ev(3 * kp), c->inv_limit);
                 if (nf > 0 && !c->panel_handover) // (with the hand-over the head tiles were written in place too)
@@ -1611,6 +1632,8 @@ int gpe_create(int device_id, gpe_handle* out)
         c->fold4 = atoi(f) != 0;
     if (const char* f = getenv("GPE_PANEL256"))
         c->panel256 = atoi(f) != 0;
+    if (const char* f = getenv("GPE_EARLY_BULK_TILES"))
+        c->early_bulk = atoll(f);
     if (const char* f = getenv("GPE_STOP_EVENT"))
         c->stop_events = atoi(f) != 0;
     if (const char* f = getenv("GPE_LOOKAHEAD"))
@@ -1640,6 +1663,8 @@ int gpe_destroy(gpe_handle c)
     for (auto e : c->pool)
         hipEventDestroy(e);
     free_dev(c);
+    for (auto e : c->pl_events)
+        hipEventDestroy(e);
     for (auto e : c->la_events)
         hipEventDestroy(e);
     for (auto e : c->inv_events)

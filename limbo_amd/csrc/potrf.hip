@@ -1542,7 +1542,7 @@ __global__ __launch_bounds__(512) void k_panel256(double* __restrict__ A, int64_
 static std::atomic<gpe_epoch_t> g_handover_epoch{0}; // a value no earlier launch of this process has used; 64 bits: never wraps
 
 void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t M, double* Xt, int* info, double* Hs,
-                     int64_t dnext, double* Dacc, gpe_epoch_t* fl)
+                     int64_t dnext, double* Dacc, gpe_epoch_t* fl, hipEvent_t stop)
 {
     const gpe_epoch_t epoch = ++g_handover_epoch;
     static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
@@ -1550,8 +1550,12 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
     const int64_t rows = M - (p0 + NB);
     if (rows <= 0)
         return;
-    GPE_LAUNCH(k_panel256, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, p0, M, Xt, info, Hs, dnext, Dacc, fl,
-               epoch, spin_limit);
+    if (stop)
+        GPE_LAUNCH_STOP("k_panel256", k_panel256, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, stop, A, lda, p0, M, Xt, info,
+                        Hs, dnext, Dacc, fl, epoch, spin_limit);
+    else
+        GPE_LAUNCH(k_panel256, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, p0, M, Xt, info, Hs, dnext, Dacc, fl,
+                   epoch, spin_limit);
 }
 
 // ---------------------------------------------------------------------------------------------
