@@ -47,10 +47,14 @@ struct DiagSync {
 // three quarters of its solve overlap with this factorisation.
 typedef unsigned long long diag_epoch_t;
 struct DiagEarly {
-    bool xearly, mute;     // xearly: raise f_early / f_x22; mute (test hook): raise no flag at all
-    double* L21s;
-    diag_epoch_t *f_early, *f_x22;
-    diag_epoch_t epoch;
+    bool mute; // test hook: nothing leaves
+    // Polled copies, 1024 doubles each, [col + 32 row]: S[0 .. 1023] = X11, S[1024 ..] = L21 (row = row of L21 = row 32 + . of
+    // the block), S[2048 ..] = X22.  They hold an all-ones pattern no arithmetic produces until the inversion wave (X11, X22:
+    // four rows per round) and the store wave (L21: four columns per round) put the values there; consumers poll the values
+    // themselves (an aligned 8-byte store is never torn and needs no ordering with anything else — the hand-off of the one-launch
+    // sweeps, solve.hip).  No acknowledgement is awaited on this side and no flag travels behind the data: X11 and L21 are
+    // visible one store latency after round 9 of 16, the last rows of X22 one store latency after they are computed.
+    double* S;
 };
 
 static __device__ __forceinline__ int lds_peek(const int* p)
@@ -340,9 +344,9 @@ struct XFold { // rows i0 + 4 + XFOLD_CH CHK ..: q holds this chunk's multiplier
 template <int G>
 struct FlowX {
     static __device__ __forceinline__ void run(double (&S)[32], const double* Ls, const double* invd, double* __restrict__ Xt,
-                                               DiagSync* sy, double* Xw, int c, int h)
+                                               DiagSync* sy, double* Xw, int c, int h, double* __restrict__ S22)
     {
-        FlowX<G - 1>::run(S, Ls, invd, Xt, sy, Xw, c, h);
+        FlowX<G - 1>::run(S, Ls, invd, Xt, sy, Xw, c, h, S22);
         constexpr int hb = G >> 3, i0 = 4 * (G & 7), base = 32 * hb, nrow = 28 - i0;
         if (G == 8) { // second half-block: start again from the identity
 #pragma unroll
@@ -373,6 +377,13 @@ struct FlowX {
             DIAG_XT_STORE(Xt + base + c + NB * (base + i0 + 1), x1);
             DIAG_XT_STORE(Xt + base + c + NB * (base + i0 + 2), x2);
             DIAG_XT_STORE(Xt + base + c + NB * (base + i0 + 3), x3);
+            if (S22) { // ... and to the polled copy of this half-block (X11 at + 0, X22 at + 2048)
+                double* Sp = S22 + 2048 * hb;
+                DIAG_XT_STORE(Sp + c + 32 * (i0 + 0), x0);
+                DIAG_XT_STORE(Sp + c + 32 * (i0 + 1), x1);
+                DIAG_XT_STORE(Sp + c + 32 * (i0 + 2), x2);
+                DIAG_XT_STORE(Sp + c + 32 * (i0 + 3), x3);
+            }
             double* xh = Xw + hb * (32 * XH) + i0 * XH + c; // and into LDS, for the off-diagonal quarter (flow_x21)
             xh[0] = x0;
             xh[XH] = x1;
@@ -388,7 +399,7 @@ struct FlowX {
 };
 template <>
 struct FlowX<-1> {
-    static __device__ __forceinline__ void run(double (&)[32], const double*, const double*, double*, DiagSync*, double*, int, int) {}
+    static __device__ __forceinline__ void run(double (&)[32], const double*, const double*, double*, DiagSync*, double*, int, int, double*) {}
 };
 
 // ---- the off-diagonal quarter X21 = -X22 (L21 X11) -------------------------------------------------------------------------
@@ -397,31 +408,9 @@ struct FlowX<-1> {
 // product (trsm_tile_full, potrf.hip).  Here: W = L21 X11 by the eighth wave while the second half of the block is still being
 // factored, X21 = -X22 W by the four update waves once X22 is complete — 32 matrix-core instructions each, ~1 k cycles behind
 // the inversion wave.  mfma4 layouts as in mm16 / st16 (potrf.hip).
-static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* sy, double* Xw, int lane,
-                                                   double* __restrict__ Xt, const DiagEarly* ea)
+static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* sy, double* Xw, int lane)
 {
     lds_await(&sy->xprog, 8);
-    if (ea && ea->xearly) { // X11 is complete in Xw, L21 in Ls (prog >= 8: the inversion wave is one round behind P): both go out from here,
-              // this wave waits for ITS stores only and raises the flag (the inversion wave's own stores of X11 may still be
-              // on their way: the same values to the same addresses)
-        lds_await(&sy->prog, 8);
-        double xv[16], lv[16]; // all LDS reads in flight, then the stores
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = lane + 64 * i, hi = e >> 5, lo = e & 31;
-            xv[i] = Xw[hi * XH + lo];
-            lv[i] = Ls[(32 + lo) * XS + hi];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = lane + 64 * i, hi = e >> 5, lo = e & 31;
-            DIAG_XT_STORE(Xt + lo + NB * hi, xv[i]);   // Xt[col + 64 row] = X11[row][col]
-            DIAG_XT_STORE(ea->L21s + e, lv[i]);        // L21s[c + 32 k] = L[32 + c][k]
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0 && !ea->mute)
-            __hip_atomic_store(ea->f_early, ea->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     // ... and not before panel 10 is out: this wave shares its SIMD with update wave U2, which hands groups 8..11 to P in
     // rounds 6..9 — started at round 8 its matrix-core instructions delayed those hand-overs and P with them (round 10:
     // 1.6 k cycles instead of 1.0 k, r02_diag_flow_stamps.log of that build).  Three rounds are enough for W.
@@ -497,9 +486,10 @@ static __device__ __forceinline__ void flow_x21(DiagSync* sy, const double* Xw, 
 template <int G>
 struct FlowS {
     static __device__ __forceinline__ void run(int& bad, const double* Ls, const double* invd,
-                                               double* __restrict__ Ad, int64_t lda, const DiagSync* sy, int r)
+                                               double* __restrict__ Ad, int64_t lda, const DiagSync* sy, int r,
+                                               double* __restrict__ SL21)
     {
-        FlowS<G - 1>::run(bad, Ls, invd, Ad, lda, sy, r);
+        FlowS<G - 1>::run(bad, Ls, invd, Ad, lda, sy, r, SL21);
         lds_await(&sy->prog, G + 1);
         constexpr int c0 = 4 * G;
 #pragma unroll
@@ -507,6 +497,8 @@ struct FlowS {
             const double v = Ls[r * XS + c0 + e];
             if (c0 + e <= r)
                 Ad[r + (int64_t)(c0 + e) * lda] = v;
+            if (G < 8 && SL21 && r >= 32) // the polled copy of L21: [row - 32 + 32 col]
+                DIAG_XT_STORE(SL21 + (r - 32) + 32 * (c0 + e), v);
             // first non-positive pivot (the reference never checks LLT::info(), gp.hpp:565): its inverse root is not a
             // positive finite number, and neither is any later one
             const double y = invd[c0 + e];
@@ -518,7 +510,7 @@ struct FlowS {
 };
 template <>
 struct FlowS<-1> {
-    static __device__ __forceinline__ void run(int&, const double*, const double*, double*, int64_t, const DiagSync*, int) {}
+    static __device__ __forceinline__ void run(int&, const double*, const double*, double*, int64_t, const DiagSync*, int, double*) {}
 };
 
 // Factor the 64 x 64 block held in Ls (Ls[row * XS + col], lower triangle meaningful) and invert its two 32 x 32 diagonal
@@ -544,7 +536,7 @@ static __device__ __forceinline__ void diag_flow(double* Ls, double* H, double* 
         return; // s_barrier only counts the waves that are still alive
     if (wave == 7) {
         __syncthreads();
-        flow_w_wave(Ls, sy, Xw, lane, Xt, ea);
+        flow_w_wave(Ls, sy, Xw, lane);
         return;
     }
     if (wave >= 1 && wave <= 4) {
@@ -573,16 +565,11 @@ static __device__ __forceinline__ void diag_flow(double* Ls, double* H, double* 
 #pragma unroll
         for (int k = 0; k < 32; ++k)
             S[k] = (lane < 32 && k == lane) ? 1.0 : 0.0;
-        FlowX<15>::run(S, Ls, invd, Xt, sy, Xw, lane & 31, lane >> 5);
-        if (ea && ea->xearly) { // X22's last rows are this wave's last stores
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0 && !ea->mute)
-                __hip_atomic_store(ea->f_x22, ea->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        FlowX<15>::run(S, Ls, invd, Xt, sy, Xw, lane & 31, lane >> 5, (ea && !ea->mute) ? ea->S : nullptr);
         return;
     }
     int bad = 0;
-    FlowS<15>::run(bad, Ls, invd, Ad, lda, sy, lane);
+    FlowS<15>::run(bad, Ls, invd, Ad, lda, sy, lane, (ea && !ea->mute) ? ea->S + 1024 : nullptr);
     if (lane == 0 && bad != 0 && *info == 0)
         *info = (int)(goff + bad);
 }

@@ -96,6 +96,7 @@ struct gpe_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead: bulk of a trailing update runs here, behind the next panel
     std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
+    unsigned p256_count = 0;           // launches of k_panel256 so far: its polled X22 copies alternate between two buffers
     std::vector<hipEvent_t> pl_events; // ... one per outer panel: the one-launch panel is complete (early release of the look-ahead stream)
     int64_t early_bulk = 100;          // release the look-ahead stream at the END OF THE PANEL (not of the fused next-panel update)
                                        // when the far update has at least this many 128 x 128 tiles (GPE_EARLY_BULK_TILES; -1: never)
@@ -585,7 +586,10 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
             }
             PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - p0 - NB) * NB * NB * 2.5 * 4);
             launch_panel256(s, A, ld, p0, M, Xt, c->dInfo, Hbase, fuse_diag ? pe : -1, c->dHead + 64 * NB * NB,
-                            (gpe_epoch_t*)(c->dHead + 65 * NB * NB) + ((p0 / nbo) & 1) * 32, p_done);
+                            (gpe_epoch_t*)(c->dHead + 65 * NB * NB) + ((p0 / nbo) & 1) * 32,
+                            c->dHead + ((c->p256_count & 1) * 32 + GPE_S22_TILE) * (NB * NB),
+                            c->dHead + (((c->p256_count + 1) & 1) * 32 + GPE_S22_TILE) * (NB * NB), p_done);
+            ++c->p256_count;
         }
         for (int64_t j0 = p0; j0 < pe && !p256; j0 += NB) {
             const int jb = (int)std::min<int64_t>(NB, pe - j0);
@@ -1603,6 +1607,9 @@ int gpe_create(int device_id, gpe_handle* out)
         return GPE_ERR_HIP;
     }
     c->dHead = c->dScal + 1024;
+    // the polled X22 copies of k_panel256 (both buffers: a block from the pool may have been left in either state)
+    hipMemsetAsync(c->dHead + GPE_S22_TILE * (NB * NB), 0xFF, sizeof(double) * GPE_S22_TILES * NB * NB, c->stream);
+    hipMemsetAsync(c->dHead + (32 + GPE_S22_TILE) * (NB * NB), 0xFF, sizeof(double) * GPE_S22_TILES * NB * NB, c->stream);
     c->hInfo = (int*)c->hPinned;
     c->hSmallSeq = (unsigned long long*)(c->hPinned + 64);
     c->hScal = (double*)(c->hPinned + 128);

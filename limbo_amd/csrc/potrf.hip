@@ -1126,22 +1126,12 @@ __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, in
 // dnext >= 0: the strip of rows dnext (the next panel's first diagonal block) also leaves sum_s L_bs L_bs^T in Dacc for
 // k_upd_fused.  Full 64-column blocks, nbo = 256 only; everything else goes the step-by-step way.
 // ---------------------------------------------------------------------------------------------
-static __device__ __forceinline__ void p256_wait(const gpe_epoch_t* w, gpe_epoch_t epoch, int spin_limit, int* __restrict__ info, int lane)
-{
-    int spins = 0;
-    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-        if (++spins > spin_limit) {
-            if (lane == 0)
-                info[2] = 1;
-            break;
-        }
-    asm volatile("" ::: "memory"); // what the flag guards is loaded behind the poll (the hardware returns a wave's loads in order)
-}
 // flag words: fl[s - 1] = X_s is out (s = 1..3); fl[3 + h] = head tile h, h = P256_H(s, t) for strip t at step s (t = s..2);
-// fl[8 + s] = X11 and L21 of diagonal block s are out, fl[11 + s] = X22 is (s = 1..3; diag_flow.h: DiagEarly).  Hs: tiles 0..5
-// the head tiles, tile 5 + s the L21 quarter of diagonal block s.
+// (the block inverses travel without flags: diag_flow.h: DiagEarly).  Hs: tiles 0..5 the head tiles.
 #define P256_H(s, t) ((s) == 0 ? (t) : ((s) == 1 ? 2 + (t) : 5))
 
+#define P256_POLLED_S (9 * 1024)                          // X11 | L21 | X22 of three diagonal blocks
+#define P256_POLLED_DOUBLES (P256_POLLED_S + 6 * NB * NB) // ... and six head tiles: 33,792 doubles per buffer
 struct P256 {
     double* A;
     int64_t lda, p0, R0;
@@ -1153,6 +1143,49 @@ struct P256 {
     int spin_limit, nrows;
     bool mute, want_d;
     double *Bx, *T0, *T1, *T2;
+    double* S22; // the polled copies of X11 | L21 | X22 of diagonal blocks 1..3 (3 x 3 x 1024 doubles), armed by the launch before
+    double* HP;  // ... and of the six head tiles (P256_H), 4096 doubles each: they travel the same way, no flag, no acknowledgement
+};
+
+// a 64 x 64 tile (ld 64) that another workgroup of this launch is writing, or has written, over an all-ones pattern:
+// thread t holds elements (t & 63, (t >> 6) + 8 q) as in TileRegs
+struct PolledTile {
+    unsigned long long b[8];
+    __device__ __forceinline__ void issue(const double* G)
+    {
+        const unsigned long long* g = reinterpret_cast<const unsigned long long*>(G) + (threadIdx.x & 63) + (threadIdx.x >> 6) * NB;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            b[q] = __hip_atomic_load(g + 8 * q * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void finish(const double* G, int spin_limit, int* __restrict__ info)
+    {
+        const unsigned long long SENT = ~0ull;
+        const unsigned long long* g = reinterpret_cast<const unsigned long long*>(G) + (threadIdx.x & 63) + (threadIdx.x >> 6) * NB;
+        int spins = 0;
+        while (b[0] == SENT || b[1] == SENT || b[2] == SENT || b[3] == SENT || b[4] == SENT || b[5] == SENT || b[6] == SENT
+               || b[7] == SENT) {
+            if (++spins > spin_limit) {
+                info[2] = 1;
+                break;
+            }
+            if (b[0] == SENT) b[0] = __hip_atomic_load(g + 0 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[1] == SENT) b[1] = __hip_atomic_load(g + 8 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[2] == SENT) b[2] = __hip_atomic_load(g + 16 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[3] == SENT) b[3] = __hip_atomic_load(g + 24 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[4] == SENT) b[4] = __hip_atomic_load(g + 32 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[5] == SENT) b[5] = __hip_atomic_load(g + 40 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[6] == SENT) b[6] = __hip_atomic_load(g + 48 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[7] == SENT) b[7] = __hip_atomic_load(g + 56 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __device__ __forceinline__ void store(double* __restrict__ T) const
+    {
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            T[(kk0 + 8 * q) * PS + i] = __longlong_as_double((long long)b[q]);
+    }
 };
 
 // The strip that factors next solves against the block inverse in the half-block form, in two phases: three quarters of its
@@ -1172,28 +1205,35 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
     const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
     const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
     double* Bx = x.Bx;
-    const double* Xs = x.Xt + S * (NB * NB);
-    const double* L21s = x.Hs + (int64_t)(5 + S) * (NB * NB);
     P2TS(6 * S + 0);
 #pragma unroll
     for (int it = 0; it < 8; ++it)
         T[(ccol + 2 * it) * PS + crow] = own[it];
-    // ---- phase A: behind the early flag ----
-    p256_wait(x.fl + 8 + S, x.epoch, x.spin_limit, x.info, lane);
-    P2TS(6 * S + 1);
+    // ---- phase A: X11 and L21, polled value by value (diag_flow.h: DiagEarly) ----
+    const unsigned long long SENT = ~0ull;
+    const unsigned long long* Sp = reinterpret_cast<const unsigned long long*>(x.S22 + (S - 1) * 3072) + threadIdx.x;
     {
-        double xa[2], la[2];
+        unsigned long long b[4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = threadIdx.x + 512 * q; // e = k + 32 c
-            xa[q] = __hip_atomic_load(Xs + (e & 31) + NB * (e >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // X11[c][k]
-            la[q] = __hip_atomic_load(L21s + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // e = c + 32 k
+        for (int q = 0; q < 4; ++q) // X11: e, e + 512; L21: 1024 + e, 1024 + e + 512
+            b[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (b[0] == SENT || b[1] == SENT || b[2] == SENT || b[3] == SENT) {
+            if (++spins > x.spin_limit) {
+                x.info[2] = 1;
+                break;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (b[q] == SENT)
+                    b[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        P2TS(6 * S + 1);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int e = threadIdx.x + 512 * q;
-            Bx[(e >> 5) * XS + (e & 31)] = xa[q];
-            Ld[(e & 31) * XS + (e >> 5)] = la[q]; // Ld[c][k] = L21[c][k]
+            const int e = threadIdx.x + 512 * q; // X11: e = k + 32 c ; L21: e = c + 32 k
+            Bx[(e >> 5) * XS + (e & 31)] = __longlong_as_double((long long)b[q]);
+            Ld[(e & 31) * XS + (e >> 5)] = __longlong_as_double((long long)b[2 + q]); // Ld[c][k] = L21[c][k]
         }
     }
     __syncthreads();
@@ -1225,7 +1265,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = kk0 + 8 * q;
-            __hip_atomic_store(x.Hs + (int64_t)P256_H(S, S) * (NB * NB) + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED,
+            __hip_atomic_store(x.HP + (int64_t)P256_H(S, S) * (NB * NB) + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -1233,19 +1273,23 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
         mmk<false, 32, 4>(T, 0, T, 0, wm, wn, lane, a2); // the product's first half: Y1 Y1^T (columns 0..31 of T are final)
     P2TS(6 * S + 2);
     // ---- phase B: X22 ----
-    p256_wait(x.fl + 11 + S, x.epoch, x.spin_limit, x.info, lane);
     {
-        double xb[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = threadIdx.x + 512 * q; // e = k + 32 c
-            xb[q] = __hip_atomic_load(Xs + 32 + (e & 31) + NB * (32 + (e >> 5)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long b0 = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long b1 = __hip_atomic_load(Sp + 2048 + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (b0 == SENT || b1 == SENT) {
+            if (++spins > x.spin_limit) {
+                x.info[2] = 1;
+                break;
+            }
+            if (b0 == SENT)
+                b0 = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b1 == SENT)
+                b1 = __hip_atomic_load(Sp + 2048 + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = threadIdx.x + 512 * q;
-            Bx[(32 + (e >> 5)) * XS + 32 + (e & 31)] = xb[q];
-        }
+        const int e0 = threadIdx.x, e1 = threadIdx.x + 512; // e = k + 32 c
+        Bx[(32 + (e0 >> 5)) * XS + 32 + (e0 & 31)] = __longlong_as_double((long long)b0);
+        Bx[(32 + (e1 >> 5)) * XS + 32 + (e1 & 31)] = __longlong_as_double((long long)b1);
     }
     __syncthreads(); // X22 is in LDS (and T[:, 32:64] complete)
     P2TS(6 * S + 3);
@@ -1263,12 +1307,45 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
 #pragma unroll
         for (int q = 4; q < 8; ++q) {
             const int col = kk0 + 8 * q;
-            __hip_atomic_store(x.Hs + (int64_t)P256_H(S, S) * (NB * NB) + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED,
+            __hip_atomic_store(x.HP + (int64_t)P256_H(S, S) * (NB * NB) + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (acc_on)
         mmk<false, 32, 4>(T, 32, T, 32, wm, wn, lane, a2); // the product's second half
+}
+
+// the update of a strip's tile of column block T + 1 with the step's tile of strip T (its own: in TT; another strip's: polled)
+template <int S, int ROLE, int T>
+static __device__ __forceinline__ void p256_update(const P256& x, const double* __restrict__ TT, PolledTile (&hd)[3],
+                                                   double (&cv)[4][8], int& nb)
+{
+    constexpr int CMAX = ROLE < 3 ? ROLE + 1 : 3;
+    if constexpr (T >= S && T <= 2 && T + 1 <= CMAX) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
+        const double* Bop = TT;
+        if constexpr (T != ROLE) {
+            double* buf = (nb & 1) ? x.T2 : x.T1;
+            ++nb;
+            hd[T].finish(x.HP + (int64_t)P256_H(S, T) * (NB * NB), x.spin_limit, x.info);
+            hd[T].store(buf);
+            __syncthreads();
+            Bop = buf;
+        }
+        double a2[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                a2[m][n] = 0.0;
+        mm64<false>(TT, Bop, wm, wn, lane, a2);
+        double a2r[8];
+        wave_tile_to_rows(a2, a2r, lane);
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            cv[T + 1][it] -= a2r[it];
+    }
 }
 
 // One step of one strip.  ROLE = 0..2: the strip with that index (it factors the diagonal block of column block ROLE + 1 at the
@@ -1328,89 +1405,39 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
                 for (int q = 0; q < 8; ++q) {
                     const int col = kk0 + 8 * q;
                     const double v = TT[col * PS + i];
-                    if constexpr (HEAD) // write-through: other XCDs read this tile during this launch
-                        __hip_atomic_store(x.Hs + (int64_t)P256_H(S, ROLE) * (NB * NB) + i + NB * col, v, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (HEAD && !(CHAIN && S > 0)) // (the factoring strip's went out in two halves inside its solve)
+                        __hip_atomic_store(x.HP + (int64_t)P256_H(S, ROLE) * (NB * NB) + i + NB * col, v, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT); // polled by the other strips: no flag, no acknowledgement
                     if (i < x.nrows)
                         Ag[i + (int64_t)col * x.lda] = v;
                 }
             }
-            if constexpr (HEAD && !CHAIN) {
-                if (!x.mute) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's part of the tile is acknowledged
-                    __syncthreads();
-                    if (threadIdx.x == 0)
-                        __hip_atomic_store(x.fl + 3 + P256_H(S, ROLE), x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            if constexpr (HEAD) {
             }
             else if (S == 0 && !HEAD && x.want_d) // this strip's piece of the next panel's first diagonal block (later steps: inside the solve)
                 mm64<false>(TT, TT, wm, wn, lane, pr);
             P2TS(6 * S + 4);
             if constexpr (S < 3) {
                 // ---- updates of the strip's remaining column blocks c = S+1 .. CMAX with the tile of strip t = c - 1 ----
-                // Highest t first: the tile of strip t = S, the one that factors next, comes out last (under its factorisation).
-                // The tiles alternate between two LDS buffers: one barrier per update.
-                // The tile of strip t = S — the strip that factors next — is the last to come out; its flag is looked at between
-                // the other updates and its loads go out as soon as it is seen.
-                constexpr bool NEED_S = S != ROLE && S + 1 <= CMAX;
-                TileRegs hd[3];
-                gpe_epoch_t seen[3];
-#pragma unroll
-                for (int t = 2; t >= S; --t) // all flag words at once: a poll is a round trip to memory even when the word is set
-                    seen[t] = (t != ROLE && t + 1 <= CMAX)
-                        ? __hip_atomic_load(x.fl + 3 + P256_H(S, t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                        : x.epoch;
-#pragma unroll
-                for (int t = 2; t > S; --t)
-                    if (t != ROLE && t + 1 <= CMAX) {
-                        if (seen[t] != x.epoch)
-                            p256_wait(x.fl + 3 + P256_H(S, t), x.epoch, x.spin_limit, x.info, lane);
-                        asm volatile("" ::: "memory");
-                        hd[t].load_coherent(x.Hs + (int64_t)P256_H(S, t) * (NB * NB));
-                    }
-                bool got_s = false;
-                int nb = 0;
+                // All tiles are asked for at once; each is completed (polled) where it is used.  Order: the strip's own tile first
+                // (nothing to wait for), then highest t first — the tile of strip t = S, the one that factors next, is the last
+                // to be complete.  The tiles alternate between two LDS buffers: one barrier per update.
+                PolledTile hd[3];
 #pragma unroll
                 for (int t = 2; t >= S; --t)
-                    if (t + 1 <= CMAX) {
-                        if constexpr (NEED_S) {
-                            if (t > S && !got_s) { // a look at the last tile's flag; not there: ask again for the next look
-                                if (seen[S] == x.epoch) {
-                                    asm volatile("" ::: "memory");
-                                    hd[S].load_coherent(x.Hs + (int64_t)P256_H(S, S) * (NB * NB));
-                                    got_s = true;
-                                }
-                                else
-                                    seen[S] = __hip_atomic_load(x.fl + 3 + P256_H(S, S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                            if (t == S && !got_s) {
-                                if (seen[S] != x.epoch)
-                                    p256_wait(x.fl + 3 + P256_H(S, S), x.epoch, x.spin_limit, x.info, lane);
-                                asm volatile("" ::: "memory");
-                                hd[S].load_coherent(x.Hs + (int64_t)P256_H(S, S) * (NB * NB));
-                            }
-                        }
-                        const double* Bop = TT;
-                        if (t != ROLE) {
-                            double* buf = (nb & 1) ? x.T2 : x.T1;
-                            ++nb;
-                            hd[t].store(buf);
-                            __syncthreads();
-                            Bop = buf;
-                        }
-                        double a2[2][4];
-#pragma unroll
-                        for (int m = 0; m < 2; ++m)
-#pragma unroll
-                            for (int n = 0; n < 4; ++n)
-                                a2[m][n] = 0.0;
-                        mm64<false>(TT, Bop, wm, wn, lane, a2);
-                        double a2r[8];
-                        wave_tile_to_rows(a2, a2r, lane);
-#pragma unroll
-                        for (int it = 0; it < 8; ++it)
-                            cv[t + 1][it] -= a2r[it];
-                    }
+                    if (t != ROLE && t + 1 <= CMAX)
+                        hd[t].issue(x.HP + (int64_t)P256_H(S, t) * (NB * NB));
+                int nb = 0;
+                if constexpr (HEAD && !CHAIN)
+                    p256_update<S, ROLE, ROLE>(x, TT, hd, cv, nb); // with its own tile first: the polled ones are on their way meanwhile
+                if constexpr (ROLE != 2)
+                    p256_update<S, ROLE, 2>(x, TT, hd, cv, nb);
+                if constexpr (S <= 1 && ROLE != 1)
+                    p256_update<S, ROLE, 1>(x, TT, hd, cv, nb);
+                if constexpr (S == 0 && ROLE != 0)
+                    p256_update<S, ROLE, 0>(x, TT, hd, cv, nb);
+                if constexpr (CHAIN)
+                    p256_update<S, ROLE, ROLE>(x, TT, hd, cv, nb); // (S = 0 only: later steps update inside the solve)
                 if constexpr (!CHAIN)
                     __syncthreads(); // T0 and the buffers are free again
             }
@@ -1418,13 +1445,7 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
         }
         if constexpr (CHAIN) {
             // ---- tile S + 1 is the finished diagonal block of column block S + 1 ----
-            // the strip's head-tile copy (S = 0: all of it, before its update; S > 0: the first 32 columns since phase A of
-            // its solve, the rest since before the last product) has been on its way for a microsecond or more: this wait is
-            // (nearly) free, and behind the barrier every wave's part is acknowledged
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();   // [Bx | T0] have no readers left
-            if (threadIdx.x == 0 && !x.mute)
-                __hip_atomic_store(x.fl + 3 + P256_H(S, ROLE), x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             double* Ls = x.Bx; // [Ls | Ltb | invd | sync | Xw] re-carved over [Bx | T0], as in k_panel_step; T1 = this strip's L tile
             double* Ltb = Ls + NB * XS;
             double* invd = Ltb + DIAG_LTB;
@@ -1436,12 +1457,8 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
             __syncthreads();
             P2TS(26);
             DiagEarly ea;
-            ea.xearly = true; // every strip solves in two phases
-            ea.L21s = x.Hs + (int64_t)(5 + S + 1) * (NB * NB);
-            ea.f_early = x.fl + 8 + S + 1;
-            ea.f_x22 = x.fl + 11 + S + 1;
-            ea.epoch = x.epoch;
             ea.mute = x.mute;
+            ea.S = x.S22 + S * 3072;
             diag_flow(Ls, Ltb, invd, sy, x.A + x.R0 + x.R0 * x.lda, x.lda, x.Xt + (S + 1) * (NB * NB), x.info, x.R0, wave, lane,
                       invd + NB + 8, &ea);
             P2TS(27);
@@ -1506,7 +1523,8 @@ static __device__ __forceinline__ void p256_strip(const P256& x, double* __restr
 __global__ __launch_bounds__(512) void k_panel256(double* __restrict__ A, int64_t lda, int64_t p0, int64_t M,
                                                   double* __restrict__ Xt, int* __restrict__ info, double* __restrict__ Hs,
                                                   int64_t dnext, double* __restrict__ Dacc, gpe_epoch_t* fl,
-                                                  gpe_epoch_t epoch, int spin_limit)
+                                                  gpe_epoch_t epoch, int spin_limit, double* __restrict__ S22,
+                                                  double* __restrict__ S22_next)
 {
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS]; // [Bx | T0 | T1 | T2]: 156,672 B
     static_assert(NB * XS + DIAG_LTB + NB + 8 + DIAG_XW_DOUBLES <= NB * XS + NB * PS, "the factoring strips' carve fits into [Bx | T0]");
@@ -1529,6 +1547,20 @@ __global__ __launch_bounds__(512) void k_panel256(double* __restrict__ A, int64_
     x.T0 = lds + NB * XS;
     x.T1 = x.T0 + NB * PS;
     x.T2 = x.T1 + NB * PS;
+    x.S22 = S22;
+    x.HP = S22 + P256_POLLED_S;
+    { // the polled copies of the NEXT launch start from the all-ones pattern (this launch's were armed by the one before: same
+      // stream, complete before this one began); a quarter each for the last four strips
+        unsigned long long* nx = reinterpret_cast<unsigned long long*>(S22_next);
+        constexpr int QUARTER = P256_POLLED_DOUBLES / 4;
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {
+            const int owner = (int)gridDim.x - 1 - part > 0 ? (int)gridDim.x - 1 - part : 0;
+            if (b == owner)
+                for (int idx = threadIdx.x; idx < QUARTER; idx += 512)
+                    nx[part * QUARTER + idx] = ~0ull;
+        }
+    }
     P2TS(30);
     switch (b) {
     case 0: p256_strip<0>(x, Dacc); break;
@@ -1542,7 +1574,7 @@ __global__ __launch_bounds__(512) void k_panel256(double* __restrict__ A, int64_
 static std::atomic<gpe_epoch_t> g_handover_epoch{0}; // a value no earlier launch of this process has used; 64 bits: never wraps
 
 void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t M, double* Xt, int* info, double* Hs,
-                     int64_t dnext, double* Dacc, gpe_epoch_t* fl, hipEvent_t stop)
+                     int64_t dnext, double* Dacc, gpe_epoch_t* fl, double* S22, double* S22_next, hipEvent_t stop)
 {
     const gpe_epoch_t epoch = ++g_handover_epoch;
     static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
@@ -1552,10 +1584,10 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
         return;
     if (stop)
         GPE_LAUNCH_STOP("k_panel256", k_panel256, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, stop, A, lda, p0, M, Xt, info,
-                        Hs, dnext, Dacc, fl, epoch, spin_limit);
+                        Hs, dnext, Dacc, fl, epoch, spin_limit, S22, S22_next);
     else
         GPE_LAUNCH(k_panel256, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, p0, M, Xt, info, Hs, dnext, Dacc, fl,
-                   epoch, spin_limit);
+                   epoch, spin_limit, S22, S22_next);
 }
 
 // ---------------------------------------------------------------------------------------------

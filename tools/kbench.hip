@@ -143,8 +143,9 @@ int main(int argc, char** argv)
 #ifdef DIAG_TIMING
     { // all steps of the first outer panel in one launch (k_panel256)
         static double* Hs3 = nullptr;
-        CHK(hipMalloc(&Hs3, sizeof(double) * 8 * 4096));
-        CHK(hipMemset(Hs3, 0, sizeof(double) * 8 * 4096));
+        CHK(hipMalloc(&Hs3, sizeof(double) * 34 * 4096));
+        CHK(hipMemset(Hs3, 0, sizeof(double) * 34 * 4096));
+        CHK(hipMemset(Hs3 + 14 * 4096, 0xFF, sizeof(double) * 20 * 4096)); // the polled hand-over buffers (two of them)
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
         hipEventCreate(&e1);
@@ -154,7 +155,8 @@ int main(int argc, char** argv)
             launch_diag(s, A, ld, 64, Xi, info, 0, 1);
             CHK(hipStreamSynchronize(s));
             hipEventRecord(e0, s);
-            launch_panel256(s, A, ld, 0, N, Xi, info, Hs3, 256, Hs3 + 6 * 4096, (gpe_epoch_t*)(Hs3 + 7 * 4096));
+            launch_panel256(s, A, ld, 0, N, Xi, info, Hs3, 256, Hs3 + 12 * 4096, (gpe_epoch_t*)(Hs3 + 13 * 4096),
+                            Hs3 + (14 + 10 * (rep & 1)) * 4096, Hs3 + (14 + 10 * ((rep + 1) & 1)) * 4096);
             hipEventRecord(e1, s);
             CHK(hipStreamSynchronize(s));
             float ms;
