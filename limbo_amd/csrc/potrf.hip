@@ -1147,6 +1147,25 @@ struct P256 {
     double* HP;  // ... and of the six head tiles (P256_H), 4096 doubles each: they travel the same way, no flag, no acknowledgement
 };
 
+// Waiting for a polled block costs memory traffic: 60 strips x 512 threads each re-reading their 2..8 words every microsecond
+// is 10^5 uncached transactions per look — it slows everybody's loads (measured: 1.452 -> 1.436 ms per evaluation without it).
+// So a wave first watches ONE word of the block, the same for all its lanes (one transaction per look, with a pause), chosen
+// among the last to be written, and only then fetches and checks its own.
+static __device__ __forceinline__ void poll_one(const double* p, int spin_limit, int* __restrict__ info)
+{
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(p);
+    int spins = 0;
+    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ~0ull) {
+        if (++spins > spin_limit) {
+            if ((threadIdx.x & 63) == 0)
+                info[2] = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+}
+
 // a 64 x 64 tile (ld 64) that another workgroup of this launch is writing, or has written, over an all-ones pattern:
 // thread t holds elements (t & 63, (t >> 6) + 8 q) as in TileRegs
 struct PolledTile {
@@ -1169,6 +1188,7 @@ struct PolledTile {
                 info[2] = 1;
                 break;
             }
+            poll_one(G + NB * NB - 1, spin_limit, info);
             if (b[0] == SENT) b[0] = __hip_atomic_load(g + 0 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (b[1] == SENT) b[1] = __hip_atomic_load(g + 8 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (b[2] == SENT) b[2] = __hip_atomic_load(g + 16 * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1223,6 +1243,8 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
                 x.info[2] = 1;
                 break;
             }
+            poll_one(x.S22 + (S - 1) * 3072 + 1023, x.spin_limit, x.info);            // X11's last row
+            poll_one(x.S22 + (S - 1) * 3072 + 1024 + 32 * 31, x.spin_limit, x.info);  // L21's last column
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (b[q] == SENT)
@@ -1282,6 +1304,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
                 x.info[2] = 1;
                 break;
             }
+            poll_one(x.S22 + (S - 1) * 3072 + 2048 + 1023, x.spin_limit, x.info); // X22's last row
             if (b0 == SENT)
                 b0 = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (b1 == SENT)
@@ -1462,13 +1485,8 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
             diag_flow(Ls, Ltb, invd, sy, x.A + x.R0 + x.R0 * x.lda, x.lda, x.Xt + (S + 1) * (NB * NB), x.info, x.R0, wave, lane,
                       invd + NB + 8, &ea);
             P2TS(27);
-            if (!x.mute) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // X went out with write-through stores (DIAG_XT_STORE)
-                __syncthreads();
-                P2TS(28);
-                if (threadIdx.x == 0)
-                    __hip_atomic_store(x.fl + S, x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            __syncthreads(); // (the tile in T1 is still to be copied into the matrix: after every wave's part of the factorisation)
+            P2TS(28);
             P2TS(29);
             if constexpr (S > 0) { // this strip's L tile of the step into the matrix: nobody reads it there before the launch ends
                 const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
