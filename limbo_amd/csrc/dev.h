@@ -151,8 +151,18 @@ void gpe_trace_add(const char* name, hipStream_t s, hipEvent_t e0, hipEvent_t e1
 // ---- kernel-matrix build (kbuild.hip) ----------------------------------------------
 // Xt: SoA, D x ldx (sample index contiguous).  Writes the LOWER triangle (incl. diagonal,
 // + diag_add) of K into A (col-major, lda).  gp.hpp:556-558 + kernel.hpp:81-84.
-void launch_build_K(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp,
-                    double* A, int64_t lda);
+// tail (optional): what launch_cols_to_rows does, by extra workgroups of the same launch (kbuild.hip); returns whether it was
+// taken (the wide build kernel, single-GP launches) — otherwise the caller launches it itself
+struct BuildRowsTail {
+    const double* V; // N x P (ld ldv)
+    int64_t ldv;
+    int P;
+    double* Arows;   // A + N: row p of column i at Arows[p + i * lda]
+    double* sent;    // optional, as for launch_cols_to_rows
+    int64_t first;   // (set by the launcher)
+};
+bool launch_build_K(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp,
+                    double* A, int64_t lda, const BuildRowsTail* tail = nullptr);
 // full symmetric K (tests / gpe_get_K)
 void launch_build_K_full(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp,
                          double* A, int64_t lda);

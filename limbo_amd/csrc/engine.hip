@@ -936,6 +936,8 @@ int compute_enqueue(gpe_ctx* c)
     c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
     if (c->handover_off_left > 0 && --c->handover_off_left == 0)
         c->panel_handover = c->panel_handover_cfg; // re-armed after a run of clean evaluations without it
+    const bool flow_al = c->flow_solve && (c->N + NB - 1) / NB <= 256;
+    bool rows_done = false; // obs_mean^T under the matrix + the sweep's sentinel: by the build launch itself where it can
     if (c->host_K) {
         if (!c->dKhost)
             return GPE_ERR_STATE;
@@ -949,12 +951,14 @@ int compute_enqueue(gpe_ctx* c)
         // workgroups it shares CUs with as much as it saves; bounded to 128 looping workgroups it takes
         // 250 us — a tile is latency-bound and needs ~8 co-resident workgroups per CU.)
         project_lambda(c, s, c->dXt, c->ld, 0, c->N);
-        launch_build_K(s, c->dXt, c->ld, c->N, c->kp, c->dA, c->ld);
+        const BuildRowsTail rt{c->dOm, c->ld, c->P, c->dA + c->N, flow_al ? c->dAl : nullptr, 0};
+        static const bool tail = !(getenv("GPE_ROWS_TAIL") && atoi(getenv("GPE_ROWS_TAIL")) == 0);
+        rows_done = launch_build_K(s, c->dXt, c->ld, c->N, c->kp, c->dA, c->ld, tail ? &rt : nullptr);
     }
     {
-        const bool flow = c->flow_solve && (c->N + NB - 1) / NB <= 256;
-        launch_cols_to_rows(s, c->dOm, c->ld, c->N, c->P, c->dA + c->N, c->ld, flow ? c->dAl : nullptr);
-        c->al_prefilled = flow;
+        if (!rows_done)
+            launch_cols_to_rows(s, c->dOm, c->ld, c->N, c->P, c->dA + c->N, c->ld, flow_al ? c->dAl : nullptr);
+        c->al_prefilled = flow_al;
     }
     // K^-1 behind the factorisation (gpe_hp_objective with a gradient; not in batched launches or profiling runs)
     if (c->inv_pending) { // an earlier chain nobody waited for (an error path): it must not write under this evaluation

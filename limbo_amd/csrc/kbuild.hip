@@ -307,11 +307,25 @@ static void launch_build_lower_kind(hipStream_t s, const double* Xt, int64_t ldx
 // k_build_wide<KIND, DMAX, BATCH> — as k_build_lower, but shaped for the memory side: a workgroup owns 128 rows x 64
 // columns, a lane owns TWO consecutive rows and stores them as one 16-byte double2 (1 KiB contiguous per wave store
 // instead of 512 B), the 64 column samples are staged once through LDS (wave-uniform LDS reads: broadcasts).
+// rt (single-GP launches): the workgroups from rt.first on do what k_cols_to_rows (solve.hip) does — obs_mean^T into the rows
+// under the matrix, the backward sweep's output pre-filled with its sentinel — instead of a launch of its own behind this one
+// (4.6 us + a launch boundary at the head of every evaluation).
 template <int KIND, int DMAX, bool BATCH>
 __global__ __launch_bounds__(256) void k_build_wide(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp_,
-                                                     double* __restrict__ A, int64_t lda, const BatchTab* __restrict__ bt)
+                                                     double* __restrict__ A, int64_t lda, const BatchTab* __restrict__ bt,
+                                                     BuildRowsTail rt)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[]; // xj[D][64]
+    if (!BATCH && rt.V && (int64_t)blockIdx.x >= rt.first) {
+        const int64_t i = ((int64_t)blockIdx.x - rt.first) * 256 + threadIdx.x;
+        if (i < N)
+            for (int p = 0; p < rt.P; ++p) {
+                rt.Arows[p + i * lda] = rt.V[i + (int64_t)p * rt.ldv];
+                if (rt.sent)
+                    ((unsigned long long*)rt.sent)[i + (int64_t)p * rt.ldv] = ~0ull;
+            }
+        return;
+    }
     if (BATCH) {
         Xt = bt_rebase(bt, (int)blockIdx.z, Xt);
         A = bt_rebase(bt, (int)blockIdx.z, A);
@@ -395,22 +409,26 @@ __global__ __launch_bounds__(256) void k_build_wide(const double* __restrict__ X
 }
 
 template <int KIND>
-static void launch_build_wide_kind(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A, int64_t lda)
+static void launch_build_wide_kind(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A, int64_t lda,
+                                   BuildRowsTail rt)
 {
     const int64_t nt = (N + 127) / 128;
     // live tiles: sum over ti of min(2 ti + 2, column blocks)
     const int64_t ncb = (N + TILE - 1) / TILE;
     int64_t tiles = nt * (nt + 1); // the last block-row may count a column block past N: those workgroups find j >= N and leave
     (void)ncb;
+    rt.first = tiles;
+    if (rt.V)
+        tiles += (N + 255) / 256;
     dim3 grid((unsigned)tiles, 1, (unsigned)g_batch.G);
     const BatchTab* bt = g_batch.bt;
     const size_t sh = (size_t)kp.D * TILE * sizeof(double);
 #define LBW(DM)                                                                                                     \
     do {                                                                                                            \
         if (bt)                                                                                                     \
-            GPE_LAUNCH((k_build_wide<KIND, DM, true>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt);  \
+            GPE_LAUNCH((k_build_wide<KIND, DM, true>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt, rt);  \
         else                                                                                                        \
-            GPE_LAUNCH((k_build_wide<KIND, DM, false>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt); \
+            GPE_LAUNCH((k_build_wide<KIND, DM, false>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt, rt); \
     } while (0)
     if (kp.D <= 4)
         LBW(4);
@@ -425,27 +443,31 @@ static void launch_build_wide_kind(hipStream_t s, const double* Xt, int64_t ldx,
 #undef LBW
 }
 
-void launch_build_K(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A, int64_t lda)
+bool launch_build_K(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A, int64_t lda,
+                    const BuildRowsTail* tail)
 {
+    BuildRowsTail rt{};
+    if (tail && !g_batch.bt && tail->P > 0)
+        rt = *tail;
     // GPE_KBUILD: 0 = the generic tile kernel (k_build), 1 = k_build_lower (scalar-unit column samples), 2 = k_build_wide
     static const int variant = getenv("GPE_KBUILD") ? atoi(getenv("GPE_KBUILD")) : 2;
     const bool fast = variant != 0;
     if (!fast || N <= 0 || (lda & 1)) {
         launch_build<0>(s, Xt, ldx, N, nullptr, 0, 0, kp, A, lda);
-        return;
+        return false;
     }
     if (variant == 9) {
-        launch_build_wide_kind<9>(s, Xt, ldx, N, kp, A, lda);
-        return;
+        launch_build_wide_kind<9>(s, Xt, ldx, N, kp, A, lda, rt);
+        return rt.V != nullptr;
     }
     if (variant == 2) {
         switch (kp.kind) {
         case 0:
-        case 3: launch_build_wide_kind<0>(s, Xt, ldx, N, kp, A, lda); break;
-        case 1: launch_build_wide_kind<1>(s, Xt, ldx, N, kp, A, lda); break;
-        default: launch_build_wide_kind<2>(s, Xt, ldx, N, kp, A, lda); break;
+        case 3: launch_build_wide_kind<0>(s, Xt, ldx, N, kp, A, lda, rt); break;
+        case 1: launch_build_wide_kind<1>(s, Xt, ldx, N, kp, A, lda, rt); break;
+        default: launch_build_wide_kind<2>(s, Xt, ldx, N, kp, A, lda, rt); break;
         }
-        return;
+        return rt.V != nullptr;
     }
     switch (kp.kind) {
     case 0:
@@ -453,6 +475,7 @@ void launch_build_K(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, con
     case 1: launch_build_lower_kind<1>(s, Xt, ldx, N, kp, A, lda); break;
     default: launch_build_lower_kind<2>(s, Xt, ldx, N, kp, A, lda); break;
     }
+    return false;
 }
 void launch_build_K_full(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A,
                          int64_t lda)
