@@ -1,6 +1,7 @@
 // diagbench.hip — the 64 x 64 diagonal-block kernel (k_diag) alone: average launch time and the in-kernel round stamps.
 // build: make -C tools diagflow diagbench_0   (the data-flow form / the barrier rounds, -DDIAG_FLOW=0)
 #include "../limbo_amd/csrc/potrf.hip"
+#include "trace_stub.h"
 #include <vector>
 thread_local BatchLaunch g_batch;
 void launch_gemm_sub(hipStream_t, const GemmArgs&) {}
