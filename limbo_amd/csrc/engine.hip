@@ -1227,7 +1227,11 @@ int ensure_inv(gpe_ctx* c)
         };
         {
             PhaseScope ps(c, GPE_PH_INV, 0.0);
-            launch_zero2d(s, c->dKinv, ld, N, N); // (a kernel: it takes part in batched launches, dev.h)
+            // (a kernel: it takes part in batched launches, dev.h).  With the overlap only the second stream's rank-k updates
+            // touch the K^-1 buffer: it is zeroed there, beside the block inverses instead of in front of them (21 us + a
+            // launch boundary of every gradient evaluation); that stream's work of the factorisation was joined long ago, and
+            // whatever read the buffer last on the main stream precedes the events those launches waited for
+            launch_zero2d(overlap ? c->stream2 : s, c->dKinv, ld, N, N);
             if (overlap)
                 launch_inv_panels(s, c->dA, ld, N, (int)nbo, c->dXinv, c->dXp, 0, c->dLinv, ld); // X_p compact, X_p^T -> U's diagonal blocks
             else

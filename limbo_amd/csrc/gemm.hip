@@ -710,7 +710,8 @@ static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds6
         // LDS-fed MFMA rate (~48 us per tile); below ~200 live tiles too many CUs idle and the
         // 64 x 64 tile (4x the workgroups) wins; the 32 x 64 tile serves the tiny panel steps
         const int64_t GB = g_batch.G; // a batched launch runs GB problems of this shape at once
-        if (glds_ok(g) && GB * live_tiles(g, 128, 128) >= 200)
+        static const int64_t t128_min = getenv("GPE_TILE128_MIN") ? atoll(getenv("GPE_TILE128_MIN")) : 200;
+        if (glds_ok(g) && GB * live_tiles(g, 128, 128) >= t128_min)
             tile = 128;
         else if (glds_ok(g) && !g.ktri && use_glds64 && GB * live_tiles(g, 64, 64) >= 96) // (the 64 x 64 body has no ktri form)
             tile = 64; // deep-prefetch 64 x 64 glds kernel: also the latency-critical next-panel update
