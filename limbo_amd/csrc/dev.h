@@ -200,9 +200,9 @@ void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_
                        double* Xt_next, int do_next, int* info, double* Hs, int64_t dnext, int64_t dfirst, int dinit,
                        double* Dacc, gpe_epoch_t* hflag);
 // all steps of the 256-column outer panel at p0 in one launch (potrf.hip: k_panel256); Xt = inverse of the diagonal block at
-// p0 (the next three follow at + 4096 each and are written), Hs: 6 scratch tiles, fl: 9 flag words, dnext as above
-void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t M, double* Xt, int* info, double* Hs,
-                     int64_t dnext, double* Dacc, gpe_epoch_t* fl, double* S22, double* S22_next, hipEvent_t stop = nullptr);
+// p0 (the next three follow at + 4096 each and are written), dnext / Dacc as above
+void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t M, double* Xt, int* info, int64_t dnext,
+                     double* Dacc, double* S22, double* S22_next, hipEvent_t stop = nullptr);
 // S22 / S22_next: the polled hand-over buffers (block inverses + head tiles), 33,792 doubles each, holding the all-ones
 // pattern when the launch starts (the launch arms S22_next)
 #define GPE_S22_TILE 20 // the two buffers sit in tiles 20..28 of either half of gpe_ctx::dHead

@@ -585,8 +585,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 launch_diag(s, A + p0 + p0 * ld, ld, NB, Xt, c->dInfo, p0, 1);
             }
             PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - p0 - NB) * NB * NB * 2.5 * 4);
-            launch_panel256(s, A, ld, p0, M, Xt, c->dInfo, Hbase, fuse_diag ? pe : -1, c->dHead + 64 * NB * NB,
-                            (gpe_epoch_t*)(c->dHead + 65 * NB * NB) + ((p0 / nbo) & 1) * 32,
+            launch_panel256(s, A, ld, p0, M, Xt, c->dInfo, fuse_diag ? pe : -1, c->dHead + 64 * NB * NB,
                             c->dHead + ((c->p256_count & 1) * 32 + GPE_S22_TILE) * (NB * NB),
                             c->dHead + (((c->p256_count + 1) & 1) * 32 + GPE_S22_TILE) * (NB * NB), p_done);
             ++c->p256_count;

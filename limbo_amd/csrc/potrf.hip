@@ -1126,8 +1126,7 @@ __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, in
 // dnext >= 0: the strip of rows dnext (the next panel's first diagonal block) also leaves sum_s L_bs L_bs^T in Dacc for
 // k_upd_fused.  Full 64-column blocks, nbo = 256 only; everything else goes the step-by-step way.
 // ---------------------------------------------------------------------------------------------
-// flag words: fl[s - 1] = X_s is out (s = 1..3); fl[3 + h] = head tile h, h = P256_H(s, t) for strip t at step s (t = s..2);
-// (the block inverses travel without flags: diag_flow.h: DiagEarly).  Hs: tiles 0..5 the head tiles.
+// head tile h = P256_H(s, t): the tile of strip t at step s (t = s..2), six per panel
 #define P256_H(s, t) ((s) == 0 ? (t) : ((s) == 1 ? 2 + (t) : 5))
 
 #define P256_POLLED_S (9 * 1024)                          // X11 | L21 | X22 of three diagonal blocks
@@ -1137,9 +1136,6 @@ struct P256 {
     int64_t lda, p0, R0;
     double* Xt;
     int* info;
-    double* Hs;
-    gpe_epoch_t* fl;
-    gpe_epoch_t epoch;
     int spin_limit, nrows;
     bool mute, want_d;
     double *Bx, *T0, *T1, *T2;
@@ -1539,9 +1535,8 @@ static __device__ __forceinline__ void p256_strip(const P256& x, double* __restr
 }
 
 __global__ __launch_bounds__(512) void k_panel256(double* __restrict__ A, int64_t lda, int64_t p0, int64_t M,
-                                                  double* __restrict__ Xt, int* __restrict__ info, double* __restrict__ Hs,
-                                                  int64_t dnext, double* __restrict__ Dacc, gpe_epoch_t* fl,
-                                                  gpe_epoch_t epoch, int spin_limit, double* __restrict__ S22,
+                                                  double* __restrict__ Xt, int* __restrict__ info, int64_t dnext,
+                                                  double* __restrict__ Dacc, int spin_limit, double* __restrict__ S22,
                                                   double* __restrict__ S22_next)
 {
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS]; // [Bx | T0 | T1 | T2]: 156,672 B
@@ -1554,9 +1549,6 @@ __global__ __launch_bounds__(512) void k_panel256(double* __restrict__ A, int64_
     x.R0 = p0 + (int64_t)NB * (b + 1);
     x.Xt = Xt;
     x.info = info;
-    x.Hs = Hs;
-    x.fl = fl;
-    x.epoch = epoch;
     x.mute = spin_limit < 0; // test hook (GPE_HANDOVER_FAULT): nobody publishes, every consumer gives up at once
     x.spin_limit = spin_limit < 0 ? -spin_limit : spin_limit;
     x.nrows = (int)((M - x.R0 < NB) ? M - x.R0 : NB);
@@ -1591,21 +1583,19 @@ __global__ __launch_bounds__(512) void k_panel256(double* __restrict__ A, int64_
 
 static std::atomic<gpe_epoch_t> g_handover_epoch{0}; // a value no earlier launch of this process has used; 64 bits: never wraps
 
-void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t M, double* Xt, int* info, double* Hs,
-                     int64_t dnext, double* Dacc, gpe_epoch_t* fl, double* S22, double* S22_next, hipEvent_t stop)
+void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t M, double* Xt, int* info, int64_t dnext,
+                     double* Dacc, double* S22, double* S22_next, hipEvent_t stop)
 {
-    const gpe_epoch_t epoch = ++g_handover_epoch;
     static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
     const int spin_limit = fault ? -16 : GPE_FLOW_SPIN_LIMIT;
     const int64_t rows = M - (p0 + NB);
     if (rows <= 0)
         return;
+    const dim3 grid((unsigned)((rows + NB - 1) / NB)), block(512);
     if (stop)
-        GPE_LAUNCH_STOP("k_panel256", k_panel256, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, stop, A, lda, p0, M, Xt, info,
-                        Hs, dnext, Dacc, fl, epoch, spin_limit, S22, S22_next);
+        GPE_LAUNCH_STOP("k_panel256", k_panel256, grid, block, 0, s, stop, A, lda, p0, M, Xt, info, dnext, Dacc, spin_limit, S22, S22_next);
     else
-        GPE_LAUNCH(k_panel256, dim3((unsigned)((rows + NB - 1) / NB)), dim3(512), 0, s, A, lda, p0, M, Xt, info, Hs, dnext, Dacc, fl,
-                   epoch, spin_limit, S22, S22_next);
+        GPE_LAUNCH(k_panel256, grid, block, 0, s, A, lda, p0, M, Xt, info, dnext, Dacc, spin_limit, S22, S22_next);
 }
 
 // ---------------------------------------------------------------------------------------------

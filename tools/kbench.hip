@@ -155,8 +155,8 @@ int main(int argc, char** argv)
             launch_diag(s, A, ld, 64, Xi, info, 0, 1);
             CHK(hipStreamSynchronize(s));
             hipEventRecord(e0, s);
-            launch_panel256(s, A, ld, 0, N, Xi, info, Hs3, 256, Hs3 + 12 * 4096, (gpe_epoch_t*)(Hs3 + 13 * 4096),
-                            Hs3 + (14 + 10 * (rep & 1)) * 4096, Hs3 + (14 + 10 * ((rep + 1) & 1)) * 4096);
+            launch_panel256(s, A, ld, 0, N, Xi, info, 256, Hs3 + 12 * 4096, Hs3 + (14 + 10 * (rep & 1)) * 4096,
+                            Hs3 + (14 + 10 * ((rep + 1) & 1)) * 4096);
             hipEventRecord(e1, s);
             CHK(hipStreamSynchronize(s));
             float ms;
