@@ -1115,14 +1115,19 @@ __global__ __launch_bounds__(512) void k_panel_step_b(double* __restrict__ A, in
 // Here workgroup b owns the 64-row strip R_b = rows p0 + 64 (b + 1) .. +63 of the panel for the whole launch and keeps its
 // (up to four) 64 x 64 tiles in REGISTERS between the steps: every tile is read once and written once, as L.
 //   step s (column block s of the panel), strips b >= s:
-//     wait for X_s (s = 0: the diagonal block at p0 was factored by the launch before; s > 0: flag word xs)  ->  L_bs = A_bs X_s^T
-//     strips b <= 2 publish L_bs (a "head tile": the rows of column block b + 1) through Hs + a flag word, as k_panel_step does
+//     X_s (s = 0: the diagonal block at p0 was factored by the launch before; s > 0: polled, below)  ->  L_bs = A_bs X_s^T
+//     strips b <= 2 publish L_bs (a "head tile": the rows of column block b + 1)
 //     A_bc -= L_bs L_{c-1,s}^T for the strip's remaining column blocks c = s+1 .. min(3, b+1)
 //     strip b = s now holds the finished diagonal block of column block s + 1: it factors it (diag_flow), X_{s+1} goes out
-//       with write-through stores, then the flag — and the strip is done.
+//       quarter by quarter while it is being computed — and the strip is done.
+// Nothing inside the launch is handed over with a flag: block inverses and head tiles are stored, with device-scope stores,
+// into buffers that hold an all-ones pattern when the launch starts, and their consumers poll the values (P256::S22 / HP,
+// PolledTile, poll_one; diag_flow.h: DiagEarly).  The launch arms the other buffer of the pair for the launch after it.
 // A strip only ever waits for lower-numbered strips (X_s comes from strip s - 1 <= b - 1, head tiles from strips < b), so
 // with workgroups dispatched in index order nobody waits for a workgroup that is not running (dev.h, requirement (1));
 // the polls are bounded all the same and a timeout is reported exactly like k_panel_step's (info[2], the host re-runs).
+// From step 1 on every strip solves in the half-block form of the inverse, in two phases (p256_half_solve): three quarters of
+// the solve, and the first k-half of the factoring strip's update, run while the previous block is still being factored.
 // dnext >= 0: the strip of rows dnext (the next panel's first diagonal block) also leaves sum_s L_bs L_bs^T in Dacc for
 // k_upd_fused.  Full 64-column blocks, nbo = 256 only; everything else goes the step-by-step way.
 // ---------------------------------------------------------------------------------------------
@@ -1278,7 +1283,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
 #pragma unroll
         for (int n = 0; n < 2; ++n)
             T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = t2[m][n];
-    if constexpr (PUBHALF) { // columns 0..31 of the strip's L tile are final: its head-tile copy starts its way now (the flag follows the rest)
+    if constexpr (PUBHALF) { // columns 0..31 of the strip's L tile are final: its head-tile copy starts its way now (the rest follows behind phase B)
         const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1381,7 +1386,7 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
         const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
         const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
         // the strip's L tile of this step: the factoring strip keeps it in T1, which its factorisation (re-carving [Bx | T0])
-        // leaves alone — the tile goes out to memory from there UNDER the factorisation (diag_flow.h: DiagEarly::Lt)
+        // leaves alone — the tile's copy into the matrix waits until the factorisation is over
         double* const TT = CHAIN ? x.T1 : x.T0;
         if constexpr (CHAIN && S > 0) {
             double a2c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
