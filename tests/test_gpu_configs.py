@@ -358,6 +358,35 @@ def test_gpu_panel_head_tiles_handed_over_or_rederived_give_the_same_factor(engi
     assert np.max(np.abs(Ls["no_handover"] - L1)) <= 1e-13 * np.max(np.abs(L1))
 
 
+def test_gpu_one_launch_panels_polled_buffers_across_handles(engine_lib):
+    """k_panel256 hands block inverses and head tiles over through buffers that must hold an all-ones pattern when a launch
+    starts: every launch arms the other buffer of the handle's pair, both are armed when a handle is created — also when its
+    streams and scratch block come out of the pool of destroyed handles, in whatever state the last launch left them.  An odd
+    and an even number of one-launch panels per evaluation (N = 1100: 4, N = 1400: 5), handles destroyed and re-created in
+    between and two handles taking turns: every evaluation must reproduce the first one bit for bit."""
+    ref = {}
+    for rnd in range(3):
+        for N in (1100, 1400, 1100):
+            X, Y = synth.make_problem("c2", N=N)
+            om, _ = synth.obs_mean_data(Y)
+            h = new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(7), 0.01)
+            for _ in range(1 + rnd):
+                assert h.compute() == 0 and h.flow_retries() == 0
+                ll = h.log_lik()
+                assert ref.setdefault(N, ll) == ll
+            h.close()
+    hs = []
+    for N in (1100, 1400):
+        X, Y = synth.make_problem("c2", N=N)
+        om, _ = synth.obs_mean_data(Y)
+        hs.append((N, new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(7), 0.01)))
+    for _ in range(3):
+        for N, h in hs:
+            assert h.compute() == 0 and h.log_lik() == ref[N]
+    for _, h in hs:
+        h.close()
+
+
 def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib):
     """GPE_HANDOVER_FAULT=1: no head workgroup publishes and every consumer gives up after a few polls, i.e. every fused
     panel step of the first attempt reports a lost hand-over.  The host must notice (info word 2), run the evaluation again
