@@ -96,6 +96,10 @@ struct gpe_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead: bulk of a trailing update runs here, behind the next panel
     std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
+    int64_t tail_max = 2560;           // the last <= this many columns by one launch (k_tail; GPE_TAIL_MAX=0: by panels to the end)
+    double* dTail = nullptr;           // its two polled hand-over buffers (2 x tail_cap doubles, all-ones between launches)
+    int64_t tail_cap = 0;
+    unsigned tail_count = 0;
     unsigned p256_count = 0;           // launches of k_panel256 so far: its polled X22 copies alternate between two buffers
     std::vector<hipEvent_t> pl_events; // ... one per outer panel: the one-launch panel is complete (early release of the look-ahead stream)
     int64_t early_bulk = 100;          // release the look-ahead stream at the END OF THE PANEL (not of the fused next-panel update)
@@ -540,7 +544,27 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     bool next_diag_done = false; // the fused next-panel update factored the first diagonal block of the coming panel
     bool la_pending = false; // a bulk update is (possibly) still running on stream2
     size_t la_last = 0;
-    for (int64_t p0 = 0; p0 < N; p0 += nbo) {
+    // The last <= tail_max columns (all of them when N <= tail_max) go to ONE launch, a tiled data-flow factorisation
+    // (potrf.hip: k_tail): the panels end at t0, the panel in front of it updates everything that is left in one piece.
+    int64_t t0 = -1;
+    if (c->tail_max >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && !g_batch.bt && nbo == 4 * NB && N % NB == 0
+        && N >= 2 * NB && M - N <= NB) {
+        t0 = N > c->tail_max ? (N - c->tail_max + nbo - 1) / nbo * nbo : 0;
+        const int64_t need = tail_buf_doubles((N - t0) / NB, M - N);
+        if (c->tail_cap < need) { // (both buffers all-ones: whatever the old ones held is irrelevant)
+            if (c->dTail)
+                hipFree(c->dTail);
+            c->dTail = nullptr;
+            c->tail_cap = 0;
+            if (hipMalloc(&c->dTail, sizeof(double) * 2 * need) == hipSuccess) {
+                hipMemsetAsync(c->dTail, 0xFF, sizeof(double) * 2 * need, s);
+                c->tail_cap = need;
+            }
+            else
+                t0 = -1;
+        }
+    }
+    for (int64_t p0 = 0; p0 < N && p0 != t0; p0 += nbo) {
         const int64_t pw = std::min<int64_t>(nbo, N - p0);
         const int64_t pe = p0 + pw;
         bool diag_done = next_diag_done; // the previous fused step (or fused update) already factored this diagonal block
@@ -555,7 +579,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
         // diagonal block (k_upd_fused)?  Then the steps of this panel pre-apply their pieces of that block.
         const bool fuse_diag = c->lookahead && !c->prof && std::min<int64_t>(pe + nbo, N) < N && c->fuse_panel && c->fuse_diag
             && c->stop_events && pw == nbo && nbo % NB == 0 && nbo >= 2 * NB && ld % 2 == 0
-            && std::min<int64_t>(nbo, N - pe) % NB == 0;
+            && std::min<int64_t>(nbo, N - pe) % NB == 0 && pe != t0;
         // the whole panel in one launch (potrf.hip: k_panel256): full 256 columns, head tiles and block inverses handed over
         // between its workgroups
         const bool p256 = c->panel256 && c->fuse_panel && c->panel_handover && !g_batch.bt && nbo == 4 * NB && pw == nbo && pe <= M;
@@ -691,7 +715,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 launch_gemm_sub(st, g);
             };
             const int64_t pe2 = std::min<int64_t>(pe + nbo, N);
-            if (c->lookahead && !c->prof && pe2 < N) {
+            if (c->lookahead && !c->prof && pe2 < N && pe != t0) {
                 // look-ahead: the next panel's columns are updated on the main stream, the rest of the
                 // trailing matrix on the second stream while the next panel is factored
                 auto ev = [&](size_t i) {
@@ -791,6 +815,13 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     }
     if (la_pending)
         hipStreamWaitEvent(s, c->la_events[la_last], 0);
+    if (t0 >= 0) {
+        PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(N - t0) * (N - t0) * (N - t0) / 3.0);
+        launch_tail(s, A, ld, t0, N, M, c->dXinv, c->dInfo, c->dTail + (c->tail_count & 1) * c->tail_cap,
+                    c->dTail + ((c->tail_count + 1) & 1) * c->tail_cap);
+        ++c->tail_count;
+        c->xinv_done = N / NB;
+    }
     if (c->fuse_panel && N / NB > c->xinv_done) { // off-diagonal quarters of the remaining block inverses
         PhaseScope ps(c, GPE_PH_POTRF_PANEL, 0.0);
         launch_xinv_complete(s, A, ld, c->xinv_done, N / NB - c->xinv_done, c->dXinv);
@@ -1648,6 +1679,8 @@ int gpe_create(int device_id, gpe_handle* out)
         c->panel256 = atoi(f) != 0;
     if (const char* f = getenv("GPE_EARLY_BULK_TILES"))
         c->early_bulk = atoll(f);
+    if (const char* f = getenv("GPE_TAIL_MAX"))
+        c->tail_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), GPE_TAIL_MAX);
     if (const char* f = getenv("GPE_STOP_EVENT"))
         c->stop_events = atoi(f) != 0;
     if (const char* f = getenv("GPE_LOOKAHEAD"))
@@ -1677,6 +1710,8 @@ int gpe_destroy(gpe_handle c)
     for (auto e : c->pool)
         hipEventDestroy(e);
     free_dev(c);
+    if (c->dTail)
+        hipFree(c->dTail);
     for (auto e : c->pl_events)
         hipEventDestroy(e);
     for (auto e : c->la_events)

@@ -1216,9 +1216,11 @@ struct PolledTile {
 // Every strip solves this way from step 1 on (PUBHALF / acc_on: the factoring strip publishes the first half of its tile after
 // phase A and accumulates its update; the strip of the next panel's first diagonal block accumulates its piece of that block;
 // the others only solve): what a strip still has to do once the last rows of X are out is a quarter of the solve.
+// Sq: the block's polled quarters (X11 | L21 | X22, 1024 doubles each); pub (PUBHALF): where the strip's own tile goes, polled
 template <int S, bool PUBHALF>
 static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __restrict__ T, double* __restrict__ Ld,
-                                                       const double (&own)[8], double (&a2)[2][4], const bool acc_on)
+                                                       const double (&own)[8], double (&a2)[2][4], const bool acc_on,
+                                                       const double* __restrict__ Sq, double* __restrict__ pub)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16; // the 64 x 64 product's wave tile
@@ -1232,7 +1234,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
         T[(ccol + 2 * it) * PS + crow] = own[it];
     // ---- phase A: X11 and L21, polled value by value (diag_flow.h: DiagEarly) ----
     const unsigned long long SENT = ~0ull;
-    const unsigned long long* Sp = reinterpret_cast<const unsigned long long*>(x.S22 + (S - 1) * 3072) + threadIdx.x;
+    const unsigned long long* Sp = reinterpret_cast<const unsigned long long*>(Sq) + threadIdx.x;
     {
         unsigned long long b[4];
 #pragma unroll
@@ -1244,8 +1246,8 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
                 x.info[2] = 1;
                 break;
             }
-            poll_one(x.S22 + (S - 1) * 3072 + 1023, x.spin_limit, x.info);            // X11's last row
-            poll_one(x.S22 + (S - 1) * 3072 + 1024 + 32 * 31, x.spin_limit, x.info);  // L21's last column
+            poll_one(Sq + 1023, x.spin_limit, x.info);            // X11's last row
+            poll_one(Sq + 1024 + 32 * 31, x.spin_limit, x.info);  // L21's last column
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (b[q] == SENT)
@@ -1288,8 +1290,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = kk0 + 8 * q;
-            __hip_atomic_store(x.HP + (int64_t)P256_H(S, S) * (NB * NB) + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pub + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (acc_on)
@@ -1305,7 +1306,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
                 x.info[2] = 1;
                 break;
             }
-            poll_one(x.S22 + (S - 1) * 3072 + 2048 + 1023, x.spin_limit, x.info); // X22's last row
+            poll_one(Sq + 2048 + 1023, x.spin_limit, x.info); // X22's last row
             if (b0 == SENT)
                 b0 = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (b1 == SENT)
@@ -1331,8 +1332,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
 #pragma unroll
         for (int q = 4; q < 8; ++q) {
             const int col = kk0 + 8 * q;
-            __hip_atomic_store(x.HP + (int64_t)P256_H(S, S) * (NB * NB) + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pub + i + NB * col, T[col * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (acc_on)
@@ -1390,7 +1390,7 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
         double* const TT = CHAIN ? x.T1 : x.T0;
         if constexpr (CHAIN && S > 0) {
             double a2c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            p256_half_solve<S, true>(x, TT, x.T0, cv[S], a2c, true);
+            p256_half_solve<S, true>(x, TT, x.T0, cv[S], a2c, true, x.S22 + (S - 1) * 3072, x.HP + (int64_t)P256_H(S, S) * (NB * NB));
             double a2r[8];
             wave_tile_to_rows(a2c, a2r, lane);
 #pragma unroll
@@ -1400,7 +1400,7 @@ static __device__ __forceinline__ void p256_step(const P256& x, double (&cv)[4][
         }
         else {
             if constexpr (S > 0)
-                p256_half_solve<S, false>(x, TT, x.T2, cv[S], pr, !HEAD && x.want_d);
+                p256_half_solve<S, false>(x, TT, x.T2, cv[S], pr, !HEAD && x.want_d, x.S22 + (S - 1) * 3072, nullptr);
             else {
                 // ---- X_0 (from the launch before) and this strip's tile of column block 0 into LDS ----
                 P2TS(6 * S + 0);
@@ -1601,6 +1601,245 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
         GPE_LAUNCH_STOP("k_panel256", k_panel256, grid, block, 0, s, stop, A, lda, p0, M, Xt, info, dnext, Dacc, spin_limit, S22, S22_next);
     else
         GPE_LAUNCH(k_panel256, grid, block, 0, s, A, lda, p0, M, Xt, info, dnext, Dacc, spin_limit, S22, S22_next);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tail (round 3) — the LAST T <= 1024 columns of the factorisation (or all of it when N <= 1024) as ONE launch: a tiled
+// data-flow Cholesky.  The last four outer panels of N = 4096 hold 1.5 % of the flops and took 20 % of the time: each is a
+// k_panel256 of 4-16 strips (~48 us: three diagonal blocks one after the other), a fused update for a handful of tiles
+// (~16 us) and two launch boundaries, although the whole remaining matrix — 136 tiles of 64 x 64 — fits on the chip with one
+// workgroup per tile.  Here workgroup (b, c) owns tile (b, c) of the lower triangle (b >= c; row strip nt = the right-hand-side
+// rows) and keeps it in registers for the whole launch:
+//   steps s = 0 .. c-1:  tile -= L(b, s) L(c, s)^T, both operands polled from the owners of those tiles (PolledTile; the next
+//                        step's operands are asked for before this step's product)
+//   step c, b == c:      the diagonal block is complete: factor it (diag_flow), its inverse leaves in polled quarters
+//   step c, b >  c:      L(b, c) = tile X_c^T in the half-block form, in two phases (p256_half_solve), published in two halves
+// Workgroups are numbered column by column, the diagonal tile first: every wait is for a lower-numbered workgroup.  The chain
+// diag(c) -> X_c -> L(c+1, c) -> last update of tile (c+1, c+1) -> diag(c+1) is what k_panel256's is, without the fused
+// updates and launch boundaries in between.  Polled buffers: LP (a 4096-double slot per tile, blockIdx order) and SP (3072 doubles
+// per diagonal block), all-ones when the launch starts; every workgroup arms its own slot of the OTHER pair for the next launch.
+// ---------------------------------------------------------------------------------------------
+struct TailArgs {
+    double* A;
+    int64_t lda, t0; // the tail starts at row / column t0
+    int nt, nb;      // tile columns; row strips (nt, + 1 for the right-hand-side rows)
+    int rhs_rows;
+    double* Xt;      // inverse of the diagonal block at t0 (the others follow at + 4096 each)
+    int* info;
+    double *LP, *SP, *LPn, *SPn;
+    int spin_limit;
+};
+static __device__ __forceinline__ int tail_tile_id(int nb, int b, int c) { return c * nb - (c * (c - 1)) / 2 + (b - c); }
+
+__global__ __launch_bounds__(512) void k_tail(TailArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS]; // [Bx | T0 | T1 | T2]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
+    const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
+    int c = 0, b;
+    {
+        int id = (int)blockIdx.x, colh = a.nb;
+        while (id >= colh) {
+            id -= colh;
+            ++c;
+            --colh;
+        }
+        b = c + id;
+    }
+    const bool mute = a.spin_limit < 0;
+    P256 x;
+    x.A = a.A;
+    x.lda = a.lda;
+    x.p0 = a.t0;
+    x.R0 = a.t0 + (int64_t)NB * b;
+    x.Xt = a.Xt;
+    x.info = a.info;
+    x.mute = mute;
+    x.spin_limit = mute ? -a.spin_limit : a.spin_limit;
+    x.nrows = b < a.nt ? NB : a.rhs_rows;
+    x.want_d = false;
+    x.Bx = lds;
+    x.T0 = lds + NB * XS;
+    x.T1 = x.T0 + NB * PS;
+    x.T2 = x.T1 + NB * PS;
+    x.S22 = a.SP;
+    x.HP = a.LP;
+    double* const myslot = a.LP + (int64_t)blockIdx.x * (NB * NB);
+    { // the other pair of buffers, for the next launch: this tile's slot (and its diagonal block's quarters)
+        unsigned long long* nx = reinterpret_cast<unsigned long long*>(a.LPn + (int64_t)blockIdx.x * (NB * NB));
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            nx[threadIdx.x + 512 * q] = ~0ull;
+        if (b == c) {
+            unsigned long long* ns = reinterpret_cast<unsigned long long*>(a.SPn + (int64_t)c * 3072);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                ns[threadIdx.x + 512 * q] = ~0ull;
+        }
+    }
+    if (b == c + 1 && b < a.nt)
+        return; // the sub-diagonal tile (c + 1, c) belongs to the workgroup of the diagonal tile of its row (below)
+    // the tile, lane = row layout
+    const int crc = crow < x.nrows ? crow : x.nrows - 1;
+    double cv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        cv[it] = a.A[x.R0 + crc + (a.t0 + (int64_t)NB * c + ccol + 2 * it) * a.lda];
+    if (b == c) {
+        // ---- a diagonal tile's workgroup: the chain.  It also owns the tile to the left, (c, c-1): L(c, c-1) never has to
+        // travel to reach the block it completes, and its product with itself is accumulated inside its two-phase solve
+        // (k_panel256's factoring strip).  Steps s < c-1 update both tiles with the same polled L(c, s).
+        double cl[8]; // tile (c, c-1)
+        if (c > 0) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                cl[it] = a.A[x.R0 + crow + (a.t0 + (int64_t)NB * (c - 1) + ccol + 2 * it) * a.lda];
+            PolledTile pa, pb;
+            if (c > 1) {
+                pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
+                pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, 0) * (NB * NB));
+            }
+#pragma unroll 1
+            for (int s = 0; s < c - 1; ++s) {
+                pa.finish(a.LP + (int64_t)tail_tile_id(a.nb, c, s) * (NB * NB), x.spin_limit, x.info);
+                pa.store(x.T0);
+                pb.finish(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s) * (NB * NB), x.spin_limit, x.info);
+                pb.store(x.T1);
+                if (s + 1 < c - 1) {
+                    pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, s + 1) * (NB * NB));
+                    pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s + 1) * (NB * NB));
+                }
+                __syncthreads();
+                double a2[2][4], a2r[8];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        a2[m][n] = 0.0;
+                mm64<false>(x.T0, x.T1, wm, wn, lane, a2);
+                wave_tile_to_rows(a2, a2r, lane);
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    cl[it] -= a2r[it];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        a2[m][n] = 0.0;
+                mm64<false>(x.T0, x.T0, wm, wn, lane, a2);
+                wave_tile_to_rows(a2, a2r, lane);
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    cv[it] -= a2r[it];
+                __syncthreads(); // T0 / T1 are free again
+            }
+            // step c-1: L(c, c-1) = tile X_{c-1}^T in two phases (T1 keeps it: the factorisation re-carves [Bx | T0]), its product
+            // with itself accumulated on the way, published in two halves for the tiles below
+            double a2c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            p256_half_solve<0, true>(x, x.T1, x.T0, cl, a2c, true, a.SP + (int64_t)(c - 1) * 3072,
+                                     a.LP + (int64_t)tail_tile_id(a.nb, c, c - 1) * (NB * NB));
+            double a2r[8];
+            wave_tile_to_rows(a2c, a2r, lane);
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                cv[it] -= a2r[it];
+            __syncthreads(); // [Bx | T0] have no readers left
+        }
+        double* Ls = x.Bx;
+        double* Ltb = Ls + NB * XS;
+        double* invd = Ltb + DIAG_LTB;
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            Ls[crow * XS + ccol + 2 * it] = cv[it];
+        DiagSync* sy = reinterpret_cast<DiagSync*>(invd + NB);
+        diag_flow_init(sy);
+        __syncthreads();
+        DiagEarly ea;
+        ea.mute = mute;
+        ea.S = a.SP + (int64_t)c * 3072;
+        diag_flow(Ls, Ltb, invd, sy, a.A + x.R0 + x.R0 * a.lda, a.lda, a.Xt + (int64_t)c * (NB * NB), a.info, x.R0, wave, lane,
+                  invd + NB + 8, &ea);
+        if (c > 0) { // L(c, c-1) into the matrix: nobody reads it there before the launch ends
+            __syncthreads();
+            const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+            double* Ag = a.A + x.R0 + (a.t0 + (int64_t)NB * (c - 1)) * a.lda;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int col = kk0 + 8 * q;
+                Ag[i + (int64_t)col * a.lda] = x.T1[col * PS + i];
+            }
+        }
+        return;
+    }
+    // ---- any other tile: steps 0 .. c-1, then its solve ----
+    PolledTile pa, pb;
+    if (c > 0) {
+        pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, b, 0) * (NB * NB));
+        pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
+    }
+#pragma unroll 1
+    for (int s = 0; s < c; ++s) {
+        pa.finish(a.LP + (int64_t)tail_tile_id(a.nb, b, s) * (NB * NB), x.spin_limit, x.info);
+        pa.store(x.T0);
+        pb.finish(a.LP + (int64_t)tail_tile_id(a.nb, c, s) * (NB * NB), x.spin_limit, x.info);
+        pb.store(x.T1);
+        if (s + 1 < c) { // the next step's operands: on their way under this step's product
+            pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, b, s + 1) * (NB * NB));
+            pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, s + 1) * (NB * NB));
+        }
+        __syncthreads();
+        double a2[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                a2[m][n] = 0.0;
+        mm64<false>(x.T0, x.T1, wm, wn, lane, a2);
+        double a2r[8];
+        wave_tile_to_rows(a2, a2r, lane);
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            cv[it] -= a2r[it];
+        __syncthreads(); // T0 / T1 are free again
+    }
+    double unused[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    p256_half_solve<0, true>(x, x.T0, x.T2, cv, unused, false, a.SP + (int64_t)c * 3072, myslot);
+    { // L(b, c) into the matrix
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+        double* Ag = a.A + x.R0 + (a.t0 + (int64_t)NB * c) * a.lda;
+        if (i < x.nrows) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int col = kk0 + 8 * q;
+                Ag[i + (int64_t)col * a.lda] = x.T0[col * PS + i];
+            }
+        }
+    }
+}
+
+// the T = N - t0 <= 1024 trailing columns (T a multiple of 64; rows t0 .. M-1, M - N <= 64 right-hand-side rows), fully updated
+// by everything in front of them.  buf_cur / buf_next: tail_buf_doubles(nt, rhs rows) each, all-ones (this launch arms buf_next)
+void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t N, int64_t M, double* Xt_all, int* info, double* buf_cur,
+                 double* buf_next)
+{
+    TailArgs a{};
+    a.A = A;
+    a.lda = lda;
+    a.t0 = t0;
+    a.nt = (int)((N - t0) / NB);
+    a.rhs_rows = (int)(M - N);
+    a.nb = a.nt + (a.rhs_rows > 0 ? 1 : 0);
+    a.Xt = Xt_all + (t0 / NB) * (NB * NB);
+    a.info = info;
+    a.SP = buf_cur;
+    a.LP = buf_cur + (int64_t)a.nt * 3072;
+    a.SPn = buf_next;
+    a.LPn = buf_next + (int64_t)a.nt * 3072;
+    static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
+    a.spin_limit = fault ? -16 : GPE_FLOW_SPIN_LIMIT;
+    const int tiles = a.nt * a.nb - (a.nt * (a.nt - 1)) / 2;
+    GPE_LAUNCH(k_tail, dim3((unsigned)tiles), dim3(512), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

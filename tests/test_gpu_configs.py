@@ -387,12 +387,13 @@ def test_gpu_one_launch_panels_polled_buffers_across_handles(engine_lib):
         h.close()
 
 
-def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib):
+@pytest.mark.parametrize("N", [1100, 1152])
+def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, N):
     """GPE_HANDOVER_FAULT=1: no head workgroup publishes and every consumer gives up after a few polls, i.e. every fused
     panel step of the first attempt reports a lost hand-over.  The host must notice (info word 2), run the evaluation again
     from K on without the hand-over, count it in flow_retries(), and return the same log-likelihood as an undisturbed
-    process (child process: the switch is read once)."""
-    N = 1100
+    process (child process: the switch is read once).  N = 1100: the one-launch panels (k_panel256); N = 1152 = 18 x 64: the
+    whole factorisation as one tiled data-flow launch (k_tail), whose block inverses are muted the same way."""
     X, Y = synth.make_problem("c2", N=N)
     om, _ = synth.obs_mean_data(Y)
     h = new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(7), 0.01)
@@ -413,6 +414,42 @@ def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib):
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     # the re-run factorises without the hand-over and hence without the folded last step (round 3): the same factor to rounding
     assert abs(float(r.stdout.split("child ok")[1]) - ll) <= 1e-13 * abs(ll)
+
+
+@pytest.mark.parametrize("N,P,tail", [(128, 1, None), (320, 2, None), (704, 3, None), (1344, 1, None), (1344, 2, "512"), (1792, 1, "768"),
+                                      (2624, 1, None)])
+def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, tail):
+    """k_tail: the last <= 2560 columns (GPE_TAIL_MAX; all of them when N is no larger) of a factorisation whose order is a
+    multiple of 64 are factored by ONE launch, a workgroup per 64 x 64 tile, operands polled between them.  Against LAPACK on the
+    host: L to 1e-10 of max|L|, alpha (the forward substitution rides along as the right-hand-side strip, P rows) to 1e-7,
+    log-lik to 1e-10.  Sizes: a single tile column pair (128), tails that are the whole matrix, tails behind one-launch panels
+    (1344 with a 512 tail: panels to 1024, then 5 tile columns; 1792 with 768; 2624 = 41 x 64: one panel, 37 tile columns, more
+    tiles than CUs), one to three outputs.  Two evaluations: the second one runs on the other pair of polled buffers."""
+    import scipy.linalg as sl
+    if tail is not None:
+        monkeypatch.setenv("GPE_TAIL_MAX", tail)
+    rng = np.random.default_rng(N + P)
+    X = rng.uniform(0, 1, size=(N, 4))
+    Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.05 * rng.normal(size=(N, P))
+    om, _ = O.obs_mean_data(Y)
+    h = new_gp(engine_lib, O.SE_ARD, X, om, rng.uniform(-0.3, 0.2, size=5), 0.01)
+    for rep in range(2):
+        assert h.compute() == 0 and h.flow_retries() == 0
+        L = np.tril(h.get_L())
+        K = h.get_K()
+        Ks = np.tril(K) + np.tril(K, -1).T
+        Lref = sl.cholesky(Ks, lower=True)
+        assert np.max(np.abs(L - Lref)) <= 1e-10 * np.max(np.abs(Lref))
+        aref = sl.cho_solve((Lref, True), om)
+        assert relerr_norm(h.get_alpha(), aref) < 1e-7
+        # gp.hpp:267-282: log det and n log 2 pi are NOT multiplied by the number of outputs
+        llref = -0.5 * np.sum(om * aref) - np.sum(np.log(np.diag(Lref))) - 0.5 * N * np.log(2 * np.pi)
+        assert abs(h.log_lik() - llref) <= 1e-10 * abs(llref)
+        if rep == 0:
+            L0, ll0 = L, h.log_lik()
+        else:
+            assert np.array_equal(L, L0) and h.log_lik() == ll0
+    h.close()
 
 
 @pytest.mark.parametrize("kind,D,P,lam", [(O.SE_ARD, 6, 1, 0), (O.MATERN52, 3, 2, 0), (O.SE_ARD, 4, 3, 1), (O.EXP, 2, 1, 0)])

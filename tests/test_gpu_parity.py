@@ -488,7 +488,7 @@ def _small_parity(engine_lib, oracle_lib, N=300, D=3, P=2, seed=0):
 
 @pytest.mark.parametrize("env", [{"GPE_FLOW_SOLVE": "0"}, {"GPE_LOOKAHEAD": "0"}, {"GPE_FUSE_PANEL": "0"},
                                  {"GPE_FUSE_DIAG": "0", "GPE_STOP_EVENT": "0"}, {"GPE_NBO": "192"}, {"GPE_FOLD4": "0", "GPE_PANEL256": "0"},
-                                 {"GPE_PANEL256": "0"}],
+                                 {"GPE_PANEL256": "0"}, {"GPE_TAIL_MAX": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_alternate_schedules(engine_lib, oracle_lib, monkeypatch, env):
     """The switches read when a handle is created select the schedules that also serve as fall-backs (per-block
