@@ -546,11 +546,17 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     size_t la_last = 0;
     // The last <= tail_max columns (all of them when N <= tail_max) go to ONE launch, a tiled data-flow factorisation
     // (potrf.hip: k_tail): the panels end at t0, the panel in front of it updates everything that is left in one piece.
+    // Its columns are whole 64-blocks: t0 .. N64; a ragged last block (N64 .. N, fewer than 64 columns) and the right-hand-side
+    // rows ride in it as one more row strip and are finished by the panel code below (one small update, the ragged block).
     int64_t t0 = -1;
-    if (c->tail_max >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && !g_batch.bt && nbo == 4 * NB && N % NB == 0
-        && N >= 2 * NB && M - N <= NB) {
-        t0 = N > c->tail_max ? (N - c->tail_max + nbo - 1) / nbo * nbo : 0;
-        const int64_t need = tail_buf_doubles((N - t0) / NB, M - N);
+    const int64_t N64 = N / NB * NB;
+    if (c->tail_max >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && !g_batch.bt && nbo == 4 * NB && M - N64 <= NB) {
+        t0 = N64 > c->tail_max ? (N64 - c->tail_max + nbo - 1) / nbo * nbo : 0;
+        if (N64 - t0 < 2 * NB)
+            t0 = -1;
+    }
+    if (t0 >= 0) {
+        const int64_t need = tail_buf_doubles((N64 - t0) / NB, M - N64);
         if (c->tail_cap < need) { // (both buffers all-ones: whatever the old ones held is irrelevant)
             if (c->dTail)
                 hipFree(c->dTail);
@@ -564,7 +570,41 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 t0 = -1;
         }
     }
-    for (int64_t p0 = 0; p0 < N && p0 != t0; p0 += nbo) {
+    for (int64_t p0 = 0; p0 < N; p0 += nbo) {
+        if (p0 == t0) {
+            if (la_pending) {
+                hipStreamWaitEvent(s, c->la_events[la_last], 0);
+                la_pending = false;
+            }
+            {
+                PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(N64 - t0) * (N64 - t0) * (N64 - t0) / 3.0);
+                launch_tail(s, A, ld, t0, N64, M, c->dXinv, c->dInfo, c->dTail + (c->tail_count & 1) * c->tail_cap,
+                            c->dTail + ((c->tail_count + 1) & 1) * c->tail_cap);
+                ++c->tail_count;
+                c->xinv_done = N64 / NB;
+            }
+            if (N64 == N)
+                break;
+            { // the ragged block and what lies under it: -= L[N64:M, t0:N64] L[N64:N, t0:N64]^T, then the panel code factors it
+                GemmArgs g{};
+                g.C = A + N64 + N64 * ld;
+                g.ldc = ld;
+                g.A = A + N64 + t0 * ld;
+                g.lda = ld;
+                g.B = A + N64 + t0 * ld;
+                g.ldb = ld;
+                g.m = M - N64;
+                g.n = N - N64;
+                g.k = N64 - t0;
+                g.tri = 1;
+                g.grow0 = N64;
+                g.gcol0 = N64;
+                PhaseScope ps(c, GPE_PH_POTRF_UPDATE, gemm_flops(g));
+                launch_gemm_sub(s, g);
+            }
+            p0 = N64;
+            next_diag_done = false;
+        }
         const int64_t pw = std::min<int64_t>(nbo, N - p0);
         const int64_t pe = p0 + pw;
         bool diag_done = next_diag_done; // the previous fused step (or fused update) already factored this diagonal block
@@ -815,13 +855,6 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     }
     if (la_pending)
         hipStreamWaitEvent(s, c->la_events[la_last], 0);
-    if (t0 >= 0) {
-        PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(N - t0) * (N - t0) * (N - t0) / 3.0);
-        launch_tail(s, A, ld, t0, N, M, c->dXinv, c->dInfo, c->dTail + (c->tail_count & 1) * c->tail_cap,
-                    c->dTail + ((c->tail_count + 1) & 1) * c->tail_cap);
-        ++c->tail_count;
-        c->xinv_done = N / NB;
-    }
     if (c->fuse_panel && N / NB > c->xinv_done) { // off-diagonal quarters of the remaining block inverses
         PhaseScope ps(c, GPE_PH_POTRF_PANEL, 0.0);
         launch_xinv_complete(s, A, ld, c->xinv_done, N / NB - c->xinv_done, c->dXinv);

@@ -1818,8 +1818,8 @@ __global__ __launch_bounds__(512) void k_tail(TailArgs a)
     }
 }
 
-// the T = N - t0 <= 1024 trailing columns (T a multiple of 64; rows t0 .. M-1, M - N <= 64 right-hand-side rows), fully updated
-// by everything in front of them.  buf_cur / buf_next: tail_buf_doubles(nt, rhs rows) each, all-ones (this launch arms buf_next)
+// columns t0 .. N-1 (N - t0 a multiple of 64), rows t0 .. M-1: the M - N <= 64 rows below them — right-hand-side rows, and the
+// rows of a ragged last block the caller finishes — ride along as one more row strip.  Fully updated by everything in front.  buf_cur / buf_next: tail_buf_doubles(nt, rhs rows) each, all-ones (this launch arms buf_next)
 void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t N, int64_t M, double* Xt_all, int* info, double* buf_cur,
                  double* buf_next)
 {

@@ -417,14 +417,16 @@ def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, N):
 
 
 @pytest.mark.parametrize("N,P,tail", [(128, 1, None), (320, 2, None), (704, 3, None), (1344, 1, None), (1344, 2, "512"), (1792, 1, "768"),
-                                      (2624, 1, None)])
+                                      (2624, 1, None), (150, 1, None), (1100, 3, None), (1407, 2, "512"), (2500, 1, None)])
 def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, tail):
     """k_tail: the last <= 2560 columns (GPE_TAIL_MAX; all of them when N is no larger) of a factorisation whose order is a
     multiple of 64 are factored by ONE launch, a workgroup per 64 x 64 tile, operands polled between them.  Against LAPACK on the
     host: L to 1e-10 of max|L|, alpha (the forward substitution rides along as the right-hand-side strip, P rows) to 1e-7,
     log-lik to 1e-10.  Sizes: a single tile column pair (128), tails that are the whole matrix, tails behind one-launch panels
     (1344 with a 512 tail: panels to 1024, then 5 tile columns; 1792 with 768; 2624 = 41 x 64: one panel, 37 tile columns, more
-    tiles than CUs), one to three outputs.  Two evaluations: the second one runs on the other pair of polled buffers."""
+    tiles than CUs), one to three outputs; orders that are not multiples of 64 (150, 1100, 1407 = 21 x 64 + 63, 2500): the ragged
+    last block and the right-hand-side rows ride in the launch as one more row strip and the panel code finishes them.  Two
+    evaluations: the second one runs on the other pair of polled buffers."""
     import scipy.linalg as sl
     if tail is not None:
         monkeypatch.setenv("GPE_TAIL_MAX", tail)
