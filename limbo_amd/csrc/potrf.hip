@@ -50,11 +50,14 @@ __device__ long long g_diag_ts[32];
 #ifdef DIAG_TIMING
 __device__ long long g_panel_ts[64];
 #define PTS(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_panel_ts[(blockIdx.x == 0 ? 0 : 32) + (i)] = clock64(); } while (0)
+__device__ long long g_tail_ts[64][4]; // k_tail, the diagonal workgroup of column c: updates done | solved | factoring | factored
+#define TTS(c, i) do { if (threadIdx.x == 0 && (c) < 64) g_tail_ts[(c)][(i)] = wall_clock64(); } while (0)
 __device__ long long g_p256_ts[5][32]; // k_panel256: strips 0..3 and the last one; [6 S + i] = stamp i of step S, [30] start, [31] end
 #define P2TS(i) do { if (threadIdx.x == 0 && (blockIdx.x < 4 || blockIdx.x == gridDim.x - 1)) g_p256_ts[blockIdx.x < 4 ? blockIdx.x : 4][(i)] = wall_clock64(); } while (0)
 #else
 #define PTS(i) do { } while (0)
 #define P2TS(i) do { } while (0)
+#define TTS(c, i) do { } while (0)
 #endif
 #define XS 66 // LDS row stride (doubles) of the 64 x 64 work matrices: conflict-free MFMA operand reads
 
@@ -1734,6 +1737,7 @@ __global__ __launch_bounds__(512) void k_tail(TailArgs a)
                     cv[it] -= a2r[it];
                 __syncthreads(); // T0 / T1 are free again
             }
+            TTS(c, 0);
             // step c-1: L(c, c-1) = tile X_{c-1}^T in two phases (T1 keeps it: the factorisation re-carves [Bx | T0]), its product
             // with itself accumulated on the way, published in two halves for the tiles below
             double a2c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
@@ -1745,6 +1749,7 @@ __global__ __launch_bounds__(512) void k_tail(TailArgs a)
             for (int it = 0; it < 8; ++it)
                 cv[it] -= a2r[it];
             __syncthreads(); // [Bx | T0] have no readers left
+            TTS(c, 1);
         }
         double* Ls = x.Bx;
         double* Ltb = Ls + NB * XS;
@@ -1758,8 +1763,10 @@ __global__ __launch_bounds__(512) void k_tail(TailArgs a)
         DiagEarly ea;
         ea.mute = mute;
         ea.S = a.SP + (int64_t)c * 3072;
+        TTS(c, 2);
         diag_flow(Ls, Ltb, invd, sy, a.A + x.R0 + x.R0 * a.lda, a.lda, a.Xt + (int64_t)c * (NB * NB), a.info, x.R0, wave, lane,
                   invd + NB + 8, &ea);
+        TTS(c, 3);
         if (c > 0) { // L(c, c-1) into the matrix: nobody reads it there before the launch ends
             __syncthreads();
             const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
@@ -2069,6 +2076,16 @@ void launch_upd_fused(hipStream_t s, const GemmArgs& g0, double* A, int64_t lda,
 }
 
 #ifdef DIAG_TIMING
+void dump_tail_timing(int nt)
+{
+    long long h[64][4];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tail_ts), sizeof(h));
+    const long long t0 = h[0][2];
+    printf("k_tail, the diagonal workgroups (us after the first one starts factoring): column | earlier updates done | its left tile solved, block complete | factoring | panel wave done\n");
+    for (int c = 0; c < nt && c < 64; ++c)
+        printf("  %2d | %7.2f | %7.2f | %7.2f | %7.2f   (step %5.2f)\n", c, c ? (h[c][0] - t0) * 0.01 : 0.0, c ? (h[c][1] - t0) * 0.01 : 0.0,
+               (h[c][2] - t0) * 0.01, (h[c][3] - t0) * 0.01, c ? (h[c][2] - h[c - 1][2]) * 0.01 : 0.0);
+}
 void dump_p256_timing()
 {
     long long h[5][32];

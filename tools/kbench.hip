@@ -168,6 +168,33 @@ int main(int argc, char** argv)
         dump_p256_timing();
     }
 #endif
+#ifdef DIAG_TIMING
+    { // the first 1024 x 1024 block of K as one tiled data-flow launch (k_tail)
+        const int64_t T = 1024;
+        const int64_t need = tail_buf_doubles(T / 64, 1);
+        double* tb;
+        CHK(hipMalloc(&tb, sizeof(double) * 2 * need));
+        CHK(hipMemset(tb, 0xFF, sizeof(double) * 2 * need));
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            launch_copy2d(s, A0, ld, A, ld, N, T);
+            CHK(hipStreamSynchronize(s));
+            hipEventRecord(e0, s);
+            launch_tail(s, A, ld, 0, T, T + 1, Xi, info, tb + (rep & 1) * need, tb + ((rep + 1) & 1) * need);
+            hipEventRecord(e1, s);
+            CHK(hipStreamSynchronize(s));
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            best = ms < best ? ms : best;
+        }
+        printf("k_tail, the leading 1024 x 1024 block of K (16 tile columns + one right-hand-side row): %.2f us (events)\n", 1e3 * best);
+        extern void dump_tail_timing(int);
+        dump_tail_timing(16);
+    }
+#endif
     printf("kbench done\n");
     return 0;
 }
