@@ -438,13 +438,16 @@ def main():
         out["roofline"] = {
             "bound": "mfma",
             "kernel": "k_gemm_glds / k_gemm_glds64 / k_gemm4 (Cholesky trailing update A22 -= L21 L21^T, v_mfma_f64_4x4x4_4b): "
-                      "all 15 launches of one factorisation, HIP events on the handle's stream",
+                      "every trailing-update launch of one factorisation, each alone, HIP events on the handle's stream "
+                      "(round 3: the panels in front of the tiled one-launch tail — 6 launches at N = 4096, 15 with GPE_TAIL_MAX=0; "
+                      "the tail's own flops are latency-bound data-flow work, in phases_ms_per_step.potrf_panel)",
             "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF,
             "traffic": traffic,
             "traffic_note": f"bytes of the first (largest) update launch, PMC (profiles/{pmc.name}); "
                             "algorithmic bytes of that launch = 2 x 60.9 MB C tiles + 7.9 MB panel",
             "launches_per_step": upd["launches"] / reps, "avg_launch_us": 1e3 * upd["ms"] / max(upd["launches"], 1),
             "algorithmic_flops_per_step": upd["flops"] / reps,
+            "share_of_factorisation_flops": (upd["flops"] / reps) / (float(N) ** 3 / 3.0),
             "measured_mfma_f64_4x4x4_peak_tflops": pk.value,
         }
         out["phases_ms_per_step"] = {k: v["ms"] / reps for k, v in ph.items() if v["launches"]}
