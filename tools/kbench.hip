@@ -28,6 +28,7 @@ int main(int argc, char** argv)
     CHK(hipMalloc(&A0, sizeof(double) * ld * N));
     CHK(hipMalloc(&A, sizeof(double) * ld * N));
     CHK(hipMalloc(&Xi, sizeof(double) * 64 * 4096));
+    CHK(hipMemset(Xi, 0, sizeof(double) * 64 * 4096)); // (only block 0's inverse is ever computed here: the sweeps must not meet NaNs)
     CHK(hipMalloc(&w, sizeof(double) * ld));
     CHK(hipMalloc(&out, sizeof(double) * ld));
     CHK(hipMalloc(&info, 64));
