@@ -79,6 +79,49 @@ def bo_inner_loop(lib, _capi, O, device):
             "batched_query_points_per_s_n200": 20000 / dtb, "log_lik": ll}
 
 
+def bo_iteration(lib, _capi, O, device, n_candidates=10000):
+    """ONE iteration of the Bayesian-optimisation loop as the reference runs it (bayes_opt/boptimizer.hpp:148-161,
+    src/benchmarks/limbo/bench.cpp:66-84): maximise the acquisition over the model — here acqui::UCB (acqui/ucb.hpp:83-90:
+    mu + alpha sqrt(sigma^2)) over a BatchGridSearch-sized candidate set through ONE gpe_query_batch (the drop-in's
+    acqui::UCB::batch + opt::BatchGridSearch, SURVEY §8(f) N1) — then add_sample() of the winner.  Through the C-ABI of `lib`
+    (the HIP engine; in the cpu_baseline leg the oracle on one core, same caller).  Mean of 3 consecutive iterations from
+    n = 50 / 100 / 200 samples."""
+    rng = np.random.default_rng(55)
+    Xall = rng.uniform(0, 1, size=(260, D_C2))
+    Yall = O.hartmann6(Xall)[:, None]
+    Xc = rng.uniform(0, 1, size=(n_candidates, D_C2))
+    alpha_ucb = 0.5  # defaults::acqui_ucb::alpha
+    res = {}
+    for n in (50, 100, 200):
+        h = _capi.Handle(lib, device)
+        h.set_kernel(O.SE_ARD, np.zeros(D_C2 + 1), 0.01)
+        X, Y = list(Xall[:n]), list(Yall[:n, 0])
+        om, mean = O.obs_mean_data(np.array(Y)[:, None])
+        h.set_data(np.array(X), om)
+        h.compute()
+        h.query_batch(Xc[:256])
+        t_q = t_add = 0.0
+        iters = 3
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            kta, var = h.query_batch(Xc)
+            mu, s2 = O.finish_query(kta, var, mean, 0.01)
+            best = int(np.argmax(mu[:, 0] + alpha_ucb * np.sqrt(s2)))
+            t1 = time.perf_counter()
+            X.append(Xc[best])
+            Y.append(float(O.hartmann6(Xc[best:best + 1])[0]))
+            om, mean = O.obs_mean_data(np.array(Y)[:, None])  # mean::Data: every obs_mean moves with the new observation
+            h.add_sample(np.ascontiguousarray(Xc[best]), np.asfortranarray(om))
+            t2 = time.perf_counter()
+            t_q += t1 - t0
+            t_add += t2 - t1
+        h.close()
+        res[f"n{n}"] = {"iteration_ms": 1e3 * (t_q + t_add) / iters, "acquisition_ms": 1e3 * t_q / iters, "add_sample_ms": 1e3 * t_add / iters,
+                        "candidates_per_s": n_candidates * iters / t_q}
+    res["candidates"] = n_candidates
+    return res
+
+
 def extras(eng, _capi, O, local_rank, steps):
     """Secondary objects of the bench line, N=1 only, outside the headline's timed region (driver-run versions of what
     bench_extra.py measures): BASELINE configs[1] as written (the gradient objective of one KernelLFOpt iteration),
@@ -167,6 +210,34 @@ def extras(eng, _capi, O, local_rank, steps):
         "c2_10_restarts": batched(10, N_C2, 4), "c4_64_restarts": batched(64, 2048, 3)}
     torch.cuda.empty_cache()
 
+    # ---- configs[1] end to end: a KernelLFOpt fit by the reference's benchmark protocol — Rprop, 50 iterations
+    # (waf_tools/benchmark_template.cpp:67, regression_benchmarks.json) x 10 restarts (opt/parallel_repeater.hpp:66,84-105),
+    # the restarts in lock-step, every iteration ONE gpe_batch_hp_objective (limbo_amd/hpfit.py = the drop-in's
+    # opt/batched_rprop.hpp)
+    from limbo_amd import hpfit
+
+    R_fit, it_fit = 10, 50
+    hs = []
+    for _ in range(R_fit):
+        hb = _capi.Handle(eng, local_rank)
+        hb.set_data(X, om)
+        hs.append(hb)
+    inits = np.random.default_rng(66).uniform(-1e-2, 1e-2, size=(R_fit, D_C2 + 1))  # parallel_repeater.hpp:88
+    hpfit.kernel_lf_opt_lockstep(hs, O.SE_ARD, inits, iterations=2)
+    tr = []
+    t0 = time.perf_counter()
+    bp, bl = hpfit.kernel_lf_opt_lockstep(hs, O.SE_ARD, inits, noise=0.01, optimize_noise=False, iterations=it_fit, eps_stop=0.0, trace=tr)
+    dt_fit = time.perf_counter() - t0
+    out["c2_fit"] = {"workload": f"configs[1] end to end: KernelLFOpt<Rprop> fit of the N={N_C2} D={D_C2} SquaredExpARD GP, {it_fit} iterations x "
+                                 f"{R_fit} restarts (the reference's benchmark protocol), restarts in lock-step through gpe_batch_hp_objective",
+                     "wall_s": dt_fit, "iterations": len(tr), "restarts": R_fit, "objective_evaluations_per_s": R_fit * len(tr) / dt_fit,
+                     "ms_per_iteration": 1e3 * dt_fit / max(len(tr), 1), "frac_of_fp64_peak": R_fit * len(tr) * float(N_C2) ** 3 / dt_fit / PEAK,
+                     "log_lik_start": float(tr[0][1].max()), "log_lik_best": float(bl.max()),
+                     "reruns": int(sum(hb.flow_retries() for hb in hs))}
+    for hb in hs:
+        hb.close()
+    torch.cuda.empty_cache()
+
     # ---- configs[2]: N=16384, D=12, Matern-5/2: compute()+log_lik, its trailing updates alone, 100k batched queries
     N3, D3, M3 = 16384, 12, 100000
     X3, Y3 = O.make_problem("c3")
@@ -234,7 +305,7 @@ def extras(eng, _capi, O, local_rank, steps):
         hh.close()
 
     # ---- configs[4]: the BO inner loop (benchmarks/limbo/bench.cpp:66-84): add_sample 10 -> 200, one-point queries at n = 200
-    out["config5"] = dict(bo_inner_loop(eng, _capi, O, local_rank),
+    out["config5"] = dict(bo_inner_loop(eng, _capi, O, local_rank), bo_iteration=bo_iteration(eng, _capi, O, local_rank),
                           workload="configs[4] regime: SquaredExpARD D=6, noise 0.01, add_sample() n = 10 -> 200 (best of 5 loops), one-point "
                                    "mu+sigma^2 at n = 200 (best of 3 blocks of 100), host to host through ctypes; fp64 throughout (bf16: DESIGN §10)")
     return out
@@ -250,6 +321,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="profiling runs: only the N=4096 evaluation loop (no H2D variant, no config 4)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (hp_objective, config3, config4_g64, config5)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (and run barrier / all_gather / all_reduce) even with ONE rank: the RCCL "
+                         "branch rehearsed on a one-GPU box (tests/test_gpu_configs.py::test_gpu_bench_one_rank_rccl)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1: nccl (= RCCL over xGMI, the default) or gloo (CPU tensors for the two "
                          "collectives; lets several ranks share one visible GPU: tests/test_gpu_configs.py)")
@@ -271,10 +345,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     coll_dev = f"cuda:{local_rank}" if args.dist_backend == "nccl" else "cpu"  # where the collectives' tensors live
-    if world > 1:
+    executed = []  # the collectives this run actually issued
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_
 
         dist = dist_
+        if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:  # --force-dist outside torch.distributed.run
+            import socket
+
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -304,6 +388,25 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+            if "barrier" not in executed:
+                executed.append("barrier")
+
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        tmax = torch.tensor([seconds], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if "all_reduce" not in executed:
+            executed.append("all_reduce")
+        return float(tmax.item())
+
+    def argmax(values, thetas):
+        res = PAR.argmax_over_ranks(values, thetas, dist, device=coll_dev, force=args.force_dist)
+        if dist is not None and "all_gather" not in executed:
+            executed.append("all_gather")
+        return res
+
+    from limbo_amd import parallel as PAR
 
     for _ in range(args.warmup):
         step()
@@ -315,15 +418,9 @@ def main():
         info, ll = step()  # returns with the result on the host: every step ends synchronised
         stamps.append(time.perf_counter())
     # arg-max over the restarts: all-gather of (log_lik, theta) -- the only collective
-    from limbo_amd import parallel as PAR
-
-    best_ll, best_theta, best_rank = PAR.argmax_over_ranks([ll], [theta], dist, device=coll_dev)
+    best_ll, best_theta, best_rank = argmax([ll], [theta])
     sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     assert info == 0 and np.isfinite(ll), (info, ll)
     evals = world * args.steps
     value = evals / dt
@@ -345,11 +442,7 @@ def main():
             h.set_data(X, om)
             step()
         sync()
-        dt_h2d = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([dt_h2d], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt_h2d = float(tmax.item())
+        dt_h2d = max_over_ranks(time.perf_counter() - t0)
         value_incl_h2d = world * n_h2d / dt_h2d
 
         # BASELINE configs[3] as written: 64 independent GPs of N=2048, D=6 sharded 8 per GPU (multi_gp.hpp:124-126 /
@@ -374,13 +467,9 @@ def main():
         for _ in range(reps4):
             st4 = _capi.batch_compute(hs4)
             ll4 = _capi.batch_log_lik(hs4)
-        best4 = PAR.argmax_over_ranks(list(ll4), th4, dist, device=coll_dev)
+        best4 = argmax(list(ll4), th4)
         sync()
-        dt4 = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([dt4], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt4 = float(tmax.item())
+        dt4 = max_over_ranks(time.perf_counter() - t0)
         assert all(s4 == 0 for s4 in st4) and np.all(np.isfinite(ll4))
         for h4 in hs4:
             h4.close()
@@ -411,46 +500,85 @@ def main():
         "value_incl_h2d": value_incl_h2d,
         "value_incl_h2d_note": "same step with gpe_set_data (X: 196 KB, obs_mean: 32 KB, host -> HBM) inside the timed region",
         "config4": config4,
+        "collectives": {"backend": args.dist_backend if dist is not None else None, "world": world,
+                        "tensors_on": coll_dev if dist is not None else None, "executed": executed,
+                        "note": "barrier + max-over-ranks all_reduce around every timed region, all_gather arg-max of (log_lik, theta) "
+                                "inside it (tools/parallel.hpp:169-191); --force-dist runs them in a group of one rank"},
+        # evaluations that had to be run a second time because a data-flow hand-over timed out (never expected: a silent 2x
+        # slowdown on some future runtime would show here) / sweeps re-run block by block
+        "handover_reruns": h.handover_reruns(), "flow_retries": h.flow_retries(),
     }
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel: the Cholesky trailing update (k_gemm_glds / k_gemm_glds64 / k_gemm4, fp64 MFMA).  HIP events on
-        # the handle's own stream around every launch of it (profiling mode), outside the timed region.
-        h.set_profiling(True)
-        h.reset_phase_ms()
-        reps = 5
-        for _ in range(reps):
-            step()
-        ph = h.get_phase_ms()
-        h.set_profiling(False)
-        upd = ph["potrf_update"]
-        tf = upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] > 0 else 0.0
+        # the handle's own stream around every launch of it (profiling mode: every phase alone on the chip), outside the
+        # timed region.  Round 4: ALL of the factorisation is accounted for — the update launch(es), the two data-flow
+        # launches (whose flops are 64^3 products inside a latency chain) and the whole-factorisation rate over the step.
         import ctypes as C
 
+        def profiled(handle_, reps_=5):
+            handle_.compute()
+            handle_.set_profiling(True)
+            handle_.reset_phase_ms()
+            for _ in range(reps_):
+                handle_.compute()
+                handle_.log_lik()
+            ph_ = handle_.get_phase_ms()
+            handle_.set_profiling(False)
+            return {k: {"us": 1e3 * v["ms"] / reps_, "launches": v["launches"] / reps_, "flops": v["flops"] / reps_} for k, v in ph_.items() if v["launches"]}
+
+        def rate(rec):
+            tf_ = rec["flops"] / (rec["us"] * 1e-6) / 1e12 if rec["us"] > 0 else 0.0
+            return {"us": rec["us"], "launches": rec["launches"], "algorithmic_flops": rec["flops"], "tflops": tf_, "frac": tf_ / FP64_MFMA_PEAK_TF}
+
+        ph = profiled(h)
+        upd = ph.get("potrf_update", {"us": 0.0, "launches": 0, "flops": 0.0})
+        fl_fact = float(N) ** 3 / 3.0 + 2.0 * float(N) * N  # N^3/3 + 2 N^2 P, P = 1
+        tf = rate(upd)["tflops"]
         pk = C.c_double()
         eng.fn("mfma_f64_peak")(local_rank, C.byref(pk))
-        # HBM traffic of the dominant launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md): profiles/, not live
+        # the round-3 accounting beside it: 256-column panels to the end (GPE_TALL=0, GPE_TAIL_MAX=0), all 15 trailing updates
+        os.environ["GPE_TALL"], os.environ["GPE_TAIL_MAX"] = "0", "0"
+        h15 = _capi.Handle(eng, local_rank)
+        os.environ.pop("GPE_TALL"), os.environ.pop("GPE_TAIL_MAX")
+        h15.set_kernel(O.SE_ARD, theta, 0.01)
+        h15.set_data(X, om)
+        ph15 = profiled(h15, 3)
+        h15.close()
+        # HBM traffic of the dominant launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # runs, FETCH doubled per MI355X_MICROARCH.md): a file under profiles/, not measured in this run (a PMC pass cannot run
+        # inside it) — null when this round's file is absent
         traffic = None
-        pmc = next((q for q in (ROOT / "profiles" / "r03_pmc_trailing_update.json", ROOT / "profiles" / "r02_pmc_trailing_update.json") if q.exists()), ROOT / "none")
+        pmc = ROOT / "profiles" / "r04_pmc_trailing_update.json"
         if pmc.exists() and N == N_C2:
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch_corrected")
         out["roofline"] = {
             "bound": "mfma",
-            "kernel": "k_gemm_glds / k_gemm_glds64 / k_gemm4 (Cholesky trailing update A22 -= L21 L21^T, v_mfma_f64_4x4x4_4b): "
-                      "every trailing-update launch of one factorisation, each alone, HIP events on the handle's stream "
-                      "(round 3: the panels in front of the tiled one-launch tail — 6 launches at N = 4096, 15 with GPE_TAIL_MAX=0; "
-                      "the tail's own flops are latency-bound data-flow work, in phases_ms_per_step.potrf_panel)",
+            "kernel": "k_gemm_glds (Cholesky trailing update A22 -= L21 L21^T, v_mfma_f64_4x4x4_4b): every trailing-update launch of one "
+                      "factorisation, each alone, HIP events on the handle's stream.  Round 4 schedule at N = 4096: ONE update with k = 1536 "
+                      "between the tall data-flow launch (columns 0..1535, all rows) and the closing one (columns 1536..4095); their flops "
+                      "are in `data_flow_launches`, the round-3 accounting (all 15 k = 256 updates) in `all_updates_like_for_like`",
             "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF,
             "traffic": traffic,
-            "traffic_note": f"bytes of the first (largest) update launch, PMC (profiles/{pmc.name}); "
-                            "algorithmic bytes of that launch = 2 x 60.9 MB C tiles + 7.9 MB panel",
-            "launches_per_step": upd["launches"] / reps, "avg_launch_us": 1e3 * upd["ms"] / max(upd["launches"], 1),
-            "algorithmic_flops_per_step": upd["flops"] / reps,
-            "share_of_factorisation_flops": (upd["flops"] / reps) / (float(N) ** 3 / 3.0),
+            "traffic_note": f"bytes of the update launch, PMC (profiles/{pmc.name}: committed, not measured in this run); algorithmic "
+                            "bytes of that launch = 2 x 26.2 MB C tiles (lower triangle of 2560^2) + 31.5 MB panel (2560 x 1536)",
+            "launches_per_step": upd["launches"], "avg_launch_us": upd["us"] / max(upd["launches"], 1),
+            "algorithmic_flops_per_step": upd["flops"],
+            "share_of_factorisation_flops": upd["flops"] / (float(N) ** 3 / 3.0),
+            "data_flow_launches": {"tall": rate(ph["potrf_tall"]) if "potrf_tall" in ph else None,
+                                   "closing": rate(ph["potrf_tail"]) if "potrf_tail" in ph else None,
+                                   "note": "k_tail: a workgroup per 64 x 64 tile, operands polled between workgroups; flops = the "
+                                           "factorisation flops of the columns the launch covers (64^3 products inside a latency chain)"},
+            "factorisation": {"algorithmic_flops": fl_fact, "tflops_over_the_step": fl_fact / (dt / args.steps) / 1e12,
+                              "frac_over_the_step": fl_fact / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TF,
+                              "note": "N^3/3 + 2 N^2 P over the whole timed step (kernel-matrix build, factorisation, both sweeps, host round trip)"},
+            "all_updates_like_for_like": dict(rate(ph15["potrf_update"]), share_of_factorisation_flops=ph15["potrf_update"]["flops"] / (float(N) ** 3 / 3.0),
+                                              note="GPE_TALL=0 GPE_TAIL_MAX=0: 256-column panels to the end, every one of the 15 trailing updates "
+                                                   "(k = 256) alone between two events — rounds 1-3's accounting"),
             "measured_mfma_f64_4x4x4_peak_tflops": pk.value,
         }
-        out["phases_ms_per_step"] = {k: v["ms"] / reps for k, v in ph.items() if v["launches"]}
+        out["factorisation_frac"] = out["roofline"]["factorisation"]["frac_over_the_step"]
+        out["phases_us_per_step_profiled"] = {k: v["us"] for k, v in ph.items()}
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # throughput with R independent evaluations in flight (the reference runs hyper-parameter
@@ -508,25 +636,82 @@ def main():
             llo = ho.log_lik()
         tc = time.perf_counter() - t0
         ho.close()
-        # all host cores: numpy kernel build + LAPACK dpotrf / dpotrs through scipy, a reported
-        # upper bound for a CPU, not the reference's code path
+        # the reference ITSELF: limbo::model::GP compiled from the unmodified headers (oracle/_ref/libref.so, built in the
+        # container where /root/reference is; the dense loops under its semantics are the Eigen stand-in's, one thread — the
+        # reference's default: no TBB call inside gp.hpp, Eigen's LLT is serial without OpenMP/MKL).  ONE evaluation (~25 s).
+        cpu_ref = None
+        if OB.REF_SO.exists() and N == N_C2:
+            rg = OB.RefGP(O.SE_ARD, D_C2, 1, noise=0.01)
+            rg.set_h_params(theta)
+            t0 = time.perf_counter()
+            rg.compute(X, Y)
+            llr = rg.log_lik()
+            tr_ = time.perf_counter() - t0
+            rg.close()
+            cpu_ref = {"value": 1.0 / tr_, "unit": "evaluations/s", "cores": 1, "kind": "reference",
+                       "sample": f"1 compute()+compute_log_lik() at N={N}, D={D_C2} through limbo's own gp.hpp (unmodified /root/reference/src "
+                                 "headers compiled against the Eigen/Boost stand-ins of oracle/ref_build: oracle/_ref/libref.so)",
+                       "log_lik": llr, "rel_diff_vs_gpu": abs(llr - ll) / abs(llr)}
+        out["cpu_baseline_reference"] = cpu_ref
+        # LAPACK on the host cores: an upper bound for a CPU, not the reference's code path.  The parts
+        # separately — round 3's single figure was dominated by a single-threaded numpy exp over N^2 entries
         import scipy.linalg as sl
 
-        best_all = 1e30
+        try:
+            from threadpoolctl import threadpool_info
+
+            blas = [{"api": i.get("internal_api"), "threads": i.get("num_threads")} for i in threadpool_info() if i.get("user_api") == "blas"]
+        except Exception:  # noqa: BLE001
+            blas = None
+        t_build = t_potrf = t_solve = 1e30
         for _ in range(3):
             t0 = time.perf_counter()
             sq = (X * X).sum(axis=1)
             Kc = np.exp(-0.5 * np.maximum(sq[:, None] + sq[None, :] - 2.0 * (X @ X.T), 0.0))
             Kc[np.diag_indices(N)] += 0.01 + 1e-8
+            t1 = time.perf_counter()
             Lc = sl.cholesky(Kc, lower=True, overwrite_a=True, check_finite=False)
+            t2 = time.perf_counter()
             ac = sl.cho_solve((Lc, True), om, check_finite=False)
             ll_all = -0.5 * float((om * ac).sum()) - float(np.log(np.diag(Lc)).sum()) - 0.5 * N * np.log(2 * np.pi)
-            best_all = min(best_all, time.perf_counter() - t0)
-        if "config5" in out:  # the same BO inner loop through the oracle on one core of this box
-            out["config5"]["cpu_oracle_1_core"] = bo_inner_loop(orc, _capi, O, 0)
-        out["cpu_baseline_all_cores"] = {"value": 1.0 / best_all, "unit": "evaluations/s", "cores": os.cpu_count(), "kind": "port",
-                                         "sample": f"best of 3 compute()+log_lik at N={N}: numpy kernel build + LAPACK dpotrf/dpotrs (scipy/OpenBLAS) "
-                                                   "on all host cores", "log_lik": ll_all}
+            t3 = time.perf_counter()
+            t_build, t_potrf, t_solve = min(t_build, t1 - t0), min(t_potrf, t2 - t1), min(t_solve, t3 - t2)
+        out["cpu_lapack"] = {"dpotrf_s": t_potrf, "dpotrf_gflops": float(N) ** 3 / 3.0 / t_potrf / 1e9, "dpotrs_and_loglik_s": t_solve,
+                             "numpy_kernel_build_s": t_build, "blas_threads": blas, "host_cores": os.cpu_count(), "log_lik": ll_all,
+                             "evaluations_per_s_factor_and_solve_only": 1.0 / (t_potrf + t_solve),
+                             "note": f"best of 3 at N={N}: scipy/OpenBLAS dpotrf + dpotrs with the BLAS thread count shown; the kernel-matrix "
+                                     "build is vectorised numpy (one thread: exp over N^2 entries) and listed apart — not the reference's path"}
+        if "config5" in out:  # the same BO inner loop / BO iteration through the oracle on one core of this box
+            out["config5"]["cpu_oracle_1_core"] = dict(bo_inner_loop(orc, _capi, O, 0), bo_iteration=bo_iteration(orc, _capi, O, 0))
+        if "config4_g64" in out:
+            # B4: configs[3] by the reference's own strategy — one GP = one host task (tools::par::loop,
+            # multi_gp.hpp:124-126), 64 tasks of the single-threaded port on the host cores
+            from concurrent.futures import ThreadPoolExecutor
+
+            N4 = 2048
+            X4, Y4 = O.make_problem("c4", N=N4)
+            rng4 = np.random.default_rng(4)
+            hos = []
+            for g_ in range(64):
+                om4, _ = O.obs_mean_data(Y4 * rng4.uniform(0.5, 1.5) + 0.1 * np.sin(3.0 * X4[:, g_ % 6: g_ % 6 + 1] + g_))
+                ho4 = _capi.Handle(orc)
+                ho4.set_kernel(O.SE_ARD, rng4.uniform(-1e-2, 1e-2, size=D_C2 + 1), 0.01)
+                ho4.set_data(X4, om4)
+                hos.append(ho4)
+            nthr = min(64, os.cpu_count() or 1)
+
+            def task(ho4):
+                ho4.compute()
+                return ho4.log_lik()
+
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=nthr) as ex:
+                lls = list(ex.map(task, hos))
+            t64 = time.perf_counter() - t0
+            for ho4 in hos:
+                ho4.close()
+            out["config4_g64"]["cpu_oracle_64_host_tasks"] = {"value": 64 / t64, "unit": "evaluations/s", "threads": nthr, "host_cores": os.cpu_count(),
+                                                              "wall_s": t64, "kind": "port", "log_lik_0": lls[0]}
         out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "evaluations/s", "cores": 1, "kind": "port",
                                "sample": f"{n_cpu} full compute()+log_lik at N={N}, D={D_C2} (oracle/gp_oracle.c, "
                                          f"gcc -O3, {os.cpu_count()} host cores present, 1 used)",

@@ -189,7 +189,9 @@ enum gpe_phase {
     GPE_PH_INV = 5,
     GPE_PH_GRAD = 6,
     GPE_PH_QUERY = 7,
-    GPE_PH_COUNT = 8
+    GPE_PH_POTRF_TALL = 8,     /* the tall data-flow launch in front of the closing one (k_tail, round 4) */
+    GPE_PH_POTRF_TAIL = 9,     /* the closing data-flow launch (k_tail) */
+    GPE_PH_COUNT = 10
 };
 int gpe_set_profiling(gpe_handle h, int on);
 int gpe_get_phase_ms(gpe_handle h, double* ms, int64_t* launches, double* flops, int n);

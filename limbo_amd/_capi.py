@@ -21,9 +21,9 @@ ENGINE_SO = _PKG / "libgpengine.so"
 KERNEL_SE_ARD, KERNEL_MATERN52, KERNEL_MATERN32, KERNEL_EXP, KERNEL_HOST_K = range(5)
 KERNEL_NAMES = {"se_ard": 0, "matern52": 1, "matern32": 2, "exp": 3, "host_k": 4}
 
-PH_KERNEL_BUILD, PH_POTRF_PANEL, PH_POTRF_UPDATE, PH_SOLVE, PH_LOGLIK, PH_INV, PH_GRAD, PH_QUERY = range(8)
-PH_COUNT = 8
-PHASE_NAMES = ["kernel_build", "potrf_panel", "potrf_update", "solve", "loglik", "inv", "grad", "query"]
+PH_KERNEL_BUILD, PH_POTRF_PANEL, PH_POTRF_UPDATE, PH_SOLVE, PH_LOGLIK, PH_INV, PH_GRAD, PH_QUERY, PH_POTRF_TALL, PH_POTRF_TAIL = range(10)
+PH_COUNT = 10
+PHASE_NAMES = ["kernel_build", "potrf_panel", "potrf_update", "solve", "loglik", "inv", "grad", "query", "potrf_tall", "potrf_tail"]
 
 _dp = C.POINTER(C.c_double)
 _i64 = C.c_int64

@@ -203,13 +203,14 @@ void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_
 // p0 (the next three follow at + 4096 each and are written), dnext / Dacc as above
 void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t M, double* Xt, int* info, int64_t dnext,
                      double* Dacc, double* S22, double* S22_next, hipEvent_t stop = nullptr);
-// the last N - t0 <= tail_max columns of the factorisation in one launch (potrf.hip: k_tail); a buffer = the polled quarters of
-// nt block inverses, then a slot per tile
+// nt tile columns of a panel of nb row strips in one data-flow launch (potrf.hip: k_tail) — the closing columns of the
+// factorisation (nb = nt [+ 1 for the right-hand-side rows]) or a tall head panel (nb > nt); a buffer = the polled quarters
+// of nt block inverses, then a slot per tile
 #define GPE_TAIL_MAX 8192 // (upper bound of the setting; the default: engine.hip)
-static inline int64_t tail_tiles(int64_t nt, int64_t rhs_rows) { return nt * (nt + (rhs_rows > 0 ? 1 : 0)) - nt * (nt - 1) / 2; }
-static inline int64_t tail_buf_doubles(int64_t nt, int64_t rhs_rows) { return nt * 3072 + tail_tiles(nt, rhs_rows) * 4096; }
-void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t N, int64_t M, double* Xt_all, int* info, double* buf_cur,
-                 double* buf_next);
+static inline int64_t tail_tiles(int64_t nt, int64_t nb) { return nt * nb - nt * (nt - 1) / 2; }
+static inline int64_t tail_buf_doubles(int64_t nt, int64_t nb) { return nt * 3072 + tail_tiles(nt, nb) * 4096; }
+void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, int64_t N64, int64_t M, double* Xt_all, int* info,
+                 double* buf_cur, double* buf_next);
 // S22 / S22_next: the polled hand-over buffers (block inverses + head tiles), 33,792 doubles each, holding the all-ones
 // pattern when the launch starts (the launch arms S22_next)
 #define GPE_S22_TILE 20 // the two buffers sit in tiles 20..28 of either half of gpe_ctx::dHead

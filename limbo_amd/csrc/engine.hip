@@ -97,9 +97,16 @@ struct gpe_ctx {
     hipStream_t stream2 = nullptr;      // look-ahead: bulk of a trailing update runs here, behind the next panel
     std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
     int64_t tail_max = 2560;           // the last <= this many columns by one launch (k_tail; GPE_TAIL_MAX=0: by panels to the end)
-    double* dTail = nullptr;           // its two polled hand-over buffers (2 x tail_cap doubles, all-ones between launches)
-    int64_t tail_cap = 0;
-    unsigned tail_count = 0;
+    int64_t tall_max = 1536;           // ... and up to this many columns in FRONT of them as one tall data-flow launch (all rows
+                                       // below ride along) followed by ONE update with k = its width (GPE_TALL=0: 256-column panels
+                                       // with look-ahead all the way to the closing launch, the round-3 schedule)
+    // the polled hand-over buffers of the data-flow launches, ONE allocation: [closing 0 | closing 1 | tall 0 | tall 1].  Of a
+    // pair, the buffer of parity `count & 1` is armed (all-ones) for the slot layout of the pair's previous launch; a launch
+    // with another layout (another N or P on this handle) first puts the whole pair back to all-ones (prepare_tail)
+    double* dTail = nullptr;
+    int64_t tail_cap = 0, tall_cap = 0; // doubles per buffer of the closing / tall pair
+    unsigned tail_count = 0, tall_count = 0;
+    int64_t tail_lay = -1, tall_lay = -1; // nt * 65536 + nb of the pair's previous launch (-1: both buffers entirely all-ones)
     unsigned p256_count = 0;           // launches of k_panel256 so far: its polled X22 copies alternate between two buffers
     std::vector<hipEvent_t> pl_events; // ... one per outer panel: the one-launch panel is complete (early release of the look-ahead stream)
     int64_t early_bulk = 100;          // release the look-ahead stream at the END OF THE PANEL (not of the fused next-panel update)
@@ -256,7 +263,8 @@ const Roctx& roctx()
     return r;
 }
 const char* const kPhaseNames[GPE_PH_COUNT] = {"gpe:kernel_build", "gpe:potrf_panel", "gpe:potrf_update", "gpe:solve",
-                                               "gpe:loglik",       "gpe:inv",         "gpe:grad",         "gpe:query"};
+                                               "gpe:loglik",       "gpe:inv",         "gpe:grad",         "gpe:query",
+                                               "gpe:potrf_tall",   "gpe:potrf_tail"};
 
 struct PhaseScope {
     gpe_ctx* c;
@@ -536,6 +544,88 @@ static void inv_follow_upto(gpe_ctx* c, int64_t upto, hipEvent_t ready, int limi
 //   the last two being calls of the same matrix-core kernel.
 // M >= N rows take part (rows N..M-1 = right-hand sides: they come out as (L^-1 b)^T).
 // ---------------------------------------------------------------------------------------------
+// Where the data-flow launches of a factorisation of order N (M >= N rows) begin: panels (k_panel256 + look-ahead updates)
+// cover [0, e0), a tall launch [e0, t0) followed by one update with k = t0 - e0, the closing launch [t0, N64).
+struct TailPlan {
+    int64_t e0 = -1, t0 = -1, N64 = 0; // e0 < 0: no tall launch; t0 < 0: neither
+    int64_t nt_tall = 0, nb_tall = 0, nt_tail = 0, nb_tail = 0;
+    int64_t need_tall = 0, need_tail = 0; // doubles per buffer
+};
+static TailPlan tail_plan(const gpe_ctx* c, int64_t N, int64_t M)
+{
+    TailPlan pl;
+    const int64_t nbo = c->nbo;
+    pl.N64 = N / NB * NB;
+    static const bool batch_tail = !(getenv("GPE_BATCH_TAIL") && atoi(getenv("GPE_BATCH_TAIL")) == 0);
+    if (!(c->tail_max >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && (batch_tail || !g_batch.bt) && nbo == 4 * NB
+          && M - pl.N64 <= NB))
+        return pl;
+    int64_t t0 = pl.N64 > c->tail_max ? (pl.N64 - c->tail_max + nbo - 1) / nbo * nbo : 0;
+    if (pl.N64 - t0 < 2 * NB)
+        return pl;
+    pl.t0 = t0;
+    const int64_t rs = M > pl.N64 ? 1 : 0;
+    pl.nt_tail = (pl.N64 - t0) / NB;
+    pl.nb_tail = pl.nt_tail + rs;
+    pl.need_tail = tail_buf_doubles(pl.nt_tail, pl.nb_tail);
+    if (t0 > 0 && c->tall_max >= 2 * NB) {
+        const int64_t e0 = t0 > c->tall_max ? (t0 - c->tall_max + nbo - 1) / nbo * nbo : 0;
+        if (t0 - e0 >= 2 * NB) {
+            pl.e0 = e0;
+            pl.nt_tall = (t0 - e0) / NB;
+            pl.nb_tall = (pl.N64 - e0) / NB + rs;
+            pl.need_tall = tail_buf_doubles(pl.nt_tall, pl.nb_tall);
+        }
+    }
+    return pl;
+}
+// The hand-over buffers of handle c for this plan, on stream s (ordered in front of the launches that poll them).
+// like != nullptr (a batched launch built from `like`'s pointers): same capacities and the same armed parity as that handle.
+static bool prepare_tail(gpe_ctx* c, const TailPlan& pl, hipStream_t s, const gpe_ctx* like = nullptr)
+{
+    if (pl.t0 < 0)
+        return true;
+    int64_t want_tail = std::max(c->tail_cap, pl.need_tail), want_tall = std::max(c->tall_cap, pl.need_tall);
+    if (like) {
+        want_tail = like->tail_cap;
+        want_tall = like->tall_cap;
+        if (want_tail < pl.need_tail || want_tall < pl.need_tall)
+            return false;
+    }
+    if (!c->dTail || c->tail_cap != want_tail || c->tall_cap != want_tall) {
+        if (c->dTail) {
+            hipStreamSynchronize(c->stream); // (an earlier launch of this handle may still be reading the old one)
+            hipFree(c->dTail);
+        }
+        c->dTail = nullptr;
+        c->tail_cap = c->tall_cap = 0;
+        const size_t bytes = sizeof(double) * 2 * (size_t)(want_tail + want_tall);
+        if (hipMalloc(&c->dTail, bytes) != hipSuccess)
+            return false;
+        hipMemsetAsync(c->dTail, 0xFF, bytes, s);
+        c->tail_cap = want_tail;
+        c->tall_cap = want_tall;
+        c->tail_lay = c->tall_lay = -1;
+    }
+    const int64_t lay_tail = pl.nt_tail * 65536 + pl.nb_tail, lay_tall = pl.e0 >= 0 ? pl.nt_tall * 65536 + pl.nb_tall : -1;
+    if (c->tail_lay == -2 || (c->tail_lay >= 0 && c->tail_lay != lay_tail)
+        || (like && c->tail_lay >= 0 && ((c->tail_count ^ like->tail_count) & 1))) {
+        hipMemsetAsync(c->dTail, 0xFF, sizeof(double) * 2 * (size_t)c->tail_cap, s);
+        c->tail_lay = -1;
+    }
+    if ((c->tall_lay == -2 && c->tall_cap > 0)
+        || (pl.e0 >= 0
+            && ((c->tall_lay >= 0 && c->tall_lay != lay_tall) || (like && c->tall_lay >= 0 && ((c->tall_count ^ like->tall_count) & 1))))) {
+        hipMemsetAsync(c->dTail + 2 * c->tail_cap, 0xFF, sizeof(double) * 2 * (size_t)c->tall_cap, s);
+        c->tall_lay = -1;
+    }
+    if (like) { // (a pair that is all-ones throughout may take any parity)
+        c->tail_count = like->tail_count;
+        c->tall_count = like->tall_count;
+    }
+    return true;
+}
+
 void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
 {
     hipStream_t s = c->stream;
@@ -545,42 +635,63 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     bool la_pending = false; // a bulk update is (possibly) still running on stream2
     size_t la_last = 0;
     // The last <= tail_max columns (all of them when N <= tail_max) go to ONE launch, a tiled data-flow factorisation
-    // (potrf.hip: k_tail): the panels end at t0, the panel in front of it updates everything that is left in one piece.
-    // Its columns are whole 64-blocks: t0 .. N64; a ragged last block (N64 .. N, fewer than 64 columns) and the right-hand-side
-    // rows ride in it as one more row strip and are finished by the panel code below (one small update, the ragged block).
-    int64_t t0 = -1;
-    const int64_t N64 = N / NB * NB;
-    if (c->tail_max >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && !g_batch.bt && nbo == 4 * NB && M - N64 <= NB) {
-        t0 = N64 > c->tail_max ? (N64 - c->tail_max + nbo - 1) / nbo * nbo : 0;
-        if (N64 - t0 < 2 * NB)
-            t0 = -1;
-    }
-    if (t0 >= 0) {
-        const int64_t need = tail_buf_doubles((N64 - t0) / NB, M - N64);
-        if (c->tail_cap < need) { // (both buffers all-ones: whatever the old ones held is irrelevant)
-            if (c->dTail)
-                hipFree(c->dTail);
-            c->dTail = nullptr;
-            c->tail_cap = 0;
-            if (hipMalloc(&c->dTail, sizeof(double) * 2 * need) == hipSuccess) {
-                hipMemsetAsync(c->dTail, 0xFF, sizeof(double) * 2 * need, s);
-                c->tail_cap = need;
-            }
-            else
-                t0 = -1;
-        }
-    }
+    // (potrf.hip: k_tail): the panels end at t0.  Its columns are whole 64-blocks: t0 .. N64; a ragged last block (N64 .. N,
+    // fewer than 64 columns) and the right-hand-side rows ride in it as one more row strip and are finished by the panel code
+    // below (one small update, the ragged block).  Round 4: up to tall_max columns in front of t0 are one launch of the same
+    // kernel too (e0 .. t0, every row strip below riding along), followed by ONE update of everything behind t0 with
+    // k = t0 - e0; 256-column panels with look-ahead only in front of e0 (none at N = 4096: three launches factor the matrix).
+    TailPlan pl = tail_plan(c, N, M);
+    if (pl.t0 >= 0 && !g_batch.bt && !prepare_tail(c, pl, s)) // (a batched launch: batch_enqueue_fused prepared every member)
+        pl = TailPlan{};
+    const int64_t t0 = pl.t0, e0 = pl.e0, N64 = pl.N64;
+    const int64_t stop0 = e0 >= 0 ? e0 : t0; // where the panels end: the panel in front of it updates everything left in one piece
     for (int64_t p0 = 0; p0 < N; p0 += nbo) {
+        if (e0 >= 0 && p0 == e0) {
+            if (la_pending) {
+                hipStreamWaitEvent(s, c->la_events[la_last], 0);
+                la_pending = false;
+            }
+            {
+                const double w = (double)(t0 - e0), h = (double)(M - e0);
+                PhaseScope ps(c, GPE_PH_POTRF_TALL, w * w * w / 3.0 + (h - w) * w * w);
+                double* pair = c->dTail + 2 * c->tail_cap;
+                launch_tail(s, A, ld, e0, t0, N64, M, c->dXinv, c->dInfo, pair + (c->tall_count & 1) * c->tall_cap,
+                            pair + ((c->tall_count + 1) & 1) * c->tall_cap);
+                ++c->tall_count;
+                c->tall_lay = pl.nt_tall * 65536 + pl.nb_tall;
+            }
+            { // everything behind t0 -= L[t0:M, e0:t0] L[t0:N, e0:t0]^T: one launch, k = t0 - e0
+                GemmArgs g{};
+                g.C = A + t0 + t0 * ld;
+                g.ldc = ld;
+                g.A = A + t0 + e0 * ld;
+                g.lda = ld;
+                g.B = A + t0 + e0 * ld;
+                g.ldb = ld;
+                g.m = M - t0;
+                g.n = N - t0;
+                g.k = t0 - e0;
+                g.tri = 1;
+                g.grow0 = t0;
+                g.gcol0 = t0;
+                g.rhs_rows = (int)(M - N);
+                PhaseScope ps(c, GPE_PH_POTRF_UPDATE, gemm_flops(g));
+                launch_gemm_sub(s, g);
+            }
+            p0 = t0;
+            next_diag_done = false;
+        }
         if (p0 == t0) {
             if (la_pending) {
                 hipStreamWaitEvent(s, c->la_events[la_last], 0);
                 la_pending = false;
             }
             {
-                PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(N64 - t0) * (N64 - t0) * (N64 - t0) / 3.0);
-                launch_tail(s, A, ld, t0, N64, M, c->dXinv, c->dInfo, c->dTail + (c->tail_count & 1) * c->tail_cap,
+                PhaseScope ps(c, GPE_PH_POTRF_TAIL, (double)(N64 - t0) * (N64 - t0) * (N64 - t0) / 3.0);
+                launch_tail(s, A, ld, t0, N64, N64, M, c->dXinv, c->dInfo, c->dTail + (c->tail_count & 1) * c->tail_cap,
                             c->dTail + ((c->tail_count + 1) & 1) * c->tail_cap);
                 ++c->tail_count;
+                c->tail_lay = pl.nt_tail * 65536 + pl.nb_tail;
                 c->xinv_done = N64 / NB;
             }
             if (N64 == N)
@@ -619,7 +730,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
         // diagonal block (k_upd_fused)?  Then the steps of this panel pre-apply their pieces of that block.
         const bool fuse_diag = c->lookahead && !c->prof && std::min<int64_t>(pe + nbo, N) < N && c->fuse_panel && c->fuse_diag
             && c->stop_events && pw == nbo && nbo % NB == 0 && nbo >= 2 * NB && ld % 2 == 0
-            && std::min<int64_t>(nbo, N - pe) % NB == 0 && pe != t0;
+            && std::min<int64_t>(nbo, N - pe) % NB == 0 && pe != stop0;
         // the whole panel in one launch (potrf.hip: k_panel256): full 256 columns, head tiles and block inverses handed over
         // between its workgroups
         const bool p256 = c->panel256 && c->fuse_panel && c->panel_handover && !g_batch.bt && nbo == 4 * NB && pw == nbo && pe <= M;
@@ -755,7 +866,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 launch_gemm_sub(st, g);
             };
             const int64_t pe2 = std::min<int64_t>(pe + nbo, N);
-            if (c->lookahead && !c->prof && pe2 < N && pe != t0) {
+            if (c->lookahead && !c->prof && pe2 < N && pe != stop0) {
                 // look-ahead: the next panel's columns are updated on the main stream, the rest of the
                 // trailing matrix on the second stream while the next panel is factored
                 auto ev = [&](size_t i) {
@@ -1156,6 +1267,7 @@ template <class Redo> int compute_finish(gpe_ctx* c, Redo redo)
         c->hInfo[0] = c->hInfo[1] = c->hInfo[2] = 0;
         c->panel_handover = false;
         c->handover_off_left = 16 + 1; // this re-run and the next 16 evaluations re-derive the tiles, then hand over again
+        c->tail_lay = c->tall_lay = -2; // the data-flow launches' buffers are in an unknown state: all-ones again before their next use
         ++c->flow_retries;
         ++c->handover_reruns;
         const BatchLaunch saved = g_batch;
@@ -1714,6 +1826,8 @@ int gpe_create(int device_id, gpe_handle* out)
         c->early_bulk = atoll(f);
     if (const char* f = getenv("GPE_TAIL_MAX"))
         c->tail_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), GPE_TAIL_MAX);
+    if (const char* f = getenv("GPE_TALL"))
+        c->tall_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), GPE_TAIL_MAX);
     if (const char* f = getenv("GPE_STOP_EVENT"))
         c->stop_events = atoi(f) != 0;
     if (const char* f = getenv("GPE_LOOKAHEAD"))
@@ -2921,6 +3035,19 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
     }
     if (c0->device >= 16)
         return GPE_ERR_UNSUPPORTED;
+    { // the data-flow launches' hand-over buffers: every member's with the capacities and the armed parity of member 0's
+        g_batch.G = Gc; // (the plan depends on the launch being batched, not on the table)
+        g_batch.bt = reinterpret_cast<const BatchTab*>(1);
+        const TailPlan pl = tail_plan(c0, c0->N, c0->N + c0->P);
+        g_batch = BatchLaunch{};
+        if (pl.t0 >= 0) {
+            if (!prepare_tail(c0, pl, c0->stream))
+                return GPE_ERR_NOMEM;
+            for (int q = 1; q < Gc; ++q)
+                if (!prepare_tail(cs[q], pl, c0->stream, c0))
+                    return GPE_ERR_NOMEM;
+        }
+    }
     BatchTab* dtab = acquire_tab(c0->device); // held until the batch has finished (batch_finish_fused's caller releases it)
     if (!dtab)
         return GPE_ERR_NOMEM;
@@ -2936,7 +3063,7 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
         c->hInfo[0] = c->hInfo[1] = 0;
         const char* b[GPE_BT_CLS] = {(const char*)c->dA, (const char*)c->dXt, (const char*)c->dOm, (const char*)c->dAl,
                                      (const char*)c->dXinv, (const char*)c->dHead, (const char*)c->hInfo, (const char*)c->hScal,
-                                     (const char*)c->dLinv, (const char*)c->dKinv, (const char*)c->dGradPartial, nullptr};
+                                     (const char*)c->dLinv, (const char*)c->dKinv, (const char*)c->dGradPartial, (const char*)c->dTail};
         for (int k = 0; k < GPE_BT_CLS; ++k)
             t.base[k][q] = b[k];
         t.kp[q] = c->kp;
@@ -2947,7 +3074,8 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
                                                (unsigned long long)(dbl * c0->ld * c0->P), (unsigned long long)(dbl * c0->ld * c0->P),
                                                (unsigned long long)(dbl * (c0->cap / NB) * NB * NB), (unsigned long long)(dbl * GPE_HEAD_TILES * NB * NB), 64, 8192,
                                                (unsigned long long)(c0->dLinv ? dbl * c0->ld * c0->cap : 0), (unsigned long long)(c0->dKinv ? dbl * c0->ld * c0->cap : 0),
-                                               (unsigned long long)(c0->dGradPartial ? dbl * c0->grad_partial_cap : 0), 0};
+                                               (unsigned long long)(c0->dGradPartial ? dbl * c0->grad_partial_cap : 0),
+                                               (unsigned long long)(c0->dTail ? dbl * 2 * (c0->tail_cap + c0->tall_cap) : 0)};
     for (int k = 0; k < GPE_BT_CLS; ++k) {
         t.base0[k] = t.base[k][0];
         t.size[k] = sz[k];
@@ -2959,6 +3087,12 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
     g_batch.bt = dtab;
     g_batch.G = Gc;
     int e = compute_enqueue(c0);
+    for (int q = 1; q < Gc; ++q) { // the members' hand-over buffers went through the same launches as member 0's
+        cs[q]->tail_count = c0->tail_count;
+        cs[q]->tall_count = c0->tall_count;
+        cs[q]->tail_lay = c0->tail_lay;
+        cs[q]->tall_lay = c0->tall_lay;
+    }
     if (e == GPE_OK && want && want->grad) {
         // K^-1 (gp.hpp:254-264) and the gradient pair sum (gp.hpp:285-311) of every member, same launch sequence
         e = grad_enqueue(c0, want->n_grad, want->optimize_noise);

@@ -1622,10 +1622,17 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
 // updates and launch boundaries in between.  Polled buffers: LP (a 4096-double slot per tile, blockIdx order) and SP (3072 doubles
 // per diagonal block), all-ones when the launch starts; every workgroup arms its own slot of the OTHER pair for the next launch.
 // ---------------------------------------------------------------------------------------------
+// Round 4: the launch is no longer tied to the END of the matrix.  A "tall" launch factors the nt tile columns t0 .. t1 of a
+// panel that has nfull >= nt full row strips under its first row (rows t0 .. N64) plus the right-hand-side strip: the whole
+// 1536-column head of an N = 4096 factorisation is one such launch (24 tile columns x 64 row strips), one k = 1536 update and
+// the closing launch (nfull = nt) follow — no 256-column panels, no look-ahead stream.  Batched (k_tail_b): the tiles of G
+// members interleave in the 1-D grid (id = tile * G + member), so that the G chains advance side by side and every wait is
+// still for a lower-numbered workgroup.
 struct TailArgs {
     double* A;
-    int64_t lda, t0; // the tail starts at row / column t0
-    int nt, nb;      // tile columns; row strips (nt, + 1 for the right-hand-side rows)
+    int64_t lda, t0; // the launch starts at row / column t0
+    int nt, nb;      // tile columns; row strips (nfull, + 1 for the right-hand-side rows)
+    int nfull;       // full 64-row strips (>= nt; == nt for the closing launch)
     int rhs_rows;
     double* Xt;      // inverse of the diagonal block at t0 (the others follow at + 4096 each)
     int* info;
@@ -1634,15 +1641,14 @@ struct TailArgs {
 };
 static __device__ __forceinline__ int tail_tile_id(int nb, int b, int c) { return c * nb - (c * (c - 1)) / 2 + (b - c); }
 
-__global__ __launch_bounds__(512) void k_tail(TailArgs a)
+static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wgid, double* __restrict__ lds)
 {
-    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS]; // [Bx | T0 | T1 | T2]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
     const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
     int c = 0, b;
     {
-        int id = (int)blockIdx.x, colh = a.nb;
+        int id = wgid, colh = a.nb;
         while (id >= colh) {
             id -= colh;
             ++c;
@@ -1660,7 +1666,7 @@ __global__ __launch_bounds__(512) void k_tail(TailArgs a)
     x.info = a.info;
     x.mute = mute;
     x.spin_limit = mute ? -a.spin_limit : a.spin_limit;
-    x.nrows = b < a.nt ? NB : a.rhs_rows;
+    x.nrows = b < a.nfull ? NB : a.rhs_rows;
     x.want_d = false;
     x.Bx = lds;
     x.T0 = lds + NB * XS;
@@ -1668,9 +1674,9 @@ __global__ __launch_bounds__(512) void k_tail(TailArgs a)
     x.T2 = x.T1 + NB * PS;
     x.S22 = a.SP;
     x.HP = a.LP;
-    double* const myslot = a.LP + (int64_t)blockIdx.x * (NB * NB);
+    double* const myslot = a.LP + (int64_t)wgid * (NB * NB);
     { // the other pair of buffers, for the next launch: this tile's slot (and its diagonal block's quarters)
-        unsigned long long* nx = reinterpret_cast<unsigned long long*>(a.LPn + (int64_t)blockIdx.x * (NB * NB));
+        unsigned long long* nx = reinterpret_cast<unsigned long long*>(a.LPn + (int64_t)wgid * (NB * NB));
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             nx[threadIdx.x + 512 * q] = ~0ull;
@@ -1825,18 +1831,42 @@ __global__ __launch_bounds__(512) void k_tail(TailArgs a)
     }
 }
 
-// columns t0 .. N-1 (N - t0 a multiple of 64), rows t0 .. M-1: the M - N <= 64 rows below them — right-hand-side rows, and the
-// rows of a ragged last block the caller finishes — ride along as one more row strip.  Fully updated by everything in front.  buf_cur / buf_next: tail_buf_doubles(nt, rhs rows) each, all-ones (this launch arms buf_next)
-void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t N, int64_t M, double* Xt_all, int* info, double* buf_cur,
-                 double* buf_next)
+__global__ __launch_bounds__(512) void k_tail(TailArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS]; // [Bx | T0 | T1 | T2]
+    tail_body(a, (int)blockIdx.x, lds);
+}
+// G members at once: blockIdx.x = tile * G + member (the members' chains advance side by side; a wait is for a lower tile of
+// the same member, i.e. a lower-numbered workgroup)
+__global__ __launch_bounds__(512) void k_tail_b(TailArgs a, const BatchTab* __restrict__ bt)
+{
+    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS];
+    const int G = bt->G, gp = (int)blockIdx.x % G;
+    a.A = bt_rebase(bt, gp, a.A);
+    a.Xt = bt_rebase(bt, gp, a.Xt);
+    a.info = bt_rebase(bt, gp, a.info);
+    a.LP = bt_rebase(bt, gp, a.LP);
+    a.SP = bt_rebase(bt, gp, a.SP);
+    a.LPn = bt_rebase(bt, gp, a.LPn);
+    a.SPn = bt_rebase(bt, gp, a.SPn);
+    tail_body(a, (int)blockIdx.x / G, lds);
+}
+
+// Tile columns t0 .. t1-1 (whole 64-blocks) of the rows t0 .. M-1: N64 - t0 full row strips (N64 = the matrix order rounded down
+// to 64; t1 == N64: the closing launch) and, as one more row strip, the M - N64 <= 64 rows below them — right-hand-side rows and
+// the rows of a ragged last block the caller finishes.  Fully updated by everything in front of t0.  buf_cur / buf_next:
+// tail_buf_doubles(nt, nb) each, all-ones (this launch arms buf_next)
+void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, int64_t N64, int64_t M, double* Xt_all, int* info,
+                 double* buf_cur, double* buf_next)
 {
     TailArgs a{};
     a.A = A;
     a.lda = lda;
     a.t0 = t0;
-    a.nt = (int)((N - t0) / NB);
-    a.rhs_rows = (int)(M - N);
-    a.nb = a.nt + (a.rhs_rows > 0 ? 1 : 0);
+    a.nt = (int)((t1 - t0) / NB);
+    a.nfull = (int)((N64 - t0) / NB);
+    a.rhs_rows = (int)(M - N64);
+    a.nb = a.nfull + (a.rhs_rows > 0 ? 1 : 0);
     a.Xt = Xt_all + (t0 / NB) * (NB * NB);
     a.info = info;
     a.SP = buf_cur;
@@ -1845,8 +1875,11 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t N, i
     a.LPn = buf_next + (int64_t)a.nt * 3072;
     static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
     a.spin_limit = fault ? -16 : GPE_FLOW_SPIN_LIMIT;
-    const int tiles = a.nt * a.nb - (a.nt * (a.nt - 1)) / 2;
-    GPE_LAUNCH(k_tail, dim3((unsigned)tiles), dim3(512), 0, s, a);
+    const int64_t tiles = tail_tiles(a.nt, a.nb);
+    if (g_batch.bt)
+        GPE_LAUNCH(k_tail_b, dim3((unsigned)(tiles * g_batch.G)), dim3(512), 0, s, a, g_batch.bt);
+    else
+        GPE_LAUNCH(k_tail, dim3((unsigned)tiles), dim3(512), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -21,10 +21,12 @@ def shard(n_units: int, rank: int, world: int) -> range:
     return range(rank, n_units, world)
 
 
-def argmax_over_ranks(values, thetas, dist=None, device="cpu"):
+def argmax_over_ranks(values, thetas, dist=None, device="cpu", force=False):
     """values: this rank's objective values (len k); thetas: (k, T).  Returns (best_value,
     best_theta, owner_rank) identical on every rank — the parallel_reduce max of
-    tools/parallel.hpp:169-191.  Ranks may hold different numbers of units (ragged shards)."""
+    tools/parallel.hpp:169-191.  Ranks may hold different numbers of units (ragged shards).
+    force: run the two collectives even in a group of one rank (bench.py --force-dist: the RCCL path
+    rehearsed on a one-GPU box)."""
     import torch
 
     values = np.atleast_1d(np.asarray(values, dtype=np.float64))
@@ -35,7 +37,7 @@ def argmax_over_ranks(values, thetas, dist=None, device="cpu"):
         rec = np.concatenate([[values[i]], thetas[i]])
     else:  # a rank without units never wins
         rec = np.concatenate([[-np.inf], np.zeros(T)])
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return float(rec[0]), rec[1:].copy(), 0
     # T can differ only if a rank had no unit: agree on the record length first
     n = torch.tensor([len(rec)], dtype=torch.int64, device=device)

@@ -106,11 +106,15 @@ def test_gpu_c4_batch_64_vs_oracle(engine_lib, oracle_lib):
         assert relerr(vg + 0.01, vo + 0.01) < PC.TOL_VAR
         o.close()
     single = new_gp(engine_lib, O.SE_ARD, X, oms[0], ths[0], 0.01)
-    for g in range(G):  # one at a time on one handle (two-stream look-ahead schedule): equal to rounding
+    for g in range(G):  # one at a time on one handle: equal to rounding
         single.set_data(X, oms[g])
         single.set_kernel(O.SE_ARD, ths[g], 0.01)
         assert single.compute() == 0
         assert abs(single.log_lik() - ll[g]) <= 1e-12 * abs(ll[g]), g
+        if g in (0, 31, 63):
+            # round 4: N = 2048 is ONE data-flow launch (k_tail) in both forms — the batched one interleaves the members'
+            # tiles in its grid (k_tail_b), every tile does the same arithmetic in the same order: the factor is bitwise equal
+            assert np.array_equal(np.tril(single.get_L()), np.tril(hs[g].get_L())), g
     single.close()
     assert _capi.batch_compute(hs) == [0] * G  # the batched launch sequence itself is bitwise reproducible
     assert np.array_equal(_capi.batch_log_lik(hs), ll)
@@ -358,12 +362,14 @@ def test_gpu_panel_head_tiles_handed_over_or_rederived_give_the_same_factor(engi
     assert np.max(np.abs(Ls["no_handover"] - L1)) <= 1e-13 * np.max(np.abs(L1))
 
 
-def test_gpu_one_launch_panels_polled_buffers_across_handles(engine_lib):
-    """k_panel256 hands block inverses and head tiles over through buffers that must hold an all-ones pattern when a launch
+def test_gpu_one_launch_panels_polled_buffers_across_handles(engine_lib, monkeypatch):
+    """(GPE_TAIL_MAX=0: panels to the end — under the defaults every N <= 2560 is one k_tail launch and never reaches
+    k_panel256.)  k_panel256 hands block inverses and head tiles over through buffers that must hold an all-ones pattern when a launch
     starts: every launch arms the other buffer of the handle's pair, both are armed when a handle is created — also when its
     streams and scratch block come out of the pool of destroyed handles, in whatever state the last launch left them.  An odd
     and an even number of one-launch panels per evaluation (N = 1100: 4, N = 1400: 5), handles destroyed and re-created in
     between and two handles taking turns: every evaluation must reproduce the first one bit for bit."""
+    monkeypatch.setenv("GPE_TAIL_MAX", "0")
     ref = {}
     for rnd in range(3):
         for N in (1100, 1400, 1100):
@@ -387,13 +393,16 @@ def test_gpu_one_launch_panels_polled_buffers_across_handles(engine_lib):
         h.close()
 
 
-@pytest.mark.parametrize("N", [1100, 1152])
-def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, N):
+@pytest.mark.parametrize("N,tail", [(1100, "0"), (1152, None), (4096, None)])
+def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, monkeypatch, N, tail):
     """GPE_HANDOVER_FAULT=1: no head workgroup publishes and every consumer gives up after a few polls, i.e. every fused
     panel step of the first attempt reports a lost hand-over.  The host must notice (info word 2), run the evaluation again
     from K on without the hand-over, count it in flow_retries(), and return the same log-likelihood as an undisturbed
-    process (child process: the switch is read once).  N = 1100: the one-launch panels (k_panel256); N = 1152 = 18 x 64: the
-    whole factorisation as one tiled data-flow launch (k_tail), whose block inverses are muted the same way."""
+    process (child process: the switch is read once).  N = 1100 with GPE_TAIL_MAX=0: the one-launch panels (k_panel256);
+    N = 1152 = 18 x 64: the whole factorisation as one tiled data-flow launch (k_tail), whose block inverses are muted the same
+    way; N = 4096: the tall launch + update + closing launch of round 4."""
+    if tail is not None:
+        monkeypatch.setenv("GPE_TAIL_MAX", tail)
     X, Y = synth.make_problem("c2", N=N)
     om, _ = synth.obs_mean_data(Y)
     h = new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(7), 0.01)
@@ -409,16 +418,24 @@ def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, N):
             "assert h.flow_retries() == 1, h.flow_retries()\n"
             "assert h.compute() == 0 and h.flow_retries() == 1  # the handle stays without the hand-over\n"
             "print('child ok %%.17g' %% h.log_lik())\n") % (str(ROOT), N)
-    env = dict(os.environ, GPE_HANDOVER_FAULT="1")
+    env = dict(os.environ, GPE_HANDOVER_FAULT="1")  # (GPE_TAIL_MAX: inherited from the monkeypatched environment)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     # the re-run factorises without the hand-over and hence without the folded last step (round 3): the same factor to rounding
     assert abs(float(r.stdout.split("child ok")[1]) - ll) <= 1e-13 * abs(ll)
 
 
-@pytest.mark.parametrize("N,P,tail", [(128, 1, None), (320, 2, None), (704, 3, None), (1344, 1, None), (1344, 2, "512"), (1792, 1, "768"),
-                                      (2624, 1, None), (150, 1, None), (1100, 3, None), (1407, 2, "512"), (2500, 1, None)])
-def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, tail):
+@pytest.mark.parametrize("N,P,tail,tall", [(128, 1, None, None), (320, 2, None, None), (704, 3, None, None), (1344, 1, None, None),
+                                           (1344, 2, "512", "0"), (1792, 1, "768", "0"), (2624, 1, None, "0"), (150, 1, None, None),
+                                           (1100, 3, None, None), (1407, 2, "512", "0"), (2500, 1, None, None),
+                                           # round 4: a tall data-flow launch + ONE update in front of the closing launch
+                                           (2624, 1, None, None),      # tall 0..256 (4 tile columns x 41 row strips), closing 37
+                                           (1344, 2, "512", None),     # tall 0..1024, closing 5 tile columns, two outputs
+                                           (2000, 3, "512", "256"),    # panels to 1280, tall 1280..1536, closing 7, ragged, P = 3
+                                           (3200, 1, "1024", "512"),   # panels to 1792, tall 1792..2304, closing 14
+                                           (3000, 2, "1280", "1536"),  # tall 0..1792 (28 x 46 strips + ragged/rhs strip), closing 18
+                                           ])
+def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, tail, tall):
     """k_tail: the last <= 2560 columns (GPE_TAIL_MAX; all of them when N is no larger) of a factorisation whose order is a
     multiple of 64 are factored by ONE launch, a workgroup per 64 x 64 tile, operands polled between them.  Against LAPACK on the
     host: L to 1e-10 of max|L|, alpha (the forward substitution rides along as the right-hand-side strip, P rows) to 1e-7,
@@ -426,10 +443,14 @@ def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, t
     (1344 with a 512 tail: panels to 1024, then 5 tile columns; 1792 with 768; 2624 = 41 x 64: one panel, 37 tile columns, more
     tiles than CUs), one to three outputs; orders that are not multiples of 64 (150, 1100, 1407 = 21 x 64 + 63, 2500): the ragged
     last block and the right-hand-side rows ride in the launch as one more row strip and the panel code finishes them.  Two
-    evaluations: the second one runs on the other pair of polled buffers."""
+    evaluations: the second one runs on the other pair of polled buffers.  Round 4 (`tall`, GPE_TALL): the columns in front of
+    the closing launch as ONE tall launch of the same kernel (every row strip below rides along) + one update with k = its
+    width, behind 256-column panels or from column 0 on.  (K itself is the engine's: it is held to the oracle elsewhere.)"""
     import scipy.linalg as sl
     if tail is not None:
         monkeypatch.setenv("GPE_TAIL_MAX", tail)
+    if tall is not None:
+        monkeypatch.setenv("GPE_TALL", tall)
     rng = np.random.default_rng(N + P)
     X = rng.uniform(0, 1, size=(N, 4))
     Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.05 * rng.normal(size=(N, P))
@@ -451,6 +472,30 @@ def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, t
             L0, ll0 = L, h.log_lik()
         else:
             assert np.array_equal(L, L0) and h.log_lik() == ll0
+    h.close()
+
+
+def test_gpu_data_flow_buffers_across_sizes_on_one_handle(engine_lib):
+    """the data-flow launches (k_tail) hand tiles over through buffers that must hold an all-ones pattern
+    where the launch polls, and a launch only re-arms ITS OWN slot layout of the other buffer.  One handle whose N and P change
+    between evaluations — a BO run growing past the closing launch's width (2560 -> 2624 -> 2688 changes the tile-column count
+    40 -> 37 -> 38), a P change, sizes with and without a tall launch in front — must give LAPACK's factor every time: the
+    engine puts the pair back to all-ones when the layout differs from the previous launch's (engine.hip: prepare_tail)."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(7)
+    h = _capi.Handle(engine_lib)
+    for N, P in [(2560, 1), (2624, 1), (2688, 1), (2624, 2), (2560, 1), (4096, 1), (3000, 1), (4096, 2), (2688, 1), (2688, 1)]:
+        X = rng.uniform(0, 1, size=(N, 4))
+        Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.05 * rng.normal(size=(N, P))
+        om, _ = O.obs_mean_data(Y)
+        h.set_data(X, om)
+        h.set_kernel(int(O.SE_ARD), rng.uniform(-0.3, 0.2, size=5), 0.01)
+        assert h.compute() == 0 and h.flow_retries() == 0, (N, P)
+        L = np.tril(h.get_L())
+        K = h.get_K()
+        Lref = sl.cholesky(np.tril(K) + np.tril(K, -1).T, lower=True)
+        assert np.max(np.abs(L - Lref)) <= 1e-10 * np.max(np.abs(Lref)), (N, P)
+        assert relerr_norm(h.get_alpha(), sl.cho_solve((Lref, True), om)) < 1e-7, (N, P)
     h.close()
 
 
@@ -691,6 +736,51 @@ def test_gpu_c2_full_size_gradient_objective_vs_lapack(engine_lib, on):
     h.close()
 
 
+def test_gpu_c2_full_size_fit_lockstep_vs_lapack(engine_lib):
+    """BASELINE configs[1] end to end at its own size: a KernelLFOpt fit (model/gp/kernel_lf_opt.hpp:60-69 -> opt/rprop.hpp:84-144)
+    at N = 4096 with 4 restarts (parallel_repeater.hpp:84-105) advanced in lock-step, every iteration ONE
+    gpe_batch_hp_objective (limbo_amd/hpfit.py, the mirror of the drop-in's opt/batched_rprop.hpp).  The first 5 iterates of
+    restart 0 against limbo's sequential Rprop driven by a LAPACK objective on the host (theta 1e-8, log-lik 1e-10 — Rprop
+    only looks at gradient signs, so equal iterates mean every sign agreed), and the 10th iterate of restarts 0 and 3
+    evaluated by LAPACK where the device fit stands (log-lik 1e-10, gradient 1e-6)."""
+    from limbo_amd import hpfit
+
+    N, G, iters = 4096, 4, 10
+    X, Y = synth.make_problem("c2", N=N)
+    om, _ = synth.obs_mean_data(Y)
+    rng = np.random.default_rng(11)
+    inits = rng.uniform(-1e-2, 1e-2, size=(G, 7))
+    inits[0] = 0.0
+    hs = []
+    for _ in range(G):
+        h = _capi.Handle(engine_lib)
+        h.set_data(X, om)
+        hs.append(h)
+    trace = []
+    bp, bl = hpfit.kernel_lf_opt_lockstep(hs, O.SE_ARD, inits, noise=0.01, optimize_noise=False, iterations=iters, trace=trace)
+    assert len(trace) == iters and all(h.flow_retries() == 0 for h in hs)
+    seq = []
+
+    def lapack_objective(p):
+        ll, g, _, _ = _lapack_grad_se_ard(X, p, 0.01, om, False)
+        seq.append((p.copy(), ll, g))
+        return ll, g
+
+    _rprop(lapack_objective, inits[0], 5)
+    for i, (p, ll, g) in enumerate(seq):
+        pd, ld, gd = trace[i][0][0], trace[i][1][0], trace[i][2][0]
+        assert np.max(np.abs(pd - p)) <= 1e-8, (i, pd, p)
+        assert abs(ld - ll) <= PC.TOL_LL * abs(ll) and relerr_norm(gd, g) < PC.TOL_GRAD, (i, ld, ll)
+    for r in (0, 3):
+        pd, ld, gd = trace[iters - 1][0][r], trace[iters - 1][1][r], trace[iters - 1][2][r]
+        ll, g, _, _ = _lapack_grad_se_ard(X, pd, 0.01, om, False)
+        assert abs(ld - ll) <= PC.TOL_LL * abs(ll) and relerr_norm(gd, g) < PC.TOL_GRAD, (r, ld, ll)
+    assert np.all(bl >= np.array([t[1] for t in trace]).max(axis=0) - 1e-12)  # best seen (rprop.hpp:115-118)
+    assert bl[0] > trace[0][1][0]  # the fit improved the likelihood
+    for h in hs:
+        h.close()
+
+
 def test_gpu_bench_two_ranks_on_one_gpu():
     """bench.py's world > 1 branch (one process per GPU under torch.distributed.run, barrier + max-over-ranks timing, the
     all-gather arg-max of tools/parallel.hpp:169-191) executed before the first 8-GPU run: two ranks share the one
@@ -715,6 +805,38 @@ def test_gpu_bench_two_ranks_on_one_gpu():
     assert out["config4"]["gps_total"] == 16 and out["config4"]["value"] > 0
     assert out["argmax"]["owner_rank"] in (0, 1) and np.isfinite(out["argmax"]["best_log_lik"])
     assert "roofline" in out and "cpu_baseline" not in out  # rank 0 at N = 1 only
+
+
+def test_gpu_bench_one_rank_rccl():
+    """The RCCL branch of bench.py executed before the driver's 8-GPU run does it for the first time: `--force-dist` initialises
+    the `nccl` (= RCCL) process group even with one rank, so barrier / all_gather / all_reduce run on cuda:0 tensors exactly
+    as they will at N > 1 (tools/parallel.hpp:169-191: the arg-max over the restarts).  One JSON line, the collectives
+    listed as executed, the value of the same order as a run without the group (the collectives are microseconds)."""
+    import json
+    import socket
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    common = ["--gpus", "1", "--steps", "20", "--warmup", "3", "--no-extras", "--no-cpu-baseline", "--no-roofline"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--force-dist"] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["collectives"]["backend"] == "nccl" and out["collectives"]["tensors_on"].startswith("cuda")
+    assert {"barrier", "all_gather", "all_reduce"} <= set(out["collectives"]["executed"])
+    assert out["argmax"]["owner_rank"] == 0 and np.isfinite(out["argmax"]["best_log_lik"])
+    assert out["config4"]["gps_total"] == 8 and out["config4"]["value"] > 0
+    r2 = subprocess.run([sys.executable, str(ROOT / "bench.py")] + common, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    plain = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][0])
+    print(f"one rank with the RCCL group: {out['value']:.1f} evaluations/s, without: {plain['value']:.1f}")
+    assert plain["collectives"]["executed"] == [] and abs(out["value"] - plain["value"]) <= 0.10 * plain["value"]
+    assert out["log_lik"] == plain["log_lik"]
 
 
 @pytest.mark.parametrize("N,G,kind,on,P", [(2048, 8, O.SE_ARD, False, 1), (700, 5, O.MATERN52, True, 2), (1100, 18, O.SE_ARD, True, 1),

@@ -172,7 +172,7 @@ int main(int argc, char** argv)
 #ifdef DIAG_TIMING
     { // the first 1024 x 1024 block of K as one tiled data-flow launch (k_tail)
         const int64_t T = 1024;
-        const int64_t need = tail_buf_doubles(T / 64, 1);
+        const int64_t need = tail_buf_doubles(T / 64, T / 64 + 1);
         double* tb;
         CHK(hipMalloc(&tb, sizeof(double) * 2 * need));
         CHK(hipMemset(tb, 0xFF, sizeof(double) * 2 * need));
@@ -184,7 +184,7 @@ int main(int argc, char** argv)
             launch_copy2d(s, A0, ld, A, ld, N, T);
             CHK(hipStreamSynchronize(s));
             hipEventRecord(e0, s);
-            launch_tail(s, A, ld, 0, T, T + 1, Xi, info, tb + (rep & 1) * need, tb + ((rep + 1) & 1) * need);
+            launch_tail(s, A, ld, 0, T, T, T + 1, Xi, info, tb + (rep & 1) * need, tb + ((rep + 1) & 1) * need);
             hipEventRecord(e1, s);
             CHK(hipStreamSynchronize(s));
             float ms;
