@@ -1172,6 +1172,21 @@ static __device__ __forceinline__ void poll_one(const double* p, int spin_limit,
 
 // a 64 x 64 tile (ld 64) that another workgroup of this launch is writing, or has written, over an all-ones pattern:
 // thread t holds elements (t & 63, (t >> 6) + 8 q) as in TileRegs
+// Round 4: the FIRST look at a polled block is an ordinary (cacheable) load, only the re-reads of words that still showed the
+// pattern are device-scope.  A device-scope load is served by the memory side, whatever the XCD's L2 holds: every one of the
+// nb - s workgroups that use an L tile fetched its 32 KB over the fabric — 2.8 GB per batch of eight N = 2048 factorisations,
+// 0.85 GB in the tall launch of N = 4096, both at the ~2 TB/s such loads reach (round-4 measurement: eight interleaved
+// factorisations took 3.3x one).  The protocol makes the cached look safe: inside a launch a slot only ever changes from the
+// pattern to its final value, word by word (the launch before armed it, and kernel boundaries write back / invalidate the
+// L2s), so whatever a cache line holds, a word that is not the pattern is final; a word that is goes the device-scope way.
+#ifndef POLL_CACHED
+#define POLL_CACHED 1
+#endif
+#if POLL_CACHED
+#define POLL_FIRST_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#else
+#define POLL_FIRST_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
 struct PolledTile {
     unsigned long long b[8];
     __device__ __forceinline__ void issue(const double* G)
@@ -1179,7 +1194,7 @@ struct PolledTile {
         const unsigned long long* g = reinterpret_cast<const unsigned long long*>(G) + (threadIdx.x & 63) + (threadIdx.x >> 6) * NB;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            b[q] = __hip_atomic_load(g + 8 * q * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b[q] = __hip_atomic_load(g + 8 * q * NB, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
     }
     __device__ __forceinline__ void finish(const double* G, int spin_limit, int* __restrict__ info)
     {
@@ -1241,8 +1256,8 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
     {
         unsigned long long b[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) // X11: e, e + 512; L21: 1024 + e, 1024 + e + 512
-            b[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 4; ++q) // X11: e, e + 512; L21: 1024 + e, 1024 + e + 512   (first look: cacheable, see PolledTile)
+            b[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
         int spins = 0;
         while (b[0] == SENT || b[1] == SENT || b[2] == SENT || b[3] == SENT) {
             if (++spins > x.spin_limit) {
@@ -1301,8 +1316,8 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
     P2TS(6 * S + 2);
     // ---- phase B: X22 ----
     {
-        unsigned long long b0 = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long b1 = __hip_atomic_load(Sp + 2048 + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long b0 = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
+        unsigned long long b1 = __hip_atomic_load(Sp + 2048 + 512, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
         int spins = 0;
         while (b0 == SENT || b1 == SENT) {
             if (++spins > x.spin_limit) {
@@ -1638,6 +1653,7 @@ struct TailArgs {
     int* info;
     double *LP, *SP, *LPn, *SPn;
     int spin_limit;
+    const int* order; // dispatch order: workgroup w works on tile (b, c) = (order[2 w], order[2 w + 1]); null: column by column
 };
 static __device__ __forceinline__ int tail_tile_id(int nb, int b, int c) { return c * nb - (c * (c - 1)) / 2 + (b - c); }
 
@@ -1647,7 +1663,11 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
     const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
     int c = 0, b;
-    {
+    if (a.order) {
+        b = __builtin_amdgcn_readfirstlane(a.order[2 * wgid]);
+        c = __builtin_amdgcn_readfirstlane(a.order[2 * wgid + 1]);
+    }
+    else {
         int id = wgid, colh = a.nb;
         while (id >= colh) {
             id -= colh;
@@ -1656,6 +1676,7 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
         }
         b = c + id;
     }
+    const int slot = tail_tile_id(a.nb, b, c); // the tile's slot in the polled buffers (independent of the dispatch order)
     const bool mute = a.spin_limit < 0;
     P256 x;
     x.A = a.A;
@@ -1674,9 +1695,9 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
     x.T2 = x.T1 + NB * PS;
     x.S22 = a.SP;
     x.HP = a.LP;
-    double* const myslot = a.LP + (int64_t)wgid * (NB * NB);
+    double* const myslot = a.LP + (int64_t)slot * (NB * NB);
     { // the other pair of buffers, for the next launch: this tile's slot (and its diagonal block's quarters)
-        unsigned long long* nx = reinterpret_cast<unsigned long long*>(a.LPn + (int64_t)wgid * (NB * NB));
+        unsigned long long* nx = reinterpret_cast<unsigned long long*>(a.LPn + (int64_t)slot * (NB * NB));
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             nx[threadIdx.x + 512 * q] = ~0ull;
@@ -1852,6 +1873,100 @@ __global__ __launch_bounds__(512) void k_tail_b(TailArgs a, const BatchTab* __re
     tail_body(a, (int)blockIdx.x / G, lds);
 }
 
+// ---- dispatch order of a data-flow launch ----------------------------------------------------------------------------
+// Workgroups are handed out in index order and each holds a CU from its dispatch to its last store, so WHEN a tile's
+// workgroup becomes resident decides whether it spends its residency working or waiting — and 256 resident workgroups are all
+// there is.  Column by column (rounds 3's order) a tall launch fills the chip with the 65 - c tiles of the next four columns,
+// all waiting for their column's block inverse, while the diagonal workgroup of column c + 4 — 2 (c + 3) catch-up products
+// of its own — is not even dispatched: from c ~ 12 on the chain waits for catch-up work (round-4 measurement: 18.9 us per
+// column in the tall launch of N = 4096 against 13 in the closing launch); in a batch of G members every member has 256 / G
+// resident workgroups, i.e. no look-ahead at all.  Any order is legal in which every wait is for a lower-numbered workgroup.
+// Here: time slot tau per tile (in units of columns), sorted by (tau, column, row):
+//   diagonal workgroup of column c (it also owns tile (c, c-1))          as early as its operands allow: behind slot c - 2
+//   tile (b, c) of the triangle, b >= c + 2                              slot max(c, b - W): just in time for row b's
+//                                                                        diagonal workgroup — by then its operands are there
+//   tile (b, c) below the triangle (tall launch; the right-hand-side strip)   slot c + lag: behind the chain, operands ready
+// W = 0 and lag = 0: column by column.  The table is checked against the dependencies before it is used.
+#include <array>
+#include <map>
+#include <mutex>
+#include <vector>
+static const int* tail_order(int nt, int nb, int W, int lag)
+{
+    if (W <= 0 && lag <= 0)
+        return nullptr;
+    static std::mutex mu;
+    static std::map<std::array<int, 5>, int*> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const std::array<int, 5> key{dev, nt, nb, W, lag};
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end())
+        return it->second;
+    struct T {
+        int key, c, b;
+    };
+    std::vector<T> ts;
+    for (int c = 0; c < nt; ++c)
+        for (int b = c; b < nb; ++b) {
+            int k;
+            if (b == c)
+                k = 2 * c - 3; // behind the tiles of slot c - 2 (its last operands: (c, c-2) and the diagonal workgroup c - 1)
+            else if (b >= nt)
+                k = 2 * (c + (lag > 0 ? lag : 0));
+            else if (b == c + 1)
+                k = 2 * c; // (owned by the diagonal workgroup of its row: this workgroup only arms its slot)
+            else
+                k = 2 * (W > 0 ? std::max(c, b - W) : c);
+            ts.push_back(T{k, c, b});
+        }
+    std::stable_sort(ts.begin(), ts.end(), [](const T& x, const T& y) {
+        if (x.key != y.key)
+            return x.key < y.key;
+        if (x.c != y.c)
+            return x.c < y.c;
+        return x.b < y.b;
+    });
+    auto tid = [&](int b, int c) { return c * nb - (c * (c - 1)) / 2 + (b - c); };
+    std::vector<int> pos(ts.size());
+    for (size_t i = 0; i < ts.size(); ++i)
+        pos[tid(ts[i].b, ts[i].c)] = (int)i;
+    // who publishes the slot of tile (b, s)?  the diagonal workgroup of row b for the sub-diagonal tile, its own otherwise
+    auto owner = [&](int b, int s) { return (b == s + 1 && b < nt) ? pos[tid(b, b)] : pos[tid(b, s)]; };
+    bool legal = true;
+    for (const T& t : ts) {
+        const int me = pos[tid(t.b, t.c)];
+        if (t.b == t.c) {
+            for (int s2 = 0; s2 < t.c - 1 && legal; ++s2)
+                legal = owner(t.c, s2) < me && owner(t.c - 1, s2) < me;
+            if (t.c > 0)
+                legal = legal && pos[tid(t.c - 1, t.c - 1)] < me;
+        }
+        else if (!(t.b == t.c + 1 && t.b < nt)) {
+            for (int s2 = 0; s2 < t.c && legal; ++s2)
+                legal = owner(t.b, s2) < me && owner(t.c, s2) < me;
+            legal = legal && pos[tid(t.c, t.c)] < me;
+        }
+        if (!legal)
+            break;
+    }
+    int* d = nullptr;
+    if (legal) {
+        std::vector<int> flat(2 * ts.size());
+        for (size_t i = 0; i < ts.size(); ++i) {
+            flat[2 * i] = ts[i].b;
+            flat[2 * i + 1] = ts[i].c;
+        }
+        if (hipMalloc(&d, sizeof(int) * flat.size()) != hipSuccess || hipMemcpy(d, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice) != hipSuccess)
+            d = nullptr;
+    }
+    else
+        fprintf(stderr, "gpe: tail_order(%d, %d, W %d, lag %d) violates a dependency — column-by-column order used\n", nt, nb, W, lag);
+    cache[key] = d;
+    return d;
+}
+
 // Tile columns t0 .. t1-1 (whole 64-blocks) of the rows t0 .. M-1: N64 - t0 full row strips (N64 = the matrix order rounded down
 // to 64; t1 == N64: the closing launch) and, as one more row strip, the M - N64 <= 64 rows below them — right-hand-side rows and
 // the rows of a ragged last block the caller finishes.  Fully updated by everything in front of t0.  buf_cur / buf_next:
@@ -1875,6 +1990,13 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
     a.LPn = buf_next + (int64_t)a.nt * 3072;
     static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
     a.spin_limit = fault ? -16 : GPE_FLOW_SPIN_LIMIT;
+    static const int ord_w = getenv("GPE_TAIL_W") ? atoi(getenv("GPE_TAIL_W")) : 0;
+    // measured (profiles/r04_dispatch_order.log, N = 4096): lag 2..4 -> 794-800 evaluations/s against 735 column by column; a
+    // just-in-time window W > 0 LOSES (6: 675, 8: 694, 12: 738, 16: 770): a tile dispatched late has its catch-up products still
+    // to do when its row's diagonal workgroup asks for it; waiting workgroups are not what limits the closing launch
+    static const int ord_lag = getenv("GPE_TAIL_LAG") ? atoi(getenv("GPE_TAIL_LAG")) : 3;
+    static const int ord_wb = getenv("GPE_TAIL_W_BATCH") ? atoi(getenv("GPE_TAIL_W_BATCH")) : ord_w;
+    a.order = tail_order(a.nt, a.nb, g_batch.bt ? ord_wb : ord_w, ord_lag);
     const int64_t tiles = tail_tiles(a.nt, a.nb);
     if (g_batch.bt)
         GPE_LAUNCH(k_tail_b, dim3((unsigned)(tiles * g_batch.G)), dim3(512), 0, s, a, g_batch.bt);

@@ -17,7 +17,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from limbo_amd import _capi, synth as O  # noqa: E402
 
-eng = _capi.load_engine()
+# R4_SO: an A/B copy of the library (tools/build_variant.sh) instead of limbo_amd/libgpengine.so
+eng = _capi.Lib(os.environ["R4_SO"], "gpe_") if os.environ.get("R4_SO") else _capi.load_engine()
 
 
 def handle(X, om, kind, th, tall=None, tail=None):
@@ -59,6 +60,24 @@ def single():
         med, mn, ll = timed(h)
         ref = ll if ref is None else ref
         print(f"tall_max {tall:5d} tail_max {tail:5d}: {med:.3f} / {mn:.3f} ms  -> {1e3 / med:7.1f} evaluations/s   log_lik rel diff {abs(ll - ref) / abs(ref):.1e}  reruns {h.flow_retries()}")
+        h.close()
+
+
+def single2():
+    X, Y = O.make_problem("c2", N=4096)
+    om, _ = O.obs_mean_data(Y)
+    tag = " ".join(f"{k}={os.environ[k]}" for k in ("GPE_TAIL_W", "GPE_TAIL_LAG", "GPE_TAIL_W_BATCH") if k in os.environ)
+    for tall, tail in [(4096, 2560), (4096, 2816), (0, 2560)]:
+        h = handle(X, om, O.SE_ARD, np.zeros(7), tall, tail)
+        med, mn, ll = timed(h, steps=20, warm=3)
+        print(f"[{tag}] tall_max {tall:5d} tail_max {tail:5d}: {med:.3f} / {mn:.3f} ms  -> {1e3 / med:7.1f} evaluations/s  log_lik {ll:.12g} reruns {h.flow_retries()}")
+        h.close()
+    for N in (2048, 1024):
+        X2, Y2 = O.make_problem("c2", N=N)
+        om2, _ = O.obs_mean_data(Y2)
+        h = handle(X2, om2, O.SE_ARD, np.zeros(7), None, None)
+        med, mn, ll = timed(h, steps=20, warm=3)
+        print(f"[{tag}] N {N}: {med:.3f} / {mn:.3f} ms  log_lik {ll:.12g}")
         h.close()
 
 
@@ -150,6 +169,8 @@ if __name__ == "__main__":
         sizes()
     if what == "batch":
         batch()
+    if what == "single2":
+        single2()
     if what == "all":
         for env in ({"GPE_BATCH_TAIL": "0"}, {}, {"GPE_TAIL_MAX": "4096"}, {"GPE_TAIL_MAX": "2816"}):
             r = subprocess.run([sys.executable, __file__, "batch"], env=dict(os.environ, **env), capture_output=True, text=True)
