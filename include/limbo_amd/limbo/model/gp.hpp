@@ -18,6 +18,13 @@
 // the host while factorisation and solves stay on the device.  There is no CPU fallback for the
 // linear algebra: without libgpengine.so / a GPU, construction throws.
 //
+// Round 4: below Params::gpu::min_n_for_gpu() samples (default 256, limbo/model/gp/host_small.hpp) the factor and alpha live in
+// the host matrices _matrixL / _alpha and compute(), add_sample(), recompute(), compute_log_lik() and the single-point query(),
+// mu(), sigma() never touch the device: one core's O(n^2) call is cheaper than a launch plus a PCIe round trip (the BO inner
+// loop of bayes_opt/boptimizer.hpp:148-161 on models of 10..200 samples).  Whatever has no host form — K^-1, the gradients,
+// the LOO objectives, the batched hyper-parameter objectives — moves the model to the device for good (_host_off); a large
+// query_batch() answers from a device copy of the host model that is refreshed when the host model has changed.
+//
 // Additions (not in the reference): query_batch() — the batched acquisition path of SURVEY.md
 // §8 row a13/N1 — and last_status().
 // Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
@@ -44,6 +51,7 @@
 #include <limbo/kernel/squared_exp_ard.hpp>
 #include <limbo/mean/constant.hpp>
 #include <limbo/mean/data.hpp>
+#include <limbo/model/gp/host_small.hpp>
 #include <limbo/model/gp/kernel_lf_opt.hpp>
 #include <limbo/model/gp/no_lf_opt.hpp>
 #include <limbo/tools/math.hpp>
@@ -142,7 +150,7 @@ namespace limbo {
 
             /// the same onto another device of the node (addition: how the parallel policies spread independent GPs)
             GP(const GP& o, int device)
-                : _dim_in(o._dim_in), _dim_out(o._dim_out), _kernel_function(o._kernel_function), _mean_function(o._mean_function), _samples(o._samples), _observations(o._observations), _mean_vector(o._mean_vector), _obs_mean(o._obs_mean), _alpha(o._alpha), _mean_observation(o._mean_observation), _kernel(o._kernel), _inv_kernel(o._inv_kernel), _matrixL(o._matrixL), _log_lik(o._log_lik), _log_loo_cv(o._log_loo_cv), _inv_kernel_updated(o._inv_kernel_updated), _hp_optimize(o._hp_optimize), _eng(o._eng, device), _status(o._status), _L_stale(o._L_stale), _alpha_stale(o._alpha_stale), _Kinv_stale(o._Kinv_stale), _dev_theta(o._dev_theta), _dev_noise(o._dev_noise), _dev_kernel_ok(o._dev_kernel_ok) {}
+                : _dim_in(o._dim_in), _dim_out(o._dim_out), _kernel_function(o._kernel_function), _mean_function(o._mean_function), _samples(o._samples), _observations(o._observations), _mean_vector(o._mean_vector), _obs_mean(o._obs_mean), _alpha(o._alpha), _mean_observation(o._mean_observation), _kernel(o._kernel), _inv_kernel(o._inv_kernel), _matrixL(o._matrixL), _log_lik(o._log_lik), _log_loo_cv(o._log_loo_cv), _inv_kernel_updated(o._inv_kernel_updated), _hp_optimize(o._hp_optimize), _eng(o._eng, device), _status(o._status), _L_stale(o._L_stale), _alpha_stale(o._alpha_stale), _Kinv_stale(o._Kinv_stale), _dev_theta(o._dev_theta), _dev_noise(o._dev_noise), _dev_kernel_ok(o._dev_kernel_ok), _host_mode(o._host_mode), _host_off(o._host_off) {}
 
             /// device this GP lives on / move it (additions)
             int device() const { return _eng.device(); }
@@ -264,7 +272,12 @@ namespace limbo {
                     return;
                 }
                 std::vector<double> kta((size_t)(M * _dim_out)), var((size_t)M);
-                _query_many(points, kta.data(), var.data());
+                if (_host_mode && M * (int64_t)_samples.size() < (int64_t)limbo_amd::host_batch_crossover())
+                    for (int64_t m = 0; m < M; ++m) { // a handful of points on a small model: still cheaper here
+                        _host_query(points[m], &kta[(size_t)m], M, &var[(size_t)m]);
+                    }
+                else
+                    _query_many(points, kta.data(), var.data());
                 for (int64_t m = 0; m < M; ++m) {
                     Eigen::VectorXd mv = _mean_function(points[m], *this);
                     for (int p = 0; p < _dim_out; ++p)
@@ -318,6 +331,7 @@ namespace limbo {
             /// gp.hpp:254-264: K^-1 from L, cached until K changes
             void compute_inv_kernel()
             {
+                _need_device();
                 _status_or(_eng.check(gpe_compute_inv_kernel(_eng.get()), "gpe_compute_inv_kernel"));
                 _Kinv_stale = true;
                 _inv_kernel_updated = true;
@@ -326,6 +340,19 @@ namespace limbo {
             /// gp.hpp:267-282
             double compute_log_lik()
             {
+                if (_host_mode) { // gp.hpp:267-282, the P-quirk kept: log det and n log 2 pi are not multiplied by dim_out
+                    const int64_t n = _samples.size();
+                    long double logdet = 0.0L;
+                    for (int64_t i = 0; i < n; ++i)
+                        logdet += std::log(_matrixL.data()[i + i * n]);
+                    logdet *= 2;
+                    double a = 0.0;
+                    for (int p = 0; p < _dim_out; ++p)
+                        for (int64_t i = 0; i < n; ++i)
+                            a += _obs_mean(i, p) * _alpha(i, p);
+                    _log_lik = -0.5 * a - 0.5 * logdet - 0.5 * n * std::log(2 * M_PI);
+                    return _log_lik;
+                }
                 double ll = 0.0;
                 _eng.check(gpe_log_lik(_eng.get(), &ll), "gpe_log_lik");
                 _log_lik = ll;
@@ -335,6 +362,7 @@ namespace limbo {
             /// gp.hpp:285-311
             Eigen::VectorXd compute_kernel_grad_log_lik()
             {
+                _need_device();
                 const int T = _kernel_function.h_params_size();
                 Eigen::VectorXd grad = Eigen::VectorXd::Zero(T);
                 if (limbo_amd::device_kernel<KernelFunction>::kind != limbo_amd::KIND_HOST_K) {
@@ -389,6 +417,7 @@ namespace limbo {
             /// gp.hpp:339-351 on the device (K^-1 diagonal and alpha never leave HBM)
             double compute_log_loo_cv()
             {
+                _need_device();
                 double v = 0.0;
                 _eng.check(gpe_log_loo_cv(_eng.get(), &v), "gpe_log_loo_cv");
                 _inv_kernel_updated = true; // gp.hpp:342-344
@@ -402,6 +431,7 @@ namespace limbo {
             /// W (one N^3 product, limbo_amd/csrc/grad.hip) and the gradient is sum_ab W_ab dK_j,ab.
             Eigen::VectorXd compute_kernel_grad_log_loo_cv()
             {
+                _need_device();
                 const int T = _kernel_function.h_params_size();
                 Eigen::VectorXd grad = Eigen::VectorXd::Zero(T);
                 if (limbo_amd::device_kernel<KernelFunction>::kind != limbo_amd::KIND_HOST_K) {
@@ -432,7 +462,7 @@ namespace limbo {
             const Eigen::MatrixXd& matrixL() const
             {
                 std::lock_guard<std::mutex> lk(_mirror_mu);
-                if (_L_stale) {
+                if (_L_stale && !_host_mode) {
                     const int64_t n = _samples.size();
                     _matrixL.resize(n, n);
                     _eng.check(gpe_get_L(_eng.get(), _matrixL.data(), n), "gpe_get_L");
@@ -443,7 +473,7 @@ namespace limbo {
             const Eigen::MatrixXd& alpha() const
             {
                 std::lock_guard<std::mutex> lk(_mirror_mu);
-                if (_alpha_stale) {
+                if (_alpha_stale && !_host_mode) {
                     _alpha.resize(_samples.size(), _dim_out);
                     _eng.check(gpe_get_alpha(_eng.get(), _alpha.data()), "gpe_get_alpha");
                     _alpha_stale = false;
@@ -524,6 +554,14 @@ namespace limbo {
                     this->_compute_obs_mean();
                     archive.load(_matrixL, "matrixL");
                     archive.load(_alpha, "alpha");
+                    if (_use_host((int64_t)_samples.size())) { // a small model stays where single-point calls are cheapest
+                        _host_mode = true;
+                        _dev_shadow_ok = false;
+                        _L_stale = _alpha_stale = false;
+                        _inv_kernel_updated = false;
+                        return;
+                    }
+                    _host_mode = false;
                     _push_data();
                     _push_kernel();
                     _eng.check(gpe_set_L(_eng.get(), _matrixL.data(), _matrixL.rows()), "gpe_set_L");
@@ -566,6 +604,23 @@ namespace limbo {
             double _dev_noise = -1.0;
             bool _dev_kernel_ok = false;
             mutable std::mutex _mirror_mu;
+            // ---- host side (round 4): a small model's factor and alpha are _matrixL / _alpha themselves ----
+            bool _host_mode = false;            // the host matrices are the model (the device holds nothing current)
+            bool _host_off = false;             // this object has needed the device for something with no host form: it stays there
+            mutable bool _dev_shadow_ok = false; // (host mode) the device copy that serves large query_batch() calls is current
+
+            bool _use_host(int64_t n) const { return !_host_off && n < (int64_t)limbo_amd::min_n_for_gpu<Params>(); }
+            /// everything without a host form: the model moves to the device and stays there
+            void _need_device()
+            {
+                _host_off = true;
+                if (_host_mode) {
+                    _host_mode = false;
+                    _data_on_device = false;
+                    if (!_samples.empty())
+                        _compute_full_kernel();
+                }
+            }
 
             void _swap(GP& o)
             {
@@ -594,6 +649,9 @@ namespace limbo {
                 std::swap(_dev_theta, o._dev_theta);
                 std::swap(_dev_noise, o._dev_noise);
                 std::swap(_dev_kernel_ok, o._dev_kernel_ok);
+                std::swap(_host_mode, o._host_mode);
+                std::swap(_host_off, o._host_off);
+                std::swap(_dev_shadow_ok, o._dev_shadow_ok);
             }
 
             void _status_or(int rc)
@@ -658,8 +716,98 @@ namespace limbo {
             /// gp.hpp:550-571: K -> L -> alpha, all on the device
             void _compute_full_kernel()
             {
+                if (_use_host((int64_t)_samples.size())) {
+                    _host_full_kernel();
+                    return;
+                }
+                _host_mode = false;
                 _stage_full_kernel();
                 _commit_full_kernel(_eng.check(gpe_compute(_eng.get()), "gpe_compute"));
+            }
+
+            /// gp.hpp:550-571 on the host: K (lower, +noise+1e-8 on the diagonal through the functor's i == j) -> L -> alpha
+            void _host_full_kernel()
+            {
+                const int64_t n = _samples.size();
+                _matrixL.resize(n, n);
+                double* L = _matrixL.data();
+                for (int64_t j = 0; j < n; ++j)
+                    for (int64_t i = j; i < n; ++i)
+                        L[i + j * n] = _kernel_function(_samples[i], _samples[j], i, j);
+                _status = limbo_amd::host_small::llt_lower(L, n, n);
+                _host_mode = true;
+                _data_on_device = false;
+                _dev_shadow_ok = false;
+                _host_alpha();
+                _L_stale = false;
+                _Kinv_stale = true;
+                _inv_kernel_updated = false; // gp.hpp:570
+            }
+            /// gp.hpp:605-611 on the host
+            void _host_alpha()
+            {
+                const int64_t n = _samples.size();
+                _alpha = _obs_mean;
+                limbo_amd::host_small::solve_lower(_matrixL.data(), n, n, _alpha.data(), _dim_out, n);
+                limbo_amd::host_small::solve_lower_t(_matrixL.data(), n, n, _alpha.data(), _dim_out, n);
+                _alpha_stale = false;
+                _dev_shadow_ok = false;
+            }
+            /// gp.hpp:613-632 on the host: kta[p * ldk] = k*^T alpha_p, *var = k(v, v) - |L^-1 k*|^2 (before mean / clamp / noise)
+            void _host_query(const Eigen::VectorXd& v, double* kta, int64_t ldk, double* var) const
+            {
+                const int64_t n = _samples.size();
+                std::vector<double> k((size_t)n);
+                for (int64_t i = 0; i < n; ++i)
+                    k[(size_t)i] = _kernel_function(_samples[i], v);
+                if (kta)
+                    for (int p = 0; p < _dim_out; ++p) {
+                        double s = 0.0;
+                        const double* a = _alpha.data() + (int64_t)p * n;
+                        for (int64_t i = 0; i < n; ++i)
+                            s += k[(size_t)i] * a[i];
+                        kta[(int64_t)p * ldk] = s;
+                    }
+                if (var) {
+                    limbo_amd::host_small::solve_lower(_matrixL.data(), n, n, k.data(), 1, n);
+                    double zz = 0.0;
+                    for (int64_t i = 0; i < n; ++i)
+                        zz += k[(size_t)i] * k[(size_t)i];
+                    *var = _kernel_function(v, v) - zz;
+                }
+            }
+            /// (host mode) the device copy behind large query_batch() calls: the same data and hyper-parameters factored on
+            /// the device — equal to the host factor to rounding.  const: batched queries are const and may come from several
+            /// threads (multi_gp.hpp:191-195); the refresh is serialised, the queries are by the handle's own lock.
+            void _sync_device_shadow() const
+            {
+                std::lock_guard<std::mutex> lk(_mirror_mu);
+                if (_dev_shadow_ok)
+                    return;
+                const int64_t n = _samples.size();
+                std::vector<double> X((size_t)(n * _dim_in));
+                for (int64_t i = 0; i < n; ++i)
+                    for (int d = 0; d < _dim_in; ++d)
+                        X[(size_t)(i * _dim_in + d)] = _samples[i](d);
+                _eng.check(gpe_set_data(_eng.get(), X.data(), n, _dim_in, _obs_mean.data(), _dim_out), "gpe_set_data");
+                constexpr int kind = limbo_amd::device_kernel<KernelFunction>::kind;
+                if (kind == limbo_amd::KIND_HOST_K) {
+                    _eng.check(gpe_set_kernel(_eng.get(), kind, nullptr, 0, _kernel_function.noise()), "gpe_set_kernel");
+                    Eigen::MatrixXd K(n, n);
+                    for (int64_t i = 0; i < n; i++)
+                        for (int64_t j = 0; j <= i; ++j) {
+                            K(i, j) = _kernel_function(_samples[i], _samples[j], i, j);
+                            K(j, i) = K(i, j);
+                        }
+                    _eng.check(gpe_set_K_host(_eng.get(), K.data(), n), "gpe_set_K_host");
+                }
+                else {
+                    Eigen::VectorXd hp = _kernel_function.h_params();
+                    const int nk = (int)hp.size() - (Params::kernel::optimize_noise() ? 1 : 0);
+                    _eng.check(gpe_set_kernel(_eng.get(), kind, hp.data(), nk, _kernel_function.noise()), "gpe_set_kernel");
+                }
+                _eng.check(gpe_compute(_eng.get()), "gpe_compute");
+                _dev_shadow_ok = true;
             }
 
         public:
@@ -668,6 +816,11 @@ namespace limbo {
             /// factorisations as ONE batched launch sequence (`compute_full_kernels_batched` -> gpe_batch_compute).
             void _stage_full_kernel()
             {
+                if (_host_mode) { // (the batched callers: this object computes on the device from here on)
+                    _host_off = true;
+                    _host_mode = false;
+                    _data_on_device = false;
+                }
                 if (!_data_on_device)
                     _push_data();
                 else
@@ -741,6 +894,11 @@ namespace limbo {
                 const bool on = Params::kernel::optimize_noise();
                 std::vector<int> devs;
                 for (GP* g : gps) {
+                    if (g->_host_mode || !g->_host_off) { // lock-step restarts / outputs run on the device
+                        g->_host_off = true;
+                        g->_host_mode = false;
+                        g->_data_on_device = false;
+                    }
                     if (!g->_data_on_device)
                         g->_push_data();
                     if (std::find(devs.begin(), devs.end(), g->device()) == devs.end())
@@ -786,6 +944,38 @@ namespace limbo {
             /// gp.hpp:573-603
             void _compute_incremental_kernel()
             {
+                const int64_t n1 = _samples.size(); // samples including the new one
+                if (_host_mode && _use_host(n1) && n1 >= 2 && (int64_t)_matrixL.rows() == n1 - 1) {
+                    // gp.hpp:573-603 on the host: one more row of L, then alpha (gp.hpp:599)
+                    const int64_t n = n1 - 1;
+                    std::vector<double> kcol((size_t)n), row((size_t)n1);
+                    for (int64_t i = 0; i < n; ++i)
+                        kcol[(size_t)i] = _kernel_function(_samples[i], _samples[n], i, n);
+                    const double knn = _kernel_function(_samples[n], _samples[n], n, n);
+                    const int bad = limbo_amd::host_small::append_row(_matrixL.data(), n, n, kcol.data(), knn, row.data());
+                    Eigen::MatrixXd L2 = Eigen::MatrixXd::Zero(n1, n1);
+                    for (int64_t j = 0; j < n; ++j) {
+                        const double* src = _matrixL.data() + j * n;
+                        double* dst = L2.data() + j * n1;
+                        for (int64_t i = j; i < n; ++i)
+                            dst[i] = src[i];
+                        dst[n] = row[(size_t)j];
+                    }
+                    L2.data()[n + n * n1] = row[(size_t)n];
+                    _matrixL = L2;
+                    if (bad)
+                        _status = bad;
+                    _host_alpha();
+                    _L_stale = false;
+                    _Kinv_stale = true;
+                    _inv_kernel_updated = false; // gp.hpp:602
+                    return;
+                }
+                if (_host_mode || _use_host(n1)) { // crossing the threshold (or the first samples): the full path decides where
+                    _data_on_device = false;
+                    _compute_full_kernel();
+                    return;
+                }
                 if (limbo_amd::device_kernel<KernelFunction>::kind == limbo_amd::KIND_HOST_K || !_data_on_device || _samples.size() == 1) {
                     _data_on_device = false;
                     _compute_full_kernel(); // first sample / functor-built K: full path
@@ -800,12 +990,17 @@ namespace limbo {
             /// gp.hpp:605-611 with the existing factor
             void _compute_alpha()
             {
+                if (_host_mode) {
+                    _host_alpha();
+                    return;
+                }
                 _eng.check(gpe_update_alpha(_eng.get(), _obs_mean.data()), "gpe_update_alpha");
                 _alpha_stale = true;
             }
 
             const Eigen::MatrixXd& _host_Kinv() const
             {
+                assert(!_host_mode); // (K^-1 only exists on the device: compute_inv_kernel() moved the model there)
                 std::lock_guard<std::mutex> lk(_mirror_mu);
                 if (_Kinv_stale) {
                     const int64_t n = _samples.size();
@@ -820,6 +1015,8 @@ namespace limbo {
             void _query_many(const std::vector<Eigen::VectorXd>& pts, double* kta, double* var) const
             {
                 const int64_t M = pts.size(), n = _samples.size();
+                if (_host_mode)
+                    _sync_device_shadow();
                 if (limbo_amd::device_kernel<KernelFunction>::kind != limbo_amd::KIND_HOST_K) {
                     std::vector<double> Xq((size_t)(M * _dim_in));
                     for (int64_t m = 0; m < M; ++m) {
@@ -842,6 +1039,12 @@ namespace limbo {
             }
             void _query_one(const Eigen::VectorXd& v, Eigen::VectorXd* kta, double* var) const
             {
+                if (_host_mode) {
+                    if (kta)
+                        kta->resize(_dim_out);
+                    _host_query(v, kta ? kta->data() : nullptr, 1, var);
+                    return;
+                }
                 std::vector<Eigen::VectorXd> one(1, v);
                 std::vector<double> k((size_t)_dim_out);
                 double vv = 0.0;

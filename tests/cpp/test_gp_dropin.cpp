@@ -601,6 +601,106 @@ CASE(test_gp_bw_inversion_timing)
     CHECK((double)failures / N < 0.1);
 }
 
+// Round 4: the host path below Params::gpu::min_n_for_gpu (limbo/model/gp/host_small.hpp).  A model with the threshold at 64
+// against an all-device model (threshold 0) fed the same samples: mu / sigma^2 at every step of the add_sample loop 10 -> 100
+// (the hand-over to the device happens at n = 64), the factor on both sides of the threshold, a large query_batch() on the
+// host-resident model (answered from a device copy) against its own per-point answers, and what has no host form
+// (K^-1, the gradient, a KernelLFOpt fit) moving the model to the device with the same results as the all-device model.
+struct ParamsHost64 : public Params {
+    struct gpu {
+        BO_PARAM(int, min_n_for_gpu, 64);
+    };
+};
+struct ParamsDeviceOnly : public Params {
+    struct gpu {
+        BO_PARAM(int, min_n_for_gpu, 0);
+    };
+};
+CASE(test_host_path_threshold)
+{
+    using GP_h = model::GP<ParamsHost64, kernel::SquaredExpARD<ParamsHost64>, mean::Data<ParamsHost64>, model::gp::KernelLFOpt<ParamsHost64>>;
+    using GP_d = model::GP<ParamsDeviceOnly, kernel::SquaredExpARD<ParamsDeviceOnly>, mean::Data<ParamsDeviceOnly>, model::gp::KernelLFOpt<ParamsDeviceOnly>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(100, 3, 2, X, Y);
+    GP_h h;
+    GP_d d;
+    h.compute(std::vector<VectorXd>(X.begin(), X.begin() + 10), std::vector<VectorXd>(Y.begin(), Y.begin() + 10));
+    d.compute(std::vector<VectorXd>(X.begin(), X.begin() + 10), std::vector<VectorXd>(Y.begin(), Y.begin() + 10));
+    std::vector<VectorXd> Q;
+    for (int m = 0; m < 3; ++m)
+        Q.push_back(rand_vec(3, 0, 1));
+    double worst_mu = 0, worst_s2 = 0, worst_L = 0;
+    for (size_t i = 10; i < X.size(); ++i) {
+        h.add_sample(X[i], Y[i]);
+        d.add_sample(X[i], Y[i]);
+        for (const auto& q : Q) {
+            worst_mu = std::max(worst_mu, (h.mu(q) - d.mu(q)).norm());
+            worst_s2 = std::max(worst_s2, std::abs(h.sigma(q) - d.sigma(q)) / d.sigma(q));
+        }
+        const int n = (int)i + 1;
+        if (n == 40 || n == 63 || n == 64 || n == 65 || n == 100) {
+            const MatrixXd &Lh = h.matrixL(), &Ld = d.matrixL();
+            double e = 0, sc = 0;
+            for (int a = 0; a < n; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    e = std::max(e, std::abs(Lh(a, b) - Ld(a, b)));
+                    sc = std::max(sc, std::abs(Ld(a, b)));
+                }
+            worst_L = std::max(worst_L, e / sc);
+        }
+        CHECK(std::abs(h.compute_log_lik() - d.compute_log_lik()) <= 1e-9 * std::abs(d.compute_log_lik()));
+    }
+    std::printf("    host (n < 64) / device (n >= 64) vs all-device over the add_sample loop: mu %.2e  sigma^2 %.2e (rel)  L %.2e\n", worst_mu, worst_s2, worst_L);
+    CHECK(worst_mu < 1e-8);
+    CHECK(worst_s2 < 1e-8);
+    CHECK(worst_L < 1e-10);
+    // a host-resident model: large batches from a device copy, small ones and single points from the host
+    GP_h small;
+    small.compute(std::vector<VectorXd>(X.begin(), X.begin() + 50), std::vector<VectorXd>(Y.begin(), Y.begin() + 50));
+    std::vector<VectorXd> pts;
+    for (int m = 0; m < 400; ++m)
+        pts.push_back(rand_vec(3, 0, 1));
+    MatrixXd mu;
+    VectorXd s2;
+    small.query_batch(pts, mu, s2); // 400 x 50 >= the crossover: device copy
+    double eb = 0, es = 0;
+    for (int m = 0; m < 400; ++m) {
+        VectorXd mm;
+        double ss;
+        std::tie(mm, ss) = small.query(pts[m]); // host
+        eb = std::max(eb, std::abs(mm(0) - mu(m, 0)) + std::abs(mm(1) - mu(m, 1)));
+        es = std::max(es, std::abs(ss - s2(m)) / ss);
+    }
+    CHECK(eb < 1e-9);
+    CHECK(es < 1e-8);
+    small.add_sample(X[50], Y[50]); // the host model moves on: the device copy must follow
+    small.query_batch(pts, mu, s2);
+    VectorXd m0;
+    double s0;
+    std::tie(m0, s0) = small.query(pts[7]);
+    CHECK(std::abs(m0(0) - mu(7, 0)) < 1e-9 && std::abs(s0 - s2(7)) < 1e-8 * s0);
+    // what has no host form moves the model to the device
+    GP_d dev50;
+    dev50.compute(std::vector<VectorXd>(X.begin(), X.begin() + 51), std::vector<VectorXd>(Y.begin(), Y.begin() + 51));
+    CHECK(!small.inv_kernel_computed());
+    VectorXd gh = small.compute_kernel_grad_log_lik(), gd = dev50.compute_kernel_grad_log_lik();
+    CHECK((gh - gd).norm() <= 1e-8 * gd.norm());
+    CHECK(small.inv_kernel_computed());
+    GP_h fit_h;
+    GP_d fit_d;
+    fit_h.compute(std::vector<VectorXd>(X.begin(), X.begin() + 40), std::vector<VectorXd>(Y.begin(), Y.begin() + 40));
+    fit_d.compute(std::vector<VectorXd>(X.begin(), X.begin() + 40), std::vector<VectorXd>(Y.begin(), Y.begin() + 40));
+    const double ll0 = fit_h.compute_log_lik();
+    fit_h.optimize_hyperparams(); // (the restarts' starting points are drawn from std::random_device: no second fit to compare with)
+    CHECK(fit_h.compute_log_lik() >= ll0);
+    // ... and the fitted model is the model an all-device GP gives with the same hyper-parameters
+    fit_d.kernel_function().set_h_params(fit_h.kernel_function().h_params());
+    fit_d.recompute(false);
+    CHECK(std::abs(fit_h.compute_log_lik() - fit_d.compute_log_lik()) <= 1e-9 * std::abs(fit_d.compute_log_lik()));
+    CHECK((fit_h.mu(Q[0]) - fit_d.mu(Q[0])).norm() < 1e-8);
+    CHECK(std::abs(fit_h.sigma(Q[0]) - fit_d.sigma(Q[0])) <= 1e-8 * fit_d.sigma(Q[0]));
+}
+
 // value semantics (kernel_lf_opt.hpp:79, multi_gp.hpp:73-76): a copy owns its own device state
 CASE(test_gp_copy_semantics)
 {
@@ -1120,6 +1220,7 @@ int main()
     test_sparse_gp_accuracy_run();
     test_multi_device_placement_run();
     test_lockstep_restarts_run();
+    test_host_path_threshold_run();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%d checks, %d failed cases, %.1f s\n", g_checks, g_failed, s);
     return g_failed;

@@ -38,15 +38,19 @@ def test_dropin_keeps_the_policy_api_names():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("virtual_devices", [0, 4])
-def test_dropin_cases_on_device(virtual_devices):
+@pytest.mark.parametrize("virtual_devices,min_n", [(0, None), (4, None), (0, 0)])
+def test_dropin_cases_on_device(virtual_devices, min_n):
     """all cases on the visible device(s); then once more with 4 logical devices dealt over the physical ones
     (GPE_VIRTUAL_DEVICES): MultiGP members, restart clones and explicit copies land on devices 0..3 through
-    gpe_clone_to — the multi-GPU placement of the drop-in, exercised on a one-GPU box"""
+    gpe_clone_to — the multi-GPU placement of the drop-in, exercised on a one-GPU box.  Round 4: by default models below
+    Params::gpu::min_n_for_gpu (256) samples live on the host (most of these cases' models are that small: they exercise
+    the host path and its hand-over to the device); LIMBO_AMD_MIN_N_FOR_GPU=0 runs everything on the device as rounds 1-3 did."""
     import os
 
     exe = _build()
     env = dict(os.environ)
+    if min_n is not None:
+        env["LIMBO_AMD_MIN_N_FOR_GPU"] = str(min_n)
     if virtual_devices:
         env["GPE_VIRTUAL_DEVICES"] = str(virtual_devices)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900, env=env)
