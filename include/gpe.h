@@ -203,14 +203,6 @@ int gpe_flow_retries(gpe_handle h, int64_t* n);
 int gpe_handover_reruns(gpe_handle h, int64_t* n);
 /* calls (add_sample, point queries) served by the one-launch small-N path (csrc/small.hip; GPE_SMALL=0 disables it) */
 int gpe_small_calls(gpe_handle h, int64_t* n);
-/* ... of which served by the RESIDENT workgroup of the small path: after a run of small calls on a handle the next ones are
- * requests written into a pinned mailbox that one persistent workgroup polls (csrc/small.hip: k_small_server) instead of
- * kernel launches; it leaves on any other call on the handle or after 1 ms without a request.  OFF by default
- * (GPE_SMALL_SERVER=1 enables it, GPE_SMALL_SERVER_IDLE_US sets the idle time): measured 2 us slower per call than a
- * launch — the body, not the launch, is what a small call costs */
-int gpe_server_calls(gpe_handle h, int64_t* n);
-/* microseconds the resident workgroup spent on its last request: us[0] copying it out of the mailbox, us[1] in the body */
-int gpe_server_last_us(gpe_handle h, double* us);
 /* Launch trace of the PRODUCTION schedule: while on, every kernel launch of the library carries its own start and stop
  * event (hipExtLaunchKernelGGL, the dispatch's own timestamps: no marker packets, no profiler) — rocprofv3's kernel trace
  * cannot show the fused next-panel update, it delays dispatches that carry a completion event by ~100 us.  gpe_trace(1/0)

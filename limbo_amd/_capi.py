@@ -94,8 +94,6 @@ def _sig(lib, prefix):
             "flow_retries": [_vp, C.POINTER(_i64)],
             "handover_reruns": [_vp, C.POINTER(_i64)],
             "small_calls": [_vp, C.POINTER(_i64)],
-            "server_calls": [_vp, C.POINTER(_i64)],
-            "server_last_us": [_vp, _dp],
             "mfma_f64_peak": [C.c_int, _dp],
             "trace": [C.c_int],
             "trace_dump": [C.c_char_p],
@@ -201,16 +199,6 @@ class Handle:
         n = _i64()
         self._chk(self.lib.fn("handover_reruns")(self._h, C.byref(n)), "handover_reruns")
         return n.value
-
-    def server_calls(self) -> int:
-        n = _i64()
-        self._chk(self.lib.fn("server_calls")(self._h, C.byref(n)), "server_calls")
-        return n.value
-
-    def server_last_us(self):
-        us = np.zeros(2)
-        self._chk(self.lib.fn("server_last_us")(self._h, _d(us)), "server_last_us")
-        return us
 
     def small_calls(self) -> int:
         n = _i64()

@@ -186,9 +186,8 @@ void launch_lambda_rows(hipStream_t s, double* Xt, int64_t ld, int64_t col0, int
 // inverse Xt[k + 64 c] = (L11^-1)[c][k] (64 x 64, identity-padded for jb < 64).  info: first bad
 // pivot (1-based, global index = goff + j + 1), written only if *info == 0.
 // half_form (jb == 64 only): only the inverses of the two 32 x 32 diagonal half-blocks are produced
-// (what k_panel_step consumes); launch_xinv_complete fills in the off-diagonal quarter afterwards.
+// (round 1; the data-flow block kernel of diag_flow.h leaves ALL of the inverse and ignores the flag).
 void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int* info, int64_t goff, int half_form);
-void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b0, int64_t nblocks, double* Xt_all);
 // one fused 64-column step below the factored diagonal block at (j0, j0): L21 = A21 X^T for rows
 // j0+64 .. M-1, the updates of the next `nt` 64-column blocks of the outer panel, and (do_next) the
 // factorisation + inversion of the next diagonal block (-> Xt_next).  Full 64-blocks only.
@@ -262,12 +261,8 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g);
 // the next-panel update g (as for launch_gemm_sub: C = A[pe:, pe:pe2], k = pe - p0, tri) and, in the same launch, the
 // update + factorisation + half-inversion of the next diagonal block A[pe:pe+64, pe:pe+64] (-> Xt_next)
 // (Dacc: sum of the pieces the panel steps already formed, subtracted as well; p0 == pe: no products here)
-// fold (j4 >= 0): the launch also does the panel's last 64-column step (columns j4 .. j4+63 = pe-64 .. pe-1): g.k covers the
-// panel's first columns only (p0 .. j4-1), L4 = A4 X3^T is formed per tile in LDS and written to the scratch panel L4s
-// ((M - pe) x 64, ld4) instead of A (potrf.hip: UpdFold)
 void launch_upd_fused(hipStream_t s, const GemmArgs& g, double* A, int64_t lda, int64_t p0, int64_t pe, double* Xt_next,
-                      int* info, const double* Dacc, int64_t j4 = -1, const double* X3 = nullptr, double* L4s = nullptr,
-                      int64_t ld4 = 0);
+                      int* info, const double* Dacc);
 double gemm_flops(const GemmArgs& g);
 
 // ---- vector solves, reductions (solve.hip) -----------------------------------------
@@ -312,8 +307,6 @@ void launch_set_identity(hipStream_t s, double* A, int64_t lda, int64_t n);
 // OutT (optional): the same blocks transposed
 void launch_inv_panels(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
                        int64_t ldo, double* OutT, int64_t ldt);
-void launch_inv_panel_one(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
-                          double* OutT, int64_t ldt, int panel);
 // A[0 : rows, 0 : cols] = 0 (column-major, lda) — a kernel, not hipMemsetAsync: it takes part in batched launches
 void launch_zero2d(hipStream_t s, double* A, int64_t lda, int64_t rows, int64_t cols);
 void launch_zero_upper(hipStream_t s, double* A, int64_t lda, int64_t n);
@@ -381,25 +374,6 @@ struct SmallAlphaArgs {
     unsigned long long seq_val;
     int n;
 };
-// the persistent form of the three (small.hip, k_small_server): requests through a pinned, coherent mailbox
-#define GPE_SMALL_OP_ADD 1
-#define GPE_SMALL_OP_QUERY 2
-#define GPE_SMALL_OP_ALPHA 3
-#define GPE_SMALL_OP_EXIT 0xFF
-struct SmallMailbox {
-    unsigned long long req_seq; // host: raised AFTER the request below is complete
-    unsigned long long state;   // 1: a server is (being) launched / running; 0: it has left (written by the server)
-    int op, P;
-    SmallAddArgs add;
-    SmallQueryArgs qry;
-    SmallAlphaArgs alp;
-    KParams kp;
-    LamParams lp;
-    double x[GPE_MAX_THETA];
-    // instrumentation, written by the server (100 MHz ticks of the last request): seen -> request copied -> body done
-    long long t_seen, t_copied, t_done;
-};
-void launch_small_server(hipStream_t s, SmallMailbox* mb, unsigned long long seen0, long long idle_ticks);
 int small_max_n();
 void launch_small_alpha(hipStream_t s, const SmallAlphaArgs& g, int P);
 void launch_small_add(hipStream_t s, const SmallAddArgs& g, int P, const KParams& kp, const LamParams& lp, const double* x);

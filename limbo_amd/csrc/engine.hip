@@ -77,8 +77,6 @@ void gpe_trace_add(const char* name, hipStream_t s, hipEvent_t e0, hipEvent_t e1
 #define NB 64
 // pinned staging of the small path: results in [0, 256), inputs (obs_mean: (n + 1) x P <= 257 x 3; query points: 8 x 64) from 256 on
 #define SMALL_STAGE_DOUBLES (256 + 1024)
-#define SMALL_MAIL_BYTES 4096
-static_assert(sizeof(SmallMailbox) <= SMALL_MAIL_BYTES, "mailbox fits its slot of the pinned block");
 
 namespace {
 
@@ -111,7 +109,6 @@ struct gpe_ctx {
     std::vector<hipEvent_t> pl_events; // ... one per outer panel: the one-launch panel is complete (early release of the look-ahead stream)
     int64_t early_bulk = 100;          // release the look-ahead stream at the END OF THE PANEL (not of the fused next-panel update)
                                        // when the far update has at least this many 128 x 128 tiles (GPE_EARLY_BULK_TILES; -1: never)
-    int64_t xinv_done = 0;      // diagonal blocks whose inverse is already complete (done per panel on stream2)
     bool stop_events = true;    // next-panel update signals through its own dispatch (hipExtLaunchKernel stop event)
     bool fuse_diag = true;      // next diagonal block factored inside the next-panel update launch (k_upd_fused)
     bool lookahead = true;             // GPE_LOOKAHEAD=0 disables
@@ -140,21 +137,9 @@ struct gpe_ctx {
     int handover_off_left = 0;      // ... for this many evaluations only, then it is re-armed (one hiccup is not forever)
     int64_t handover_reruns = 0;    // evaluations re-run after a hand-over timeout (gpe_handover_reruns)
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
-    double* dL4 = nullptr;   // ld x 64: the last 64 columns of a panel's L while the fused next-panel update forms them (fold)
     bool panel256 = true;    // all steps of a 256-column outer panel in one data-flow launch (GPE_PANEL256=0: step by step)
-    bool fold4 = true;       // the panel's last step inside the fused next-panel update (GPE_FOLD4=0: a launch of its own)
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     size_t xp_cap = 0;
-    // K^-1 BEHIND the factorisation (gpe_hp_objective with a gradient): panel p of U = L^-T needs only L's panels <= p, so
-    // its chain (and the rank-k accumulation of K^-1) runs on a third, low-priority stream as the panels become final
-    hipStream_t stream3 = nullptr;
-    std::vector<hipEvent_t> inv_events;
-    bool inv_follow_req = false; // set by gpe_hp_objective for the compute() that follows
-    bool inv_follow = false;     // this factorisation feeds the chain (potrf_blocked)
-    int inv_limit = 96;          // workgroups per chain launch while the factorisation runs (GPE_INV_FOLLOW_WGS)
-    int64_t inv_next = 0;        // next panel of the chain to enqueue
-    bool inv_followed = false;   // the chain of the current factor is enqueued: ensure_inv only has to wait for it
-    bool inv_pending = false;    // ... and nobody has waited for it yet
     int64_t grad_partial_cap = 0;
     int* dInfo = nullptr; // = hInfo: pinned host memory the kernels write directly (no copy-back, no device memset)
     double* dScal = nullptr; // [0] sum log L_ii, [1] trace(om^T alpha), [2] knn scratch, [8 .. 8 + 2 nblk) per-block partials
@@ -171,18 +156,6 @@ struct gpe_ctx {
     unsigned long long small_seq = 0;
     bool small_path = true;              // GPE_SMALL=0 disables
     int64_t small_calls = 0;             // calls served by the small path (instrumentation / tests)
-    // the persistent form of the small path (small.hip, k_small_server): after a run of small calls on this handle the next
-    // ones are requests to ONE resident workgroup instead of launches
-    SmallMailbox* hMail = nullptr;       // pinned, coherent (inside hPinned)
-    bool server_ok = false;              // GPE_SMALL_SERVER=1 enables.  OFF by default: measured (tools/srvlat.py ->
-                                         // profiles/r03_small_server_latency.log) it is 2 us SLOWER per call than a launch — the
-                                         // workgroup spends 1.9 us copying the request out of the mailbox and 10 (n = 50) .. 17.5 us
-                                         // (n = 200) in the body, a launch costs only ~7 us of the 18 .. 25 us of a call
-    bool server_on = false;              // a server kernel was launched on `stream` and has not been joined
-    unsigned long long mail_seq = 0;     // sequence number of the last request
-    int small_streak = 0;                // consecutive small calls (any other call resets it)
-    int64_t server_calls = 0;            // calls served by the resident workgroup (instrumentation / tests)
-    long long server_idle_ticks = 100000; // it leaves after this many 100 MHz ticks without a request (1 ms)
     int64_t flow_retries = 0; // sweeps re-run block by block after a hand-off timeout (never expected; see flow_failed)
     bool flow_solve = true; // one data-flow launch for the backward sweep (GPE_FLOW_SOLVE=0: per-block launches)
     bool fuse_panel = true; // k_panel_step instead of the three-launch panel step (GPE_FUSE_PANEL=0 disables)
@@ -323,13 +296,8 @@ int lam_columns(int kind, int n_theta, int D)
 
 void free_dev(gpe_ctx* c)
 {
-    if (c->stream3 && c->inv_pending) { // a K^-1 chain nobody waited for still owns these buffers
-        hipStreamSynchronize(c->stream3);
-        c->inv_pending = false;
-    }
-    c->inv_followed = false;
     double** ps[] = {&c->dXt, &c->dA, &c->dOm, &c->dAl, &c->dW, &c->dY, &c->dLinv, &c->dKinv, &c->dKhost,
-                     &c->dGradPartial, &c->dXinv, &c->dLooS, &c->dLooV, &c->dL4};
+                     &c->dGradPartial, &c->dXinv, &c->dLooS, &c->dLooV};
     for (auto p : ps) {
         if (*p)
             hipFree(*p);
@@ -362,7 +330,6 @@ int alloc_dev(gpe_ctx* c, int64_t cap, int D, int P)
     HIPCHK(c, hipMalloc(&c->dW, sizeof(double) * (size_t)(ld * std::max(P, 1))));
     HIPCHK(c, hipMalloc(&c->dY, sizeof(double) * (size_t)(ld * std::max(P, 1))));
     HIPCHK(c, hipMalloc(&c->dXinv, sizeof(double) * (size_t)(cap / NB) * NB * NB));
-    HIPCHK(c, hipMalloc(&c->dL4, sizeof(double) * (size_t)(ld * NB)));
     HIPCHK(c, hipMemsetAsync(c->dXinv, 0, sizeof(double) * (size_t)(cap / NB) * NB * NB, c->stream));
     HIPCHK(c, hipMemsetAsync(c->dXt, 0, sizeof(double) * (size_t)(ld * xt_rows(D)), c->stream));
     return GPE_OK;
@@ -384,10 +351,6 @@ int grow_dev(gpe_ctx* c, int64_t need)
     HIPCHK(c, hipMalloc(&nAl, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nW, sizeof(double) * (size_t)(nld * P)));
     HIPCHK(c, hipMalloc(&nY, sizeof(double) * (size_t)(nld * P)));
-    if (c->dL4)
-        hipFree(c->dL4);
-    c->dL4 = nullptr;
-    HIPCHK(c, hipMalloc(&c->dL4, sizeof(double) * (size_t)(nld * NB)));
     HIPCHK(c, hipMalloc(&nXi, sizeof(double) * (size_t)(ncap / NB) * NB * NB));
     HIPCHK(c, hipMemsetAsync(nXi, 0, sizeof(double) * (size_t)(ncap / NB) * NB * NB, c->stream));
     HIPCHK(c, hipMemsetAsync(nXt, 0, sizeof(double) * (size_t)(nld * xt_rows(D)), c->stream));
@@ -410,7 +373,7 @@ int grow_dev(gpe_ctx* c, int64_t need)
     c->dY = nY;
     c->dXinv = nXi;
     c->dLinv = c->dKinv = c->dLooS = c->dLooV = nullptr;
-    c->inv_ok = c->inv_followed = false;
+    c->inv_ok = false;
     c->cap = ncap;
     c->ld = nld;
     return GPE_OK;
@@ -459,83 +422,6 @@ void project_lambda(gpe_ctx* c, hipStream_t s, double* Xt, int64_t ld, int64_t c
 }
 
 
-// ---- K^-1 behind the factorisation -----------------------------------------------------------------------------
-// One panel of the transposed inversion (see ensure_inv): X_p, U[0:o0, p] = AccT[0:o0, p] X_p^T,
-// AccT[0:oe, p+1 ..] -= U[0:oe, p] L[p+1 .., p]^T, K^-1[0:oe, 0:oe] += U[0:oe, p] U[0:oe, p]^T.  `limit` > 0: at most that
-// many workgroups per launch (the factorisation is still running).
-static void inv_chain_panel(gpe_ctx* c, hipStream_t st, int64_t p, int limit)
-{
-    const int64_t N = c->N, ld = c->ld, nbo = c->nbo;
-    const int64_t o0 = p * nbo, pw = std::min<int64_t>(nbo, N - o0), oe = o0 + pw;
-    launch_inv_panel_one(st, c->dA, ld, N, (int)nbo, c->dXinv, c->dXp, c->dLinv, ld, (int)p);
-    if (o0 > 0) {
-        GemmArgs g{};
-        g.C = c->dLinv + o0 * ld;
-        g.ldc = ld;
-        g.A = c->dKinv + o0 * ld;
-        g.lda = ld;
-        g.B = c->dXp + p * (nbo * nbo);
-        g.ldb = nbo;
-        g.m = o0;
-        g.n = pw;
-        g.k = pw;
-        g.overwrite = 1;
-        g.grid_limit = limit;
-        if (limit > 0)
-            g.tile = 64;
-        launch_gemm_sub(st, g);
-    }
-    if (oe < N) {
-        GemmArgs g{};
-        g.C = c->dKinv + oe * ld;
-        g.ldc = ld;
-        g.A = c->dLinv + o0 * ld;
-        g.lda = ld;
-        g.B = c->dA + oe + o0 * ld;
-        g.ldb = ld;
-        g.m = oe;
-        g.n = N - oe;
-        g.k = pw;
-        g.grid_limit = limit;
-        if (limit > 0)
-            g.tile = 128;
-        launch_gemm_sub(st, g);
-    }
-    {
-        GemmArgs g{};
-        g.C = c->dKinv;
-        g.ldc = ld;
-        g.A = c->dLinv + o0 * ld;
-        g.lda = ld;
-        g.B = c->dLinv + o0 * ld;
-        g.ldb = ld;
-        g.m = g.n = oe;
-        g.k = pw;
-        g.tri = 1;
-        g.overwrite = 2;
-        g.grid_limit = limit;
-        if (limit > 0)
-            g.tile = 128;
-        launch_gemm_sub(st, g);
-    }
-}
-static hipEvent_t inv_event(gpe_ctx* c, size_t i)
-{
-    while (c->inv_events.size() <= i) {
-        hipEvent_t e;
-        hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        c->inv_events.push_back(e);
-    }
-    return c->inv_events[i];
-}
-// panels inv_next .. upto of the chain, after `ready` (a point of the main stream at which they are final)
-static void inv_follow_upto(gpe_ctx* c, int64_t upto, hipEvent_t ready, int limit)
-{
-    hipStreamWaitEvent(c->stream3, ready, 0);
-    for (; c->inv_next <= upto; ++c->inv_next)
-        inv_chain_panel(c, c->stream3, c->inv_next, limit);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky, two levels (replaces Eigen::LLT at gp.hpp:565):
 //   outer panels of `nbo` columns: the trailing update runs with k = nbo so that the matrix-core
@@ -556,12 +442,17 @@ static TailPlan tail_plan(const gpe_ctx* c, int64_t N, int64_t M)
     TailPlan pl;
     const int64_t nbo = c->nbo;
     pl.N64 = N / NB * NB;
-    static const bool batch_tail = !(getenv("GPE_BATCH_TAIL") && atoi(getenv("GPE_BATCH_TAIL")) == 0);
-    if (!(c->tail_max >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && (batch_tail || !g_batch.bt) && nbo == 4 * NB
-          && M - pl.N64 <= NB))
+    // Batched launches (k_tail_b: the members' tiles interleaved in one grid) take the data-flow launches only while all
+    // members' tiles together stay within ~18 rounds of the chip: every member has 256 / G resident workgroups, and a tile
+    // holds its CU from dispatch to its last store, mostly waiting — measured (profiles/r04_dispatch_order.log): 8 x N = 2048
+    // 1.45 ms per batch against 1.59 through the step-by-step panels, but 64 x 2048 9.0 against 7.0 and 10 x 4096 7.9 against 7.6
+    static const int64_t batch_tiles = getenv("GPE_BATCH_TAIL_TILES") ? atoll(getenv("GPE_BATCH_TAIL_TILES")) : 4608;
+    if (!(c->tail_max >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && nbo == 4 * NB && M - pl.N64 <= NB))
         return pl;
     int64_t t0 = pl.N64 > c->tail_max ? (pl.N64 - c->tail_max + nbo - 1) / nbo * nbo : 0;
     if (pl.N64 - t0 < 2 * NB)
+        return pl;
+    if (g_batch.bt && (t0 > 0 || (int64_t)g_batch.G * tail_tiles((pl.N64 - t0) / NB, (pl.N64 - t0) / NB + (M > pl.N64 ? 1 : 0)) > batch_tiles))
         return pl;
     pl.t0 = t0;
     const int64_t rs = M > pl.N64 ? 1 : 0;
@@ -692,7 +583,6 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                             c->dTail + ((c->tail_count + 1) & 1) * c->tail_cap);
                 ++c->tail_count;
                 c->tail_lay = pl.nt_tail * 65536 + pl.nb_tail;
-                c->xinv_done = N64 / NB;
             }
             if (N64 == N)
                 break;
@@ -734,7 +624,6 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
         // the whole panel in one launch (potrf.hip: k_panel256): full 256 columns, head tiles and block inverses handed over
         // between its workgroups
         const bool p256 = c->panel256 && c->fuse_panel && c->panel_handover && !g_batch.bt && nbo == 4 * NB && pw == nbo && pe <= M;
-        const bool fold_last = !p256 && fuse_diag && c->fold4 && c->dL4 && nbo == 4 * NB && c->panel_handover && !g_batch.bt;
         // In the first panels of a large factorisation the look-ahead stream is the longer one (N = 4096, panel 1: near + far
         // update 30 + 84 us against 54 + 18 us of chain) and the fused next-panel update, whose 155 KB workgroups need whole CUs,
         // ends up queued behind the far update of the panel before: releasing the stream when the PANEL is complete — its
@@ -777,12 +666,6 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 launch_diag(s, A + j0 + j0 * ld, ld, jb, Xt, c->dInfo, j0, fuse ? 1 : 0);
             }
             diag_done = false;
-            // the panel's last step (nothing left to update, no diagonal block to factor) rides in the fused next-panel
-            // update when that follows (potrf.hip: UpdFold)
-            if (fuse && fold_last && nt == 0 && j0 == pe - NB) {
-                diag_done = false;
-                continue;
-            }
             if (fuse) {
                 PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)(M - r0) * NB * NB * (1 + nt));
                 if (nf == 0)
@@ -902,14 +785,8 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                     g.grow0 = pe;
                     g.gcol0 = pe;
                     g.stop_event = ev(3 * kp);
-                    if (fold_last) {
-                        g.k = pw - NB; // the panel's first three column blocks through the direct-to-LDS loop, the last from LDS
-                        launch_upd_fused(s, g, A, ld, pe, pe, c->dXinv + (pe / NB) * (NB * NB), c->dInfo, c->dHead + 64 * NB * NB,
-                                         pe - NB, c->dXinv + ((pe - NB) / NB) * (NB * NB), c->dL4, ld);
-                    }
-                    else
-                        launch_upd_fused(s, g, A, ld, pe, pe, c->dXinv + (pe / NB) * (NB * NB), c->dInfo,
-                                         c->dHead + 64 * NB * NB); // the steps summed the pieces: no products here
+                    launch_upd_fused(s, g, A, ld, pe, pe, c->dXinv + (pe / NB) * (NB * NB), c->dInfo,
+                                     c->dHead + 64 * NB * NB); // the steps summed the pieces: no products here
                     next_diag_done = true;
                 }
                 else if (c->stop_events)
@@ -921,17 +798,9 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 }
                 hipStreamWaitEvent(c->stream2, p_done ? p_done : ev(3 * kp), 0); // the bulk update starts now and shares the
                                                                // chip with panel kp + 1 only (p_done: and with this update)
-                if (c->inv_follow) // panel kp of L is final: its piece of the K^-1 chain, on the third stream
-                    inv_follow_upto(c, (int64_t)kp, ev(3 * kp), c->inv_limit);
                 if (nf > 0 && !c->panel_handover) // (with the hand-over the head tiles were written in place too)
                     launch_head_copy(c->stream2, A, ld, p0, nt0, nf, Hbase);
                 nf = 0;
-                if (c->fuse_panel && c->xinv_done == p0 / NB && pw % NB == 0) { // this panel's block inverses:
-                    launch_xinv_complete(c->stream2, A, ld, p0 / NB, pw / NB, c->dXinv); // off the critical path
-                    c->xinv_done = pe / NB;
-                }
-                if (fuse_diag && fold_last) // the panel's last 64 columns of L, formed by the fused update: into place
-                    launch_copy2d(c->stream2, c->dL4, ld, A + pe + (pe - NB) * ld, ld, M - pe, NB);
                 const int64_t pe3 = std::min<int64_t>(pe2 + nbo, N);
                 upd(c->stream2, pe2, pe3, pe2, c->near_wgs >= 0 ? c->near_wgs : c->bulk_wgs, nullptr, 64); // near: what panel kp + 1's update needs
                 hipEventRecord(ev(3 * kp + 1), c->stream2);
@@ -966,11 +835,6 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     }
     if (la_pending)
         hipStreamWaitEvent(s, c->la_events[la_last], 0);
-    if (c->fuse_panel && N / NB > c->xinv_done) { // off-diagonal quarters of the remaining block inverses
-        PhaseScope ps(c, GPE_PH_POTRF_PANEL, 0.0);
-        launch_xinv_complete(s, A, ld, c->xinv_done, N / NB - c->xinv_done, c->dXinv);
-    }
-    c->xinv_done = 0;
 }
 
 // Z <- L^-1 B in place, B is N x M (ldb).  identity_structure: B starts as the identity, so at
@@ -1134,65 +998,7 @@ int compute_enqueue(gpe_ctx* c)
             launch_cols_to_rows(s, c->dOm, c->ld, c->N, c->P, c->dA + c->N, c->ld, flow_al ? c->dAl : nullptr);
         c->al_prefilled = flow_al;
     }
-    // K^-1 behind the factorisation (gpe_hp_objective with a gradient; not in batched launches or profiling runs)
-    if (c->inv_pending) { // an earlier chain nobody waited for (an error path): it must not write under this evaluation
-        hipStreamSynchronize(c->stream3);
-        c->inv_pending = false;
-    }
-    c->inv_followed = false;
-    // OFF unless GPE_INV_FOLLOW=1: measured (bench.py hp_objective, N = 4096) the chain behind the factorisation LOSES —
-    // 3.38 ms with the chain after the factorisation (its product overlapped, ensure_inv), 3.51 ms following it unrestricted,
-    // 4.1 / 4.9 / 7.0 ms with its launches held to 160 / 96 / 48 workgroups: the chain's matrix-core workgroups take CUs and
-    // LDS from the panel steps, whose chain is the critical path, and a workgroup-limited launch is long enough to become one
-    static const bool follow_ok = getenv("GPE_INV_FOLLOW") && atoi(getenv("GPE_INV_FOLLOW")) != 0;
-    const int64_t npan = (c->N + c->nbo - 1) / c->nbo;
-    bool follow = c->inv_follow_req && follow_ok && !g_batch.bt && !c->prof && c->lookahead && c->stop_events && c->fuse_panel
-        && c->panel_handover // (otherwise the panel's head tiles reach A later, on the second stream)
-        && c->nbo % 128 == 0 && c->nbo <= 256 && npan >= 6 && c->N % c->nbo == 0;
-    c->inv_follow_req = false;
-    if (follow) {
-        const size_t mat = sizeof(double) * (size_t)(c->ld * c->cap);
-        if (!c->dLinv && hipMalloc(&c->dLinv, mat) != hipSuccess)
-            follow = false;
-        if (follow && !c->dKinv && hipMalloc(&c->dKinv, mat) != hipSuccess)
-            follow = false;
-        if (follow && (int64_t)c->xp_cap < npan * c->nbo * c->nbo) {
-            if (c->dXp)
-                hipFree(c->dXp);
-            c->dXp = nullptr;
-            c->xp_cap = 0;
-            if (hipMalloc(&c->dXp, sizeof(double) * (size_t)(npan * c->nbo * c->nbo)) == hipSuccess)
-                c->xp_cap = (size_t)(npan * c->nbo * c->nbo);
-            else
-                follow = false;
-        }
-        if (follow && !c->stream3) {
-            int lo = 0, hi = 0;
-            hipDeviceGetStreamPriorityRange(&lo, &hi); // lo: the LEAST urgent
-            if (hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, lo) != hipSuccess)
-                follow = false;
-            if (const char* f = getenv("GPE_INV_FOLLOW_WGS"))
-                c->inv_limit = atoi(f);
-        }
-    }
-    if (follow) {
-        hipEventRecord(inv_event(c, 0), s); // everything of this handle that touched the K^-1 buffers is behind this point
-        hipStreamWaitEvent(c->stream3, inv_event(c, 0), 0);
-        launch_zero2d(c->stream3, c->dKinv, c->ld, c->N, c->N);
-        c->inv_follow = true;
-        c->inv_next = 0;
-        c->inv_pending = true;
-    }
     potrf_blocked(c, c->dA, c->N, c->N + c->P);
-    if (follow) {
-        // the panels the look-ahead schedule has no event for (the last two), and whatever else is left: after the whole
-        // factorisation, unrestricted
-        c->inv_follow = false;
-        hipEventRecord(inv_event(c, 1), s);
-        inv_follow_upto(c, npan - 1, inv_event(c, 1), 0);
-        hipEventRecord(inv_event(c, 2), c->stream3);
-        c->inv_followed = true;
-    }
     c->have_L = true;
     c->inv_ok = false; // gp.hpp:570
     solve_alpha_from_z(c);
@@ -1308,20 +1114,15 @@ int compute_finish(gpe_ctx* c)
 // The small kernels write their results and then a sequence word straight into pinned host memory: spin on the
 // word(s) instead of synchronising the stream (an event round trip costs more than the kernel).  Falls back to a
 // stream synchronisation after 50 ms (a fault, or a debugger).
-static void server_start(gpe_ctx* c, unsigned long long seen0);
-static int small_wait(gpe_ctx* c, int nwords, unsigned long long want, bool served = false)
+static int small_wait(gpe_ctx* c, int nwords, unsigned long long want)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spin = 0;; ++spin) {
+    for (;;) {
         bool all = true;
         for (int i = 0; i < nwords; ++i)
             all = all && (__atomic_load_n(c->hSmallSeq + i, __ATOMIC_ACQUIRE) == want);
         if (all)
             return GPE_OK;
-        // a request to the resident workgroup that crossed its leaving (idle timeout): it says so in the mailbox and the
-        // request is still there — start another one for it
-        if (served && (spin & 31) == 31 && __atomic_load_n(&c->hMail->state, __ATOMIC_ACQUIRE) == 0)
-            server_start(c, c->mail_seq - 1);
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, hipGetLastError());
@@ -1351,13 +1152,6 @@ int ensure_inv(gpe_ctx* c)
         return GPE_OK;
     if (!c->have_L)
         return GPE_ERR_STATE;
-    if (c->inv_followed) { // the chain ran behind the factorisation (compute_enqueue): wait for its end, that is all
-        hipStreamWaitEvent(c->stream, inv_event(c, 2), 0);
-        c->inv_followed = false;
-        c->inv_pending = false;
-        c->inv_ok = true; // gp.hpp:263
-        return GPE_OK;
-    }
     hipStream_t s = c->stream;
     const int64_t N = c->N, ld = c->ld;
     if (!c->dLinv)
@@ -1624,90 +1418,15 @@ int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise, bool loo = false)
 // bulk update that owns all 256 CUs would simply delay the panel: the bulk update is launched with
 // `bulk_wgs` < 256 looping workgroups (gemm.hip, GemmArgs::grid_limit), the other CUs stay free for
 // the critical path.  (A CU mask on the stream was tried first and had no effect.)
-// GPE_STREAM_PRIO=1: the panel chain's stream gets the most urgent priority, the look-ahead stream the least
-static int stream_prio_mode()
-{
-    static const int m = getenv("GPE_STREAM_PRIO") ? atoi(getenv("GPE_STREAM_PRIO")) : 0;
-    return m;
-}
-hipError_t create_main_stream(hipStream_t* st)
-{
-    if (stream_prio_mode() == 0)
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
-}
-hipError_t create_bulk_stream(hipStream_t* st)
-{
-    if (stream_prio_mode() != 0) {
-        int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);
-        return hipStreamCreateWithPriority(st, hipStreamNonBlocking, lo);
-    }
-    int keep = 4; // of every 4 CUs (GPE_BULK_CU_MASK=1..3 enables a mask; it had no measurable effect on MI355X/ROCm 7.2)
-    if (const char* e = getenv("GPE_BULK_CU_MASK"))
-        keep = atoi(e);
-    if (keep >= 4 || keep <= 0)
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    uint32_t mask[8];
-    for (int w = 0; w < 8; ++w) {
-        mask[w] = 0;
-        for (int b = 0; b < 32; ++b)
-            if (((w * 32 + b) & 3) < keep)
-                mask[w] |= 1u << b;
-    }
-    return hipExtStreamCreateWithCUMask(st, 8, mask);
-}
+// (Stream priorities and a CU mask on this stream were both tried — rounds 1 and 3 — and had no measurable effect on
+// MI355X / ROCm 7.2; neither switch is kept.)
+hipError_t create_main_stream(hipStream_t* st) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
+hipError_t create_bulk_stream(hipStream_t* st) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
 
 struct DevGuard {
     explicit DevGuard(gpe_ctx* c) { hipSetDevice(c->device); }
 };
 
-// ---- the resident workgroup of the small path (small.hip: k_small_server) --------------------------------------
-// All of this runs under the handle's mutex.  Any call that is not a small call joins the server first (server_stop): it
-// owns the handle's stream, and it holds nothing the other paths could not find in HBM.
-static void server_start(gpe_ctx* c, unsigned long long seen0)
-{
-    if (c->server_on)
-        hipStreamSynchronize(c->stream); // the previous one said it was leaving: let it
-    __atomic_store_n(&c->hMail->state, 1ull, __ATOMIC_RELEASE);
-    launch_small_server(c->stream, c->hMail, seen0, c->server_idle_ticks);
-    c->server_on = true;
-}
-static void server_join(gpe_ctx* c)
-{
-    if (!c->server_on)
-        return;
-    c->hMail->op = GPE_SMALL_OP_EXIT;
-    __atomic_store_n(&c->hMail->req_seq, ++c->mail_seq, __ATOMIC_RELEASE);
-    hipStreamSynchronize(c->stream); // (returns at once when it had already left by itself)
-    c->server_on = false;
-}
-// any call that is not a small call: join it, and the run of small calls starts over
-static void server_stop(gpe_ctx* c)
-{
-    c->small_streak = 0;
-    server_join(c);
-}
-// the request in c->hMail is complete: hand it over (starting a server if none is there)
-static void server_submit(gpe_ctx* c, int op, int P)
-{
-    SmallMailbox* mb = c->hMail;
-    mb->op = op;
-    mb->P = P;
-    const unsigned long long seq = ++c->mail_seq;
-    __atomic_store_n(&mb->req_seq, seq, __ATOMIC_RELEASE);
-    if (!c->server_on || __atomic_load_n(&mb->state, __ATOMIC_ACQUIRE) == 0)
-        server_start(c, seq - 1);
-    ++c->server_calls;
-}
-// a small call: through the resident workgroup?  (after a run of them; one output; not while profiling)
-static bool server_wanted(gpe_ctx* c, int P)
-{
-    ++c->small_streak;
-    return c->server_ok && !c->prof && P == 1 && c->small_streak > 3;
-}
 
 // what survives a handle: see gpe_create
 struct HandleShell {
@@ -1785,7 +1504,7 @@ int gpe_create(int device_id, gpe_handle* out)
             || hipMalloc(&c->dScal, 8192 + sizeof(double) * GPE_HEAD_TILES * NB * NB) != hipSuccess
             // the hand-over flag words start from zero, in the order of the stream the panel steps run on
             || hipMemsetAsync(c->dScal + 1024 + 65 * NB * NB, 0, sizeof(double) * NB * NB, c->stream) != hipSuccess
-            || hipHostMalloc(&c->hPinned, 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES + SMALL_MAIL_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)) {
+            || hipHostMalloc(&c->hPinned, 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)) {
         delete c;
         return GPE_ERR_HIP;
     }
@@ -1797,13 +1516,7 @@ int gpe_create(int device_id, gpe_handle* out)
     c->hSmallSeq = (unsigned long long*)(c->hPinned + 64);
     c->hScal = (double*)(c->hPinned + 128);
     c->hSmall = c->hScal + 1024;
-    c->hMail = (SmallMailbox*)(c->hPinned + 128 + 8192 + sizeof(double) * SMALL_STAGE_DOUBLES);
     memset(c->hPinned, 0, 128);
-    memset(c->hMail, 0, sizeof(SmallMailbox));
-    if (const char* f = getenv("GPE_SMALL_SERVER"))
-        c->server_ok = atoi(f) != 0;
-    if (const char* f = getenv("GPE_SMALL_SERVER_IDLE_US"))
-        c->server_idle_ticks = std::max<long long>(1000, atoll(f) * 100);
     if (const char* f = getenv("GPE_SMALL"))
         c->small_path = atoi(f) != 0;
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
@@ -1818,8 +1531,6 @@ int gpe_create(int device_id, gpe_handle* out)
         c->bulk_free_tiles = atoll(f);
     if (const char* f = getenv("GPE_FUSE_DIAG"))
         c->fuse_diag = atoi(f) != 0;
-    if (const char* f = getenv("GPE_FOLD4"))
-        c->fold4 = atoi(f) != 0;
     if (const char* f = getenv("GPE_PANEL256"))
         c->panel256 = atoi(f) != 0;
     if (const char* f = getenv("GPE_EARLY_BULK_TILES"))
@@ -1851,7 +1562,6 @@ int gpe_destroy(gpe_handle c)
     if (!c)
         return GPE_ERR_ARG;
     DevGuard g(c);
-    server_stop(c);
     hipStreamSynchronize(c->stream);
     drain_phases(c);
     for (auto e : c->pool)
@@ -1863,12 +1573,6 @@ int gpe_destroy(gpe_handle c)
         hipEventDestroy(e);
     for (auto e : c->la_events)
         hipEventDestroy(e);
-    for (auto e : c->inv_events)
-        hipEventDestroy(e);
-    if (c->stream3) {
-        hipStreamSynchronize(c->stream3);
-        hipStreamDestroy(c->stream3);
-    }
     hipStreamSynchronize(c->stream2);
     bool kept = false;
     if (c->device < 16) {
@@ -1897,7 +1601,6 @@ int gpe_set_data(gpe_handle c, const double* X, int64_t N, int D, const double* 
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     if (N > c->cap || D != c->D || P != c->P || !c->dA) {
         int rc = alloc_dev(c, N, D, P);
         if (rc)
@@ -1919,7 +1622,7 @@ int gpe_set_data(gpe_handle c, const double* X, int64_t N, int D, const double* 
     c->N = N;
     c->D = D;
     c->P = P;
-    c->have_L = c->inv_ok = c->ll_ok = c->inv_followed = false;
+    c->have_L = c->inv_ok = c->ll_ok = false;
     c->host_K = (c->kind == GPE_KERNEL_HOST_K);
     // stage X through the (not yet used) matrix buffer, then transpose to SoA on the device
     double* tmp = c->dA;
@@ -1937,7 +1640,6 @@ int gpe_set_data_device(gpe_handle c, const double* dX, int64_t N, int D, const 
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     if (N > c->cap || D != c->D || P != c->P || !c->dA) {
         int rc = alloc_dev(c, N, D, P);
         if (rc)
@@ -1946,7 +1648,7 @@ int gpe_set_data_device(gpe_handle c, const double* dX, int64_t N, int D, const 
     c->N = N;
     c->D = D;
     c->P = P;
-    c->have_L = c->inv_ok = c->ll_ok = c->inv_followed = false;
+    c->have_L = c->inv_ok = c->ll_ok = false;
     c->host_K = (c->kind == GPE_KERNEL_HOST_K);
     launch_transpose_x(c->stream, dX, N, D, c->dXt, c->ld, 0);
     launch_copy2d(c->stream, dOm, N, c->dOm, c->ld, N, P);
@@ -1976,7 +1678,6 @@ int gpe_set_K_host(gpe_handle c, const double* K, int64_t ldk)
     DevGuard g(c);
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        server_stop(c);
     }
     if (!c->dKhost)
         HIPCHK(c, hipMalloc(&c->dKhost, sizeof(double) * (size_t)(c->ld * c->cap)));
@@ -1993,7 +1694,6 @@ int gpe_compute(gpe_handle c)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     if (!c->host_K) {
         if (lam_columns(c->kind, c->n_theta, c->D) < 0) {
             c->err = "set_kernel: wrong number of hyper-parameters for this kernel/dimension";
@@ -2036,20 +1736,14 @@ int gpe_update_alpha(gpe_handle c, const double* obs_mean)
         a.seq = c->hSmallSeq;
         a.seq_val = ++c->small_seq;
         a.n = (int)c->N;
-        const bool served = server_wanted(c, c->P);
-        if (served) { // a request to the resident workgroup (small.hip, k_small_server) instead of a launch
-            c->hMail->alp = a;
-            server_submit(c, GPE_SMALL_OP_ALPHA, c->P);
-        }
-        else {
-            server_join(c);
+        {
             PhaseScope ps(c, GPE_PH_SOLVE, 2.0 * (double)c->N * c->N * c->P);
             launch_small_alpha(c->stream, a, c->P);
         }
         c->al_prefilled = false;
         c->ll_partials = 0;
         ++c->small_calls;
-        int rc = small_wait(c, 1, a.seq_val, served);
+        int rc = small_wait(c, 1, a.seq_val);
         drain_phases(c);
         if (rc)
             return rc;
@@ -2058,7 +1752,6 @@ int gpe_update_alpha(gpe_handle c, const double* obs_mean)
         c->ll_ok = true;
         return GPE_OK;
     }
-    server_stop(c);
     if (obs_mean)
         HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * c->ld, obs_mean, sizeof(double) * c->N,
                                    sizeof(double) * c->N, c->P, hipMemcpyHostToDevice, c->stream));
@@ -2092,7 +1785,6 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     if (c->N == 0) { // gp.hpp:128-137
         if (D > GPE_MAX_THETA - 2)
             return GPE_ERR_ARG;
-        server_stop(c);
         int rc = alloc_dev(c, 256, D, P);
         if (rc)
             return rc;
@@ -2104,8 +1796,6 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
             return GPE_ERR_ARG;
         if (!c->have_L)
             return GPE_ERR_STATE;
-        if (c->N + 1 > c->cap)
-            server_stop(c); // the buffers are about to move
         int rc = grow_dev(c, c->N + 1);
         if (rc)
             return rc;
@@ -2138,29 +1828,17 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         a.seq = c->hSmallSeq;
         a.seq_val = ++c->small_seq;
         a.n = (int)n;
-        const bool served = server_wanted(c, P);
-        if (served) { // a request to the resident workgroup instead of a launch
-            SmallMailbox* mb = c->hMail;
-            mb->add = a;
-            mb->kp = c->kp;
-            mb->lp = lam_params(c);
-            for (int d = 0; d < GPE_MAX_THETA; ++d)
-                mb->x[d] = d < c->kp.Din ? x[d] : 0.0;
-            server_submit(c, GPE_SMALL_OP_ADD, P);
-        }
-        else {
-            server_join(c);
+        {
             PhaseScope ps(c, GPE_PH_POTRF_PANEL, (double)n * n + 2.0 * (double)n * n * P);
             launch_small_add(s, a, P, c->kp, lam_params(c), x);
         }
         c->N = n + 1;
         c->have_L = true;
-        c->inv_ok = c->inv_followed = false; // gp.hpp:602
-        c->inv_followed = false;
+        c->inv_ok = false; // gp.hpp:602
         c->al_prefilled = false;
         c->ll_partials = 0;
         ++c->small_calls;
-        int rc = small_wait(c, 1, a.seq_val, served);
+        int rc = small_wait(c, 1, a.seq_val);
         drain_phases(c);
         if (rc)
             return rc;
@@ -2169,7 +1847,6 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
         c->ll_ok = true;
         return *c->hInfo;
     }
-    server_stop(c);
     // new sample -> column n of Xt (staged through dY)
     HIPCHK(c, hipMemcpyAsync(c->dY, x, sizeof(double) * D, hipMemcpyHostToDevice, s));
     launch_transpose_x(s, c->dY, 1, D, c->dXt, ld, n);
@@ -2197,7 +1874,7 @@ int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean,
     new_row();
     c->N = n + 1;
     c->have_L = true;
-    c->inv_ok = c->inv_followed = false; // gp.hpp:602
+    c->inv_ok = false; // gp.hpp:602
     solve_alpha(c);    // gp.hpp:599
     enqueue_loglik_terms(c);
     return compute_finish(c, [c, new_row] {
@@ -2217,7 +1894,6 @@ int gpe_log_lik(gpe_handle c, double* out)
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->ll_ok) {
-        server_stop(c);
         enqueue_loglik_terms(c);
         int rc = compute_finish(c);
         if (rc < 0)
@@ -2236,7 +1912,6 @@ int gpe_compute_inv_kernel(gpe_handle c)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = ensure_inv(c);
     if (rc)
         return rc;
@@ -2275,7 +1950,6 @@ int gpe_log_lik_grad(gpe_handle c, double* grad, int n_grad, int optimize_noise)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     digest_kernel(c);
     return grad_fetch(c, grad, n_grad, optimize_noise, false);
 }
@@ -2289,7 +1963,6 @@ int gpe_log_loo_cv(gpe_handle c, double* out)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = ensure_inv(c);
     if (rc)
         return rc;
@@ -2317,7 +1990,6 @@ int gpe_log_loo_cv_grad(gpe_handle c, double* grad, int n_grad, int optimize_noi
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     digest_kernel(c);
     return grad_fetch(c, grad, n_grad, optimize_noise, true);
 }
@@ -2330,7 +2002,6 @@ int gpe_hp_objective(gpe_handle c, int kind, const double* th, int n_theta, doub
     int rc = gpe_set_kernel(c, kind, th, n_theta, noise); // kernel_lf_opt.hpp:80
     if (rc)
         return rc;
-    c->inv_follow_req = want_grad != 0 && !c->host_K; // K^-1 behind the factorisation (compute_enqueue)
     int info = gpe_compute(c); // :82 recompute(false)
     if (info < 0)
         return info;
@@ -2492,21 +2163,12 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
         q.seq_val = ++c->small_seq;
         q.want_kta = kta ? 1 : 0;
         q.want_var = var ? 1 : 0;
-        const bool served = server_wanted(c, 1); // (any number of outputs: the body loops over them)
-        if (served) { // a request to the resident workgroup instead of a launch
-            SmallMailbox* mb = c->hMail;
-            mb->qry = q;
-            mb->kp = c->kp;
-            mb->lp = lam_params(c);
-            server_submit(c, GPE_SMALL_OP_QUERY, P);
-        }
-        else {
-            server_join(c);
+        {
             PhaseScope ps(c, GPE_PH_QUERY, (double)N * N * M);
             launch_small_query(s, q, c->kp, lam_params(c));
         }
         ++c->small_calls;
-        int rc = small_wait(c, (int)M, q.seq_val, served);
+        int rc = small_wait(c, (int)M, q.seq_val);
         drain_phases(c);
         if (rc)
             return rc;
@@ -2519,7 +2181,6 @@ static int query_impl(gpe_ctx* c, const double* Xq, const double* KsHost, int64_
     // a handful of points (the per-point calls of an acquisition functor, gp.hpp:159-191): the forward
     // substitution runs as ONE data-flow launch (k_trsv_fwd_flow, <= GPE_MAX_P right-hand sides) instead of a
     // blocked matrix solve, whose dependent matrix-core launches are all launch floor there
-    server_stop(c);
     static const bool sweep_ok0 = !(getenv("GPE_QUERY_SWEEP") && atoi(getenv("GPE_QUERY_SWEEP")) == 0);
     static const bool transposed_ok = !(getenv("GPE_QUERY_T") && atoi(getenv("GPE_QUERY_T")) == 0);
     const bool few0 = sweep_ok0 && c->flow_solve && M <= GPE_MAX_P && (N + NB - 1) / NB <= 256;
@@ -2642,7 +2303,6 @@ int gpe_query_batch_cross(gpe_handle c, const double* Ks, int64_t M, double* kta
         return GPE_OK;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = query_impl(c, nullptr, Ks, M, kta, zz);
     if (rc == GPE_OK && zz)
         for (int64_t m = 0; m < M; ++m)
@@ -2656,7 +2316,6 @@ int gpe_set_obs_mean(gpe_handle c, const double* obs_mean)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     HIPCHK(c, hipMemcpy2DAsync(c->dOm, sizeof(double) * c->ld, obs_mean, sizeof(double) * c->N, sizeof(double) * c->N,
                                c->P, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2680,7 +2339,6 @@ int gpe_get_L(gpe_handle c, double* L, int64_t ldh)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     const int64_t N = c->N;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(L, sizeof(double) * ldh, c->dA, sizeof(double) * c->ld, sizeof(double) * N, N,
@@ -2696,7 +2354,6 @@ int gpe_set_L(gpe_handle c, const double* L, int64_t ldh)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     HIPCHK(c, hipMemcpy2D(c->dA, sizeof(double) * c->ld, L, sizeof(double) * ldh, sizeof(double) * c->N, c->N,
                           hipMemcpyHostToDevice));
     launch_diag_inv(c->stream, c->dA, c->ld, c->N, 0, (c->N + NB - 1) / NB, c->dXinv);
@@ -2708,7 +2365,7 @@ int gpe_set_L(gpe_handle c, const double* L, int64_t ldh)
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_L = true;
-    c->inv_ok = c->inv_followed = false;
+    c->inv_ok = false;
     c->ll_ok = false;
     return GPE_OK;
 }
@@ -2721,7 +2378,6 @@ int gpe_get_alpha(gpe_handle c, double* a)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(a, sizeof(double) * c->N, c->dAl, sizeof(double) * c->ld, sizeof(double) * c->N, c->P,
                           hipMemcpyDeviceToHost));
@@ -2734,7 +2390,6 @@ int gpe_set_alpha(gpe_handle c, const double* a)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     HIPCHK(c, hipMemcpy2D(c->dAl, sizeof(double) * c->ld, a, sizeof(double) * c->N, sizeof(double) * c->N, c->P,
                           hipMemcpyHostToDevice));
     c->ll_ok = false;
@@ -2747,7 +2402,6 @@ int gpe_get_Kinv(gpe_handle c, double* Kinv, int64_t ldh)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = ensure_inv(c);
     if (rc)
         return rc;
@@ -2772,7 +2426,6 @@ int gpe_get_loo_weights(gpe_handle c, double* W, int64_t ldh)
         return GPE_ERR_STATE;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     int rc = ensure_inv(c);
     if (rc)
         return rc;
@@ -2815,7 +2468,6 @@ int gpe_get_K(gpe_handle c, double* K, int64_t ldh)
         return GPE_ERR_ARG;
     DevGuard g(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    server_stop(c); // (joins the resident workgroup of the small path, if one is up: it owns the stream)
     const int64_t N = c->N;
     if (c->host_K) {
         if (!c->dKhost)
@@ -2870,23 +2522,6 @@ int gpe_handover_reruns(gpe_handle c, int64_t* n)
     return GPE_OK;
 }
 
-int gpe_server_calls(gpe_handle c, int64_t* n)
-{
-    if (!c || !n)
-        return GPE_ERR_ARG;
-    *n = c->server_calls;
-    return GPE_OK;
-}
-// microseconds the resident workgroup spent on its last request: [0] copying it out of the mailbox, [1] in the body
-int gpe_server_last_us(gpe_handle c, double* us)
-{
-    if (!c || !us || !c->hMail)
-        return GPE_ERR_ARG;
-    us[0] = 0.01 * (double)(c->hMail->t_copied - c->hMail->t_seen);
-    us[1] = 0.01 * (double)(c->hMail->t_done - c->hMail->t_copied);
-    return GPE_OK;
-}
-
 int gpe_small_calls(gpe_handle c, int64_t* n)
 {
     if (!c || !n)
@@ -2908,7 +2543,6 @@ int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out)
     std::lock_guard<std::mutex> lk(src->mu);
     {
         DevGuard gs(src);
-        server_stop(src);
         hipStreamSynchronize(src->stream);
     }
     DevGuard g(c);
@@ -3119,10 +2753,9 @@ static int batch_finish_fused(gpe_ctx** cs, int Gc, int* rc, const BatchWant* wa
     for (int q = 0; q < Gc; ++q) {
         gpe_ctx* c = cs[q];
         c->have_L = true;
-        c->inv_ok = c->inv_followed = false;
+        c->inv_ok = false;
         c->al_prefilled = false;
         c->ll_partials = c0->flow_solve && nblk <= 256 ? (int)nblk : 0;
-        c->xinv_done = 0;
         // the usual finish on the handle's own (idle) stream: sums the per-block partials; a sweep that gave up
         // (never expected) is re-run block by block for that GP alone
         const int64_t retries = c->flow_retries;
@@ -3132,7 +2765,7 @@ static int batch_finish_fused(gpe_ctx** cs, int Gc, int* rc, const BatchWant* wa
             if (c->flow_retries != retries && rc[q] >= 0 && want->grad_out) {
                 // (never expected) this member's sweep or factorisation was re-run on its own after the batch: its
                 // K^-1 / gradient came from the first attempt — once more, alone
-                c->inv_ok = c->inv_followed = false;
+                c->inv_ok = false;
                 int e = grad_fetch(c, want->grad_out + (size_t)q * want->n_grad, want->n_grad, want->optimize_noise, false);
                 if (e < 0)
                     rc[q] = e;
@@ -3167,7 +2800,6 @@ static int batch_compute_impl(gpe_handle* hs, int G, int* status, const BatchWan
         for (gpe_ctx* c : order) {
             locks.emplace_back(c->mu);
             DevGuard dg(c);
-            server_stop(c);
         }
         int worst = GPE_OK;
         // Sub-batches of <= GPE_BT_MAXG GPs, up to four in flight on their own streams: while one sub-batch is in its
@@ -3255,7 +2887,6 @@ static int batch_compute_impl(gpe_handle* hs, int G, int* status, const BatchWan
     for (gpe_ctx* c : order) {
         locks.emplace_back(c->mu);
         DevGuard dg(c);
-        server_stop(c);
     }
     std::vector<char> first(G, 0); // first occurrence of a handle: the one that is enqueued (a second one would race it)
     for (int g = 0; g < G; ++g) {
@@ -3372,7 +3003,6 @@ int gpe_synchronize(gpe_handle c)
     DevGuard g(c);
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        server_stop(c);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GPE_OK;

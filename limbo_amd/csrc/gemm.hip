@@ -571,15 +571,8 @@ static void launch_glds64(hipStream_t s, const GemmArgs& g0)
     // LDS read latency in full (in-kernel stamps: 1944 cycles per 16-deep k-tile for 1024 cycles of MFMA work;
     // halving the number of k-tiles with BKT 32 changed nothing: it is the fragment-read latency before every
     // group of 16 MFMAs).  Eight waves on the tile (two per SIMD) cover each other.
-    static int v64 = -1;
-    if (v64 < 0) {
-        const char* e = getenv("GPE_GLDS64_VARIANT");
-        v64 = e ? atoi(e) : 0;
-    }
-    if ((int64_t)g.total * g_batch.G > 256 || g.grid_limit > 0 || v64 == 1)
+    if ((int64_t)g.total * g_batch.G > 256 || g.grid_limit > 0)
         launch_k(k_gemm_glds64<16, 4, 2, 4>, k_gemm_glds64<16, 4, 2, 4, true>, dim3((unsigned)tiles), dim3(256), s, g);
-    else if (v64 == 2)
-        launch_k(k_gemm_glds64<32, 3, 1, 4>, k_gemm_glds64<32, 3, 1, 4, true>, dim3((unsigned)tiles), dim3(256), s, g);
     else
         launch_k(k_gemm_glds64<16, 4, 1, 8>, k_gemm_glds64<16, 4, 1, 8, true>, dim3((unsigned)tiles), dim3(512), s, g);
 }
@@ -619,12 +612,7 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
     // the free CUs must stay free).  BKT 16 / 74 KB / <= 128 VGPRs: two workgroups per CU, so one tile's
     // prologue, epilogue and barrier stalls are covered by the other's MFMAs — 11 % faster on the
     // 465-tile update of N = 4096 (94 -> 84 us), 2-4 % slower when tiles <= CUs.
-    static int variant = -1;
-    if (variant < 0) {
-        const char* e = getenv("GPE_GLDS_VARIANT"); // tuning: force 0 / 1
-        variant = e ? atoi(e) : 2;
-    }
-    const bool two_per_cu = variant == 2 ? (g.grid_limit <= 0 && (int64_t)g.total * g_batch.G > 256) : variant == 1;
+    const bool two_per_cu = g.grid_limit <= 0 && (int64_t)g.total * g_batch.G > 256;
     // (ONE workgroup of 16 waves per CU — 2 x 8 waves of 64 x 16, or 4 x 4 of 32 x 32: four waves per SIMD from one barrier
     // group — was measured too: a lone 128 x 128 x 256 tile takes 47.9 us against 47.3 with 8 waves, 4 x 4 is 15 % slower.
     // What reaches 97 % of the matrix-core peak in the k loop is two INDEPENDENT barrier groups per CU: profiles/r03_sk_study.md)
@@ -651,7 +639,7 @@ static int64_t live_tiles(const GemmArgs& g, int TM, int TN)
     return cnt;
 }
 
-static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds64, int force, int deep32);
+static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds64, int force);
 void launch_gemm_sub(hipStream_t s, const GemmArgs& g0)
 {
     if (g0.m <= 0 || g0.n <= 0)
@@ -667,11 +655,6 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g0)
     if (force < 0) {
         const char* e = getenv("GPE_GEMM_TILE"); // debug/tuning: 128, 64 or 32
         force = e ? atoi(e) : 0;
-    }
-    static int deep32 = -1;
-    if (deep32 < 0) {
-        const char* e = getenv("GPE_GEMM_DEEP32");
-        deep32 = e ? atoi(e) : 0;
     }
     if (g0.rhs_rows > 0) {
         // Right-hand-side rows as FMAs inside the kernel (gemm_glds64.h) instead of a row of tiles: the FMAs cost every
@@ -690,19 +673,19 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g0)
         }
         if (fma) {
             q.rhs_rows = g0.rhs_rows;
-            launch_gemm_sub_impl(s, q, use_glds64, force, deep32);
+            launch_gemm_sub_impl(s, q, use_glds64, force);
         }
         else {
             q = g0;
             q.rhs_rows = 0;
-            launch_gemm_sub_impl(s, q, use_glds64, force, deep32);
+            launch_gemm_sub_impl(s, q, use_glds64, force);
         }
         return;
     }
-    launch_gemm_sub_impl(s, g0, use_glds64, force, deep32);
+    launch_gemm_sub_impl(s, g0, use_glds64, force);
 }
 
-static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds64, int force, int deep32)
+static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds64, int force)
 {
     int tile = g.tile ? g.tile : force;
     if (tile != 128 && tile != 64 && tile != 32) {
@@ -727,7 +710,7 @@ static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds6
             GemmArgs q = g;
             q.m += q.rhs_rows;
             q.rhs_rows = 0;
-            launch_gemm_sub_impl(s, q, use_glds64, force, deep32);
+            launch_gemm_sub_impl(s, q, use_glds64, force);
             return;
         }
     }
@@ -741,8 +724,6 @@ static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds6
         launch_tile<64, 64, 32, 2>(s, g);
     else if (g.k <= 64 && !g.ktri)
         launch_tile<32, 64, 64, 1>(s, g); // one-shot panel-step form
-    else if (deep32)
-        launch_tile<32, 64, 64, 2>(s, g); // latency-bound small updates: half the k iterations
     else
         launch_tile<32, 64, 32, 2>(s, g);
 }

@@ -160,14 +160,6 @@ void launch_inv_panels(hipStream_t s, const double* L, int64_t ld, int64_t N, in
     GPE_LAUNCH(k_inv_panels, dim3((unsigned)(nbo / SW), np, (unsigned)g_batch.G), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, ldo,
                        OutT, ldt, g_batch.bt, 0);
 }
-// the same for ONE panel (compact output only makes sense here: ldo == 0)
-void launch_inv_panel_one(hipStream_t s, const double* L, int64_t ld, int64_t N, int nbo, const double* Xt_all, double* Out,
-                          double* OutT, int64_t ldt, int panel)
-{
-    GPE_LAUNCH(k_inv_panels, dim3((unsigned)(nbo / SW), 1, 1), dim3(256), 0, s, L, ld, N, nbo, Xt_all, Out, (int64_t)0, OutT, ldt,
-                       (const BatchTab*)nullptr, panel);
-}
-
 __global__ void k_zero2d(double* __restrict__ A, int64_t lda, int64_t rows, int64_t cols, const BatchTab* bt)
 {
     BT_REBASE(bt, A);

@@ -7,7 +7,7 @@
 //               half-blocks; writes L11 in place and X^T = L11^-T (as Xt[k + 64 c] = X[c][k]) to a side
 //               buffer.  Since round 2 this is a data-flow of seven specialised waves (diag_flow.h, the
 //               default, also inside k_panel_step / k_upd_fused); the barrier rounds described below are
-//               what k_diag_full (ragged blocks, add_sample, load) still runs, and DIAG_FLOW=0 selects.
+//               what k_diag_full (ragged blocks, add_sample, load) still runs.
 //   k_diag_inv  the inversion alone, batched over blocks (load(..., recompute = false) and
 //               add_sample need the inverses of blocks they did not factor).
 //
@@ -220,57 +220,6 @@ struct DiagRound<-1> {
     static __device__ __forceinline__ void run(double (&)[4][4], double*, double*, int*, int, int, double*) {}
 };
 
-// ---- inversion pipelined behind the factorisation ------------------------------------------------
-// The panel steps only need the inverses of the two 32 x 32 diagonal half-blocks of L11 (the
-// triangular solve against L11 is then three small products: Y1 = A1 X11^T,
-// Y2 = (A2 - Y1 L21^T) X22^T); the off-diagonal block X21 = -X22 L21 X11 is filled in for all blocks
-// by k_xinv_complete after the factorisation, off the critical path.  The two half inverses cost a
-// quarter of the full inverse and are computed by ONE extra wave, row block by row block, one
-// round behind the factorisation: lane c = column c of X (lanes 0-31: X11 during rounds 0-7, lanes
-// 32-63: X22 during rounds 8-15), right-looking forward substitution on the identity with the 32
-// running right-hand sides in registers.  The wave executes the factor waves' barriers.
-template <int G>
-struct XPipe32 {
-    static __device__ __forceinline__ void run(double (&S)[32], const double* __restrict__ Ls,
-                                               const double* __restrict__ invd, double* __restrict__ Xt, int c)
-    {
-        XPipe32<G - 1>::run(S, Ls, invd, Xt, c);
-        ARR(G, 4);
-        __syncthreads(); // = the barrier that ends round G: columns 4G..4G+3 of L and their pivots are final
-        constexpr int hb = G >> 3, i0 = 4 * (G & 7), base = 32 * hb;
-        if ((c >> 5) == hb) {
-            const double* Lb = Ls + base * XS + base; // this half-block of L
-            const double x0 = S[i0] * invd[base + i0];
-            const double x1 = fma(-Lb[(i0 + 1) * XS + i0], x0, S[i0 + 1]) * invd[base + i0 + 1];
-            double t2 = fma(-Lb[(i0 + 2) * XS + i0], x0, S[i0 + 2]);
-            t2 = fma(-Lb[(i0 + 2) * XS + i0 + 1], x1, t2);
-            const double x2 = t2 * invd[base + i0 + 2];
-            double t3 = fma(-Lb[(i0 + 3) * XS + i0], x0, S[i0 + 3]);
-            t3 = fma(-Lb[(i0 + 3) * XS + i0 + 1], x1, t3);
-            t3 = fma(-Lb[(i0 + 3) * XS + i0 + 2], x2, t3);
-            const double x3 = t3 * invd[base + i0 + 3];
-            // rows base+i0 .. +3 of X are final: Xt[col + 64 row] = X[row][col]
-            Xt[c + NB * (base + i0 + 0)] = x0;
-            Xt[c + NB * (base + i0 + 1)] = x1;
-            Xt[c + NB * (base + i0 + 2)] = x2;
-            Xt[c + NB * (base + i0 + 3)] = x3;
-#pragma unroll
-            for (int i = i0 + 4; i < 32; ++i) { // fold the four new rows into every later row of the half-block
-                double v = S[i];
-                v = fma(-Lb[i * XS + i0 + 0], x0, v);
-                v = fma(-Lb[i * XS + i0 + 1], x1, v);
-                v = fma(-Lb[i * XS + i0 + 2], x2, v);
-                v = fma(-Lb[i * XS + i0 + 3], x3, v);
-                S[i] = v;
-            }
-        }
-    }
-};
-template <>
-struct XPipe32<-1> {
-    static __device__ __forceinline__ void run(double (&)[32], const double*, const double*, double*, int) {}
-};
-
 // (Round 2 also built 8-column rounds here — half the barriers and publishes, optionally with a 1/p update chain — and
 // measured them neutral, profiles/r02_diag_rounds.log; the data-flow form in diag_flow.h replaced that line of attack and
 // the code was removed.)
@@ -278,28 +227,8 @@ struct XPipe32<-1> {
 #define DIAG_COL(q, e, w) (16 * (q) + 4 * (w) + (e))
 #define DIAG_LTB (4 * NB * 4)
 #define DIAG_RUN(a, Ltb, invd, sbad, r, w, Ls) DiagRound<15>::run(a, Ltb, invd, sbad, r, w, Ls)
-static __device__ __forceinline__ void xpipe32_wave(const double* __restrict__ Ls, const double* __restrict__ invd,
-                                                    double* __restrict__ Xt, int c)
-{
-    double S[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k)
-        S[k] = (k == (c & 31)) ? 1.0 : 0.0;
-    XPipe32<15>::run(S, Ls, invd, Xt, c);
-}
-
-#ifndef DIAG_FLOW
-#define DIAG_FLOW 1 // 1: the data-flow form of the block factorisation (diag_flow.h); 0: the barrier rounds above
-#endif
 #include "diag_flow.h"
-#ifndef TRSM_FULL
-#define TRSM_FULL (DIAG_FLOW) // the panel steps solve against L11 with all of its inverse (one product); 0: half-block form
-#endif
-#if DIAG_FLOW
 #define DIAG_THREADS 512
-#else
-#define DIAG_THREADS 320
-#endif
 
 // ---- inversion of the 64 x 64 lower-triangular L (in LDS, Ls[row * XS + col]) --------------------
 // acc[n] += sum_{k < 16} P[i0 + i][pk0 + k] * Q[qk0 + k][j0 + 4 n + j]   (16 x 16 x 16, n in [n0, n1))
@@ -403,9 +332,7 @@ static __device__ __forceinline__ void store_Xt(const double* __restrict__ Xs, d
 }
 
 // The block the fused panel steps start from: L11 in place and X^T = L11^-T into Xt (the quarter above the
-// diagonal stays zero).  DIAG_FLOW = 0 (the barrier rounds): only the inverses of the two 32 x 32 diagonal
-// half-blocks, the quarter X21 is completed later by k_xinv_complete.  Waves 0-3 factor, wave 4
-// runs the inversion pipeline.  Full 64 x 64 blocks only.
+// diagonal stays zero), by the data-flow form of diag_flow.h.  Full 64 x 64 blocks only.
 static __device__ __forceinline__ void diag_body(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
                                                  int* __restrict__ info, int64_t goff)
 {
@@ -413,7 +340,6 @@ static __device__ __forceinline__ void diag_body(double* __restrict__ A, int64_t
     __shared__ __attribute__((aligned(16))) double Ltb[DIAG_LTB];
     __shared__ __attribute__((aligned(16))) double invd[NB];
     const int r = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#if DIAG_FLOW
     __shared__ DiagSync sy;
     __shared__ __attribute__((aligned(16))) double Xw[DIAG_XW_DOUBLES];
     static_assert(DIAG_H_DOUBLES <= DIAG_LTB, "H fits where the round buffers were");
@@ -426,40 +352,6 @@ static __device__ __forceinline__ void diag_body(double* __restrict__ A, int64_t
     diag_flow(Ls, Ltb, invd, &sy, A, lda, Xt, info, goff, w, r, Xw);
     TS(2);
     return;
-#endif
-    __shared__ int sbad;
-    if (threadIdx.x == 0)
-        sbad = 0;
-    double a[4][4];
-    if (w < 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = DIAG_COL(q, e, w);
-                a[q][e] = (c <= r) ? A[r + (int64_t)c * lda] : 0.0; // only the lower triangle is meaningful
-            }
-    }
-    TS(0);
-    __syncthreads();
-    TS(1);
-    if (w == 4) {
-        xpipe32_wave(Ls, invd, Xt, r);
-        return;
-    }
-    DIAG_RUN(a, Ltb, invd, &sbad, r, w, Ls);
-    TS(2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = DIAG_COL(q, e, w);
-            if (c <= r)
-                A[r + (int64_t)c * lda] = a[q][e];
-        }
-    if (threadIdx.x == 0 && sbad != 0 && *info == 0)
-        *info = (int)(goff + sbad);
-    TS(3);
 }
 // entry points: single GP (the round-1 kernel, unchanged) / batched (gridDim.z GPs, pointers rebased; dev.h)
 __global__ __launch_bounds__(DIAG_THREADS) void k_diag(double* __restrict__ A, int64_t lda, double* __restrict__ Xt,
@@ -621,53 +513,6 @@ static __device__ __forceinline__ void mm64(const double* __restrict__ Aop, cons
     mmk<BKM, NB, 4>(Aop, 0, Bop, 0, wm, wn, lane, acc);
 }
 
-#if !TRSM_FULL
-// T (64 x 64 tile, [kk = col][i = row], stride PS) <- T L11^-T with the half-block form of the inverse:
-//   Y1 = T[:, 0:32] X11^T ;  Y2 = (T[:, 32:64] - Y1 L21^T) X22^T          (L11 = [[L1, 0], [L21, L2]])
-// Bx[c * XS + k] = X[c][k] (diagonal quarters valid), Ld[c * XS + k] = L21[c][k].  512 threads, in
-// place, starts and ends with a barrier-consistent state (callers sync before reading T).
-// 8 waves: 2 (rows) x 4 (column groups of 8) per 32-column half.
-static __device__ __forceinline__ void trsm_tile_half(double* __restrict__ T, const double* __restrict__ Bx,
-                                                      const double* __restrict__ Ld, int lane, int wave)
-{
-    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 8; // column within the 32-column half
-    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
-    double y1[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    mmk<true, 32, 2>(T, 0, Bx, 0, wm, wn, lane, y1); // Y1 = T1 X11^T
-    __syncthreads();                                 // all reads of T[:, 0:32] done
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-            T[(wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y1[m][n];
-    __syncthreads();
-    double u[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    mmk<true, 32, 2>(T, 0, Ld, 0, wm, wn, lane, u); // Y1 L21^T
-    double t2[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-            t2[m][n] = T[(32 + wn + 4 * n + dcol) * PS + wm + 16 * m + drow] - u[m][n];
-    __syncthreads(); // every wave has read its part of T[:, 32:64]
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-            T[(32 + wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = t2[m][n];
-    __syncthreads();
-    double y2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    mmk<true, 32, 2>(T, 32, Bx + 32 * XS + 32, 0, wm, wn, lane, y2); // Y2 = T2 X22^T
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-            T[(32 + wn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
-    __syncthreads();
-}
-
-#endif
 // The same solve with ALL of X = L11^-1 (lower triangular; diag_flow.h leaves the off-diagonal quarter too): ONE product,
 // Y[i][c] = sum_{k <= c} T[i][k] X[c][k], two barriers instead of six.  A wave's 16 columns need k < wn + 16 only.
 static __device__ __forceinline__ void trsm_tile_full(double* __restrict__ T, const double* __restrict__ Bx, int lane, int wave)
@@ -760,24 +605,18 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
                                                        int64_t dnext, int64_t dfirst, int dinit, double* __restrict__ Dacc,
                                                        gpe_epoch_t* hflag, gpe_epoch_t epoch, int spin_limit, const int bx)
 {
-    // one LDS array, carved: [Bx | T0 | T1 (| Ld: half-block form only)]; workgroup 0 re-carves it as [Ls | Ltb | invd | sync | Xw]
-    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS + (TRSM_FULL ? 0 : 32 * XS)];
+    // one LDS array, carved: [Bx | T0 | T1]; workgroup 0 re-carves it as [Ls | Ltb | invd | sync | Xw]
+    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 2 * NB * PS];
     static_assert(NB * XS + DIAG_LTB + NB + 8 + DIAG_XW_DOUBLES <= NB * XS + 2 * NB * PS, "workgroup 0's carve fits");
-    __shared__ int sbad;
     double* Bx = lds;
     double* T0 = lds + NB * XS;
     double* T1 = T0 + NB * PS;
-#if !TRSM_FULL
-    double* Ld = T1 + NB * PS; // L21 of the current diagonal block, Ld[c * XS + k] = L[32 + c][k]
-#endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
     const int b = bx;
     const int64_t r0 = j0 + NB, R0 = r0 + (int64_t)NB * b;
     const int nrows = (int)((M - R0 < NB) ? M - R0 : NB);
     const int tmax = (b < nt - 1) ? b : nt - 1;
-    if (threadIdx.x == 0)
-        sbad = 0;
 
     // every global load this workgroup needs before its first product goes out now: X, its own
     // tile, and the head tiles it will re-derive (one exposed memory latency instead of one per tile)
@@ -794,26 +633,11 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
         if (t <= tmax && t != b)
             head[t].load(A + r0 + (int64_t)NB * t + j0 * lda, lda, NB);
 #endif
-#if !TRSM_FULL
-    double ldv[2]; // L21 of the diagonal block at (j0, j0): rows 32..63, columns 0..31
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int e = threadIdx.x + 512 * q; // e = c + 32 k  (c = row of L21, contiguous in memory)
-        ldv[q] = A[j0 + 32 + (e & 31) + (j0 + (e >> 5)) * lda];
-    }
-#endif
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int e = threadIdx.x + 512 * q;
         Bx[(e >> 6) * XS + (e & 63)] = xv[q]; // Bx[c][k] = X[c][k]
     }
-#if !TRSM_FULL
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int e = threadIdx.x + 512 * q;
-        Ld[(e & 31) * XS + (e >> 5)] = ldv[q];
-    }
-#endif
     own.store(T0);
     // the C tile of the first update (for workgroup 0: the next diagonal block) is fetched now, under
     // the triangular solve, instead of at the top of the update loop
@@ -831,11 +655,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
     PTS(1);
 
     // 1. L_b = A_b L11^-T  (half-block form of the inverse, in place in T0)
-#if TRSM_FULL
     trsm_tile_full(T0, Bx, lane, wave);
-#else
-    trsm_tile_half(T0, Bx, Ld, lane, wave);
-#endif
     PTS(2);
     {
         // Row blocks b < nt are the "head" tiles other workgroups re-derive from A while this one
@@ -951,11 +771,7 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
             }
             __syncthreads();
             if (!handed) {
-#if TRSM_FULL
                 trsm_tile_full(T1, Bx, lane, wave);
-#else
-                trsm_tile_half(T1, Bx, Ld, lane, wave);
-#endif
             }
             Bop = T1;
         }
@@ -1030,7 +846,6 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
 #pragma unroll
     for (int it = 0; it < 8; ++it)
         Ls[crow * XS + ccol + 2 * it] = cres[it];
-#if DIAG_FLOW
     {
         DiagSync* sy = reinterpret_cast<DiagSync*>(invd + NB);
         diag_flow_init(sy);
@@ -1040,43 +855,6 @@ static __device__ __forceinline__ void panel_step_body(double* __restrict__ A, i
         PTS(6);
         return;
     }
-#endif
-    __syncthreads();
-    // the serial part runs on waves 0-3 (k_diag's code), the inversion pipeline on wave 4; waves
-    // 5..7 end here — s_barrier only counts the waves of the workgroup that are still alive
-    if (wave >= 5)
-        return;
-    const int r = lane, w = wave;
-    double a[4][4];
-    if (w < 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = DIAG_COL(q, e, w);
-                a[q][e] = (c <= r) ? Ls[r * XS + c] : 0.0;
-            }
-    }
-    __syncthreads();
-    if (w == 4) {
-        xpipe32_wave(Ls, invd, Xt_next, r);
-        return;
-    }
-    PTS(5);
-    DIAG_RUN(a, Ltb, invd, &sbad, r, w, Ls);
-    PTS(6);
-    double* Ad = A + r0 + r0 * lda;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = DIAG_COL(q, e, w);
-            if (c <= r)
-                Ad[r + (int64_t)c * lda] = a[q][e];
-        }
-    if (threadIdx.x == 0 && sbad != 0 && *info == 0)
-        *info = (int)(r0 + sbad);
-    PTS(7);
 }
 // entry points: single GP (the round-1 kernel, unchanged) / batched.  Batched: blockIdx.x = b * G + gp, so that workgroup 0
 // of every GP (the one that goes on to factor the next diagonal block, twice as long as the others) is dispatched first
@@ -1324,7 +1102,13 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
                 x.info[2] = 1;
                 break;
             }
-            poll_one(Sq + 2048 + 1023, x.spin_limit, x.info); // X22's last row
+            // (the workgroup that factors next — acc_on — is ONE workgroup and the chain waits for it: its threads watch
+            // their own words, which saves the second round trip behind poll_one's; everybody else watches one word first)
+#ifndef CRIT_POLL
+#define CRIT_POLL 1
+#endif
+            if (!(CRIT_POLL && acc_on))
+                poll_one(Sq + 2048 + 1023, x.spin_limit, x.info); // X22's last row
             if (b0 == SENT)
                 b0 = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (b1 == SENT)
@@ -1990,13 +1774,11 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
     a.LPn = buf_next + (int64_t)a.nt * 3072;
     static const bool fault = getenv("GPE_HANDOVER_FAULT") && atoi(getenv("GPE_HANDOVER_FAULT")) != 0;
     a.spin_limit = fault ? -16 : GPE_FLOW_SPIN_LIMIT;
-    static const int ord_w = getenv("GPE_TAIL_W") ? atoi(getenv("GPE_TAIL_W")) : 0;
     // measured (profiles/r04_dispatch_order.log, N = 4096): lag 2..4 -> 794-800 evaluations/s against 735 column by column; a
     // just-in-time window W > 0 LOSES (6: 675, 8: 694, 12: 738, 16: 770): a tile dispatched late has its catch-up products still
     // to do when its row's diagonal workgroup asks for it; waiting workgroups are not what limits the closing launch
     static const int ord_lag = getenv("GPE_TAIL_LAG") ? atoi(getenv("GPE_TAIL_LAG")) : 3;
-    static const int ord_wb = getenv("GPE_TAIL_W_BATCH") ? atoi(getenv("GPE_TAIL_W_BATCH")) : ord_w;
-    a.order = tail_order(a.nt, a.nb, g_batch.bt ? ord_wb : ord_w, ord_lag);
+    a.order = tail_order(a.nt, a.nb, 0, ord_lag); // (W: the just-in-time window of the table, measured as a loss — kept in tail_order for the record)
     const int64_t tiles = tail_tiles(a.nt, a.nb);
     if (g_batch.bt)
         GPE_LAUNCH(k_tail_b, dim3((unsigned)(tiles * g_batch.G)), dim3(512), 0, s, a, g_batch.bt);
@@ -2012,85 +1794,18 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
 // products of 64^3 — and then factors and half-inverts it exactly like workgroup 0 of k_panel_step.
 // k_diag used to follow the update as a launch of its own (13.6 us on the critical path of every
 // outer panel, with 255 CUs idle); here it runs underneath the update (~18 us).
+// (Round 3 also folded the panel's last 64-column step into this launch — UpdFold — for the step-by-step panels; the
+// one-launch panels made it unreachable and round 4 removed it.)
 // ---------------------------------------------------------------------------------------------
-// Round 3 — `fold` (j4 >= 0): the launch also does the panel's LAST 64-column step.  That step (k_panel_step with nt = 0) only
-// solves L4 = A4 X3^T for the rows below the panel — 9.7 us of kernel plus a launch boundary on the critical path of every panel,
-// with nothing to update and no diagonal block to factor.  Here every tile workgroup forms the two L4 tiles it needs itself
-// (its row block's and its column block's: one 64^3 product each with X3 = inverse of the panel's last diagonal block, from
-// k_panel_step's third step), multiplies the first 192 columns of the panel through the direct-to-LDS loop as before and the
-// last 64 from those tiles in LDS.  The row block's L4 goes out to a scratch panel L4s (the workgroups of its tile column 0
-// write it): in place it would be read, as A4, by the workgroups of other tile rows of this same launch; the look-ahead
-// stream copies it into A in front of its updates.  The diagonal workgroup adds the L4 L4^T piece of ITS block itself.
-struct UpdFold {
-    const double* A; // the matrix (rows from pe on are the tile rows of this launch)
-    int64_t lda, pe, j4;
-    const double* X3; // Xt[k + 64 c] = (L33^-1)[c][k]
-    double* L4s;      // scratch panel, (M - pe) x 64, leading dimension ld4
-    int64_t ld4;
-    double* T1;       // LDS: this tile's row block of L4, [kk][i], stride PS
-    double* T2;       // LDS: its column block's
-    double* Bx;       // LDS (inside the operand stages, before they are requested): X3 as Bx[c * XS + k]
-    mutable bool same;
-    __device__ __forceinline__ void pre(int ti, int tj, int64_t row0, int64_t col0, int mr, int nc) const
-    {
-        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        same = ti == tj;
-        TileRegs ta, tb;
-        ta.load(A + pe + row0 + j4 * lda, lda, mr);
-        if (!same)
-            tb.load(A + pe + col0 + j4 * lda, lda, nc);
-        double xv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            xv[q] = X3[threadIdx.x + 512 * q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = threadIdx.x + 512 * q;
-            Bx[(e >> 6) * XS + (e & 63)] = xv[q]; // Bx[c][k] = X[c][k]
-        }
-        ta.store(T1);
-        if (!same)
-            tb.store(T2);
-        __syncthreads();
-        trsm_tile_full(T1, Bx, lane, wave);
-        if (!same)
-            trsm_tile_full(T2, Bx, lane, wave);
-        if (tj == 0) { // this row block's piece of the panel's last 64 columns of L
-            const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int col = kk0 + 8 * q;
-                if (i < mr)
-                    L4s[row0 + i + (int64_t)col * ld4] = T1[col * PS + i];
-            }
-        }
-        __syncthreads(); // Bx (inside the operand stages) is dead from here on
-    }
-    template <int RA_, int RB_>
-    __device__ __forceinline__ void post(double (&acc)[RA_][RB_], int wm, int wn) const
-    {
-        static_assert(RA_ == 2 && RB_ == 4, "the 8-wave 64 x 64 body");
-        mm64<false>(T1, same ? T1 : T2, wm, wn, threadIdx.x & 63, acc);
-    }
-};
-
 __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restrict__ A, int64_t lda, int64_t p0, int64_t pe,
                                                    double* __restrict__ Xt_next, int* __restrict__ info,
-                                                   const double* __restrict__ Dacc, int64_t j4, const double* __restrict__ X3,
-                                                   double* __restrict__ L4s, int64_t ld4)
+                                                   const double* __restrict__ Dacc)
 {
     constexpr int GEMM_LDS = 4 * Glds64Shape<16>::STAGE, DIAG_LDS = 2 * NB * PS;
-    static_assert(NB * XS <= GEMM_LDS, "X3 fits into the operand stages");
-    __shared__ __attribute__((aligned(16))) double lds[GEMM_LDS + 2 * NB * PS]; // [4 stages | T1 | T2] (T1, T2: fold only)
-    static_assert(GEMM_LDS + 2 * NB * PS >= DIAG_LDS, "the diagonal workgroup carves its tiles out of the same array");
-    __shared__ int sbad;
+    constexpr int LDS_DOUBLES = GEMM_LDS > DIAG_LDS ? GEMM_LDS : DIAG_LDS;
+    __shared__ __attribute__((aligned(16))) double lds[LDS_DOUBLES]; // the update's 4 operand stages / the diagonal workgroup's tiles
     if (blockIdx.x + 1 < gridDim.x) {
-        if (j4 >= 0) {
-            UpdFold h{A, lda, pe, j4, X3, L4s, ld4, lds + GEMM_LDS, lds + GEMM_LDS + NB * PS, lds, false};
-            gemm_glds64_body<16, 4, 8, UpdFold>(g, lds, (int)blockIdx.x, (int)gridDim.x - 1, true, h);
-        }
-        else
-            gemm_glds64_body<16, 4, 8>(g, lds, (int)blockIdx.x, (int)gridDim.x - 1, true);
+        gemm_glds64_body<16, 4, 8>(g, lds, (int)blockIdx.x, (int)gridDim.x - 1, true);
         return;
     }
     // ---- the diagonal workgroup ----
@@ -2101,8 +1816,6 @@ __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restric
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
     const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
-    if (threadIdx.x == 0)
-        sbad = 0;
     double c0v[8]; // the tile before the update, lane = row layout
 #pragma unroll
     for (int it = 0; it < 8; ++it)
@@ -2117,32 +1830,6 @@ __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restric
 #pragma unroll
         for (int n = 0; n < 4; ++n)
             acc[m][n] = 0.0;
-    if (j4 >= 0) { // fold: the piece of the panel's last step, L4 L4^T with L4 = A4 X3^T for this block's rows
-        TileRegs t4;
-        t4.load(A + pe + j4 * lda, lda, NB);
-        double xv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            xv[q] = X3[threadIdx.x + 512 * q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = threadIdx.x + 512 * q;
-            T1[(e >> 6) * XS + (e & 63)] = xv[q]; // (T1 as Bx: 64 x XS <= 64 x PS)
-        }
-        t4.store(T0);
-        __syncthreads();
-        trsm_tile_full(T0, T1, lane, wave);
-        mm64<false>(T0, T0, wm, wn, lane, acc);
-        { // tile (0, 0) has no workgroup of its own: this block's rows of the panel's last 64 columns of L go out from here
-            const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int col = kk0 + 8 * q;
-                L4s[i + (int64_t)col * ld4] = T0[col * PS + i];
-            }
-        }
-        __syncthreads();
-    }
 #pragma unroll 1
     for (int c = 0; c < nkb; ++c) { // two tiles alternate: a wave that refills one has passed the barrier behind its last readers
         double* T = (c & 1) ? T1 : T0;
@@ -2163,7 +1850,6 @@ __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restric
         for (int it = 0; it < 8; ++it) // Dacc: what the panel steps summed up (same thread <-> element mapping)
             Ls[crow * XS + ccol + 2 * it] = c0v[it] - a2r[it] - (Dacc ? Dacc[threadIdx.x + 512 * it] : 0.0);
     }
-#if DIAG_FLOW
     {
         DiagSync* sy = reinterpret_cast<DiagSync*>(invd + NB);
         diag_flow_init(sy);
@@ -2171,43 +1857,11 @@ __global__ __launch_bounds__(512) void k_upd_fused(GemmArgs g, double* __restric
         diag_flow(Ls, Ltb, invd, sy, A + pe + pe * lda, lda, Xt_next, info, pe, wave, lane, invd + NB + 8);
         return;
     }
-#endif
-    __syncthreads();
-    if (wave >= 5)
-        return; // s_barrier only counts the waves that are still alive
-    const int r = lane, w = wave;
-    double a[4][4];
-    if (w < 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = DIAG_COL(q, e, w);
-                a[q][e] = (c <= r) ? Ls[r * XS + c] : 0.0;
-            }
-    }
-    __syncthreads();
-    if (w == 4) {
-        xpipe32_wave(Ls, invd, Xt_next, r);
-        return;
-    }
-    DIAG_RUN(a, Ltb, invd, &sbad, r, w, Ls);
-    double* Ad = A + pe + pe * lda;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = DIAG_COL(q, e, w);
-            if (c <= r)
-                Ad[r + (int64_t)c * lda] = a[q][e];
-        }
-    if (threadIdx.x == 0 && sbad != 0 && *info == 0)
-        *info = (int)(pe + sbad);
 }
 
 // g: the next-panel update as for launch_gemm_sub (tri, 64-multiple shapes checked by the caller)
 void launch_upd_fused(hipStream_t s, const GemmArgs& g0, double* A, int64_t lda, int64_t p0, int64_t pe, double* Xt_next,
-                      int* info, const double* Dacc, int64_t j4, const double* X3, double* L4s, int64_t ld4)
+                      int* info, const double* Dacc)
 {
     constexpr int TM = 64, TN = 64;
     GemmArgs g = g0;
@@ -2225,9 +1879,9 @@ void launch_upd_fused(hipStream_t s, const GemmArgs& g0, double* A, int64_t lda,
     g.total = nsup * fold;
     const dim3 grid((unsigned)g.total + 1), block(512);
     if (g.stop_event)
-        GPE_LAUNCH_STOP("k_upd_fused", k_upd_fused, grid, block, 0, s, (hipEvent_t)g.stop_event, g, A, lda, p0, pe, Xt_next, info, Dacc, j4, X3, L4s, ld4);
+        GPE_LAUNCH_STOP("k_upd_fused", k_upd_fused, grid, block, 0, s, (hipEvent_t)g.stop_event, g, A, lda, p0, pe, Xt_next, info, Dacc);
     else
-        GPE_LAUNCH(k_upd_fused, grid, block, 0, s, g, A, lda, p0, pe, Xt_next, info, Dacc, j4, X3, L4s, ld4);
+        GPE_LAUNCH(k_upd_fused, grid, block, 0, s, g, A, lda, p0, pe, Xt_next, info, Dacc);
 }
 
 #ifdef DIAG_TIMING
@@ -2323,41 +1977,6 @@ void launch_head_copy(hipStream_t s, double* A, int64_t lda, int64_t p0, int nt0
         tiles += nt0 - f;
     if (tiles > 0)
         GPE_LAUNCH(k_head_copy, dim3((unsigned)tiles, 1, g_batch.G), dim3(256), 0, s, A, lda, p0, nt0, H, g_batch.bt);
-}
-
-// Off-diagonal quarter of the block inverses left by the half-form kernels: for blocks b0..b0+n-1
-// of the factor L (all full 64 x 64), X21 = -X22 L21 X11 into Xt_all + 4096 b.  Idempotent on a
-// block whose inverse is already complete.
-__global__ __launch_bounds__(256) void k_xinv_complete(const double* __restrict__ L, int64_t ldl, int64_t b0,
-                                                       double* __restrict__ Xt_all, const BatchTab* __restrict__ bt)
-{
-    BT_REBASE(bt, L);
-    BT_REBASE(bt, Xt_all);
-    __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
-    __shared__ __attribute__((aligned(16))) double Xs[NB * XS];
-    __shared__ __attribute__((aligned(16))) double Ts[NB * XS];
-    const int64_t b = b0 + blockIdx.x, j0 = b * NB;
-    double* Xt = Xt_all + b * (NB * NB);
-    const double* L11 = L + j0 + j0 * ldl;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
-        const int r = e & 63, c = e >> 6;
-        Ls[r * XS + c] = (c <= r) ? L11[r + (int64_t)c * ldl] : 0.0;
-        Xs[c * XS + r] = Xt[e]; // Xt[k + 64 c] = X[c][k]
-    }
-    __syncthreads();
-    invert_level2(Ls, Xs, Ts);
-    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
-        const int k = e & 31, c = 32 + (e >> 5);
-        Xt[k + NB * c] = Xs[c * XS + k];
-    }
-}
-void launch_xinv_complete(hipStream_t s, const double* L, int64_t ldl, int64_t b0, int64_t nblocks, double* Xt_all)
-{
-#if DIAG_FLOW
-    return; // the data-flow block factorisation leaves all of X (diag_flow.h: flow_w_wave, flow_x21)
-#endif
-    if (nblocks > 0)
-        GPE_LAUNCH(k_xinv_complete, dim3((unsigned)nblocks, 1, g_batch.G), dim3(256), 0, s, L, ldl, b0, Xt_all, g_batch.bt);
 }
 
 // inverses of the diagonal blocks of an existing factor: block b at L[64 b, 64 b]

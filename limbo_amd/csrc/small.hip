@@ -229,9 +229,9 @@ struct SmallX {
     double v[GPE_MAX_THETA];
 };
 
-// The bodies of the three calls.  As kernels of their own (one launch per call) and, for a run of calls on one GP, as
-// requests served by ONE persistent workgroup (k_small_server below): then the factor's tiles T and the block inverses
-// S.Xs stay where they are between requests (`reload` = false).
+// The bodies of the three calls (`reload` = false: the factor's tiles T and the block inverses S.Xs are where an earlier
+// call of the same workgroup left them — the resident-workgroup form of round 3, measured 2 us slower per call than a launch
+// and removed in round 4: profiles/r03_small_server_latency.log; the kernels below always reload).
 template <int P>
 static __device__ __forceinline__ void small_add_body(const SmallAddArgs& g, const KParams& kp, const LamParams& lp,
                                                       const double* xnew, SmallLds& S, double (&T)[SM_NT], bool reload)
@@ -482,133 +482,8 @@ __global__ __launch_bounds__(SM_T) void k_small_alpha(SmallAlphaArgs g)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The BO inner loop as REQUESTS to one persistent workgroup (bayes_opt/boptimizer.hpp:148-161: one add_sample, then
-// thousands of query() calls per iteration, all on one GP of <= 256 samples).  A launch per call costs ~12 us before the
-// first instruction runs; here the host writes the request into a pinned, coherent mailbox and raises its sequence word,
-// the workgroup — resident on one CU, the factor's tiles in its registers and the block inverses in its LDS — polls the
-// word over PCIe, copies the request into LDS (one 8-byte load per thread), runs the body and writes the results and the
-// completion word straight back to pinned memory, as the one-launch kernels do.  It leaves by itself after `idle_ticks`
-// (100 MHz ticks) without a request — a device-wide synchronisation elsewhere in the process (hipFree, hipDeviceSynchronize)
-// waits for it — and on request (op 0xFF: any other call on the handle); it tells the host through mb->state.
-// a wave-uniform struct read from LDS, moved into scalar registers word by word (as a kernel argument would be: left in
-// vector registers the pointers and sizes of a request cost the server ~100 VGPRs and it spilled)
-template <class T>
-static __device__ __forceinline__ T to_sgprs(const T& v)
-{
-    static_assert(sizeof(T) % 4 == 0, "dwords");
-    T out;
-    const int* src = (const int*)&v;
-    int* dst = (int*)&out;
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(T) / 4); ++i)
-        dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
-    return out;
-}
-
-__global__ __launch_bounds__(SM_T) void k_small_server(SmallMailbox* mb, unsigned long long seen0, long long idle_ticks)
-{
-    __shared__ SmallLds S;
-    __shared__ __attribute__((aligned(16))) SmallMailbox R; // the request being served
-    __shared__ unsigned long long s_seq;
-    __shared__ int s_leave;
-    const int tid = threadIdx.x;
-    unsigned long long seen = seen0;
-    // it also leaves after 5 idle periods of service, busy or not: work submitted before that — above all a device-wide
-    // synchronisation in another thread (hipFree waits for every stream) — is never starved by a caller that keeps it busy
-    const long long t_born = wall_clock64(), life_ticks = 5 * idle_ticks;
-    // (Keeping the factor's tiles in registers BETWEEN requests was tried: with the three bodies in one function the
-    // register file does not hold them — 256 VGPRs and 344 bytes of scratch — so every request loads them as the
-    // one-launch kernels do: 320 KB from L2, ~2 us.)
-    for (;;) {
-        if (tid == 0) {
-            const long long t0 = wall_clock64();
-            unsigned long long q;
-            for (;;) {
-                q = __hip_atomic_load(&mb->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (q != seen)
-                    break;
-                if (wall_clock64() - t0 > idle_ticks) {
-                    q = ~0ull;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            s_seq = q;
-        }
-        __syncthreads();
-        const unsigned long long q = s_seq;
-        const long long t_seen = wall_clock64();
-        if (q == ~0ull) { // idle: leave (the host relaunches on its next request)
-            if (tid == 0) {
-                __hip_atomic_store(&mb->state, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                __threadfence_system();
-            }
-            return;
-        }
-        { // the request, word by word
-            constexpr int NW = (int)(sizeof(SmallMailbox) / 8);
-            static_assert(sizeof(SmallMailbox) % 8 == 0 && NW <= 2 * SM_T, "mailbox size");
-            const unsigned long long* src = (const unsigned long long*)mb;
-            unsigned long long* dst = (unsigned long long*)&R;
-            for (int w = tid; w < NW; w += SM_T)
-                dst[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        __syncthreads();
-        const int op = __builtin_amdgcn_readfirstlane(R.op);
-        const long long t_copied = wall_clock64();
-        if (op == GPE_SMALL_OP_EXIT) {
-            if (tid == 0) {
-                __hip_atomic_store(&mb->state, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                __threadfence_system();
-            }
-            return;
-        }
-        {
-            // T is defined afresh in every round: left undefined on some path it becomes loop-carried and pins its 96
-            // registers across the whole loop (256 VGPRs + scratch spills otherwise)
-            double T[SM_NT];
-#pragma unroll
-            for (int i = 0; i < SM_NT; ++i)
-                T[i] = 0.0;
-            if (op == GPE_SMALL_OP_ADD)
-                small_add_body<1>(to_sgprs(R.add), R.kp, R.lp, R.x, S, T, true); // (one output: the host sends nothing else this way)
-            else if (op == GPE_SMALL_OP_QUERY) {
-                const SmallQueryArgs gq = to_sgprs(R.qry);
-                for (int m = 0; m < gq.M; ++m) {
-                    small_query_body(gq, R.kp, R.lp, m, S, T, true);
-                    __syncthreads();
-                }
-            }
-            else if (op == GPE_SMALL_OP_ALPHA)
-                small_alpha_body<1>(to_sgprs(R.alp), S, T, true);
-        }
-        seen = q;
-        __syncthreads();
-        if (tid == 0) {
-            mb->t_seen = t_seen;
-            mb->t_copied = t_copied;
-            mb->t_done = wall_clock64();
-        }
-        if (tid == 0) // (thread 0's reading of the clock decides for everybody, through LDS)
-            s_leave = wall_clock64() - t_born > life_ticks ? 1 : 0;
-        __syncthreads();
-        if (s_leave == 1) {
-            if (tid == 0) {
-                __hip_atomic_store(&mb->state, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                __threadfence_system();
-            }
-            return;
-        }
-    }
-}
-
 // ---- host side ------------------------------------------------------------------------------------------------------
 int small_max_n() { return SM_NBLK * NB; }
-
-void launch_small_server(hipStream_t s, SmallMailbox* mb, unsigned long long seen0, long long idle_ticks)
-{
-    GPE_LAUNCH(k_small_server, dim3(1), dim3(SM_T), 0, s, mb, seen0, idle_ticks);
-}
 
 void launch_small_add(hipStream_t s, const SmallAddArgs& g, int P, const KParams& kp, const LamParams& lp, const double* x)
 {

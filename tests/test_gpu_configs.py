@@ -111,11 +111,20 @@ def test_gpu_c4_batch_64_vs_oracle(engine_lib, oracle_lib):
         single.set_kernel(O.SE_ARD, ths[g], 0.01)
         assert single.compute() == 0
         assert abs(single.log_lik() - ll[g]) <= 1e-12 * abs(ll[g]), g
-        if g in (0, 31, 63):
-            # round 4: N = 2048 is ONE data-flow launch (k_tail) in both forms — the batched one interleaves the members'
-            # tiles in its grid (k_tail_b), every tile does the same arithmetic in the same order: the factor is bitwise equal
-            assert np.array_equal(np.tril(single.get_L()), np.tril(hs[g].get_L())), g
+    # round 4: a batch of EIGHT (BASELINE configs[3] per GPU) takes the data-flow launch in its batched form (k_tail_b: the
+    # members' tiles interleaved in one grid; 64 members stay with the step-by-step panels, engine.hip: tail_plan) — every tile
+    # does the same arithmetic in the same order as the single-handle launch: the factor is bitwise equal
+    assert _capi.batch_compute(hs[:8]) == [0] * 8
+    ll8 = _capi.batch_log_lik(hs[:8])
+    assert np.max(np.abs(ll8 - ll[:8]) / np.abs(ll[:8])) <= 1e-12
+    for g in (0, 5, 7):
+        single.set_data(X, oms[g])
+        single.set_kernel(O.SE_ARD, ths[g], 0.01)
+        assert single.compute() == 0
+        assert np.array_equal(np.tril(single.get_L()), np.tril(hs[g].get_L())), g
     single.close()
+    assert _capi.batch_compute(hs) == [0] * G  # (back to the full batch for the reproducibility check below)
+    assert np.array_equal(_capi.batch_log_lik(hs), ll)
     assert _capi.batch_compute(hs) == [0] * G  # the batched launch sequence itself is bitwise reproducible
     assert np.array_equal(_capi.batch_log_lik(hs), ll)
     for h in hs:
@@ -346,19 +355,18 @@ def test_gpu_panel_head_tiles_handed_over_or_rederived_give_the_same_factor(engi
             "np.save(%r, np.tril(h.get_L()))\n"
             "print('child ok')\n") % (str(ROOT), N, str(f))
     Ls = {}
-    for tag, extra in (("no_handover", {"GPE_PANEL_HANDOVER": "0"}), ("handover_unfolded", {"GPE_FOLD4": "0", "GPE_PANEL256": "0"}),
-                       ("handover_folded", {"GPE_PANEL256": "0"})):
+    for tag, extra in (("no_handover", {"GPE_PANEL_HANDOVER": "0"}), ("handover_steps", {"GPE_PANEL256": "0", "GPE_TAIL_MAX": "0"}),
+                       ("handover_panel256", {"GPE_TAIL_MAX": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
         assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
         Ls[tag] = np.load(f)
     # handed over or re-derived: the same products in the same order, bitwise the same factor
-    assert np.array_equal(Ls["no_handover"], Ls["handover_unfolded"]), float(np.max(np.abs(Ls["no_handover"] - Ls["handover_unfolded"])))
-    # the step-by-step default (GPE_PANEL256=0) folds the panel's last step into the fused next-panel update (potrf.hip:
-    # UpdFold): the last 64 columns of a panel enter that update from LDS tiles instead of through the direct-to-LDS loop —
-    # another grouping of the same sum; the default (k_panel256: the whole panel as one data-flow launch) solves the factoring
-    # strips' tiles in the half-block form of the inverse and sums the next diagonal block's pieces in one accumulator
-    assert np.max(np.abs(Ls["no_handover"] - Ls["handover_folded"])) <= 1e-13 * np.max(np.abs(L1))
+    assert np.array_equal(Ls["no_handover"], Ls["handover_steps"]), float(np.max(np.abs(Ls["no_handover"] - Ls["handover_steps"])))
+    # k_panel256 (the whole panel as one data-flow launch) solves the factoring strips' tiles in the half-block form of the
+    # inverse and sums the next diagonal block's pieces in one accumulator; the default (N = 1100 <= 2560: the whole matrix as
+    # ONE k_tail launch) groups the same sums by 64-column tile: another order of the same arithmetic
+    assert np.max(np.abs(Ls["no_handover"] - Ls["handover_panel256"])) <= 1e-13 * np.max(np.abs(L1))
     assert np.max(np.abs(Ls["no_handover"] - L1)) <= 1e-13 * np.max(np.abs(L1))
 
 
@@ -880,61 +888,3 @@ def test_gpu_batch_hp_objective_vs_single_and_oracle(engine_lib, oracle_lib, N, 
     assert all(h.flow_retries() == 0 for h in hs)
     for h in hs + [single, orc]:
         h.close()
-
-
-def test_gpu_small_path_resident_workgroup(engine_lib, oracle_lib):
-    """The BO inner loop (bayes_opt/boptimizer.hpp:148-161: add_sample, then many query() calls) as REQUESTS to one resident
-    workgroup (csrc/small.hip: k_small_server) instead of launches: bitwise the results of the one-launch kernels (same
-    bodies), through every transition — the run of small calls that brings it up, another call on the handle that joins it
-    (get_L, compute), its idle timeout, capacity growth at 256 -> 257 samples (general path) — and the oracle's numbers."""
-    import time
-
-    rng = np.random.default_rng(55)
-    n0, n1, D = 8, 270, 4
-    X = rng.uniform(0, 1, size=(n1, D))
-    Y = np.cos(3.0 * X.sum(axis=1))[:, None] + 0.05 * rng.normal(size=(n1, 1))
-    th, noise = rng.uniform(-0.3, 0.3, size=D + 1), 0.01
-    pts = rng.uniform(0, 1, size=(n1, 3, D))
-
-    def run(server):
-        os.environ["GPE_SMALL_SERVER"] = "1" if server else "0"  # read when a handle is created
-        try:
-            h = _capi.Handle(engine_lib)
-        finally:
-            del os.environ["GPE_SMALL_SERVER"]
-        h.set_kernel(O.SE_ARD, th, noise)
-        h.set_data(X[:n0], synth.obs_mean_data(Y[:n0])[0])
-        assert h.compute() == 0
-        out = []
-        for n in range(n0, n1):
-            assert h.add_sample(X[n], synth.obs_mean_data(Y[: n + 1])[0]) == 0
-            out.append(h.log_lik())
-            for q in range(3):
-                k, v = h.query_batch(pts[n, q: q + 1])
-                out += [k[0, 0], v[0]]
-            if n % 40 == 17:
-                out.append(float(np.sum(h.get_L())))  # another call on the handle: joins the resident workgroup
-            if n % 50 == 33:
-                time.sleep(0.004)  # longer than its idle time: it leaves by itself, the next request restarts it
-            if n % 60 == 41:
-                h.update_alpha(synth.obs_mean_data(Y[: n + 1])[0] * 1.5)
-                out.append(h.log_lik())
-                h.update_alpha(synth.obs_mean_data(Y[: n + 1])[0])
-            if n == 100:
-                k8, v8 = h.query_batch(pts[n0: n0 + 8, 0])  # eight points in one request
-                out += list(k8[:, 0]) + list(v8)
-        served, small = h.server_calls(), h.small_calls()
-        al = h.get_alpha()
-        h.close()
-        return np.array(out), al, served, small
-
-    a, al_a, served_a, small_a = run(True)
-    b, al_b, served_b, small_b = run(False)
-    assert served_b == 0 and served_a > 0.8 * small_a and small_a == small_b
-    assert np.array_equal(a, b) and np.array_equal(al_a, al_b)
-    o = _capi.Handle(oracle_lib)
-    o.set_kernel(O.SE_ARD, th, noise)
-    o.set_data(X, synth.obs_mean_data(Y)[0])
-    o.compute()
-    assert relerr_norm(al_a, o.get_alpha()) < 1e-7
-    o.close()

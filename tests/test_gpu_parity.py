@@ -487,8 +487,8 @@ def _small_parity(engine_lib, oracle_lib, N=300, D=3, P=2, seed=0):
 
 
 @pytest.mark.parametrize("env", [{"GPE_FLOW_SOLVE": "0"}, {"GPE_LOOKAHEAD": "0"}, {"GPE_FUSE_PANEL": "0"},
-                                 {"GPE_FUSE_DIAG": "0", "GPE_STOP_EVENT": "0"}, {"GPE_NBO": "192"}, {"GPE_FOLD4": "0", "GPE_PANEL256": "0"},
-                                 {"GPE_PANEL256": "0"}, {"GPE_TAIL_MAX": "0"}],
+                                 {"GPE_FUSE_DIAG": "0", "GPE_STOP_EVENT": "0"}, {"GPE_NBO": "192"},
+                                 {"GPE_PANEL256": "0"}, {"GPE_TAIL_MAX": "0"}, {"GPE_TALL": "0"}, {"GPE_TAIL_LAG": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_alternate_schedules(engine_lib, oracle_lib, monkeypatch, env):
     """The switches read when a handle is created select the schedules that also serve as fall-backs (per-block
@@ -500,16 +500,16 @@ def test_gpu_alternate_schedules(engine_lib, oracle_lib, monkeypatch, env):
 
 
 @pytest.mark.parametrize("env", [{"GPE_QUERY_SWEEP": "0", "GPE_INV_PANELS": "0"}, {"GPE_QUERY_T": "0", "GPE_INV_OVERLAP": "0"},
-                                 {"GPE_RHS_FMA": "2"}, {"GPE_RHS_FMA": "0", "GPE_INV_FOLLOW": "1"}, {"GPE_SMALL_SERVER": "1"}, {"GPE_PANEL256": "0"},
+                                 {"GPE_RHS_FMA": "2"}, {"GPE_RHS_FMA": "0"}, {"GPE_PANEL256": "0", "GPE_TAIL_MAX": "0"}, {"GPE_TAIL_MAX": "0"},
                                  {"GPE_EARLY_BULK_TILES": "0", "GPE_ROWS_TAIL": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_process_wide_switches(env):
     """Switches that are read once per process (the blocked point-query solve, the in-panel substitution chain for K^-1; round 3:
     the sample-contiguous batched queries, K^-1's product after its chain, right-hand-side rows always / never as FMAs,
-    the K^-1 chain behind the factorisation, the resident small-path workgroup, the look-ahead stream released by every panel
-    and obs_mean's rows by a launch of their own): the same parity checks in a child, at a size
-    with seven outer panels (N = 1700: look-ahead, the one-launch panels — or, GPE_PANEL256=0, the step-by-step ones with the folded
-    last step —, ragged last panel) and, for the hyper-parameter objective, through gpe_hp_objective."""
+    the look-ahead stream released by every panel and obs_mean's rows by a launch of their own; round 4: 256-column panels to
+    the end — one-launch (GPE_TAIL_MAX=0) or step by step (+ GPE_PANEL256=0): the schedules the data-flow launches replaced and
+    what a hand-over timeout falls back to): the same parity checks in a child, at a size
+    with seven outer panels (N = 1700: ragged last panel) and, for the hyper-parameter objective, through gpe_hp_objective."""
     import os
     import subprocess
     import sys

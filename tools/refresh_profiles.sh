@@ -47,7 +47,7 @@ cd $root
 # in-kernel stamps: the diagonal block alone (data-flow form, and the barrier rounds it replaced), the four steps of an outer
 # panel (workgroup 0 / last workgroup), with and without the head-tile hand-over
 python tools/make_k64.py > /dev/null
-{ echo "# tools/diagflow (diag_flow.h) and tools/diagbench_0 (the barrier rounds, DIAG_FLOW=0): k_diag alone on tools/tmp/K64.bin if present"; tools/diagflow; tools/diagbench_0; } > $out/${tag}_diag_flow_stamps.log 2>&1
+{ echo "# tools/diagflow (diag_flow.h): k_diag alone on tools/tmp/K64.bin if present"; tools/diagflow; } > $out/${tag}_diag_flow_stamps.log 2>&1
 { echo "# tools/kbench_t: k_panel_step at the first panel of N = 4096, nt = head tiles of the step (3, 2, 1, 0); s_memtime cycles at 2.38 GHz"; echo "## head tiles handed over (default)"; tools/kbench_t 1 | grep -A2 "step with nt"; } > $out/${tag}_panel_step_stamps.log 2>&1
 { echo "# tools/kbench_t: k_panel256 (all steps of the first outer panel of N = 4096 in one launch) alone; wall_clock64 stamps of strips 0-3 and the last one"; tools/kbench_t 1 | grep -A7 "^k_panel256"; } > $out/${tag}_panel256_stamps.log 2>&1
 { echo "# tools/kbench_t: k_tail (a 1024-column tail = the leading 1024 x 1024 block of K as one tiled data-flow launch) alone; wall_clock64 stamps of the diagonal workgroups"; tools/kbench_t 1 | grep -A18 "^k_tail"; echo "# compute()+log_lik by size, default (tail 2560) and GPE_TAIL_MAX=0"; python tools/tail_try.py 150 520 1024 1100 1700 2048 2500 3072 4096 8192; GPE_TAIL_MAX=0 python tools/tail_try.py 150 520 1024 1100 1700 2048 2500 3072 4096 8192; } > $out/${tag}_tail_stamps.log 2>&1
@@ -58,5 +58,4 @@ python tools/trace_eval.py hp 4096 > $out/${tag}_production_timeline_hp_objectiv
 # (tools/updbench, tools/updbench_t: built where hipcc is, make -C tools updbench updbench_t; the binaries travel with the snapshot)
 { tools/updbench 4096 5; } > $out/${tag}_updbench_trailing_update.log 2>&1
 { tools/updbench_t 4096 2 | head -120; } > $out/${tag}_updbench_stream_k_stamps.log 2>&1
-python tools/srvlat.py > $out/${tag}_small_server_latency_raw.log 2>&1
 ls -la $out
