@@ -208,8 +208,20 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
 #define GPE_TAIL_MAX 8192 // (upper bound of the setting; the default: engine.hip)
 static inline int64_t tail_tiles(int64_t nt, int64_t nb) { return nt * nb - nt * (nt - 1) / 2; }
 static inline int64_t tail_buf_doubles(int64_t nt, int64_t nb) { return nt * 3072 + tail_tiles(nt, nb) * 4096; }
+// gen (optional): the launch generates its tiles of K from the samples (and obs_mean's rows from Om) instead of reading A,
+// and pre-fills the sweep's sentinel in Al for its columns — no kernel-matrix build in front of it
+struct TailGen {
+    const double* Xg; // SoA samples
+    int64_t ldx, Ns;
+    const double* Om;
+    int64_t ldom;
+    double* Al; // may be null
+    int64_t ldal;
+    int P;
+    const KParams* kp; // host copy (single launches pass it by value; batched ones read the batch table)
+};
 void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, int64_t N64, int64_t M, double* Xt_all, int* info,
-                 double* buf_cur, double* buf_next);
+                 double* buf_cur, double* buf_next, const TailGen* gen = nullptr);
 // S22 / S22_next: the polled hand-over buffers (block inverses + head tiles), 33,792 doubles each, holding the all-ones
 // pattern when the launch starts (the launch arms S22_next)
 #define GPE_S22_TILE 20 // the two buffers sit in tiles 20..28 of either half of gpe_ctx::dHead

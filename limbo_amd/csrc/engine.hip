@@ -105,6 +105,9 @@ struct gpe_ctx {
     int64_t tail_cap = 0, tall_cap = 0; // doubles per buffer of the closing / tall pair
     unsigned tail_count = 0, tall_count = 0;
     int64_t tail_lay = -1, tall_lay = -1; // nt * 65536 + nb of the pair's previous launch (-1: both buffers entirely all-ones)
+    int gen_mode = 0; // this evaluation's data-flow launches generate their own tiles of K (compute_enqueue): 0 no, 1 the one
+                      // launch that is the whole factorisation, 2 the tall launch (the rest of K is built beside it)
+    hipEvent_t gen_ev = nullptr;
     unsigned p256_count = 0;           // launches of k_panel256 so far: its polled X22 copies alternate between two buffers
     std::vector<hipEvent_t> pl_events; // ... one per outer panel: the one-launch panel is complete (early release of the look-ahead stream)
     int64_t early_bulk = 100;          // release the look-ahead stream at the END OF THE PANEL (not of the fused next-panel update)
@@ -534,6 +537,8 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     TailPlan pl = tail_plan(c, N, M);
     if (pl.t0 >= 0 && !g_batch.bt && !prepare_tail(c, pl, s)) // (a batched launch: batch_enqueue_fused prepared every member)
         pl = TailPlan{};
+    // gen_mode (compute_enqueue): the first data-flow launch generates its tiles of K itself — nobody built them
+    TailGen gen{c->dXt, ld, N, c->dOm, ld, (c->flow_solve && (N + NB - 1) / NB <= 256) ? c->dAl : nullptr, ld, c->P, &c->kp};
     const int64_t t0 = pl.t0, e0 = pl.e0, N64 = pl.N64;
     const int64_t stop0 = e0 >= 0 ? e0 : t0; // where the panels end: the panel in front of it updates everything left in one piece
     for (int64_t p0 = 0; p0 < N; p0 += nbo) {
@@ -547,7 +552,9 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 PhaseScope ps(c, GPE_PH_POTRF_TALL, w * w * w / 3.0 + (h - w) * w * w);
                 double* pair = c->dTail + 2 * c->tail_cap;
                 launch_tail(s, A, ld, e0, t0, N64, M, c->dXinv, c->dInfo, pair + (c->tall_count & 1) * c->tall_cap,
-                            pair + ((c->tall_count + 1) & 1) * c->tall_cap);
+                            pair + ((c->tall_count + 1) & 1) * c->tall_cap, c->gen_mode == 2 ? &gen : nullptr);
+                if (c->gen_mode == 2 && c->gen_ev) // the rest of K, built on the second stream beside this launch
+                    hipStreamWaitEvent(s, c->gen_ev, 0);
                 ++c->tall_count;
                 c->tall_lay = pl.nt_tall * 65536 + pl.nb_tall;
             }
@@ -580,7 +587,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
             {
                 PhaseScope ps(c, GPE_PH_POTRF_TAIL, (double)(N64 - t0) * (N64 - t0) * (N64 - t0) / 3.0);
                 launch_tail(s, A, ld, t0, N64, N64, M, c->dXinv, c->dInfo, c->dTail + (c->tail_count & 1) * c->tail_cap,
-                            c->dTail + ((c->tail_count + 1) & 1) * c->tail_cap);
+                            c->dTail + ((c->tail_count + 1) & 1) * c->tail_cap, c->gen_mode == 1 ? &gen : nullptr);
                 ++c->tail_count;
                 c->tail_lay = pl.nt_tail * 65536 + pl.nb_tail;
             }
@@ -976,24 +983,66 @@ int compute_enqueue(gpe_ctx* c)
         c->panel_handover = c->panel_handover_cfg; // re-armed after a run of clean evaluations without it
     const bool flow_al = c->flow_solve && (c->N + NB - 1) / NB <= 256;
     bool rows_done = false; // obs_mean^T under the matrix + the sweep's sentinel: by the build launch itself where it can
+    // Round 4: where the data-flow launches begin decides whether K is built at all.  When the first of them starts at
+    // column 0 it generates its tiles itself (potrf.hip: tail_gen_tile): for N <= 2560 the kernel matrix is never written,
+    // for the tall launch of N = 4096 only the 2560 x 2560 block behind it is — beside the tall launch, on the second stream.
+    c->gen_mode = 0;
+    {
+        // GPE_TAIL_GEN: 0 never; 1 (default) when ONE launch is the whole factorisation (N <= 2560: 0.489 -> 0.477 ms at
+        // N = 2048, 0.254 -> 0.247 at 1024); 2 / 3: also the tall launch of N <= 4096, the block behind it built on the second
+        // stream beside it / on the main stream in front of it — measured at N = 4096: 2 LOSES (1.253 -> 1.272 ms: the build
+        // takes CUs from the first columns of the chain and the update then waits for an event)
+        static const int gen_lvl = getenv("GPE_TAIL_GEN") ? atoi(getenv("GPE_TAIL_GEN")) : 1;
+        const TailPlan pl = tail_plan(c, c->N, c->N + c->P);
+        const int64_t N64 = c->N / NB * NB;
+        if (gen_lvl > 0 && !c->host_K && !c->prof && pl.t0 >= 0 && (g_batch.bt || prepare_tail(c, pl, s))) {
+            if (pl.t0 == 0 && (N64 == c->N || !g_batch.bt))
+                c->gen_mode = 1;
+            else if (pl.e0 == 0 && !g_batch.bt && gen_lvl >= 2)
+                c->gen_mode = 2;
+        }
+    }
     if (c->host_K) {
         if (!c->dKhost)
             return GPE_ERR_STATE;
         PhaseScope ps(c, GPE_PH_KERNEL_BUILD, 0.0);
         launch_copy2d(s, c->dKhost, c->ld, c->dA, c->ld, c->N, c->N);
     }
+    else if (c->gen_mode != 0) {
+        project_lambda(c, s, c->dXt, c->ld, 0, c->N);
+        // what is left to build: the ragged last block (mode 1) / everything behind the tall launch (mode 2), with
+        // obs_mean's rows and the sweep's sentinel for those columns
+        const TailPlan pl = tail_plan(c, c->N, c->N + c->P);
+        const int64_t b0 = c->gen_mode == 1 ? c->N / NB * NB : pl.t0;
+        rows_done = true;
+        if (b0 < c->N) {
+            const BuildRowsTail rt{c->dOm + b0, c->ld, c->P, c->dA + c->N + b0 * c->ld, flow_al ? c->dAl + b0 : nullptr, 0};
+            hipStream_t sb = s;
+            static const bool beside = !(getenv("GPE_TAIL_GEN") && atoi(getenv("GPE_TAIL_GEN")) == 3);
+            if (c->gen_mode == 2 && c->kp.k_lam == 0 && beside) { // beside the tall launch (nothing of this handle is in flight on stream2)
+                sb = c->stream2;
+                if (!c->gen_ev)
+                    hipEventCreateWithFlags(&c->gen_ev, hipEventDisableTiming);
+            }
+            if (!launch_build_K(sb, c->dXt + b0, c->ld, c->N - b0, c->kp, c->dA + b0 + b0 * c->ld, c->ld, &rt))
+                launch_cols_to_rows(sb, c->dOm + b0, c->ld, c->N - b0, c->P, c->dA + c->N + b0 * c->ld, c->ld, flow_al ? c->dAl + b0 : nullptr);
+            if (sb != s)
+                hipEventRecord(c->gen_ev, sb);
+            else if (c->gen_ev) { // (mode 2 on the main stream: no event to wait for)
+                hipEventDestroy(c->gen_ev);
+                c->gen_ev = nullptr;
+            }
+        }
+        c->al_prefilled = flow_al;
+    }
     else {
         PhaseScope ps(c, GPE_PH_KERNEL_BUILD, 0.0);
-        // (Building only the first panel's columns here and the rest on the second stream, underneath the
-        // first panel's factorisation, was tried: unbounded it slows the latency-bound k_diag / panel-step
-        // workgroups it shares CUs with as much as it saves; bounded to 128 looping workgroups it takes
-        // 250 us — a tile is latency-bound and needs ~8 co-resident workgroups per CU.)
         project_lambda(c, s, c->dXt, c->ld, 0, c->N);
         const BuildRowsTail rt{c->dOm, c->ld, c->P, c->dA + c->N, flow_al ? c->dAl : nullptr, 0};
         static const bool tail = !(getenv("GPE_ROWS_TAIL") && atoi(getenv("GPE_ROWS_TAIL")) == 0);
         rows_done = launch_build_K(s, c->dXt, c->ld, c->N, c->kp, c->dA, c->ld, tail ? &rt : nullptr);
     }
-    {
+    if (c->gen_mode == 0) {
         if (!rows_done)
             launch_cols_to_rows(s, c->dOm, c->ld, c->N, c->P, c->dA + c->N, c->ld, flow_al ? c->dAl : nullptr);
         c->al_prefilled = flow_al;
@@ -1563,6 +1612,8 @@ int gpe_destroy(gpe_handle c)
         return GPE_ERR_ARG;
     DevGuard g(c);
     hipStreamSynchronize(c->stream);
+    if (c->gen_ev)
+        hipEventDestroy(c->gen_ev);
     drain_phases(c);
     for (auto e : c->pool)
         hipEventDestroy(e);

@@ -188,39 +188,7 @@ static void launch_build(hipStream_t s, const double* Xt, int64_t ldx, int64_t N
 //     polynomial on |r| <= 0.347 (remainder 4e-18 relative), ldexp.  < 1 ulp from the correctly rounded value.
 // Same pair formula and summation order as k_build: z = sum_d ((x_i,d - x_j,d) / ell_d)^2, d ascending, fma.
 // ---------------------------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ double exp_nonpos(double x)
-{
-    const double n = __builtin_rint(x * 1.44269504088896338700e+00);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.60590438368216145994e-10; // 1/13!
-    p = fma(p, r, 2.08767569878680989792e-09);
-    p = fma(p, r, 2.50521083854417187751e-08);
-    p = fma(p, r, 2.75573192239858906526e-07);
-    p = fma(p, r, 2.75573192239858906526e-06);
-    p = fma(p, r, 2.48015873015873015873e-05);
-    p = fma(p, r, 1.98412698412698412698e-04);
-    p = fma(p, r, 1.38888888888888888889e-03);
-    p = fma(p, r, 8.33333333333333333333e-03);
-    p = fma(p, r, 4.16666666666666666667e-02);
-    p = fma(p, r, 1.66666666666666666667e-01);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return x < -745.2 ? 0.0 : ldexp(p, (int)n);
-}
-template <int KIND>
-static __device__ __forceinline__ double kfun_fast(double z, double sf2)
-{
-    if (KIND == 0 || KIND == 3)
-        return sf2 * exp_nonpos(-0.5 * z);
-    if (KIND == 1) {
-        const double t1 = 2.23606797749978969641 * sqrt(z);
-        return sf2 * (1.0 + t1 + (5.0 / 3.0) * z) * exp_nonpos(-t1);
-    }
-    const double t = 1.73205080756887729353 * sqrt(z);
-    return sf2 * (1.0 + t) * exp_nonpos(-t);
-}
+#include "kfun_fast.h"
 
 template <int KIND, int DMAX, bool BATCH>
 __global__ __launch_bounds__(256) void k_build_lower(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp_,

@@ -228,6 +228,7 @@ struct DiagRound<-1> {
 #define DIAG_LTB (4 * NB * 4)
 #define DIAG_RUN(a, Ltb, invd, sbad, r, w, Ls) DiagRound<15>::run(a, Ltb, invd, sbad, r, w, Ls)
 #include "diag_flow.h"
+#include "kfun_fast.h"
 #define DIAG_THREADS 512
 
 // ---- inversion of the 64 x 64 lower-triangular L (in LDS, Ls[row * XS + col]) --------------------
@@ -1102,13 +1103,9 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
                 x.info[2] = 1;
                 break;
             }
-            // (the workgroup that factors next — acc_on — is ONE workgroup and the chain waits for it: its threads watch
-            // their own words, which saves the second round trip behind poll_one's; everybody else watches one word first)
-#ifndef CRIT_POLL
-#define CRIT_POLL 1
-#endif
-            if (!(CRIT_POLL && acc_on))
-                poll_one(Sq + 2048 + 1023, x.spin_limit, x.info); // X22's last row
+            // (Round 4 let the one workgroup the chain waits for watch its own words instead of poll_one's: no difference,
+            // 798.9 against 797.9 evaluations/s — the second look is not what a hop costs.)
+            poll_one(Sq + 2048 + 1023, x.spin_limit, x.info); // X22's last row
             if (b0 == SENT)
                 b0 = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (b1 == SENT)
@@ -1438,10 +1435,53 @@ struct TailArgs {
     double *LP, *SP, *LPn, *SPn;
     int spin_limit;
     const int* order; // dispatch order: workgroup w works on tile (b, c) = (order[2 w], order[2 w + 1]); null: column by column
+    // gen (Xg != null): the launch GENERATES its tiles of K from the samples instead of reading them from A — the kernel matrix
+    // is never written for the columns this launch factors (kernel/kernel.hpp:81-84 with the functors of kfun_fast.h, the
+    // pair formula and summation order of kbuild.hip); rows >= Ns of the last strip are obs_mean's rows, read from Om
+    const double* Xg; // SoA samples, Xg[d * ldx + i]
+    int64_t ldx, Ns;  // Ns: samples (rows below Ns in the last strip: right-hand sides)
+    const double* Om; // obs_mean, Om[i + p * ldom]
+    int64_t ldom;
+    double* Al;       // optional: the backward sweep's output, pre-filled with its sentinel here (what the build launch does)
+    int64_t ldal;
+    int P;
 };
 static __device__ __forceinline__ int tail_tile_id(int nb, int b, int c) { return c * nb - (c * (c - 1)) / 2 + (b - c); }
 
-static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wgid, double* __restrict__ lds)
+// element it of a thread's tile slice: global row I (clamped into the strip by the caller), global columns J0 + 2 it
+static __device__ __forceinline__ void tail_gen_tile(const TailArgs& a, const KParams* __restrict__ kp, int64_t I, int64_t J0,
+                                                     double (&out)[8])
+{
+    if (I >= a.Ns) { // a right-hand-side row: obs_mean^T
+        const double* om = a.Om + (I - a.Ns) * a.ldom;
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            out[it] = om[J0 + 2 * it];
+        return;
+    }
+    double z[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        z[it] = 0.0;
+    const int D = kp->D;
+    for (int d = 0; d < D; ++d) {
+        const double* xr = a.Xg + (int64_t)d * a.ldx;
+        const double xi = xr[I], ie = kp->inv_ell[d];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const double q = (xi - xr[J0 + 2 * it]) * ie;
+            z[it] = fma(q, q, z[it]);
+        }
+    }
+    const int kind = kp->kind;
+    const double sf2 = kp->sf2, da = kp->diag_add;
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        out[it] = kfun_fast_rt(kind, z[it], sf2) + (I == J0 + 2 * it ? da : 0.0);
+}
+
+static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wgid, double* __restrict__ lds,
+                                                 const KParams* __restrict__ kp = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
@@ -1497,18 +1537,30 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
     // the tile, lane = row layout
     const int crc = crow < x.nrows ? crow : x.nrows - 1;
     double cv[8];
+    if (kp) {
+        tail_gen_tile(a, kp, x.R0 + crc, a.t0 + (int64_t)NB * c + ccol, cv);
+        if (a.Al && b >= a.nfull && threadIdx.x < NB) // the right-hand-side strip: the sweep's sentinel for these columns
+            for (int p = 0; p < a.P; ++p)
+                reinterpret_cast<unsigned long long*>(a.Al)[a.t0 + (int64_t)NB * c + threadIdx.x + (int64_t)p * a.ldal] = ~0ull;
+    }
+    else {
 #pragma unroll
-    for (int it = 0; it < 8; ++it)
-        cv[it] = a.A[x.R0 + crc + (a.t0 + (int64_t)NB * c + ccol + 2 * it) * a.lda];
+        for (int it = 0; it < 8; ++it)
+            cv[it] = a.A[x.R0 + crc + (a.t0 + (int64_t)NB * c + ccol + 2 * it) * a.lda];
+    }
     if (b == c) {
         // ---- a diagonal tile's workgroup: the chain.  It also owns the tile to the left, (c, c-1): L(c, c-1) never has to
         // travel to reach the block it completes, and its product with itself is accumulated inside its two-phase solve
         // (k_panel256's factoring strip).  Steps s < c-1 update both tiles with the same polled L(c, s).
         double cl[8]; // tile (c, c-1)
         if (c > 0) {
+            if (kp)
+                tail_gen_tile(a, kp, x.R0 + crow, a.t0 + (int64_t)NB * (c - 1) + ccol, cl);
+            else {
 #pragma unroll
-            for (int it = 0; it < 8; ++it)
-                cl[it] = a.A[x.R0 + crow + (a.t0 + (int64_t)NB * (c - 1) + ccol + 2 * it) * a.lda];
+                for (int it = 0; it < 8; ++it)
+                    cl[it] = a.A[x.R0 + crow + (a.t0 + (int64_t)NB * (c - 1) + ccol + 2 * it) * a.lda];
+            }
             PolledTile pa, pb;
             if (c > 1) {
                 pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
@@ -1641,6 +1693,12 @@ __global__ __launch_bounds__(512) void k_tail(TailArgs a)
     __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS]; // [Bx | T0 | T1 | T2]
     tail_body(a, (int)blockIdx.x, lds);
 }
+// the same generating its own tiles of K (a.Xg; the kernel parameters ride in the kernel arguments)
+__global__ __launch_bounds__(512) void k_tail_g(TailArgs a, KParams kp)
+{
+    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS];
+    tail_body(a, (int)blockIdx.x, lds, &kp);
+}
 // G members at once: blockIdx.x = tile * G + member (the members' chains advance side by side; a wait is for a lower tile of
 // the same member, i.e. a lower-numbered workgroup)
 __global__ __launch_bounds__(512) void k_tail_b(TailArgs a, const BatchTab* __restrict__ bt)
@@ -1654,7 +1712,12 @@ __global__ __launch_bounds__(512) void k_tail_b(TailArgs a, const BatchTab* __re
     a.SP = bt_rebase(bt, gp, a.SP);
     a.LPn = bt_rebase(bt, gp, a.LPn);
     a.SPn = bt_rebase(bt, gp, a.SPn);
-    tail_body(a, (int)blockIdx.x / G, lds);
+    if (a.Xg) { // (every member's own samples, obs_mean and kernel parameters)
+        a.Xg = bt_rebase(bt, gp, a.Xg);
+        a.Om = bt_rebase(bt, gp, a.Om);
+        a.Al = bt_rebase(bt, gp, a.Al);
+    }
+    tail_body(a, (int)blockIdx.x / G, lds, a.Xg ? &bt->kp[gp] : nullptr);
 }
 
 // ---- dispatch order of a data-flow launch ----------------------------------------------------------------------------
@@ -1756,7 +1819,7 @@ static const int* tail_order(int nt, int nb, int W, int lag)
 // the rows of a ragged last block the caller finishes.  Fully updated by everything in front of t0.  buf_cur / buf_next:
 // tail_buf_doubles(nt, nb) each, all-ones (this launch arms buf_next)
 void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, int64_t N64, int64_t M, double* Xt_all, int* info,
-                 double* buf_cur, double* buf_next)
+                 double* buf_cur, double* buf_next, const TailGen* gen)
 {
     TailArgs a{};
     a.A = A;
@@ -1780,8 +1843,20 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
     static const int ord_lag = getenv("GPE_TAIL_LAG") ? atoi(getenv("GPE_TAIL_LAG")) : 3;
     a.order = tail_order(a.nt, a.nb, 0, ord_lag); // (W: the just-in-time window of the table, measured as a loss — kept in tail_order for the record)
     const int64_t tiles = tail_tiles(a.nt, a.nb);
+    if (gen) {
+        a.Xg = gen->Xg;
+        a.ldx = gen->ldx;
+        a.Ns = gen->Ns;
+        a.Om = gen->Om;
+        a.ldom = gen->ldom;
+        a.Al = gen->Al;
+        a.ldal = gen->ldal;
+        a.P = gen->P;
+    }
     if (g_batch.bt)
         GPE_LAUNCH(k_tail_b, dim3((unsigned)(tiles * g_batch.G)), dim3(512), 0, s, a, g_batch.bt);
+    else if (gen)
+        GPE_LAUNCH(k_tail_g, dim3((unsigned)tiles), dim3(512), 0, s, a, *gen->kp);
     else
         GPE_LAUNCH(k_tail, dim3((unsigned)tiles), dim3(512), 0, s, a);
 }
