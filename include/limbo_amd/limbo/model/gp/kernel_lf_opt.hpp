@@ -63,7 +63,7 @@ namespace limbo {
                             out.push_back(gr ? opt::eval_t{liks[i], opt::eval_t::second_type(grads[i])} : opt::no_grad(liks[i]));
                         return out;
                     };
-                    auto res = opt::rprop_lockstep<Params>(fb, inits, false);
+                    auto res = opt::rprop_lockstep<typename opt::rprop_params_of<Optimizer, Params>::type>(fb, inits, false); // (Rprop<P>: P's settings)
                     std::vector<GP*> orig;
                     for (size_t i = 0; i < gps.size(); ++i) {
                         gps[i].kernel_function().set_h_params(res[i].first);

@@ -24,7 +24,19 @@ namespace limbo {
         template <typename T>
         struct is_rprop : std::false_type {};
         template <typename P>
-        struct is_rprop<Rprop<P>> : std::true_type {};
+        struct is_rprop<Rprop<P>> : std::true_type {
+            using params = P; // the Params Rprop<P> itself reads its iterations / eps_stop from (rprop.hpp:84-88)
+        };
+
+        /// the Params an optimiser reads its Rprop settings from: P for Rprop<P>, `Fallback` for anything else (never used then)
+        template <typename T, typename Fallback>
+        struct rprop_params_of {
+            using type = Fallback;
+        };
+        template <typename P, typename Fallback>
+        struct rprop_params_of<Rprop<P>, Fallback> {
+            using type = P;
+        };
 
         /// does an objective functor evaluate many points at once?  eval_batch(xs, grad) -> std::vector<eval_t>
         template <typename F, typename = void>

@@ -51,7 +51,8 @@ namespace limbo {
                                 start(j) += u(g);
                             starts.push_back(start);
                         }
-                        auto res = rprop_lockstep<Params>([&](const std::vector<Eigen::VectorXd>& xs, bool gr) { return f.eval_batch(xs, gr); }, starts, bounded);
+                        // (Optimizer = Rprop<P>: P's opt_rprop settings, which need not be this repeater's Params — ADVICE r3)
+                        auto res = rprop_lockstep<typename is_rprop<Optimizer>::params>([&](const std::vector<Eigen::VectorXd>& xs, bool gr) { return f.eval_batch(xs, gr); }, starts, bounded);
                         Eigen::VectorXd best = init;
                         double best_val = -std::numeric_limits<float>::max();
                         for (auto& r : res)

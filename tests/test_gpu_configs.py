@@ -439,8 +439,8 @@ def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, mon
                                            # round 4: a tall data-flow launch + ONE update in front of the closing launch
                                            (2624, 1, None, None),      # tall 0..256 (4 tile columns x 41 row strips), closing 37
                                            (1344, 2, "512", None),     # tall 0..1024, closing 5 tile columns, two outputs
-                                           (2000, 3, "512", "256"),    # panels to 1280, tall 1280..1536, closing 7, ragged, P = 3
-                                           (3200, 1, "1024", "512"),   # panels to 1792, tall 1792..2304, closing 14
+                                           (2000, 3, "512", "256"),    # (tall only from column 0: here panels to 1536, closing 7, ragged, P = 3)
+                                           (3200, 1, "1024", "2304"),  # tall 0..2304 (36 x 50 row strips), closing 14
                                            (3000, 2, "1280", "1536"),  # tall 0..1792 (28 x 46 strips + ragged/rhs strip), closing 18
                                            ])
 def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, tail, tall):

@@ -87,3 +87,27 @@ def test_host_path_vs_reference_and_oracle(tmp_path, oracle_lib, kind, mean, P, 
         o.close()
     b = out["batch2"]
     assert np.array_equal(b[:2], out["incremental"]["mu"].reshape(len(Q), P)[:2, 0]) and np.array_equal(b[2:], out["incremental"]["sigma"][:2])
+
+
+def test_host_path_under_asan_ubsan(tmp_path):
+    """SURVEY §5 (the reference's memory / race checks are host-side tooling): the drop-in header set with
+    -fsanitize=address,undefined (`make -C tests/cpp asan`).  The host path needs no GPU, so the instrumented driver runs
+    here: compute, the add_sample loop, copies and queries must finish without a sanitizer report."""
+    import os
+
+    subprocess.check_call(["make", "-s", "-C", str(ROOT / "tests" / "cpp"), "test_host_path_asan"])
+    exe = ROOT / "tests" / "cpp" / "test_host_path_asan"
+    rng = np.random.default_rng(1)
+    n1, D, P, n0 = 48, 3, 2, 15
+    X, Y, Q = rng.uniform(-1, 1, (n1, D)), rng.normal(size=(n1, P)), rng.uniform(-1, 1, (4, D))
+    f = tmp_path / "in.txt"
+    with open(f, "w") as fh:
+        fh.write(f"0 0 {P} {D} {n0} {n1} {len(Q)}\n")
+        for i in range(n1):
+            fh.write(" ".join(repr(float(v)) for v in list(X[i]) + list(Y[i])) + "\n")
+        for q in Q:
+            fh.write(" ".join(repr(float(v)) for v in q) + "\n")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([str(exe), str(f)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert "incremental n 48" in r.stdout
