@@ -714,6 +714,8 @@ static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds6
             return;
         }
     }
+    // (Half-height 64 x 128 tiles for launches with fewer 128 x 128 tiles than CUs — two co-resident workgroups per CU — were
+    // built and measured no faster: profiles/r04_half_height_ab.log.)
     if (tile == 128 && glds_ok(g))
         launch_glds128(s, g);
     else if (tile == 128)

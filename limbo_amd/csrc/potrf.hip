@@ -1738,7 +1738,7 @@ __global__ __launch_bounds__(512) void k_tail_b(TailArgs a, const BatchTab* __re
 #include <map>
 #include <mutex>
 #include <vector>
-static const int* tail_order(int nt, int nb, int W, int lag)
+static const int* tail_order(int nt, int nb, int W, int lag, int slope = 0)
 {
     if (W <= 0 && lag <= 0)
         return nullptr;
@@ -1746,7 +1746,7 @@ static const int* tail_order(int nt, int nb, int W, int lag)
     static std::map<std::array<int, 5>, int*> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const std::array<int, 5> key{dev, nt, nb, W, lag};
+    const std::array<int, 5> key{dev, nt, nb, W, lag * 64 + slope};
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it != cache.end())
@@ -1760,8 +1760,11 @@ static const int* tail_order(int nt, int nb, int W, int lag)
             int k;
             if (b == c)
                 k = 2 * c - 3; // behind the tiles of slot c - 2 (its last operands: (c, c-2) and the diagonal workgroup c - 1)
-            else if (b >= nt)
-                k = 2 * (c + (lag > 0 ? lag : 0));
+            else if (b >= nt) // slope > 0: the lag shrinks by one column every `slope` columns, down to -1 (right behind the
+                              // column's diagonal workgroup): a late column's tile has c catch-up products to do before it can use
+                              // the block inverse at all — started early it is through with them when the inverse arrives, and
+                              // the launch does not end with a drain of catch-up work
+                k = 2 * (c + std::max(-1, (lag > 0 ? lag : 0) - (slope > 0 ? c / slope : 0)));
             else if (b == c + 1)
                 k = 2 * c; // (owned by the diagonal workgroup of its row: this workgroup only arms its slot)
             else
@@ -1841,7 +1844,8 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
     // just-in-time window W > 0 LOSES (6: 675, 8: 694, 12: 738, 16: 770): a tile dispatched late has its catch-up products still
     // to do when its row's diagonal workgroup asks for it; waiting workgroups are not what limits the closing launch
     static const int ord_lag = getenv("GPE_TAIL_LAG") ? atoi(getenv("GPE_TAIL_LAG")) : 3;
-    a.order = tail_order(a.nt, a.nb, 0, ord_lag); // (W: the just-in-time window of the table, measured as a loss — kept in tail_order for the record)
+    static const int ord_slope = getenv("GPE_TAIL_LAG_SLOPE") ? atoi(getenv("GPE_TAIL_LAG_SLOPE")) : 0;
+    a.order = tail_order(a.nt, a.nb, 0, ord_lag, ord_slope); // (W: the just-in-time window of the table, measured as a loss — kept in tail_order for the record)
     const int64_t tiles = tail_tiles(a.nt, a.nb);
     if (gen) {
         a.Xg = gen->Xg;
