@@ -1469,9 +1469,20 @@ int grad_enqueue(gpe_ctx* c, int n_grad, int optimize_noise, bool loo = false)
 // bulk update that owns all 256 CUs would simply delay the panel: the bulk update is launched with
 // `bulk_wgs` < 256 looping workgroups (gemm.hip, GemmArgs::grid_limit), the other CUs stay free for
 // the critical path.  (A CU mask on the stream was tried first and had no effect.)
-// (Stream priorities and a CU mask on this stream were both tried — rounds 1 and 3 — and had no measurable effect on
-// MI355X / ROCm 7.2; neither switch is kept.)
-hipError_t create_main_stream(hipStream_t* st) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
+// The main stream is created at the device's HIGHEST priority, the look-ahead stream at the default one: the runtime keeps a
+// pool of hardware queues per priority, so the two can never share a hardware queue.  With both at the default priority the
+// runtime mapped them onto the SAME queue for some creation histories (a third handle alive, sixteen streams created and
+// destroyed before: profiles/r04_stream_queue_mapping.log) and every overlap of this file — look-ahead updates, K^-1 beside
+// the gradient's pair sums — silently serialised: gpe_hp_objective 3.22 ms instead of 2.85.  (The priority itself has no
+// measurable effect on how the chip schedules the two; GPE_STREAM_PRIO=0 restores two default-priority streams.)
+hipError_t create_main_stream(hipStream_t* st)
+{
+    static const bool use = !(getenv("GPE_STREAM_PRIO") && atoi(getenv("GPE_STREAM_PRIO")) == 0);
+    int lo = 0, hi = 0;
+    if (use && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+        return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
 hipError_t create_bulk_stream(hipStream_t* st) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
 
 struct DevGuard {
