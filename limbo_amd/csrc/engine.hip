@@ -98,6 +98,9 @@ struct gpe_ctx {
     int64_t tall_max = 1536;           // ... and up to this many columns in FRONT of them as one tall data-flow launch (all rows
                                        // below ride along) followed by ONE update with k = its width (GPE_TALL=0: 256-column panels
                                        // with look-ahead all the way to the closing launch, the round-3 schedule)
+    int64_t batch_tail_max = 1536;     // tail_max of a batched launch sequence (GPE_BATCH_TAIL_MAX): G members share the chip, so
+                                       // more of the work belongs in the one update between the two data-flow launches (measured,
+                                       // profiles/r04_batch_split_ab.log: 8 x N = 2048 1.29 ms per batch at 1536 against 1.48 at 2560)
     // the polled hand-over buffers of the data-flow launches, ONE allocation: [closing 0 | closing 1 | tall 0 | tall 1].  Of a
     // pair, the buffer of parity `count & 1` is armed (all-ones) for the slot layout of the pair's previous launch; a launch
     // with another layout (another N or P on this handle) first puts the whole pair back to all-ones (prepare_tail)
@@ -450,28 +453,33 @@ static TailPlan tail_plan(const gpe_ctx* c, int64_t N, int64_t M)
     // holds its CU from dispatch to its last store, mostly waiting — measured (profiles/r04_dispatch_order.log): 8 x N = 2048
     // 1.45 ms per batch against 1.59 through the step-by-step panels, but 64 x 2048 9.0 against 7.0 and 10 x 4096 7.9 against 7.6
     static const int64_t batch_tiles = getenv("GPE_BATCH_TAIL_TILES") ? atoll(getenv("GPE_BATCH_TAIL_TILES")) : 4608;
-    if (!(c->tail_max >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && nbo == 4 * NB && M - pl.N64 <= NB))
+    const int64_t tmax = g_batch.bt ? c->batch_tail_max : c->tail_max;
+    if (!(tmax >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && nbo == 4 * NB && M - pl.N64 <= NB))
         return pl;
-    int64_t t0 = pl.N64 > c->tail_max ? (pl.N64 - c->tail_max + nbo - 1) / nbo * nbo : 0;
+    const int64_t t0 = pl.N64 > tmax ? (pl.N64 - tmax + nbo - 1) / nbo * nbo : 0;
     if (pl.N64 - t0 < 2 * NB)
         return pl;
-    if (g_batch.bt && (t0 > 0 || (int64_t)g_batch.G * tail_tiles((pl.N64 - t0) / NB, (pl.N64 - t0) / NB + (M > pl.N64 ? 1 : 0)) > batch_tiles))
-        return pl;
-    pl.t0 = t0;
     const int64_t rs = M > pl.N64 ? 1 : 0;
-    pl.nt_tail = (pl.N64 - t0) / NB;
-    pl.nb_tail = pl.nt_tail + rs;
-    pl.need_tail = tail_buf_doubles(pl.nt_tail, pl.nb_tail);
+    const int nt_tail = (int)((pl.N64 - t0) / NB), nb_tail = nt_tail + (int)rs;
     // the tall launch only from column 0 on: behind 256-column panels the look-ahead schedule in front of the closing launch is
     // the better one (measured, profiles/r04_schedule_ab.log: N = 5000 1.94 against 2.10 ms, 8192 5.14 against 5.34)
-    if (t0 > 0 && c->tall_max >= 2 * NB && t0 <= c->tall_max) {
-        const int64_t e0 = 0;
-        if (t0 - e0 >= 2 * NB) {
-            pl.e0 = e0;
-            pl.nt_tall = (t0 - e0) / NB;
-            pl.nb_tall = (pl.N64 - e0) / NB + rs;
-            pl.need_tall = tail_buf_doubles(pl.nt_tall, pl.nb_tall);
-        }
+    const bool tall = t0 >= 2 * NB && c->tall_max >= 2 * NB && t0 <= c->tall_max;
+    const int nt_tall = tall ? (int)(t0 / NB) : 0, nb_tall = tall ? (int)(pl.N64 / NB + rs) : 0;
+    if (g_batch.bt) { // (a batch has no look-ahead panels: the data-flow launches cover the matrix from column 0 or not at all)
+        if (t0 > 0 && !tall)
+            return pl;
+        if ((int64_t)g_batch.G * std::max(tail_tiles(nt_tail, nb_tail), tall ? tail_tiles(nt_tall, nb_tall) : (int64_t)0) > batch_tiles)
+            return pl;
+    }
+    pl.t0 = t0;
+    pl.nt_tail = nt_tail;
+    pl.nb_tail = nb_tail;
+    pl.need_tail = tail_buf_doubles(nt_tail, nb_tail);
+    if (tall) {
+        pl.e0 = 0;
+        pl.nt_tall = nt_tall;
+        pl.nb_tall = nb_tall;
+        pl.need_tall = tail_buf_doubles(nt_tall, nb_tall);
     }
     return pl;
 }
@@ -1601,6 +1609,9 @@ int gpe_create(int device_id, gpe_handle* out)
         c->tail_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), GPE_TAIL_MAX);
     if (const char* f = getenv("GPE_TALL"))
         c->tall_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), GPE_TAIL_MAX);
+    c->batch_tail_max = std::min(c->batch_tail_max, c->tail_max);
+    if (const char* f = getenv("GPE_BATCH_TAIL_MAX"))
+        c->batch_tail_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), c->tail_max);
     if (const char* f = getenv("GPE_STOP_EVENT"))
         c->stop_events = atoi(f) != 0;
     if (const char* f = getenv("GPE_LOOKAHEAD"))

@@ -1446,6 +1446,10 @@ struct TailArgs {
     int64_t ldal;
     int P;
 };
+// LDS of a k_tail workgroup: [Bx | T0 | T1 | T2] for the solves and the factorisation, re-carved as two pairs of operand tiles
+// [A0 | B0 | A1 | B1] (40 KB each: all of the CU's 160 KB) for the pipelined products in front of them
+#define TAIL_LDS_DOUBLES (4 * NB * PS)
+static_assert(TAIL_LDS_DOUBLES >= NB * XS + 3 * NB * PS && TAIL_LDS_DOUBLES * 8 <= 160 * 1024, "k_tail LDS carve");
 static __device__ __forceinline__ int tail_tile_id(int nb, int b, int c) { return c * nb - (c * (c - 1)) / 2 + (b - c); }
 
 // element it of a thread's tile slice: global row I (clamped into the strip by the caller), global columns J0 + 2 it
@@ -1561,44 +1565,43 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
                 for (int it = 0; it < 8; ++it)
                     cl[it] = a.A[x.R0 + crow + (a.t0 + (int64_t)NB * (c - 1) + ccol + 2 * it) * a.lda];
             }
+            // Steps s < c-1, software-pipelined over two pairs of operand buffers ([A0 | B0 | A1 | B1] re-carved over the whole
+            // LDS block): the operands of step s+1 are on their way (registers) under the products of step s and land in the
+            // other pair, so a step has ONE barrier, and the products accumulate in the matrix-core layout — one conversion to
+            // the lane = row layout behind the loop, not one per step.
             PolledTile pa, pb;
             if (c > 1) {
                 pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
                 pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, 0) * (NB * NB));
             }
+            double a2l[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, a2v[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll 1
             for (int s = 0; s < c - 1; ++s) {
+                double* const opA = lds + (s & 1) * (2 * NB * PS);
+                double* const opB = opA + NB * PS;
                 pa.finish(a.LP + (int64_t)tail_tile_id(a.nb, c, s) * (NB * NB), x.spin_limit, x.info);
-                pa.store(x.T0);
+                pa.store(opA);
                 pb.finish(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s) * (NB * NB), x.spin_limit, x.info);
-                pb.store(x.T1);
+                pb.store(opB);
                 if (s + 1 < c - 1) {
                     pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, s + 1) * (NB * NB));
                     pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s + 1) * (NB * NB));
                 }
-                __syncthreads();
-                double a2[2][4], a2r[8];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        a2[m][n] = 0.0;
-                mm64<false>(x.T0, x.T1, wm, wn, lane, a2);
-                wave_tile_to_rows(a2, a2r, lane);
+                __syncthreads(); // this step's operands are in LDS (and every wave is through with the pair of step s-1)
+                mm64<false>(opA, opB, wm, wn, lane, a2l);
+                mm64<false>(opA, opA, wm, wn, lane, a2v);
+            }
+            if (c > 1) {
+                double a2r[8];
+                wave_tile_to_rows(a2l, a2r, lane);
 #pragma unroll
                 for (int it = 0; it < 8; ++it)
                     cl[it] -= a2r[it];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        a2[m][n] = 0.0;
-                mm64<false>(x.T0, x.T0, wm, wn, lane, a2);
-                wave_tile_to_rows(a2, a2r, lane);
+                wave_tile_to_rows(a2v, a2r, lane);
 #pragma unroll
                 for (int it = 0; it < 8; ++it)
                     cv[it] -= a2r[it];
-                __syncthreads(); // T0 / T1 are free again
+                __syncthreads(); // the operand buffers are free again: [Bx | T0 | T1 | T2] from here on
             }
             TTS(c, 0);
             // step c-1: L(c, c-1) = tile X_{c-1}^T in two phases (T1 keeps it: the factorisation re-carves [Bx | T0]), its product
@@ -1648,30 +1651,29 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
         pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, b, 0) * (NB * NB));
         pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
     }
+    double a2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll 1
-    for (int s = 0; s < c; ++s) {
+    for (int s = 0; s < c; ++s) { // (pipelined over two pairs of operand buffers, one barrier a step: see the diagonal workgroup's loop)
+        double* const opA = lds + (s & 1) * (2 * NB * PS);
+        double* const opB = opA + NB * PS;
         pa.finish(a.LP + (int64_t)tail_tile_id(a.nb, b, s) * (NB * NB), x.spin_limit, x.info);
-        pa.store(x.T0);
+        pa.store(opA);
         pb.finish(a.LP + (int64_t)tail_tile_id(a.nb, c, s) * (NB * NB), x.spin_limit, x.info);
-        pb.store(x.T1);
+        pb.store(opB);
         if (s + 1 < c) { // the next step's operands: on their way under this step's product
             pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, b, s + 1) * (NB * NB));
             pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, s + 1) * (NB * NB));
         }
         __syncthreads();
-        double a2[2][4];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                a2[m][n] = 0.0;
-        mm64<false>(x.T0, x.T1, wm, wn, lane, a2);
+        mm64<false>(opA, opB, wm, wn, lane, a2);
+    }
+    if (c > 0) {
         double a2r[8];
         wave_tile_to_rows(a2, a2r, lane);
 #pragma unroll
         for (int it = 0; it < 8; ++it)
             cv[it] -= a2r[it];
-        __syncthreads(); // T0 / T1 are free again
+        __syncthreads(); // the operand buffers are free again
     }
     double unused[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     p256_half_solve<0, true>(x, x.T0, x.T2, cv, unused, false, a.SP + (int64_t)c * 3072, myslot);
@@ -1690,20 +1692,20 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
 
 __global__ __launch_bounds__(512) void k_tail(TailArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS]; // [Bx | T0 | T1 | T2]
+    __shared__ __attribute__((aligned(16))) double lds[TAIL_LDS_DOUBLES]; // [Bx | T0 | T1 | T2] / [A0 | B0 | A1 | B1]: all 160 KB
     tail_body(a, (int)blockIdx.x, lds);
 }
 // the same generating its own tiles of K (a.Xg; the kernel parameters ride in the kernel arguments)
 __global__ __launch_bounds__(512) void k_tail_g(TailArgs a, KParams kp)
 {
-    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS];
+    __shared__ __attribute__((aligned(16))) double lds[TAIL_LDS_DOUBLES];
     tail_body(a, (int)blockIdx.x, lds, &kp);
 }
 // G members at once: blockIdx.x = tile * G + member (the members' chains advance side by side; a wait is for a lower tile of
 // the same member, i.e. a lower-numbered workgroup)
 __global__ __launch_bounds__(512) void k_tail_b(TailArgs a, const BatchTab* __restrict__ bt)
 {
-    __shared__ __attribute__((aligned(16))) double lds[NB * XS + 3 * NB * PS];
+    __shared__ __attribute__((aligned(16))) double lds[TAIL_LDS_DOUBLES];
     const int G = bt->G, gp = (int)blockIdx.x % G;
     a.A = bt_rebase(bt, gp, a.A);
     a.Xt = bt_rebase(bt, gp, a.Xt);
@@ -1738,7 +1740,7 @@ __global__ __launch_bounds__(512) void k_tail_b(TailArgs a, const BatchTab* __re
 #include <map>
 #include <mutex>
 #include <vector>
-static const int* tail_order(int nt, int nb, int W, int lag, int slope = 0)
+static const int* tail_order(int nt, int nb, int W, int lag)
 {
     if (W <= 0 && lag <= 0)
         return nullptr;
@@ -1746,7 +1748,7 @@ static const int* tail_order(int nt, int nb, int W, int lag, int slope = 0)
     static std::map<std::array<int, 5>, int*> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const std::array<int, 5> key{dev, nt, nb, W, lag * 64 + slope};
+    const std::array<int, 5> key{dev, nt, nb, W, lag};
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it != cache.end())
@@ -1760,11 +1762,9 @@ static const int* tail_order(int nt, int nb, int W, int lag, int slope = 0)
             int k;
             if (b == c)
                 k = 2 * c - 3; // behind the tiles of slot c - 2 (its last operands: (c, c-2) and the diagonal workgroup c - 1)
-            else if (b >= nt) // slope > 0: the lag shrinks by one column every `slope` columns, down to -1 (right behind the
-                              // column's diagonal workgroup): a late column's tile has c catch-up products to do before it can use
-                              // the block inverse at all — started early it is through with them when the inverse arrives, and
-                              // the launch does not end with a drain of catch-up work
-                k = 2 * (c + std::max(-1, (lag > 0 ? lag : 0) - (slope > 0 ? c / slope : 0)));
+            else if (b >= nt) // (a lag that shrinks along the launch — late columns' tiles started early for their catch-up
+                              // products — measured slower at every slope: profiles/r04_lag_slope_negative.log)
+                k = 2 * (c + std::max(lag, 0));
             else if (b == c + 1)
                 k = 2 * c; // (owned by the diagonal workgroup of its row: this workgroup only arms its slot)
             else
@@ -1844,8 +1844,7 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
     // just-in-time window W > 0 LOSES (6: 675, 8: 694, 12: 738, 16: 770): a tile dispatched late has its catch-up products still
     // to do when its row's diagonal workgroup asks for it; waiting workgroups are not what limits the closing launch
     static const int ord_lag = getenv("GPE_TAIL_LAG") ? atoi(getenv("GPE_TAIL_LAG")) : 3;
-    static const int ord_slope = getenv("GPE_TAIL_LAG_SLOPE") ? atoi(getenv("GPE_TAIL_LAG_SLOPE")) : 0;
-    a.order = tail_order(a.nt, a.nb, 0, ord_lag, ord_slope); // (W: the just-in-time window of the table, measured as a loss — kept in tail_order for the record)
+    a.order = tail_order(a.nt, a.nb, 0, ord_lag); // (W: the just-in-time window of the table, measured as a loss — kept in tail_order for the record)
     const int64_t tiles = tail_tiles(a.nt, a.nb);
     if (gen) {
         a.Xg = gen->Xg;

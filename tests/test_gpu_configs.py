@@ -106,22 +106,34 @@ def test_gpu_c4_batch_64_vs_oracle(engine_lib, oracle_lib):
         assert relerr(vg + 0.01, vo + 0.01) < PC.TOL_VAR
         o.close()
     single = new_gp(engine_lib, O.SE_ARD, X, oms[0], ths[0], 0.01)
-    for g in range(G):  # one at a time on one handle: equal to rounding
-        single.set_data(X, oms[g])
+    for g in range(G):  # one at a time on one handle (the data-flow launch; the 64 went through the panels): equal to rounding —
+        single.set_data(X, oms[g])  # two summation orders of a 2048-term factorisation differ by ~N eps sum|terms| ~ 1e-12 |log_lik|
         single.set_kernel(O.SE_ARD, ths[g], 0.01)
         assert single.compute() == 0
-        assert abs(single.log_lik() - ll[g]) <= 1e-12 * abs(ll[g]), g
-    # round 4: a batch of EIGHT (BASELINE configs[3] per GPU) takes the data-flow launch in its batched form (k_tail_b: the
-    # members' tiles interleaved in one grid; 64 members stay with the step-by-step panels, engine.hip: tail_plan) — every tile
-    # does the same arithmetic in the same order as the single-handle launch: the factor is bitwise equal
+        assert abs(single.log_lik() - ll[g]) <= 1e-11 * abs(ll[g]), (g, single.log_lik(), ll[g])
+    # round 4: a batch of EIGHT (BASELINE configs[3] per GPU) takes the data-flow launches in their batched form (k_tail_b: the
+    # members' tiles interleaved in one grid; 64 members stay with the step-by-step panels, engine.hip: tail_plan), split as
+    # tall launch | one update | closing launch (GPE_BATCH_TAIL_MAX, 1536) where the single handle runs one launch: equal to
+    # rounding.  Below 1536 samples both run ONE launch and every tile does the same arithmetic in the same order: bitwise equal.
     assert _capi.batch_compute(hs[:8]) == [0] * 8
     ll8 = _capi.batch_log_lik(hs[:8])
-    assert np.max(np.abs(ll8 - ll[:8]) / np.abs(ll[:8])) <= 1e-12
+    assert np.max(np.abs(ll8 - ll[:8]) / np.abs(ll[:8])) <= 1e-11
     for g in (0, 5, 7):
         single.set_data(X, oms[g])
         single.set_kernel(O.SE_ARD, ths[g], 0.01)
         assert single.compute() == 0
-        assert np.array_equal(np.tril(single.get_L()), np.tril(hs[g].get_L())), g
+        Ls, Lb = np.tril(single.get_L()), np.tril(hs[g].get_L())
+        assert np.max(np.abs(Ls - Lb)) <= 1e-12 * np.max(np.abs(Ls)), g
+    n1 = 1024
+    h1 = [new_gp(engine_lib, O.SE_ARD, X[:n1], oms[g][:n1], ths[g], 0.01) for g in range(8)]
+    assert _capi.batch_compute(h1) == [0] * 8
+    for g in (0, 5, 7):
+        single.set_data(X[:n1], oms[g][:n1])
+        single.set_kernel(O.SE_ARD, ths[g], 0.01)
+        assert single.compute() == 0
+        assert np.array_equal(np.tril(single.get_L()), np.tril(h1[g].get_L())), g
+    for h in h1:
+        h.close()
     single.close()
     assert _capi.batch_compute(hs) == [0] * G  # (back to the full batch for the reproducibility check below)
     assert np.array_equal(_capi.batch_log_lik(hs), ll)
@@ -429,8 +441,8 @@ def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, mon
     env = dict(os.environ, GPE_HANDOVER_FAULT="1")  # (GPE_TAIL_MAX: inherited from the monkeypatched environment)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    # the re-run factorises without the hand-over and hence without the folded last step (round 3): the same factor to rounding
-    assert abs(float(r.stdout.split("child ok")[1]) - ll) <= 1e-13 * abs(ll)
+    # the re-run factorises without the hand-over (step-by-step panels): the same factor to rounding (N eps ~ 5e-13 at N = 4096)
+    assert abs(float(r.stdout.split("child ok")[1]) - ll) <= 1e-12 * abs(ll)
 
 
 @pytest.mark.parametrize("N,P,tail,tall", [(128, 1, None, None), (320, 2, None, None), (704, 3, None, None), (1344, 1, None, None),

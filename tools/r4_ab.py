@@ -126,7 +126,7 @@ def sizes():
 
 def batch():
     print(f"# batched launches, GPE_BATCH_TAIL={os.environ.get('GPE_BATCH_TAIL', '1')} GPE_TAIL_MAX={os.environ.get('GPE_TAIL_MAX', '-')} GPE_TALL={os.environ.get('GPE_TALL', '-')}")
-    for G, N in ((8, 2048), (64, 2048), (10, 4096)):
+    for G, N in (((8, 2048),) if os.environ.get("R4_BATCH8") else ((8, 2048), (64, 2048), (10, 4096))):
         X, Y = O.make_problem("c4" if N == 2048 else "c2", N=N)
         rng = np.random.default_rng(4)
         hs = []
@@ -146,6 +146,20 @@ def batch():
         fl = N ** 3 / 3.0 + 2.0 * N * N
         assert all(s == 0 for s in st)
         print(f"batch_compute   G {G:3d} N {N}: {1e3 * dt:8.3f} ms/batch  {G / dt:9.1f} evaluations/s  {G * fl / dt / 78.6e12:.3f} of peak  ll[0] {ll[0]:.12g} reruns {sum(h.flow_retries() for h in hs)}")
+        if os.environ.get("R4_BATCH8"):  # the same members as G host threads, one launch chain each
+            import threading
+            def worker(h):
+                for _ in range(reps):
+                    h.compute()
+                    h.log_lik()
+            for h in hs:
+                h.compute()
+            ths = [threading.Thread(target=worker, args=(h,)) for h in hs]
+            t0 = time.perf_counter()
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            dtt = (time.perf_counter() - t0) / reps
+            print(f"  the same as {G} host threads, one chain each: {1e3 * dtt:8.3f} ms/batch  reruns {[h.handover_reruns() for h in hs]} retries {[h.flow_retries() for h in hs]}")
         if (G, N) != (8, 2048):
             th = rng.uniform(-1e-2, 1e-2, size=(G, 7))
             _capi.batch_hp_objective(hs, O.SE_ARD, th, 0.01, want_grad=True)
