@@ -29,7 +29,7 @@ struct DiagSync {
     int prog;     // number of 4-column panels P has published into Ls (and their inverse pivots into invd)
     int hflag[2]; // hflag[g & 1] == g: H[g & 1] holds group g with the panels 0..g-2 applied
     int xprog;    // rounds the inversion wave has finished (8: X11 complete in Xw, 16: X22 too)
-    int wdone;    // W = L21 X11 is in Xw
+    int wdone;    // W = L21 X11 is in Xw (diag_flow2.h: of block 0 -> 1, of block 1 -> 2)
     int pad[3];
 };
 #define DIAG_H_DOUBLES (2 * NB * 4)
@@ -93,6 +93,9 @@ static __device__ __forceinline__ double rsq_newton(double p)
     return fma(y0, eh, y0);
 }
 
+#ifndef FLOWP_LATE_CHECK
+#define FLOWP_LATE_CHECK 1 // 1: P waits for a missing hand-over at the END of its round, where it is needed, instead of half-way through (the hand-over loop takes ~600 cycles: 15.7 k -> 14.6 k cycles per block, tools/diagbench); 0: round 2
+#endif
 #ifndef FLOWP_LDSMUL
 #define FLOWP_LDSMUL 1 // P's look-ahead multipliers of x0..x2 through LDS (1) or all by v_readlane (0)
 #endif
@@ -135,6 +138,7 @@ struct FlowP {
         dst[0] = x0; // out as soon as they exist: the multipliers of the look-ahead update come back through LDS (below)
         dst[1] = x1;
 #endif
+#if !FLOWP_LATE_CHECK
         if (fetch && seen < G + 1) { // rare: the hand-over was not there yet
             lds_await(&sy->hflag[(G + 1) & 1], G + 1);
             n[0] = h[0];
@@ -142,6 +146,7 @@ struct FlowP {
             n[2] = h[2];
             n[3] = h[3];
         }
+#endif
         // from here on the update of the next group by this panel (multipliers = rows c0+4 .. c0+7 of the new columns)
         // fills the gaps of the pivot chain
         const double y2 = rsq_newton(fma(-l21, l21, fma(-l20, l20, b22)));
@@ -181,6 +186,15 @@ struct FlowP {
             invd[c0 + 3] = y3;
             lds_post(&sy->prog, G + 1);
         }
+#if FLOWP_LATE_CHECK
+        if (fetch && seen < G + 1) { // the hand-over was not there at the top of the round: wait for it where it is needed
+            lds_await(&sy->hflag[(G + 1) & 1], G + 1);
+            n[0] = h[0];
+            n[1] = h[1];
+            n[2] = h[2];
+            n[3] = h[3];
+        }
+#endif
         if (G < 15) {
 #if FLOWP_LDSMUL
 #pragma unroll
@@ -266,7 +280,7 @@ template <int BJ>
 struct FlowU<BJ, -1> {
     static __device__ __forceinline__ void run(double (&)[4][4], const double*, double*, DiagSync*, int) {}
 };
-static __device__ __forceinline__ void flow_x21(DiagSync* sy, const double* Xw, double* __restrict__ Xt, int u, int lane);
+static __device__ __forceinline__ void flow_x21(DiagSync* sy, const double* Xw, double* __restrict__ Xt, int u, int lane, int poff);
 template <int BJ>
 static __device__ __forceinline__ void flow_u_wave(const double* Ls, double* H, DiagSync* sy, const double* Xw,
                                                    double* __restrict__ Xt, int lane)
@@ -279,7 +293,7 @@ static __device__ __forceinline__ void flow_u_wave(const double* Ls, double* H, 
             acc[bi][nq] = Ls[(16 * bi + 4 * ((lane >> 2) & 3) + (lane >> 4)) * XS + 16 * BJ + 4 * nq + (lane & 3)];
     __syncthreads(); // every wave has its part of the block in registers: P may start overwriting Ls with L
     FlowU<BJ, 13>::run(acc, Ls, H, sy, lane);
-    flow_x21(sy, Xw, Xt, BJ, lane);
+    flow_x21(sy, Xw, Xt, BJ, lane, 0);
 }
 
 // ---- X ---------------------------------------------------------------------------------------------------------------------
@@ -341,19 +355,19 @@ struct XFold { // rows i0 + 4 + XFOLD_CH CHK ..: q holds this chunk's multiplier
         }
     }
 };
-template <int G>
+template <int G, int POFF = 0> // POFF: added to the panel / round counters (diag_flow2.h runs the pipeline a second time with 16)
 struct FlowX {
     static __device__ __forceinline__ void run(double (&S)[32], const double* Ls, const double* invd, double* __restrict__ Xt,
                                                DiagSync* sy, double* Xw, int c, int h, double* __restrict__ S22)
     {
-        FlowX<G - 1>::run(S, Ls, invd, Xt, sy, Xw, c, h, S22);
+        FlowX<G - 1, POFF>::run(S, Ls, invd, Xt, sy, Xw, c, h, S22);
         constexpr int hb = G >> 3, i0 = 4 * (G & 7), base = 32 * hb, nrow = 28 - i0;
         if (G == 8) { // second half-block: start again from the identity
 #pragma unroll
             for (int k = 0; k < 32; ++k)
                 S[k] = (h == 0 && k == c) ? 1.0 : 0.0;
         }
-        lds_await(&sy->prog, G + 1); // columns 4G..4G+3 of L and their inverse pivots are final
+        lds_await(&sy->prog, POFF + G + 1); // columns 4G..4G+3 of L and their inverse pivots are final
         const double* Lb = Ls + base * XS + base; // this half-block of L
         // my two columns (2h, 2h+1) of the panel, as an LDS byte address; the reads name rows relative to Lb's first
         const unsigned lbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) double*)(Lb + i0 + 2 * h);
@@ -393,12 +407,12 @@ struct FlowX {
         const double xa = h ? x2 : x0, xb = h ? x3 : x1;
         XFold<G, 0>::run(S, q, lbase, xa, xb);
         if ((G & 7) == 7 && c == 0 && h == 0)
-            lds_post(&sy->xprog, G + 1); // a half-block of X is complete in Xw
+            lds_post(&sy->xprog, POFF + G + 1); // a half-block of X is complete in Xw
         FTS(5, G);
     }
 };
-template <>
-struct FlowX<-1> {
+template <int POFF>
+struct FlowX<-1, POFF> {
     static __device__ __forceinline__ void run(double (&)[32], const double*, const double*, double*, DiagSync*, double*, int, int, double*) {}
 };
 
@@ -408,13 +422,13 @@ struct FlowX<-1> {
 // product (trsm_tile_full, potrf.hip).  Here: W = L21 X11 by the eighth wave while the second half of the block is still being
 // factored, X21 = -X22 W by the four update waves once X22 is complete — 32 matrix-core instructions each, ~1 k cycles behind
 // the inversion wave.  mfma4 layouts as in mm16 / st16 (potrf.hip).
-static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* sy, double* Xw, int lane)
+static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* sy, double* Xw, int lane, int poff = 0)
 {
-    lds_await(&sy->xprog, 8);
+    lds_await(&sy->xprog, poff + 8);
     // ... and not before panel 10 is out: this wave shares its SIMD with update wave U2, which hands groups 8..11 to P in
     // rounds 6..9 — started at round 8 its matrix-core instructions delayed those hand-overs and P with them (round 10:
     // 1.6 k cycles instead of 1.0 k, r02_diag_flow_stamps.log of that build).  Three rounds are enough for W.
-    lds_await(&sy->prog, 11);
+    lds_await(&sy->prog, poff + 11);
     const double* X11 = Xw;
     double* W = Xw + 2 * (32 * XH);
     const int kq = lane >> 4;
@@ -447,13 +461,13 @@ static __device__ __forceinline__ void flow_w_wave(const double* Ls, DiagSync* s
         for (int n = 0; n < 8; ++n)
             W[(16 * sl + row) * XH + 4 * n + col] = acc[sl][n];
     if (lane == 0)
-        lds_post(&sy->wdone, 1);
+        lds_post(&sy->wdone, (poff >> 4) + 1);
 }
 // update wave u: columns 8u .. 8u+7 of X21, all 32 rows
-static __device__ __forceinline__ void flow_x21(DiagSync* sy, const double* Xw, double* __restrict__ Xt, int u, int lane)
+static __device__ __forceinline__ void flow_x21(DiagSync* sy, const double* Xw, double* __restrict__ Xt, int u, int lane, int poff = 0)
 {
-    lds_await(&sy->wdone, 1);
-    lds_await(&sy->xprog, 16);
+    lds_await(&sy->wdone, (poff >> 4) + 1);
+    lds_await(&sy->xprog, poff + 16);
     const double* X22 = Xw + 32 * XH;
     const double* W = Xw + 2 * (32 * XH);
     const int kq = lane >> 4;

@@ -94,7 +94,9 @@ struct gpe_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead: bulk of a trailing update runs here, behind the next panel
     std::vector<hipEvent_t> la_events; // untimed events ordering the two streams
-    int64_t tail_max = 2560;           // the last <= this many columns by one launch (k_tail; GPE_TAIL_MAX=0: by panels to the end)
+    int64_t tail_max = 2816;           // the last <= this many columns by one launch (k_tail; GPE_TAIL_MAX=0: by panels to the end);
+                                       // 2816 against 2560: the one update in front of it has 253 tiles instead of 230 for the 256 CUs
+                                       // (0.64 against 0.57 of the fp64 peak), profiles/r04_tail_max_sizes.log
     int64_t tall_max = 1536;           // ... and up to this many columns in FRONT of them as one tall data-flow launch (all rows
                                        // below ride along) followed by ONE update with k = its width (GPE_TALL=0: 256-column panels
                                        // with look-ahead all the way to the closing launch, the round-3 schedule)

@@ -304,6 +304,9 @@ static __device__ __forceinline__ void trsv_bwd_flow_body(const double* __restri
                     }
                     v = __longlong_as_double((long long)bits);
                 }
+#ifdef FLOW_TIMING
+                if (t == j + 1) FTS(7); // the last contributor's values have arrived
+#endif
                 xs[lane] = v;
             }
             __syncthreads();
@@ -423,10 +426,10 @@ void dump_flow_timing(int nblk)
     static long long h[256][8];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_flow_ts), sizeof(h));
     long long t0 = h[nblk - 1][0];
-    printf("backward flow solve (10 ns ticks since the first workgroup started): block | start | fold1 fold2 fold8 done | last fold done | solved | published\n");
+    printf("backward flow solve (10 ns ticks since the first workgroup started): block | start | fold1 fold2 fold8 done | last contributor seen | last fold done | solved | published\n");
     for (int j = nblk - 1; j >= 0; j -= (j > nblk - 4 || j < 4) ? 1 : 6)
-        printf("  %3d | %5lld | %5lld %5lld %5lld | %6lld | %6lld | %6lld\n", j, h[j][0] - t0, h[j][1] - t0, h[j][2] - t0, h[j][3] - t0, h[j][4] - t0,
-               h[j][5] - t0, h[j][6] - t0);
+        printf("  %3d | %5lld | %5lld %5lld %5lld | %6lld | %6lld | %6lld | %6lld\n", j, h[j][0] - t0, h[j][1] - t0, h[j][2] - t0, h[j][3] - t0, h[j][7] - t0,
+               h[j][4] - t0, h[j][5] - t0, h[j][6] - t0);
 }
 #endif
 // a <- L^-T y in one launch (nblk <= 256: all workgroups resident); `a` must not alias y

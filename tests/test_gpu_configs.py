@@ -376,14 +376,14 @@ def test_gpu_panel_head_tiles_handed_over_or_rederived_give_the_same_factor(engi
     # handed over or re-derived: the same products in the same order, bitwise the same factor
     assert np.array_equal(Ls["no_handover"], Ls["handover_steps"]), float(np.max(np.abs(Ls["no_handover"] - Ls["handover_steps"])))
     # k_panel256 (the whole panel as one data-flow launch) solves the factoring strips' tiles in the half-block form of the
-    # inverse and sums the next diagonal block's pieces in one accumulator; the default (N = 1100 <= 2560: the whole matrix as
+    # inverse and sums the next diagonal block's pieces in one accumulator; the default (N = 1100 <= 2816: the whole matrix as
     # ONE k_tail launch) groups the same sums by 64-column tile: another order of the same arithmetic
     assert np.max(np.abs(Ls["no_handover"] - Ls["handover_panel256"])) <= 1e-13 * np.max(np.abs(L1))
     assert np.max(np.abs(Ls["no_handover"] - L1)) <= 1e-13 * np.max(np.abs(L1))
 
 
 def test_gpu_one_launch_panels_polled_buffers_across_handles(engine_lib, monkeypatch):
-    """(GPE_TAIL_MAX=0: panels to the end — under the defaults every N <= 2560 is one k_tail launch and never reaches
+    """(GPE_TAIL_MAX=0: panels to the end — under the defaults every N <= 2816 is one k_tail launch and never reaches
     k_panel256.)  k_panel256 hands block inverses and head tiles over through buffers that must hold an all-ones pattern when a launch
     starts: every launch arms the other buffer of the handle's pair, both are armed when a handle is created — also when its
     streams and scratch block come out of the pool of destroyed handles, in whatever state the last launch left them.  An odd
@@ -456,7 +456,7 @@ def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, mon
                                            (3000, 2, "1280", "1536"),  # tall 0..1792 (28 x 46 strips + ragged/rhs strip), closing 18
                                            ])
 def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, tail, tall):
-    """k_tail: the last <= 2560 columns (GPE_TAIL_MAX; all of them when N is no larger) of a factorisation whose order is a
+    """k_tail: the last <= 2816 columns (GPE_TAIL_MAX; all of them when N is no larger) of a factorisation whose order is a
     multiple of 64 are factored by ONE launch, a workgroup per 64 x 64 tile, operands polled between them.  Against LAPACK on the
     host: L to 1e-10 of max|L|, alpha (the forward substitution rides along as the right-hand-side strip, P rows) to 1e-7,
     log-lik to 1e-10.  Sizes: a single tile column pair (128), tails that are the whole matrix, tails behind one-launch panels
@@ -495,16 +495,48 @@ def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, t
     h.close()
 
 
+def test_gpu_pair_blocks_vs_lapack():
+    """GPE_TAIL_PAIR=1 (diag_flow2.h, experimental, off by default): the chain workgroup of an even tile column factors its
+    diagonal block, the tile below and the NEXT diagonal block as one 128 x 128 block — the panel wave holds two rows per lane —
+    and the odd column's diagonal tile has no workgroup of its own.  L, alpha and the log-likelihood against LAPACK for an even
+    and an odd number of tile columns, a ragged order with three outputs, and the tall launch + update + closing launch of
+    N = 4096; every size twice (both pairs of polled buffers).  Child process: the switch is read once."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, scipy.linalg as sl\n"
+            "from limbo_amd import _capi, synth as O\n"
+            "eng = _capi.load_engine()\n"
+            "for N, P in [(128, 1), (1024, 1), (1088, 2), (1407, 3), (2048, 1), (4096, 1)]:\n"
+            "    rng = np.random.default_rng(N + P)\n"
+            "    X = rng.uniform(0, 1, size=(N, 4))\n"
+            "    Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.05 * rng.normal(size=(N, P))\n"
+            "    om, _ = O.obs_mean_data(Y)\n"
+            "    h = _capi.Handle(eng); h.set_data(X, om); h.set_kernel(int(O.SE_ARD), rng.uniform(-0.3, 0.2, size=5), 0.01)\n"
+            "    for rep in range(2):\n"
+            "        assert h.compute() == 0 and h.flow_retries() == 0, (N, P)\n"
+            "        L = np.tril(h.get_L()); K = h.get_K()\n"
+            "        Lref = sl.cholesky(np.tril(K) + np.tril(K, -1).T, lower=True)\n"
+            "        assert np.max(np.abs(L - Lref)) <= 1e-10 * np.max(np.abs(Lref)), (N, P)\n"
+            "        aref = sl.cho_solve((Lref, True), om)\n"
+            "        assert np.linalg.norm(h.get_alpha() - aref) < 1e-7 * np.linalg.norm(aref), (N, P)\n"
+            "        llref = -0.5 * np.sum(om * aref) - np.sum(np.log(np.diag(Lref))) - 0.5 * N * np.log(2 * np.pi)\n"
+            "        assert abs(h.log_lik() - llref) <= 1e-10 * abs(llref), (N, P)\n"
+            "    h.close()\n"
+            "print('pair ok')\n") % str(ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPE_TAIL_PAIR="1"), capture_output=True, text=True,
+                       timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0 and "pair ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_gpu_data_flow_buffers_across_sizes_on_one_handle(engine_lib):
     """the data-flow launches (k_tail) hand tiles over through buffers that must hold an all-ones pattern
     where the launch polls, and a launch only re-arms ITS OWN slot layout of the other buffer.  One handle whose N and P change
-    between evaluations — a BO run growing past the closing launch's width (2560 -> 2624 -> 2688 changes the tile-column count
-    40 -> 37 -> 38), a P change, sizes with and without a tall launch in front — must give LAPACK's factor every time: the
+    between evaluations — a BO run growing past the closing launch's width (2816 -> 2880 -> 2944 changes the tile-column count
+    44 -> 41 -> 42), a P change, sizes with and without a tall launch in front — must give LAPACK's factor every time: the
     engine puts the pair back to all-ones when the layout differs from the previous launch's (engine.hip: prepare_tail)."""
     import scipy.linalg as sl
     rng = np.random.default_rng(7)
     h = _capi.Handle(engine_lib)
-    for N, P in [(2560, 1), (2624, 1), (2688, 1), (2624, 2), (2560, 1), (4096, 1), (3000, 1), (4096, 2), (2688, 1), (2688, 1)]:
+    for N, P in [(2816, 1), (2880, 1), (2944, 1), (2880, 2), (2816, 1), (4096, 1), (3000, 1), (4096, 2), (2944, 1), (2944, 1)]:
         X = rng.uniform(0, 1, size=(N, 4))
         Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.05 * rng.normal(size=(N, P))
         om, _ = O.obs_mean_data(Y)
