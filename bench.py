@@ -554,13 +554,13 @@ def main():
         out["roofline"] = {
             "bound": "mfma",
             "kernel": "k_gemm_glds (Cholesky trailing update A22 -= L21 L21^T, v_mfma_f64_4x4x4_4b): every trailing-update launch of one "
-                      "factorisation, each alone, HIP events on the handle's stream.  Round 4 schedule at N = 4096: ONE update with k = 1536 "
-                      "between the tall data-flow launch (columns 0..1535, all rows) and the closing one (columns 1536..4095); their flops "
+                      "factorisation, each alone, HIP events on the handle's stream.  Round 4 schedule at N = 4096: ONE update with k = 1280 "
+                      "between the tall data-flow launch (columns 0..1279, all rows) and the closing one (columns 1280..4095); their flops "
                       "are in `data_flow_launches`, the round-3 accounting (all 15 k = 256 updates) in `all_updates_like_for_like`",
             "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF,
             "traffic": traffic,
             "traffic_note": f"bytes of the update launch, PMC (profiles/{pmc.name}: committed, not measured in this run); algorithmic "
-                            "bytes of that launch = 2 x 26.2 MB C tiles (lower triangle of 2560^2) + 31.5 MB panel (2560 x 1536)",
+                            "bytes of that launch = 2 x 31.7 MB C tiles (lower triangle of 2816^2) + 28.8 MB panel (2816 x 1280)",
             "launches_per_step": upd["launches"], "avg_launch_us": upd["us"] / max(upd["launches"], 1),
             "algorithmic_flops_per_step": upd["flops"],
             "share_of_factorisation_flops": upd["flops"] / (float(N) ** 3 / 3.0),

@@ -52,12 +52,15 @@ __device__ long long g_panel_ts[64];
 #define PTS(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_panel_ts[(blockIdx.x == 0 ? 0 : 32) + (i)] = clock64(); } while (0)
 __device__ long long g_tail_ts[64][4]; // k_tail, the diagonal workgroup of column c: updates done | solved | factoring | factored
 #define TTS(c, i) do { if (threadIdx.x == 0 && (c) < 64) g_tail_ts[(c)][(i)] = wall_clock64(); } while (0)
+__device__ long long g_tail_ts2[64][8]; // ... inside its two-phase solve: X11/L21 seen | phase A done | X22 seen | X22 in LDS | Y2 written | done
+#define TTS2(x, on, i) do { if ((on) && threadIdx.x == 0 && ((x).R0 - (x).p0) / NB < 64) g_tail_ts2[((x).R0 - (x).p0) / NB][(i)] = wall_clock64(); } while (0)
 __device__ long long g_p256_ts[5][32]; // k_panel256: strips 0..3 and the last one; [6 S + i] = stamp i of step S, [30] start, [31] end
 #define P2TS(i) do { if (threadIdx.x == 0 && (blockIdx.x < 4 || blockIdx.x == gridDim.x - 1)) g_p256_ts[blockIdx.x < 4 ? blockIdx.x : 4][(i)] = wall_clock64(); } while (0)
 #else
 #define PTS(i) do { } while (0)
 #define P2TS(i) do { } while (0)
 #define TTS(c, i) do { } while (0)
+#define TTS2(x, on, i) do { } while (0)
 #endif
 #define XS 66 // LDS row stride (doubles) of the 64 x 64 work matrices: conflict-free MFMA operand reads
 
@@ -1052,6 +1055,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
                     b[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         P2TS(6 * S + 1);
+        TTS2(x, acc_on && PUBHALF, 0);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = threadIdx.x + 512 * q; // X11: e = k + 32 c ; L21: e = c + 32 k
@@ -1094,6 +1098,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
     if (acc_on)
         mmk<false, 32, 4>(T, 0, T, 0, wm, wn, lane, a2); // the product's first half: Y1 Y1^T (columns 0..31 of T are final)
     P2TS(6 * S + 2);
+    TTS2(x, acc_on && PUBHALF, 1);
     // ---- phase B: X22 ----
     {
         unsigned long long b0 = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
@@ -1112,12 +1117,14 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
             if (b1 == SENT)
                 b1 = __hip_atomic_load(Sp + 2048 + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        TTS2(x, acc_on && PUBHALF, 2);
         const int e0 = threadIdx.x, e1 = threadIdx.x + 512; // e = k + 32 c
         Bx[(32 + (e0 >> 5)) * XS + 32 + (e0 & 31)] = __longlong_as_double((long long)b0);
         Bx[(32 + (e1 >> 5)) * XS + 32 + (e1 & 31)] = __longlong_as_double((long long)b1);
     }
     __syncthreads(); // X22 is in LDS (and T[:, 32:64] complete)
     P2TS(6 * S + 3);
+    TTS2(x, acc_on && PUBHALF, 3);
     double y2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
     mmk<true, 32, 2>(T, 32, Bx + 32 * XS + 32, 0, wm, hn, lane, y2); // Y2 = T2 X22^T
     __syncthreads();
@@ -1127,6 +1134,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
         for (int n = 0; n < 2; ++n)
             T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
     __syncthreads();
+    TTS2(x, acc_on && PUBHALF, 4);
     if constexpr (PUBHALF) { // ... and the other 32 columns: the product below covers most of their way
         const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
 #pragma unroll
@@ -1137,6 +1145,7 @@ static __device__ __forceinline__ void p256_half_solve(const P256& x, double* __
     }
     if (acc_on)
         mmk<false, 32, 4>(T, 32, T, 32, wm, wn, lane, a2); // the product's second half
+    TTS2(x, acc_on && PUBHALF, 5);
 }
 
 // the update of a strip's tile of column block T + 1 with the step's tile of strip T (its own: in TT; another strip's: polled)
@@ -2137,6 +2146,14 @@ void dump_tail_timing(int nt)
     for (int c = 0; c < nt && c < 64; ++c)
         printf("  %2d | %7.2f | %7.2f | %7.2f | %7.2f   (step %5.2f)\n", c, c ? (h[c][0] - t0) * 0.01 : 0.0, c ? (h[c][1] - t0) * 0.01 : 0.0,
                (h[c][2] - t0) * 0.01, (h[c][3] - t0) * 0.01, c ? (h[c][2] - h[c - 1][2]) * 0.01 : 0.0);
+    long long g[64][8];
+    hipMemcpyFromSymbol(g, HIP_SYMBOL(g_tail_ts2), sizeof(g));
+    printf("  between two blocks, us after the panel wave of column c-1 is through: X11/L21 seen | phase A done | X22 seen | X22 in LDS | Y2 written | second half product done | block complete | factoring\n");
+    for (int c = 1; c < nt && c < 64; ++c) {
+        const long long p = h[c - 1][3];
+        printf("  %2d | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f\n", c, (g[c][0] - p) * 0.01, (g[c][1] - p) * 0.01, (g[c][2] - p) * 0.01,
+               (g[c][3] - p) * 0.01, (g[c][4] - p) * 0.01, (g[c][5] - p) * 0.01, (h[c][1] - p) * 0.01, (h[c][2] - p) * 0.01);
+    }
 }
 void dump_p256_timing()
 {
