@@ -580,9 +580,11 @@ def main():
         out["phases_us_per_step_profiled"] = {k: v["us"] for k, v in ph.items()}
 
     if rank == 0 and world == 1 and not args.no_roofline:
-        # throughput with R independent evaluations in flight (the reference runs hyper-parameter
-        # restarts concurrently: opt/parallel_repeater.hpp:86-105 under tools::par::max).  One
-        # factorisation is a latency-bound chain of small kernels; R of them on R streams fill the idle CUs.
+        # R independent evaluations in flight from R host threads (the reference runs hyper-parameter restarts concurrently:
+        # opt/parallel_repeater.hpp:86-105 under tools::par::max).  Round 4: the data-flow launches of different handles no longer
+        # overlap (csrc/dev.h, FlowGate: two of them at once can starve each other's lowest unfinished workgroup — measured: four
+        # threads fell into the bounded polls and the re-run path, 1 evaluation/s), only the other launches do: the figure is the
+        # single-chain rate plus that overlap.  Restarts in lock-step (one batched launch sequence) are `batched_hp_objective`.
         import threading
 
         conc = {}

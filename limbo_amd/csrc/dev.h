@@ -206,6 +206,23 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
 // factorisation (nb = nt [+ 1 for the right-hand-side rows]) or a tall head panel (nb > nt); a buffer = the polled quarters
 // of nt block inverses, then a slot per tile
 #define GPE_TAIL_MAX 8192 // (upper bound of the setting; the default: engine.hip)
+// Data-flow launches (k_tail, k_panel256, the one-launch sweeps) wait INSIDE the launch for lower-numbered workgroups of the same
+// launch.  That is deadlock-free for one such launch at a time — its lowest unfinished workgroup is always resident — but not
+// for two from different streams: each XCD dispatches its share of every launch in order, and the CUs of the XCD that the
+// lowest unfinished workgroup of launch A belongs to can all be held by waiting workgroups of launch B and vice versa (round
+// 4: four handles evaluated from four host threads ran into the bounded polls and the re-run path, 1 evaluation/s instead of
+// 1300; profiles/r04_concurrent_flow_launches.log).  So a data-flow launch from one stream waits for the previous one on the
+// device from another stream (an event; nothing when the device has a single handle).  engine.hip.
+void flow_gate_enter(hipStream_t s);
+void flow_gate_leave(hipStream_t s);
+void flow_gate_handles(int delta);
+struct FlowGate {
+    hipStream_t s;
+    explicit FlowGate(hipStream_t s_) : s(s_) { flow_gate_enter(s); }
+    ~FlowGate() { flow_gate_leave(s); }
+    FlowGate(const FlowGate&) = delete;
+    FlowGate& operator=(const FlowGate&) = delete;
+};
 static inline int64_t tail_tiles(int64_t nt, int64_t nb) { return nt * nb - nt * (nt - 1) / 2; }
 static inline int64_t tail_buf_doubles(int64_t nt, int64_t nb) { return nt * 3072 + tail_tiles(nt, nb) * 4096; }
 // gen (optional): the launch generates its tiles of K from the samples (and obs_mean's rows from Om) instead of reading A,

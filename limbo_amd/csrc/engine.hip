@@ -1533,6 +1533,62 @@ int logical_devices()
 // =============================================================================================
 // C-ABI
 // =============================================================================================
+// ---- one data-flow launch at a time per device (dev.h: FlowGate) ----
+namespace {
+struct GateDev {
+    std::recursive_mutex mu;
+    int depth = 0, handles = 0, next = 0;
+    hipEvent_t ring[64] = {};
+    hipEvent_t last = nullptr;
+    hipStream_t last_stream = nullptr;
+};
+GateDev g_gate[16];
+bool gate_on()
+{
+    static const bool on = !(getenv("GPE_FLOW_GATE") && atoi(getenv("GPE_FLOW_GATE")) == 0);
+    return on;
+}
+GateDev& gate_dev()
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return g_gate[dev & 15];
+}
+} // namespace
+void flow_gate_handles(int delta)
+{
+    GateDev& g = gate_dev();
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    g.handles += delta;
+}
+void flow_gate_enter(hipStream_t s)
+{
+    if (!gate_on())
+        return;
+    GateDev& g = gate_dev();
+    g.mu.lock(); // (held until flow_gate_leave: the launch in between is a few microseconds of host time)
+    if (g.depth++ == 0 && g.last && g.last_stream != s)
+        (void)hipStreamWaitEvent(s, g.last, 0);
+}
+void flow_gate_leave(hipStream_t s)
+{
+    if (!gate_on())
+        return;
+    GateDev& g = gate_dev();
+    if (--g.depth == 0 && g.handles > 1) { // (a single handle on the device: its launches are ordered by its streams' events already)
+        hipEvent_t& e = g.ring[g.next];
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+            e = nullptr;
+        if (e && hipEventRecord(e, s) == hipSuccess) {
+            g.last = e;
+            g.last_stream = s;
+            g.next = (g.next + 1) % 64;
+        }
+    }
+    g.mu.unlock();
+}
+
+
 extern "C" {
 
 const char* gpe_version(void) { return "limbo_amd-gpe 0.1 (gfx950)"; }
@@ -1628,6 +1684,7 @@ int gpe_create(int device_id, gpe_handle* out)
         if (v >= 64 && v % 64 == 0)
             c->nbo = v;
     }
+    flow_gate_handles(+1); // (the device is current: the streams above were created on it)
     *out = c;
     return GPE_OK;
 }
@@ -1637,6 +1694,7 @@ int gpe_destroy(gpe_handle c)
     if (!c)
         return GPE_ERR_ARG;
     DevGuard g(c);
+    flow_gate_handles(-1);
     hipStreamSynchronize(c->stream);
     if (c->gen_ev)
         hipEventDestroy(c->gen_ev);

@@ -1406,6 +1406,7 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
     if (rows <= 0)
         return;
     const dim3 grid((unsigned)((rows + NB - 1) / NB)), block(512);
+    FlowGate gate(s); // (its strips poll each other inside the launch: dev.h)
     if (stop)
         GPE_LAUNCH_STOP("k_panel256", k_panel256, grid, block, 0, s, stop, A, lda, p0, M, Xt, info, dnext, Dacc, spin_limit, S22, S22_next);
     else
@@ -2030,6 +2031,7 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
         a.ldal = gen->ldal;
         a.P = gen->P;
     }
+    FlowGate gate(s); // (one data-flow launch at a time on the device: dev.h)
     if (g_batch.bt)
         GPE_LAUNCH(k_tail_b, dim3((unsigned)(tiles * g_batch.G)), dim3(512), 0, s, a, g_batch.bt);
     else if (gen)
@@ -2205,6 +2207,7 @@ void launch_panel_step(hipStream_t s, double* A, int64_t lda, int64_t j0, int64_
     const int64_t rows = M - (j0 + NB);
     if (rows <= 0)
         return;
+    FlowGate gate(s); // (the head tiles are handed over inside the launch: dev.h)
     if (g_batch.bt)
         GPE_LAUNCH(k_panel_step_b, dim3((unsigned)((rows + NB - 1) / NB) * g_batch.G), dim3(512), 0, s, A, lda, j0, M, nt,
                            Xt_cur, Xt_next, do_next, info, Hs, dnext, dfirst, dinit, Dacc, hflag, epoch, spin_limit, g_batch.bt);

@@ -443,6 +443,7 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
     if (!prefilled)
         for (int p = 0; p < P; ++p)
             hipMemsetAsync(a + (int64_t)p * ldw, 0xFF, sizeof(double) * (size_t)N, s);
+    FlowGate gate(s); // (one data-flow launch at a time on the device: dev.h)
     // several right-hand sides travel together, four to a pass (solve_mp.hip); a single one takes the kernel above
     for (int p0 = 0; p0 < P; p0 += 4) {
         const int pc = P - p0 < 4 ? P - p0 : 4;
@@ -598,6 +599,7 @@ void launch_trsv_fwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
     const int64_t nblk = (N + NB - 1) / NB;
     for (int p = 0; p < P; ++p)
         hipMemsetAsync(y + (int64_t)p * ldy, 0xFF, sizeof(double) * (size_t)N, s);
+    FlowGate gate(s); // (one data-flow launch at a time on the device: dev.h)
     for (int p0 = 0; p0 < P; p0 += 4) { // four right-hand sides to a pass (solve_mp.hip)
         const int pc = P - p0 < 4 ? P - p0 : 4;
         const double* bc = b + (int64_t)p0 * ldb;

@@ -185,6 +185,12 @@ if __name__ == "__main__":
         batch()
     if what == "single2":
         single2()
+    if what == "probe":  # one number: evaluations/s at N = 4096 under the defaults (tools/refresh_profiles.sh looks at it first)
+        X, Y = O.make_problem("c2", N=4096)
+        om, _ = O.obs_mean_data(Y)
+        h = handle(X, om, O.SE_ARD, np.zeros(7), None, None)
+        med, mn, ll = timed(h, steps=12, warm=3)
+        print(f"{1e3 / med:.1f}")
     if what == "all":
         for env in ({"GPE_BATCH_TAIL": "0"}, {}, {"GPE_TAIL_MAX": "4096"}, {"GPE_TAIL_MAX": "2816"}):
             r = subprocess.run([sys.executable, __file__, "batch"], env=dict(os.environ, **env), capture_output=True, text=True)
