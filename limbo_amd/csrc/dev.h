@@ -212,10 +212,10 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
 // lowest unfinished workgroup of launch A belongs to can all be held by waiting workgroups of launch B and vice versa (round
 // 4: four handles evaluated from four host threads ran into the bounded polls and the re-run path, 1 evaluation/s instead of
 // 1300; profiles/r04_concurrent_flow_launches.log).  So a data-flow launch from one stream waits for the previous one on the
-// device from another stream (an event; nothing when the device has a single handle).  engine.hip.
+// device when that one went to another stream (an event recorded at that stream's end at that moment; nothing otherwise).  engine.hip.
 void flow_gate_enter(hipStream_t s);
 void flow_gate_leave(hipStream_t s);
-void flow_gate_handles(int delta);
+void flow_gate_forget(hipStream_t s);
 struct FlowGate {
     hipStream_t s;
     explicit FlowGate(hipStream_t s_) : s(s_) { flow_gate_enter(s); }

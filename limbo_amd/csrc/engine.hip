@@ -1537,10 +1537,9 @@ int logical_devices()
 namespace {
 struct GateDev {
     std::recursive_mutex mu;
-    int depth = 0, handles = 0, next = 0;
+    int depth = 0, next = 0;
     hipEvent_t ring[64] = {};
-    hipEvent_t last = nullptr;
-    hipStream_t last_stream = nullptr;
+    hipStream_t last_stream = nullptr; // where the device's last data-flow launch went
 };
 GateDev g_gate[16];
 bool gate_on()
@@ -1555,11 +1554,13 @@ GateDev& gate_dev()
     return g_gate[dev & 15];
 }
 } // namespace
-void flow_gate_handles(int delta)
+// a stream is about to be destroyed: nobody may record on it afterwards
+void flow_gate_forget(hipStream_t s)
 {
     GateDev& g = gate_dev();
     std::lock_guard<std::recursive_mutex> lk(g.mu);
-    g.handles += delta;
+    if (g.last_stream == s)
+        g.last_stream = nullptr; // (gpe_destroy synchronises the stream first: its launches are through)
 }
 void flow_gate_enter(hipStream_t s)
 {
@@ -1567,27 +1568,27 @@ void flow_gate_enter(hipStream_t s)
         return;
     GateDev& g = gate_dev();
     g.mu.lock(); // (held until flow_gate_leave: the launch in between is a few microseconds of host time)
-    if (g.depth++ == 0 && g.last && g.last_stream != s)
-        (void)hipStreamWaitEvent(s, g.last, 0);
+    if (g.depth++ == 0 && g.last_stream && g.last_stream != s) {
+        // the previous data-flow launch of the device went to another stream: an event at that stream's current end (behind
+        // that launch; nothing is recorded per launch — a batch of 64 members steps through ~60 gated launches on one stream)
+        hipEvent_t& e = g.ring[g.next];
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+            e = nullptr;
+        if (e && hipEventRecord(e, g.last_stream) == hipSuccess) {
+            (void)hipStreamWaitEvent(s, e, 0);
+            g.next = (g.next + 1) % 64;
+        }
+    }
 }
 void flow_gate_leave(hipStream_t s)
 {
     if (!gate_on())
         return;
     GateDev& g = gate_dev();
-    if (--g.depth == 0 && g.handles > 1) { // (a single handle on the device: its launches are ordered by its streams' events already)
-        hipEvent_t& e = g.ring[g.next];
-        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
-            e = nullptr;
-        if (e && hipEventRecord(e, s) == hipSuccess) {
-            g.last = e;
-            g.last_stream = s;
-            g.next = (g.next + 1) % 64;
-        }
-    }
+    if (--g.depth == 0)
+        g.last_stream = s;
     g.mu.unlock();
 }
-
 
 extern "C" {
 
@@ -1684,7 +1685,6 @@ int gpe_create(int device_id, gpe_handle* out)
         if (v >= 64 && v % 64 == 0)
             c->nbo = v;
     }
-    flow_gate_handles(+1); // (the device is current: the streams above were created on it)
     *out = c;
     return GPE_OK;
 }
@@ -1694,7 +1694,6 @@ int gpe_destroy(gpe_handle c)
     if (!c)
         return GPE_ERR_ARG;
     DevGuard g(c);
-    flow_gate_handles(-1);
     hipStreamSynchronize(c->stream);
     if (c->gen_ev)
         hipEventDestroy(c->gen_ev);
@@ -1721,6 +1720,8 @@ int gpe_destroy(gpe_handle c)
     if (!kept) {
         hipFree(c->dScal);
         hipHostFree(c->hPinned);
+        flow_gate_forget(c->stream2);
+        flow_gate_forget(c->stream);
         hipStreamDestroy(c->stream2);
         hipStreamDestroy(c->stream);
     }

@@ -527,6 +527,40 @@ def test_gpu_pair_blocks_vs_lapack():
     assert r.returncode == 0 and "pair ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_gpu_concurrent_handles_do_not_starve_each_other(engine_lib):
+    """Round 4: data-flow launches wait inside the launch for lower-numbered workgroups, which is deadlock-free for ONE such
+    launch at a time only — four fresh handles evaluated from four host threads filled every XCD with each other's waiting
+    workgroups, ran into the bounded polls and the re-run path (1 evaluation/s).  csrc/dev.h, FlowGate: a data-flow launch
+    waits for the device's previous one when that went to another stream.  Four handles x six evaluations from four threads:
+    no re-run, every log-likelihood equal to the handle's own sequential one, and not slower than 100 evaluations/s."""
+    import threading
+    import time
+    X, Y = synth.make_problem("c2", N=4096)
+    om, _ = synth.obs_mean_data(Y)
+    hs = [new_gp(engine_lib, O.SE_ARD, X, om, np.zeros(7) + 1e-3 * r, 0.01) for r in range(4)]
+    ref = []
+    for h in hs:
+        assert h.compute() == 0
+        ref.append(h.log_lik())
+    got = [[] for _ in hs]
+
+    def worker(i):
+        for _ in range(6):
+            assert hs[i].compute() == 0
+            got[i].append(hs[i].log_lik())
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(hs))]
+    t0 = time.perf_counter()
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    for i, h in enumerate(hs):
+        assert h.handover_reruns() == 0 and h.flow_retries() == 0, i
+        assert all(v == ref[i] for v in got[i]), i
+        h.close()
+    assert 24 / dt > 100.0, dt
+
+
 def test_gpu_data_flow_buffers_across_sizes_on_one_handle(engine_lib):
     """the data-flow launches (k_tail) hand tiles over through buffers that must hold an all-ones pattern
     where the launch polls, and a launch only re-arms ITS OWN slot layout of the other buffer.  One handle whose N and P change
