@@ -210,6 +210,11 @@ int gpe_small_calls(gpe_handle h, int64_t* n);
  * start us, end us, stream index, kernel, grid, block (times from the first recorded launch's start). */
 int gpe_trace(int on);
 int gpe_trace_dump(const char* path);
+/* Test hook, host only (no device is touched): the dispatch table of a data-flow launch of `nt` tile columns x `nb` row strips
+ * (csrc/potrf.hip: tail_order; lag = GPE_TAIL_LAG, pair = GPE_TAIL_PAIR) is built and checked — 1: a permutation of the launch's
+ * tiles in which every workgroup waits for lower-numbered ones only (what makes the launch deadlock-free), 0: not, -1: bad
+ * arguments.  The engine runs the same check before it uses a table. */
+int gpe_debug_tail_order(int nt, int nb, int lag, int pair);
 /* fp64 MFMA peak micro-benchmark (v_mfma_f64_4x4x4_4b, the instruction the GEMM kernels issue), TFLOP/s */
 int gpe_mfma_f64_peak(int device_id, double* tflops);
 /* HBM write-stream micro-benchmark, GB/s */

@@ -3216,6 +3216,8 @@ int gpe_trace_dump(const char* path)
     return GPE_OK;
 }
 
+int gpe_debug_tail_order(int nt, int nb, int lag, int pair) { return debug_tail_order(nt, nb, lag, pair); }
+
 int gpe_mfma_f64_peak(int device_id, double* tflops)
 {
     if (!tflops || hipSetDevice(device_id) != hipSuccess)

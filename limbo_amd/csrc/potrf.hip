@@ -1903,19 +1903,10 @@ __global__ __launch_bounds__(512) void k_tail_b(TailArgs a, const BatchTab* __re
 #include <map>
 #include <mutex>
 #include <vector>
-static const int* tail_order(int nt, int nb, int W, int lag, int pair)
+// the table itself, on the host: flat[2 w] = row strip, flat[2 w + 1] = tile column of workgroup w; false: a wait for a
+// higher-numbered workgroup somewhere (the caller then falls back to the column-by-column order)
+static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vector<int>& flat)
 {
-    if (W <= 0 && lag <= 0 && !pair)
-        return nullptr;
-    static std::mutex mu;
-    static std::map<std::array<int, 6>, int*> cache;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const std::array<int, 6> key{dev, nt, nb, W, lag, pair};
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(key);
-    if (it != cache.end())
-        return it->second;
     struct T {
         int key, c, b;
     };
@@ -1973,13 +1964,29 @@ static const int* tail_order(int nt, int nb, int W, int lag, int pair)
         if (!legal)
             break;
     }
+    flat.assign(2 * ts.size(), 0);
+    for (size_t i = 0; i < ts.size(); ++i) {
+        flat[2 * i] = ts[i].b;
+        flat[2 * i + 1] = ts[i].c;
+    }
+    return legal;
+}
+static const int* tail_order(int nt, int nb, int W, int lag, int pair)
+{
+    if (W <= 0 && lag <= 0 && !pair)
+        return nullptr;
+    static std::mutex mu;
+    static std::map<std::array<int, 6>, int*> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const std::array<int, 6> key{dev, nt, nb, W, lag, pair};
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end())
+        return it->second;
+    std::vector<int> flat;
     int* d = nullptr;
-    if (legal) {
-        std::vector<int> flat(2 * ts.size());
-        for (size_t i = 0; i < ts.size(); ++i) {
-            flat[2 * i] = ts[i].b;
-            flat[2 * i + 1] = ts[i].c;
-        }
+    if (build_tail_order(nt, nb, W, lag, pair, flat)) {
         if (hipMalloc(&d, sizeof(int) * flat.size()) != hipSuccess || hipMemcpy(d, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice) != hipSuccess)
             d = nullptr;
     }
@@ -1987,6 +1994,26 @@ static const int* tail_order(int nt, int nb, int W, int lag, int pair)
         fprintf(stderr, "gpe: tail_order(%d, %d, W %d, lag %d, pair %d) violates a dependency — column-by-column order used\n", nt, nb, W, lag, pair);
     cache[key] = d;
     return d;
+}
+// test hook (include/gpe.h: gpe_debug_tail_order): 1 if the dispatch table of a data-flow launch of nt tile columns x nb row
+// strips is a permutation of its tiles in which every wait is for a lower-numbered workgroup, 0 if not; host only
+int debug_tail_order(int nt, int nb, int lag, int pair)
+{
+    if (nt < 1 || nb < nt || nb > 4096)
+        return -1;
+    std::vector<int> flat;
+    if (!build_tail_order(nt, nb, 0, lag, pair, flat))
+        return 0;
+    std::vector<char> seen((size_t)nt * nb, 0);
+    size_t n = 0;
+    for (size_t i = 0; i + 1 < flat.size(); i += 2) {
+        const int b = flat[i], c = flat[i + 1];
+        if (c < 0 || c >= nt || b < c || b >= nb || seen[(size_t)c * nb + b])
+            return 0;
+        seen[(size_t)c * nb + b] = 1;
+        ++n;
+    }
+    return n == (size_t)(nt * nb - nt * (nt - 1) / 2) ? 1 : 0;
 }
 
 // Tile columns t0 .. t1-1 (whole 64-blocks) of the rows t0 .. M-1: N64 - t0 full row strips (N64 = the matrix order rounded down

@@ -77,7 +77,8 @@ def test_engine_is_independent_of_the_oracle():
 
 def test_oracle_mirrors_the_abi(oracle_lib):
     skip = {"gpe_get_stream", "gpe_set_profiling", "gpe_get_phase_ms", "gpe_reset_phase_ms", "gpe_mfma_f64_peak",
-            "gpe_hbm_stream_peak", "gpe_flow_retries", "gpe_small_calls", "gpe_handover_reruns", "gpe_trace", "gpe_trace_dump"}
+            "gpe_hbm_stream_peak", "gpe_flow_retries", "gpe_small_calls", "gpe_handover_reruns", "gpe_trace", "gpe_trace_dump",
+            "gpe_debug_tail_order"}
     for s in declared_symbols():
         if s in skip:
             continue
@@ -89,3 +90,28 @@ def test_binding_loads_engine_without_gpu():
 
     lib = _capi.load_engine()  # declares argtypes for every symbol: AttributeError if one is missing
     assert lib.prefix == "gpe_"
+
+
+def test_dispatch_tables_of_the_data_flow_launches_are_deadlock_free():
+    """csrc/potrf.hip: tail_order.  A data-flow launch (k_tail) is deadlock-free because every workgroup waits for
+    lower-numbered ones only; the order is a TABLE (diagonal workgroups early, tiles below the triangle lagging the chain).
+    Built and checked on the host for every launch shape the engine can produce up to 64 tile columns — closing launches
+    (nb = nt, nt + 1 with the right-hand-side strip), tall launches (nb up to 65), lags 0..5, one and two diagonal blocks per
+    chain workgroup (GPE_TAIL_PAIR): a permutation of the tiles, no wait for a higher-numbered workgroup."""
+    from limbo_amd import _capi
+
+    lib = ctypes.CDLL(str(_capi.ENGINE_SO))
+    f = lib.gpe_debug_tail_order
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int] * 4
+    assert f(0, 1, 3, 0) == -1 and f(4, 3, 3, 0) == -1
+    bad = []
+    for nt in range(1, 65):
+        for nb in sorted({nt, nt + 1, min(nt + 7, 65), 64, 65}):
+            if nb < nt:
+                continue
+            for lag in (0, 2, 3, 5):
+                for pair in (0, 1):
+                    if f(nt, nb, lag, pair) != 1:
+                        bad.append((nt, nb, lag, pair))
+    assert not bad, bad[:10]
