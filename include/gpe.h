@@ -215,6 +215,11 @@ int gpe_trace_dump(const char* path);
  * tiles in which every workgroup waits for lower-numbered ones only (what makes the launch deadlock-free), 0: not, -1: bad
  * arguments.  The engine runs the same check before it uses a table. */
 int gpe_debug_tail_order(int nt, int nb, int lag, int pair);
+/* ... and the schedule the engine picks for n samples, p outputs and a batched sequence of g members (g <= 1: one handle) under
+ * the given widths (<= 0: the defaults GPE_TAIL_MAX / GPE_TALL / GPE_BATCH_TAIL_MAX): out8 = { t0 (first column of the closing
+ * data-flow launch; -1: panels to the end), e0 (first column of the tall launch in front of it; -1: none), tile columns and row
+ * strips of the closing launch, of the tall launch, n rounded down to 64, outer panel width }. */
+int gpe_debug_tail_plan(int64_t n, int p, int g, int64_t tail_max, int64_t tall_max, int64_t batch_tail_max, int64_t* out8);
 /* fp64 MFMA peak micro-benchmark (v_mfma_f64_4x4x4_4b, the instruction the GEMM kernels issue), TFLOP/s */
 int gpe_mfma_f64_peak(int device_id, double* tflops);
 /* HBM write-stream micro-benchmark, GB/s */

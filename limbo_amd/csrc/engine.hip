@@ -485,6 +485,33 @@ static TailPlan tail_plan(const gpe_ctx* c, int64_t N, int64_t M)
     }
     return pl;
 }
+
+// test hook (gpe_debug_tail_plan): the plan for N samples, P outputs, a batch of G members (G <= 1: a single handle) under the
+// given widths (<= 0: the defaults); no device is touched
+static void debug_tail_plan(int64_t N, int P, int G, int64_t tail_max, int64_t tall_max, int64_t batch_tail_max, int64_t* out)
+{
+    gpe_ctx c;
+    if (tail_max > 0)
+        c.tail_max = tail_max;
+    if (tall_max > 0)
+        c.tall_max = tall_max;
+    c.batch_tail_max = std::min(batch_tail_max > 0 ? batch_tail_max : c.batch_tail_max, c.tail_max);
+    const BatchLaunch saved = g_batch;
+    if (G > 1) {
+        g_batch.G = G;
+        g_batch.bt = reinterpret_cast<const BatchTab*>(1);
+    }
+    const TailPlan pl = tail_plan(&c, N, N + P);
+    g_batch = saved;
+    out[0] = pl.t0;
+    out[1] = pl.e0;
+    out[2] = pl.nt_tail;
+    out[3] = pl.nb_tail;
+    out[4] = pl.nt_tall;
+    out[5] = pl.nb_tall;
+    out[6] = pl.N64;
+    out[7] = c.nbo;
+}
 // The hand-over buffers of handle c for this plan, on stream s (ordered in front of the launches that poll them).
 // like != nullptr (a batched launch built from `like`'s pointers): same capacities and the same armed parity as that handle.
 static bool prepare_tail(gpe_ctx* c, const TailPlan& pl, hipStream_t s, const gpe_ctx* like = nullptr)
@@ -3217,6 +3244,13 @@ int gpe_trace_dump(const char* path)
 }
 
 int gpe_debug_tail_order(int nt, int nb, int lag, int pair) { return debug_tail_order(nt, nb, lag, pair); }
+int gpe_debug_tail_plan(int64_t n, int p, int g, int64_t tail_max, int64_t tall_max, int64_t batch_tail_max, int64_t* out8)
+{
+    if (!out8 || n < 1 || p < 1)
+        return GPE_ERR_ARG;
+    debug_tail_plan(n, p, g, tail_max, tall_max, batch_tail_max, out8);
+    return GPE_OK;
+}
 
 int gpe_mfma_f64_peak(int device_id, double* tflops)
 {

@@ -78,7 +78,7 @@ def test_engine_is_independent_of_the_oracle():
 def test_oracle_mirrors_the_abi(oracle_lib):
     skip = {"gpe_get_stream", "gpe_set_profiling", "gpe_get_phase_ms", "gpe_reset_phase_ms", "gpe_mfma_f64_peak",
             "gpe_hbm_stream_peak", "gpe_flow_retries", "gpe_small_calls", "gpe_handover_reruns", "gpe_trace", "gpe_trace_dump",
-            "gpe_debug_tail_order"}
+            "gpe_debug_tail_order", "gpe_debug_tail_plan"}
     for s in declared_symbols():
         if s in skip:
             continue
@@ -115,3 +115,45 @@ def test_dispatch_tables_of_the_data_flow_launches_are_deadlock_free():
                     if f(nt, nb, lag, pair) != 1:
                         bad.append((nt, nb, lag, pair))
     assert not bad, bad[:10]
+
+
+def test_schedule_of_the_factorisation_by_size():
+    """engine.hip: tail_plan (host logic, no device).  N <= 2816: ONE data-flow launch from column 0; up to tall_max + tail_max =
+    4352: tall launch from column 0 | one update | closing launch; larger: 256-column panels in front of the closing launch;
+    the panels end on a panel boundary, the closing launch is never wider than tail_max, a ragged order rides as one more row
+    strip.  Batched sequences: data-flow launches from column 0 or not at all, and only while the members' tiles fit."""
+    from limbo_amd import _capi
+
+    lib = ctypes.CDLL(str(_capi.ENGINE_SO))
+    f = lib.gpe_debug_tail_plan
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+
+    def plan(n, p=1, g=1, tail=0, tall=0, btail=0):
+        out = (ctypes.c_int64 * 8)()
+        assert f(n, p, g, tail, tall, btail, out) == 0
+        return dict(zip(("t0", "e0", "nt_tail", "nb_tail", "nt_tall", "nb_tall", "n64", "nbo"), list(out)))
+
+    assert plan(4096) == dict(t0=1280, e0=0, nt_tail=44, nb_tail=45, nt_tall=20, nb_tall=65, n64=4096, nbo=256)
+    assert plan(2048)["t0"] == 0 and plan(2048)["e0"] == -1 and plan(2048)["nt_tail"] == 32
+    assert plan(2816)["t0"] == 0 and plan(2880)["t0"] == 256 and plan(2880)["e0"] == 0
+    assert plan(5000)["t0"] == 2304 and plan(5000)["e0"] == -1  # (the tall launch only from column 0 and <= 1536 wide)
+    assert plan(100)["t0"] == -1 and plan(128)["t0"] == 0
+    assert plan(4096, tail=2560)["t0"] == 1536 and plan(4096, tail=2560, tall=1024)["e0"] == -1
+    assert plan(2048, g=8) == dict(t0=512, e0=0, nt_tail=24, nb_tail=25, nt_tall=8, nb_tall=33, n64=2048, nbo=256)
+    assert plan(2048, g=64)["t0"] == -1 and plan(4096, g=10)["t0"] == -1  # (too many tiles for the chip: panels)
+    assert plan(1024, g=16)["t0"] == 0
+    for n in list(range(64, 9000, 61)) + [16384]:
+        for p in (1, 3):
+            pl = plan(n, p)
+            if pl["t0"] < 0:  # fewer than two tile columns, or the ragged rows + obs_mean's rows do not fit ONE extra 64-row strip
+                assert n < 128 or n - n // 64 * 64 + p > 64, (n, p)
+                continue
+            assert n - n // 64 * 64 + p <= 64
+            assert pl["n64"] == n // 64 * 64 and pl["t0"] % pl["nbo"] == 0
+            assert 2 <= pl["nt_tail"] == (pl["n64"] - pl["t0"]) // 64 <= 2816 // 64
+            assert pl["nb_tail"] == pl["nt_tail"] + 1  # (obs_mean's rows, and a ragged last block, as one more row strip)
+            if pl["e0"] >= 0:
+                assert pl["e0"] == 0 and 2 <= pl["nt_tall"] == pl["t0"] // 64 <= 1536 // 64 and pl["nb_tall"] == pl["n64"] // 64 + 1
+            else:
+                assert pl["nt_tall"] == 0 and (pl["t0"] == 0 or pl["t0"] > 1536)
