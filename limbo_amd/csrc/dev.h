@@ -218,8 +218,17 @@ void flow_gate_leave(hipStream_t s);
 void flow_gate_forget(hipStream_t s);
 struct FlowGate {
     hipStream_t s;
-    explicit FlowGate(hipStream_t s_) : s(s_) { flow_gate_enter(s); }
-    ~FlowGate() { flow_gate_leave(s); }
+    bool on;
+    explicit FlowGate(hipStream_t s_, bool engage = true) : s(s_), on(engage)
+    {
+        if (on)
+            flow_gate_enter(s);
+    }
+    ~FlowGate()
+    {
+        if (on)
+            flow_gate_leave(s);
+    }
     FlowGate(const FlowGate&) = delete;
     FlowGate& operator=(const FlowGate&) = delete;
 };

@@ -1018,8 +1018,9 @@ int compute_enqueue(gpe_ctx* c)
     hipStream_t s = c->stream;
     // One evaluation's chain of launches as a unit behind the device's previous data-flow launch (dev.h: FlowGate; the gates of
     // the launches below nest inside this one): two handles evaluated from two threads run chain behind chain — 840
-    // evaluations/s in all at N = 4096, where gating launch by launch interleaved their chains at 600.
-    FlowGate gate(s);
+    // evaluations/s in all at N = 4096, where gating launch by launch interleaved their chains at 600.  Not for a batched
+    // sequence: the two sub-batches of a batch of 64 overlap on purpose (their data-flow launches are still ordered one by one).
+    FlowGate gate(s, !g_batch.bt);
     digest_kernel(c);
     c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
     if (c->handover_off_left > 0 && --c->handover_off_left == 0)
