@@ -121,6 +121,35 @@ def bo_iteration(lib, _capi, O, device, n_candidates=10000):
     return res
 
 
+def box_probe(eng, _capi, O, local_rank):
+    """How fast is THIS box on latency-bound work?  One box in about ten of the pool runs the data-flow launches at half
+    speed while its matrix-core and HBM rates are normal (profiles/r04_slow_box_observation.log: 457 / 476 evaluations/s
+    instead of 840, some CUs taking 22-30 us for a 64 x 64 block factorisation instead of 6-7).  The probe is the engine's own
+    one-launch factorisation at N = 1024 (16 chain hops, nothing else): 0.245-0.25 ms on the other boxes of rounds 3 and 4,
+    0.36-0.38 ms on the slow ones."""
+    import numpy as np
+
+    X, Y = O.make_problem("c2", N=1024)
+    om, _ = O.obs_mean_data(Y)
+    h = _capi.Handle(eng, local_rank)
+    h.set_kernel(O.SE_ARD, np.zeros(D_C2 + 1), 0.01)
+    h.set_data(X, om)
+    for _ in range(3):
+        h.compute()
+        h.log_lik()
+    per = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        h.compute()
+        h.log_lik()
+        per.append(time.perf_counter() - t0)
+    h.close()
+    ms = 1e3 * float(np.median(per))
+    return {"n1024_compute_loglik_ms": ms, "usual_ms": 0.25, "slow_box": bool(ms > 0.31),
+            "note": "compute()+log_lik at N = 1024 (ONE data-flow launch + the sweep: pure chain latency); boxes that read > 0.31 ms "
+                    "here ran every latency-bound figure of this line at about half speed in rounds 3-4, with `roofline` unaffected"}
+
+
 def extras(eng, _capi, O, local_rank, steps):
     """Secondary objects of the bench line, N=1 only, outside the headline's timed region (driver-run versions of what
     bench_extra.py measures): BASELINE configs[1] as written (the gradient objective of one KernelLFOpt iteration),
@@ -577,6 +606,7 @@ def main():
             "measured_mfma_f64_4x4x4_peak_tflops": pk.value,
         }
         out["factorisation_frac"] = out["roofline"]["factorisation"]["frac_over_the_step"]
+        out["box_probe"] = box_probe(eng, _capi, O, local_rank)
         out["phases_us_per_step_profiled"] = {k: v["us"] for k, v in ph.items()}
 
     if rank == 0 and world == 1 and not args.no_roofline:
