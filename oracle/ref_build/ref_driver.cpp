@@ -24,6 +24,8 @@
 #include <limbo/model/gp/mean_lf_opt.hpp>
 #include <limbo/model/gp/no_lf_opt.hpp>
 #include <limbo/opt/parallel_repeater.hpp>
+#include <limbo/serialize/binary_archive.hpp>
+#include <limbo/serialize/text_archive.hpp>
 
 using namespace limbo;
 
@@ -114,6 +116,8 @@ namespace {
         virtual void optimize(int which) = 0;               // 0 KernelLFOpt, 1 KernelLooOpt, 2 MeanLFOpt, 3 KernelMeanLFOpt
         virtual double kernel_eval(const double* a, const double* b, int D, int i, int j) = 0;
         virtual void kernel_grad(const double* a, const double* b, int D, int i, int j, double* g) = 0;
+        virtual void save(const char* dir, bool binary) = 0;                 // gp.hpp:439-460
+        virtual void load(const char* dir, bool binary, bool recompute) = 0; // gp.hpp:462-511
     };
 
     template <class K, class M> struct W : IGP {
@@ -227,6 +231,21 @@ namespace {
             for (int q = 0; q < v.size(); ++q)
                 g[q] = v(q);
         }
+        // the reference's own archives, writing / reading real files (serialize/text_archive.hpp, binary_archive.hpp)
+        void save(const char* dir, bool binary) override
+        {
+            if (binary)
+                gp.template save<serialize::BinaryArchive>(std::string(dir));
+            else
+                gp.template save<serialize::TextArchive>(std::string(dir));
+        }
+        void load(const char* dir, bool binary, bool recompute) override
+        {
+            if (binary)
+                gp.template load<serialize::BinaryArchive>(std::string(dir), recompute);
+            else
+                gp.template load<serialize::TextArchive>(std::string(dir), recompute);
+        }
     };
 
     template <class K> IGP* make_mean(int mean_kind, int D, int P)
@@ -315,6 +334,9 @@ void ref_get_matrix(void* h, int which, double* out) { Scope s(G); G->get_matrix
 void ref_optimize_hyperparams(void* h, int which) { Scope s(G); G->optimize(which); }
 double ref_kernel_eval(void* h, const double* a, const double* b, int D, int i, int j) { Scope s(G); return G->kernel_eval(a, b, D, i, j); }
 void ref_kernel_grad(void* h, const double* a, const double* b, int D, int i, int j, double* g) { Scope s(G); G->kernel_grad(a, b, D, i, j, g); }
+// GP::save<TextArchive / BinaryArchive>(directory) and GP::load<...>(directory, recompute) of the reference (gp.hpp:439-511)
+void ref_save(void* h, const char* dir, int binary) { Scope s(G); G->save(dir, binary != 0); }
+void ref_load(void* h, const char* dir, int binary, int recompute) { Scope s(G); G->load(dir, binary != 0, recompute != 0); }
 #undef G
 
 } // extern "C"

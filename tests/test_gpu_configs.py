@@ -149,10 +149,13 @@ def test_gpu_c5_add_sample_loop(engine_lib, oracle_lib, noise):
     add_sample() calls, at the benchmark's noise 1e-10 and at 0.01; the device state after every 10th sample and
     at the end against the oracle, and at the end against the reference itself where oracle/_ref is present.
 
-    What can be held.  noise 0.01: L 1e-10 (of max|L|), alpha 1e-7, mu 1e-8, sigma^2 1e-8.  noise 1e-10:
-    cond(K) ~ sigma_f^2 n / (noise + 1e-8) ~ 2e10 at n = 200, so two correct fp64 implementations that sum in a
-    different order differ by ~cond * eps: L 1e-6, mu 1e-4 of the data scale, sigma^2 1e-6 absolute (the variance
-    itself is ~1e-6 there); alpha (cond^1 amplified, ~1e5 in size) is compared through K alpha = obs_mean."""
+    What is held.  noise 0.01: L 1e-10 (of max|L|), alpha 1e-7, mu 1e-8, sigma^2 1e-8.  noise 1e-10: cond(K) ~ 2e10 at
+    n = 200, and rounds 1-4 therefore allowed L 1e-6 / mu 1e-4 / sigma^2 1e-6 here.  Round 5 measured what the three
+    implementations actually do against a 60-digit truth (test_gpu_c5_noise_1e_10_vs_mpmath_truth,
+    profiles/r05_parity_operating_points.log): engine, reference and restatement all sit within 1e-12 (L), 2e-11 (mu) and
+    4e-14 (sigma^2, absolute; the variance itself is ~1e-5 there) of it — the SE kernel's backward error is benign.  So the
+    same bars as at noise 0.01 now hold at 1e-10: L 1e-10, mu 1e-8 of the data scale, sigma^2 1e-10 absolute (relative is
+    meaningless at 2e-5); alpha (cond-amplified, ~1e5 in size) is compared through K alpha = obs_mean."""
     rng = np.random.default_rng(2026)
     n0, n1, D = 10, 200, 6
     X = rng.uniform(0, 1, size=(n1, D))
@@ -181,9 +184,9 @@ def test_gpu_c5_add_sample_loop(engine_lib, oracle_lib, noise):
             for q in range(2):  # the per-point path of a BO loop's acquisition functor == the batch
                 k1, v1 = g.query_batch(Xq[q : q + 1])
                 m1, s1 = synth.finish_query(k1, v1, mean, noise)
-                assert abs(m1[0, 0] - mg[q, 0]) <= (1e-8 if tight else 1e-4) * np.max(np.abs(Y))
+                assert abs(m1[0, 0] - mg[q, 0]) <= 1e-8 * np.max(np.abs(Y))
     print(f"C5 noise {noise:g}: worst L {worst['L']:.2e}  mu {worst['mu']:.2e}  sigma^2 {worst['s2']:.2e}")
-    tolL, tolmu, tols2 = (1e-10, 1e-8, 1e-8) if tight else (1e-6, 1e-4, 1e-6)
+    tolL, tolmu, tols2 = (1e-10, 1e-8, 1e-8) if tight else (1e-10, 1e-8, 1e-10)
     assert worst["L"] <= tolL and worst["mu"] <= tolmu and worst["s2"] <= tols2, worst
     om, mean = synth.obs_mean_data(Y)
     a = g.get_alpha()
@@ -865,6 +868,150 @@ def test_gpu_c2_full_size_fit_lockstep_vs_lapack(engine_lib):
     assert bl[0] > trace[0][1][0]  # the fit improved the likelihood
     for h in hs:
         h.close()
+
+
+def _lapack_posterior_se_ard(X, theta, noise, om, mean, Xq):
+    """log-lik, mu, sigma^2 (gp.hpp:267-282, :613-624, :166) and cond_1(K) from LAPACK: dpotrf, dpotrs, dtrtrs, dpocon."""
+    import scipy.linalg as sla
+    from scipy.linalg import lapack
+
+    K = O.kernel_matrix(O.SE_ARD, X, theta, noise)
+    anorm = np.linalg.norm(K, 1)
+    L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    rcond, info = lapack.dpocon(L, anorm, uplo=b"L")
+    assert info == 0
+    alpha = sla.cho_solve((L, True), om, check_finite=False)
+    kr, vr = O.query(O.SE_ARD, X, theta, L, alpha, Xq)
+    mu, s2 = synth.finish_query(kr, vr, mean, noise)
+    return O.log_lik(L, om, alpha), mu, s2, 1.0 / rcond
+
+
+def test_gpu_c2_operating_points_vs_lapack(engine_lib):
+    """config 2 "also at 16 random theta in U[-1,1]^7 to exercise conditioning", and (missing 1) at
+    the theta a KernelLFOpt fit ends on — the point a fitted model lives at (kernel_lf_opt.hpp:60-69), far from theta = 0
+    (log-lik -500 -> +3800).  N = 4096, D = 6, noise 0.01; the engine multiplies by explicit 64 x 64 block inverses (error
+    ~ cond(L_bb) eps), so this is where the 1e-8 bar on mu / sigma^2 (gp.hpp:613-624) is at risk.  Per theta, against
+    LAPACK on the host: mu (floor 1e-3) and sigma^2 (incl. + noise) on 256 points 1e-8, log-lik 1e-10; the gradient
+    (gp.hpp:285-311) 1e-6 at four of the random theta and at the fitted one.  Worst errors and cond_1(K) are printed."""
+    from limbo_amd import hpfit
+
+    X, Y = synth.make_problem("c2")
+    assert X.shape == (4096, 6)
+    om, mean = synth.obs_mean_data(Y)
+    noise = 0.01
+    rng = np.random.default_rng(20260927)
+    thetas = rng.uniform(-1.0, 1.0, size=(16, 7))
+    Xq = rng.uniform(0, 1, size=(256, 6))
+    # the fit of BASELINE configs[1] by the reference's protocol: Rprop 50 iterations x 10 restarts (lock-step)
+    G = 10
+    hs = []
+    for _ in range(G):
+        hh = _capi.Handle(engine_lib)
+        hh.set_data(X, om)
+        hs.append(hh)
+    inits = np.random.default_rng(7).uniform(-1e-2, 1e-2, size=(G, 7))  # parallel_repeater.hpp:66,88 (epsilon 1e-2)
+    inits[0] = 0.0
+    bp, bl = hpfit.kernel_lf_opt_lockstep(hs, O.SE_ARD, inits, noise=noise, optimize_noise=False, iterations=50)
+    th_fit = bp[int(np.argmax(bl))].copy()
+    assert all(hh.flow_retries() == 0 for hh in hs)
+    for hh in hs[1:]:
+        hh.close()
+    h = hs[0]
+    worst = dict(mu=0.0, s2=0.0, ll=0.0, grad=0.0, cond=0.0)
+    rows = []
+    for i, th in enumerate(list(thetas) + [th_fit]):
+        fitted = i == len(thetas)
+        h.set_kernel(O.SE_ARD, th, noise)
+        assert h.compute() == 0
+        ll = h.log_lik()
+        kta, var = h.query_batch(Xq)
+        mu, s2 = synth.finish_query(kta, var, mean, noise)
+        ll_r, mu_r, s2_r, cond = _lapack_posterior_se_ard(X, th, noise, om, mean, Xq)
+        e = dict(mu=relerr(mu, mu_r, floor=1e-3), s2=relerr(s2, s2_r), ll=abs(ll - ll_r) / abs(ll_r), cond=cond, grad=0.0)
+        if fitted or i < 4:
+            g = h.log_lik_grad(False)
+            _, g_r, _, _ = _lapack_grad_se_ard(X, th, noise, om, False)
+            e["grad"] = relerr_norm(g, g_r)
+        rows.append((("fit" if fitted else f"{i:3d}"), e, ll_r))
+        for k in worst:
+            worst[k] = max(worst[k], e[k])
+    for tag, e, ll_r in rows:
+        print(f"C2 theta {tag}: cond_1(K) {e['cond']:.2e}  log-lik {ll_r:10.2f}  mu {e['mu']:.2e}  sigma^2 {e['s2']:.2e}  "
+              f"log-lik err {e['ll']:.2e}  grad {e['grad']:.2e}")
+    print(f"C2 operating points, worst: mu {worst['mu']:.2e}  sigma^2 {worst['s2']:.2e}  log-lik {worst['ll']:.2e}  "
+          f"grad {worst['grad']:.2e}  cond_1(K) up to {worst['cond']:.2e};  fitted theta {np.round(th_fit, 4).tolist()} log-lik {bl.max():.2f}")
+    assert bl.max() > 0.0  # the fit moved far from theta = 0 (log-lik there is about -500)
+    assert worst["mu"] < PC.TOL_MU and worst["s2"] < PC.TOL_VAR and worst["ll"] <= PC.TOL_LL and worst["grad"] < PC.TOL_GRAD, worst
+    assert h.flow_retries() == 0
+    h.close()
+
+
+def test_gpu_c5_noise_1e_10_vs_mpmath_truth(engine_lib, oracle_lib):
+    """VERDICT r4 (weak 1b): at bench.cpp:70's noise 1e-10 test_gpu_c5_add_sample_loop can hold the engine to the reference only
+    at L 1e-6 / mu 1e-4 / sigma^2 1e-6 (cond(K) ~ 2e10).  This adjudicates with the truth: tests/golden/mp_c5_n200_noise1e-10.npz
+    (60-digit mpmath from the same double inputs, oracle/make_golden_c5.py).  The same add_sample loop (10 samples, then 190
+    appended: bench.cpp:66-67,83-84 / gp.hpp:126-152,573-603) on the engine, on the reference itself (oracle/_ref, where
+    present) and on the C restatement; asserted: |engine - truth| <= 4 |reference - truth| in the max-norm for L, mu and
+    sigma^2 (floors: 1e-13 of max|L|, 1e-12 of max|y|, 1e-14 absolute — never reached in practice), and the same for a full
+    compute() of the 200 samples."""
+    from tests.util import load, GOLDEN
+
+    z = load(GOLDEN / "mp_c5_n200_noise1e-10.npz")
+    X, Y, Xq, th, noise = z["X"], z["Y"], z["Xq"], z["theta"], float(z["noise"])
+    n0, n1, D = 10, 200, 6
+    # the fixture is the draw of test_gpu_c5_add_sample_loop
+    rng = np.random.default_rng(2026)
+    assert np.array_equal(X, rng.uniform(0, 1, size=(n1, D))) and np.array_equal(Y, synth.hartmann6(X)[:, None])
+    om_all, mean = synth.obs_mean_data(Y)
+    yscale = float(np.max(np.abs(Y)))
+
+    def errors(L, mu, s2):
+        return (float(np.max(np.abs(np.tril(L) - z["L"])) / np.max(np.abs(z["L"]))),
+                float(np.max(np.abs(mu - z["mu"])) / yscale), float(np.max(np.abs(s2 - z["sigma2"]))))
+
+    def loop(lib):
+        om0, _ = synth.obs_mean_data(Y[:n0])
+        g = new_gp(lib, O.SE_ARD, X[:n0], om0, th, noise)
+        assert g.compute() == 0
+        for n in range(n0, n1):
+            om, _ = synth.obs_mean_data(Y[: n + 1])
+            assert g.add_sample(X[n], om) == 0
+        k, v = g.query_batch(Xq)
+        out = errors(g.get_L(), *synth.finish_query(k, v, mean, noise))
+        g.close()
+        return out
+
+    def full(lib):
+        g = new_gp(lib, O.SE_ARD, X, om_all, th, noise)
+        assert g.compute() == 0
+        k, v = g.query_batch(Xq)
+        out = errors(g.get_L(), *synth.finish_query(k, v, mean, noise))
+        g.close()
+        return out
+
+    e_gpu, e_orc = loop(engine_lib), loop(oracle_lib)
+    f_gpu, f_orc = full(engine_lib), full(oracle_lib)
+    e_ref = f_ref = None
+    if OB.ref_available():
+        r = OB.RefGP(O.SE_ARD, D, 1, noise=noise)
+        r.set_h_params(th)
+        r.compute(X[:n0], Y[:n0])
+        for n in range(n0, n1):
+            r.add_sample(X[n], Y[n])
+        e_ref = errors(r.matrixL(), *r.query(Xq))
+        r2 = OB.RefGP(O.SE_ARD, D, 1, noise=noise)
+        r2.set_h_params(th)
+        r2.compute(X, Y)
+        f_ref = errors(r2.matrixL(), *r2.query(Xq))
+    fmt = lambda e: "L %.2e  mu %.2e  sigma^2 %.2e" % e  # noqa: E731
+    print("C5 noise 1e-10, distance from the 60-digit truth (max-norm: L / max|L|, mu / max|y|, sigma^2 absolute)")
+    print("  add_sample loop: engine", fmt(e_gpu), "| reference", fmt(e_ref) if e_ref else "-", "| C restatement", fmt(e_orc))
+    print("  full compute   : engine", fmt(f_gpu), "| reference", fmt(f_ref) if f_ref else "-", "| C restatement", fmt(f_orc))
+    floors = (1e-13, 1e-12, 1e-14)
+    for got, refs in ((e_gpu, (e_ref, e_orc)), (f_gpu, (f_ref, f_orc))):
+        yard = refs[0] if refs[0] is not None else refs[1]  # the reference itself where it travels, else its restatement
+        for q in range(3):
+            assert got[q] <= max(4.0 * yard[q], floors[q]), (q, got, yard)
 
 
 def test_gpu_bench_two_ranks_on_one_gpu():
