@@ -109,6 +109,8 @@ def load_ref():
             "ref_optimize_hyperparams": ([_vp, C.c_int], None),
             "ref_kernel_eval": ([_vp, _dp, _dp, C.c_int, C.c_int, C.c_int], C.c_double),
             "ref_kernel_grad": ([_vp, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp], None),
+            "ref_save": ([_vp, C.c_char_p, C.c_int], None),
+            "ref_load": ([_vp, C.c_char_p, C.c_int, C.c_int], None),
         }
         for name, (args, res) in sig.items():
             f = getattr(cd, name)
@@ -185,6 +187,14 @@ class RefGP:
 
     def recompute(self, update_obs_mean=True, update_full_kernel=True):
         self.lib.ref_recompute(self.h, int(update_obs_mean), int(update_full_kernel))
+
+    def save(self, directory, binary):
+        """GP::save<TextArchive | BinaryArchive>(directory) of the reference (gp.hpp:439-460): real files."""
+        self.lib.ref_save(self.h, str(directory).encode(), int(binary))
+
+    def load(self, directory, binary, recompute=True):
+        """GP::load<TextArchive | BinaryArchive>(directory, recompute) of the reference (gp.hpp:462-511)."""
+        self.lib.ref_load(self.h, str(directory).encode(), int(binary), int(recompute))
 
     def query(self, Xq):
         Xq = _c(np.atleast_2d(Xq))
