@@ -554,7 +554,11 @@ static bool prepare_tail(gpe_ctx* c, const TailPlan& pl, hipStream_t s, const gp
     }
     if (like) { // (a pair that is all-ones throughout may take any parity)
         c->tail_count = like->tail_count;
-        c->tall_count = like->tall_count;
+        // the tall pair follows member 0 only when this plan HAS a tall launch — only then was its parity checked
+        // (and the pair re-armed) above.  A batch without one (N64 <= 1536) leaves the member's tall pair, layout and count
+        // as its own last single-handle launch left them.
+        if (pl.e0 >= 0)
+            c->tall_count = like->tall_count;
     }
     return true;
 }
@@ -2837,11 +2841,14 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
     }
     if (c0->device >= 16)
         return GPE_ERR_UNSUPPORTED;
+    bool batch_has_tail = false, batch_has_tall = false; // which data-flow launches this batch's plan issues
     { // the data-flow launches' hand-over buffers: every member's with the capacities and the armed parity of member 0's
         g_batch.G = Gc; // (the plan depends on the launch being batched, not on the table)
         g_batch.bt = reinterpret_cast<const BatchTab*>(1);
         const TailPlan pl = tail_plan(c0, c0->N, c0->N + c0->P);
         g_batch = BatchLaunch{};
+        batch_has_tail = pl.t0 >= 0;
+        batch_has_tall = pl.t0 >= 0 && pl.e0 >= 0;
         if (pl.t0 >= 0) {
             if (!prepare_tail(c0, pl, c0->stream))
                 return GPE_ERR_NOMEM;
@@ -2889,11 +2896,15 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
     g_batch.bt = dtab;
     g_batch.G = Gc;
     int e = compute_enqueue(c0);
-    for (int q = 1; q < Gc; ++q) { // the members' hand-over buffers went through the same launches as member 0's
-        cs[q]->tail_count = c0->tail_count;
-        cs[q]->tall_count = c0->tall_count;
-        cs[q]->tail_lay = c0->tail_lay;
-        cs[q]->tall_lay = c0->tall_lay;
+    for (int q = 1; q < Gc; ++q) { // the members' hand-over buffers went through the same launches as member 0's — those
+        if (batch_has_tail) {      // that were issued: a pair no launch of this batch touched keeps the member's own state
+            cs[q]->tail_count = c0->tail_count;
+            cs[q]->tail_lay = c0->tail_lay;
+        }
+        if (batch_has_tall) {
+            cs[q]->tall_count = c0->tall_count;
+            cs[q]->tall_lay = c0->tall_lay;
+        }
     }
     if (e == GPE_OK && want && want->grad) {
         // K^-1 (gp.hpp:254-264) and the gradient pair sum (gp.hpp:285-311) of every member, same launch sequence

@@ -588,6 +588,47 @@ def test_gpu_data_flow_buffers_across_sizes_on_one_handle(engine_lib):
     h.close()
 
 
+def test_gpu_tall_pair_survives_a_batch_without_a_tall_launch(engine_lib):
+    """ADVICE r4 (medium).  Two handles at N = 4096 whose tall hand-over pairs are armed with DIFFERENT parities (one and two
+    single evaluations), then batched together at a size whose plan has no tall launch (N = 1024), then evaluated singly at
+    N = 4096 again.  Before the fix the batch copied member 0's tall count / layout onto the other member without looking at
+    its pair: its next tall launch polled a buffer still holding the previous launch's tiles (not the all-ones pattern) and
+    accepted them — a silently wrong factor.  Now a pair that no launch of the batch touches keeps its own state: both handles
+    give LAPACK's factor, no re-run."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(55)
+    D = 4
+
+    def data(N, seed):
+        r = np.random.default_rng(seed)
+        X = r.uniform(0, 1, size=(N, D))
+        Y = np.cos(X.sum(axis=1))[:, None] + 0.05 * r.normal(size=(N, 1))
+        return X, O.obs_mean_data(Y)[0]
+
+    hs = [_capi.Handle(engine_lib) for _ in range(2)]
+    th = rng.uniform(-0.3, 0.2, size=D + 1)
+    big = [data(4096, 1), data(4096, 2)]
+    for q, h in enumerate(hs):
+        h.set_data(*big[q])
+        h.set_kernel(int(O.SE_ARD), th, 0.01)
+    assert hs[0].compute() == 0 and hs[0].compute() == 0  # member 0: two tall launches
+    assert hs[1].compute() == 0                            # member 1: one -> the other parity
+    for q, h in enumerate(hs):
+        h.set_data(*data(1024, 10 + q))
+        h.set_kernel(int(O.SE_ARD), th, 0.01)
+    assert _capi.batch_compute(hs) == [0, 0]
+    for q, h in enumerate(hs):
+        X, om = data(4096, 20 + q)
+        h.set_data(X, om)
+        h.set_kernel(int(O.SE_ARD), th + 0.05, 0.01)
+        assert h.compute() == 0 and h.flow_retries() == 0, q
+        K = h.get_K()
+        Lref = sl.cholesky(np.tril(K) + np.tril(K, -1).T, lower=True)
+        assert np.max(np.abs(np.tril(h.get_L()) - Lref)) <= 1e-10 * np.max(np.abs(Lref)), q
+        assert relerr_norm(h.get_alpha(), sl.cho_solve((Lref, True), om)) < 1e-7, q
+        h.close()
+
+
 @pytest.mark.parametrize("kind,D,P,lam", [(O.SE_ARD, 6, 1, 0), (O.MATERN52, 3, 2, 0), (O.SE_ARD, 4, 3, 1), (O.EXP, 2, 1, 0)])
 def test_gpu_small_path_vs_oracle(engine_lib, oracle_lib, kind, D, P, lam):
     """The one-launch small-N path (csrc/small.hip: add_sample and point queries below 256 samples) across every
