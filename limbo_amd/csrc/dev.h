@@ -36,7 +36,7 @@ static __device__ __forceinline__ d4_t mfma_f64(double a, double b, d4_t c)
 // Every GP has its own buffers, allocated separately.  The launch sequence is built once, from GP 0's pointers, with
 // gridDim.z = G; workgroup z translates each pointer argument from GP 0's buffer into GP z's buffer of the same class
 // (wave-uniform: a handful of scalar compares per pointer).  The per-GP kernel parameters travel in the same table.
-#define GPE_BT_CLS 12
+#define GPE_BT_CLS 13
 #define GPE_BT_MAXG 64
 struct BatchTab {
     int G;
@@ -303,6 +303,36 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g);
 void launch_upd_fused(hipStream_t s, const GemmArgs& g, double* A, int64_t lda, int64_t p0, int64_t pe, double* Xt_next,
                       int* info, const double* Dacc);
 double gemm_flops(const GemmArgs& g);
+
+// ---- K^-1 by recursion (inv2.hip): lists of 128 x 128 x k products and of tile folds ------------------------------
+// One launch = a LIST of independent tile products C = (+/-) A B^T, A and B contiguous along their non-k index (the operand
+// form of k_gemm_glds), each with its own k; persistent workgroups, each with a host-built share of the list (longest first).
+// A product whose k range was cut into chunks leaves chunk c > 0 in a partial buffer; a fold list adds them up in fixed
+// order (bitwise reproducible) and, where asked, also writes the tile transposed.
+struct GemmItem {
+    const double* A; // tile row origin at the first k of the chunk: A[r + kk * ld]
+    const double* B; // tile column origin likewise: B[c + kk * ld]
+    double* C;       // tile origin, overwritten
+    int32_t k;       // multiple of 32
+    int32_t neg;     // 1: C = -A B^T
+};
+struct FoldItem {
+    double* D;          // 128 x 128 tile: D += P[0] + P[1] + P[2] (null entries skipped; D is not rewritten without any)
+    const double* P[3];
+    double* T;          // optional: the resulting tile transposed, T[c + r * ld] = D[r + c * ld]
+};
+// (batched launches, g_batch: the lists hold member 0's pointers, workgroup z rebases them — dev.h: bt_rebase)
+void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld);
+void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld);
+// the plan of one inversion (inv2.hip): host-built once per (N, ld, buffers), resident on the device
+struct Inv2Plan;
+Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride);
+void inv2_plan_free(Inv2Plan* p);
+bool inv2_supported(int64_t N);
+int inv2_partials();                // N x N partial buffers behind the W / T-form buffer in S (S holds 1 + this many)
+double inv2_flops(const Inv2Plan* p); // algorithmic flops of the products (2 N^3 / 3 less the leaves)
+void inv2_run(hipStream_t s, Inv2Plan* p, const double* Xt_all, int part = 0); // enqueues the launches (part: inv2.hip)
+int inv2_debug_plan(int64_t N, int64_t ld, int nbins, int load_pct, int64_t* out, int64_t cap_rows); // host only (tests)
 
 // ---- vector solves, reductions (solve.hip) -----------------------------------------
 // one full triangular sweep over P <= GPE_MAX_P right-hand sides (ceil(N/64) launches):

@@ -147,6 +147,11 @@ struct gpe_ctx {
     double* dXinv = nullptr; // transposed inverses of the 64 x 64 diagonal blocks of L, 4096 doubles each
     bool panel256 = true;    // all steps of a 256-column outer panel in one data-flow launch (GPE_PANEL256=0: step by step)
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
+    double* dInvS = nullptr; // the recursive K^-1's scratch (inv2.hip): T-forms / W | three partial buffers, ld x cap each
+    Inv2Plan* inv2 = nullptr; // ... and its plan, rebuilt when N, ld or a buffer changes
+    bool inv_early = false;   // set by gpe_hp_objective around compute_enqueue: start K^-1's lowest level beside the sweep
+    bool inv_prefix_done = false; // ... done on stream2 for the factor at hand; inv_ev completes behind it
+    hipEvent_t inv_ev = nullptr, inv_ev0 = nullptr;
     size_t xp_cap = 0;
     int64_t grad_partial_cap = 0;
     int* dInfo = nullptr; // = hInfo: pinned host memory the kernels write directly (no copy-back, no device memset)
@@ -319,6 +324,11 @@ void free_dev(gpe_ctx* c)
         hipFree(c->dXp);
     c->dXp = nullptr;
     c->xp_cap = 0;
+    if (c->dInvS)
+        hipFree(c->dInvS);
+    c->dInvS = nullptr;
+    inv2_plan_free(c->inv2);
+    c->inv2 = nullptr;
     c->grad_partial_cap = 0;
     c->cap = c->ld = 0;
 }
@@ -369,10 +379,11 @@ int grow_dev(gpe_ctx* c, int64_t need)
                        c->stream);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    double* old[] = {c->dXt, c->dA, c->dOm, c->dAl, c->dW, c->dY, c->dLinv, c->dKinv, c->dXinv, c->dLooS, c->dLooV};
+    double* old[] = {c->dXt, c->dA, c->dOm, c->dAl, c->dW, c->dY, c->dLinv, c->dKinv, c->dXinv, c->dLooS, c->dLooV, c->dInvS};
     for (double* p : old)
         if (p)
             hipFree(p);
+    c->dInvS = nullptr;
     c->dXt = nXt;
     c->dA = nA;
     c->dOm = nOm;
@@ -1015,6 +1026,7 @@ void enqueue_loglik_terms(gpe_ctx* c)
     }
 }
 
+static void inv2_start_early(gpe_ctx* c); // (below, with ensure_inv)
 int compute_enqueue(gpe_ctx* c)
 {
     if (c->N <= 0 || !c->dA)
@@ -1098,6 +1110,7 @@ int compute_enqueue(gpe_ctx* c)
     potrf_blocked(c, c->dA, c->N, c->N + c->P);
     c->have_L = true;
     c->inv_ok = false; // gp.hpp:570
+    inv2_start_early(c);
     solve_alpha_from_z(c);
     enqueue_loglik_terms(c);
     return GPE_OK;
@@ -1243,6 +1256,42 @@ static LamParams lam_params(const gpe_ctx* c)
     return lp;
 }
 
+// buffers and plan of the recursive K^-1 (inv2.hip) for the factor at hand
+static int inv2_prepare(gpe_ctx* c)
+{
+    const int64_t ld = c->ld;
+    if (!c->dLinv)
+        HIPCHK(c, hipMalloc(&c->dLinv, sizeof(double) * (size_t)(ld * c->cap)));
+    if (!c->dKinv)
+        HIPCHK(c, hipMalloc(&c->dKinv, sizeof(double) * (size_t)(ld * c->cap)));
+    if (!c->dInvS)
+        HIPCHK(c, hipMalloc(&c->dInvS, sizeof(double) * (size_t)(ld * c->cap) * (size_t)(1 + inv2_partials())));
+    c->inv2 = inv2_plan_get(c->inv2, c->N, ld, c->dA, c->dLinv, c->dKinv, c->dInvS, ld * c->cap);
+    if (!c->inv2) {
+        c->err = "K^-1: no memory for the plan of the recursion";
+        return GPE_ERR_NOMEM;
+    }
+    return GPE_OK;
+}
+
+// gpe_hp_objective: the leaves and the lowest level of K^-1's recursion on the SECOND stream, behind the factorisation and
+// beside the backward sweep of alpha (a 64-hop latency chain on 64 CUs: 115 us in which the chip is otherwise idle)
+static void inv2_start_early(gpe_ctx* c)
+{
+    c->inv_prefix_done = false;
+    if (!c->inv_early || c->prof || g_batch.bt || !c->stream2 || !inv2_supported(c->N) || inv2_prepare(c) != GPE_OK)
+        return;
+    if (!c->inv_ev) {
+        hipEventCreateWithFlags(&c->inv_ev, hipEventDisableTiming);
+        hipEventCreateWithFlags(&c->inv_ev0, hipEventDisableTiming);
+    }
+    hipEventRecord(c->inv_ev0, c->stream); // the factor is final
+    hipStreamWaitEvent(c->stream2, c->inv_ev0, 0);
+    inv2_run(c->stream2, c->inv2, c->dXinv, 1);
+    hipEventRecord(c->inv_ev, c->stream2);
+    c->inv_prefix_done = true;
+}
+
 int ensure_inv(gpe_ctx* c)
 {
     if (c->inv_ok)
@@ -1255,6 +1304,27 @@ int ensure_inv(gpe_ctx* c)
         HIPCHK(c, hipMalloc(&c->dLinv, sizeof(double) * (size_t)(ld * c->cap)));
     if (!c->dKinv)
         HIPCHK(c, hipMalloc(&c->dKinv, sizeof(double) * (size_t)(ld * c->cap)));
+    if (inv2_supported(N)) {
+        // Round 5: the recursion of inv2.hip — a dozen launches of tile-product lists with k = 256 .. N / 2 instead of 48
+        // launches of k = 256 (N a multiple of 256; everything else keeps the panel form below).  A batched sequence runs the
+        // same lists for every member (gridDim.z; batch_enqueue_fused allocated every member's scratch).
+        int rc = inv2_prepare(c);
+        if (rc)
+            return rc;
+        {
+            PhaseScope ps(c, GPE_PH_INV, inv2_flops(c->inv2));
+            if (c->inv_prefix_done) { // (inv2_start_early: the lowest level ran beside the sweep)
+                hipStreamWaitEvent(s, c->inv_ev, 0);
+                inv2_run(s, c->inv2, c->dXinv, 2);
+                c->inv_prefix_done = false;
+            }
+            else
+                inv2_run(s, c->inv2, c->dXinv, 0);
+        }
+        HIPCHK(c, hipGetLastError());
+        c->inv_ok = true; // gp.hpp:263
+        return GPE_OK;
+    }
     static const bool inv_panels = !(getenv("GPE_INV_PANELS") && atoi(getenv("GPE_INV_PANELS")) == 0);
     if (inv_panels && c->nbo % 128 == 0 && c->nbo <= 256) {
         // Transposed formulation: U = L^-T (upper triangular) is built in dLinv, K^-1 = U U^T.  Every product below
@@ -1733,6 +1803,10 @@ int gpe_destroy(gpe_handle c)
     hipStreamSynchronize(c->stream);
     if (c->gen_ev)
         hipEventDestroy(c->gen_ev);
+    if (c->inv_ev) {
+        hipEventDestroy(c->inv_ev);
+        hipEventDestroy(c->inv_ev0);
+    }
     drain_phases(c);
     for (auto e : c->pool)
         hipEventDestroy(e);
@@ -2174,6 +2248,44 @@ int gpe_hp_objective(gpe_handle c, int kind, const double* th, int n_theta, doub
     int rc = gpe_set_kernel(c, kind, th, n_theta, noise); // kernel_lf_opt.hpp:80
     if (rc)
         return rc;
+    static const bool fused_ok = !(getenv("GPE_HP_FUSED") && atoi(getenv("GPE_HP_FUSED")) == 0);
+    if (want_grad && grad && fused_ok) {
+        // Round 5: ONE enqueue for the whole objective — factorisation, alpha, log-lik terms, K^-1, gradient — and one wait.
+        // The separate calls below cost a host round trip between the sweep and K^-1 (~20 us of idle chip), and K^-1's
+        // lowest level (latency-bound launches on an eighth of the chip) can now run on the second stream BESIDE the sweep
+        // (inv2_start_early).  Results are those of the separate calls bit for bit (same kernels, same order per buffer).
+        DevGuard g(c);
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->host_K && lam_columns(c->kind, c->n_theta, c->D) < 0) {
+            c->err = "set_kernel: wrong number of hyper-parameters for this kernel/dimension";
+            return GPE_ERR_ARG;
+        }
+        const int n_grad = n_theta + (optimize_noise ? 1 : 0);
+        const int64_t retries0 = c->flow_retries;
+        c->inv_early = true;
+        rc = compute_enqueue(c);
+        c->inv_early = false;
+        if (rc == GPE_OK)
+            rc = grad_enqueue(c, n_grad, optimize_noise, false);
+        if (c->inv_prefix_done) { // (not consumed: an error on the way) nothing may outlive this call on the second stream
+            hipStreamWaitEvent(c->stream, c->inv_ev, 0);
+            c->inv_prefix_done = false;
+        }
+        if (rc)
+            return rc;
+        HIPCHK(c, hipMemcpyAsync(grad, c->dGrad, sizeof(double) * n_grad, hipMemcpyDeviceToHost, c->stream));
+        const int info = compute_finish(c); // one wait; a hand-over / sweep timeout (never expected) re-runs the evaluation
+        if (info < 0)
+            return info;
+        if (c->flow_retries != retries0) { // ... and then the gradient belongs to the first attempt: again, on its own
+            rc = grad_fetch(c, grad, n_grad, optimize_noise, false);
+            if (rc)
+                return rc;
+        }
+        const long double logdet = 2 * c->hScal[0]; // gp.hpp:274-279, as gpe_log_lik
+        *lik = (double)(-0.5 * c->hScal[1] - 0.5 * logdet - 0.5 * c->N * std::log(2 * M_PI));
+        return info;
+    }
     int info = gpe_compute(c); // :82 recompute(false)
     if (info < 0)
         return info;
@@ -2834,6 +2946,8 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
                 HIPCHK(c, hipMalloc(&c->dLinv, mat));
             if (!c->dKinv)
                 HIPCHK(c, hipMalloc(&c->dKinv, mat));
+            if (!c->dInvS && inv2_supported(c->N)) // the recursive K^-1's scratch (inv2.hip)
+                HIPCHK(c, hipMalloc(&c->dInvS, mat * (size_t)(1 + inv2_partials())));
             int rc = ensure_grad_partial(c, want->n_grad);
             if (rc)
                 return rc;
@@ -2872,7 +2986,8 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
         c->hInfo[0] = c->hInfo[1] = 0;
         const char* b[GPE_BT_CLS] = {(const char*)c->dA, (const char*)c->dXt, (const char*)c->dOm, (const char*)c->dAl,
                                      (const char*)c->dXinv, (const char*)c->dHead, (const char*)c->hInfo, (const char*)c->hScal,
-                                     (const char*)c->dLinv, (const char*)c->dKinv, (const char*)c->dGradPartial, (const char*)c->dTail};
+                                     (const char*)c->dLinv, (const char*)c->dKinv, (const char*)c->dGradPartial, (const char*)c->dTail,
+                                     (const char*)c->dInvS};
         for (int k = 0; k < GPE_BT_CLS; ++k)
             t.base[k][q] = b[k];
         t.kp[q] = c->kp;
@@ -2884,7 +2999,8 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
                                                (unsigned long long)(dbl * (c0->cap / NB) * NB * NB), (unsigned long long)(dbl * GPE_HEAD_TILES * NB * NB), 64, 8192,
                                                (unsigned long long)(c0->dLinv ? dbl * c0->ld * c0->cap : 0), (unsigned long long)(c0->dKinv ? dbl * c0->ld * c0->cap : 0),
                                                (unsigned long long)(c0->dGradPartial ? dbl * c0->grad_partial_cap : 0),
-                                               (unsigned long long)(c0->dTail ? dbl * 2 * (c0->tail_cap + c0->tall_cap) : 0)};
+                                               (unsigned long long)(c0->dTail ? dbl * 2 * (c0->tail_cap + c0->tall_cap) : 0),
+                                               (unsigned long long)(c0->dInvS ? dbl * c0->ld * c0->cap * (1 + inv2_partials()) : 0)};
     for (int k = 0; k < GPE_BT_CLS; ++k) {
         t.base0[k] = t.base[k][0];
         t.size[k] = sz[k];
@@ -3260,6 +3376,11 @@ int gpe_trace_dump(const char* path)
 }
 
 int gpe_debug_tail_order(int nt, int nb, int lag, int pair) { return debug_tail_order(nt, nb, lag, pair); }
+int gpe_debug_inv_plan(int64_t n, int64_t ld, int nbins, int load_pct, int64_t* out, int64_t cap_rows)
+{
+    return inv2_debug_plan(n, ld, nbins, load_pct, out, cap_rows);
+}
+
 int gpe_debug_tail_plan(int64_t n, int p, int g, int64_t tail_max, int64_t tall_max, int64_t batch_tail_max, int64_t* out8)
 {
     if (!out8 || n < 1 || p < 1)

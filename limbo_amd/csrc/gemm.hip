@@ -622,6 +622,113 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
         launch_k(k_gemm_glds<128, 128, 2, 4, 32, 2>, k_gemm_glds<128, 128, 2, 4, 32, 2, 0, 1, true>, dim3((unsigned)tiles), dim3(512), s, g);
 }
 
+// ---------------------------------------------------------------------------------------------
+// A LIST of 128 x 128 tile products, each with its own operands and depth (dev.h: GemmItem) — the recursive K^-1
+// (inv2.hip).  The k loop is k_gemm_glds's in its two-workgroups-per-CU shape (BKT 16, two LDS stages, 74 KB, <= 128
+// VGPRs: two independent barrier groups per CU run the loop at the matrix-core rate, profiles/r03_sk_study.md); what
+// differs is where the work comes from: workgroup b walks items bin_start[b] .. bin_start[b + 1] of a host-built
+// list (longest first, shares of equal length), every tile is full, C is overwritten (never read).
+// ---------------------------------------------------------------------------------------------
+template <int BKT, int NST, int EPC, int MINB>
+__global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __restrict__ items, const int32_t* __restrict__ bin_start,
+                                                          int64_t ld, const BatchTab* __restrict__ bt)
+{
+    constexpr int TM = 128, TN = 128, WM = 2, WN = 4, NWV = WM * WN;
+    constexpr int SA = TM + 16, SB = TN + 16;
+    constexpr int STAGE = BKT * (SA + SB);
+    constexpr int RA = TM / WM / 16, RB = TN / WN / 4;
+    constexpr int LPW = 2 * BKT / NWV;
+    __shared__ __attribute__((aligned(16))) double lds[NST * STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave % WM) * (TM / WM), wn = (wave / WM) * (TN / WN);
+    const int arow = wm + (lane & 15), bcol = wn + (lane & 3), kq = lane >> 4;
+    const int i0 = bin_start[blockIdx.x], i1 = bin_start[blockIdx.x + 1];
+    const int64_t step = (int64_t)NWV * ld;
+    for (int it = i0; it < i1; ++it) {
+        GemmItem item = items[it];
+        if (bt) { // batched launch: the list holds member 0's pointers
+            item.A = bt_rebase(bt, (int)blockIdx.z, item.A);
+            item.B = bt_rebase(bt, (int)blockIdx.z, item.B);
+            item.C = bt_rebase(bt, (int)blockIdx.z, item.C);
+        }
+        // this lane's 16-byte piece of every k-row: rows (2 lane, 2 lane + 1); wave w moves k-rows w, w + 8, ..
+        const double* pa = item.A + 2 * lane + (int64_t)wave * ld;
+        const double* pb = item.B + 2 * lane + (int64_t)wave * ld;
+        auto issue = [&](int stage) {
+            double* sa = lds + stage * STAGE + wave * SA;
+            double* sb = lds + stage * STAGE + BKT * SA + wave * SB;
+#pragma unroll
+            for (int q = 0; q < BKT / NWV; ++q) {
+                __builtin_amdgcn_global_load_lds(pa, (lds_void_t*)(sa + q * NWV * SA), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(pb, (lds_void_t*)(sb + q * NWV * SB), 16, 0, 0);
+                pa += step;
+                pb += step;
+            }
+        };
+        double acc[RA][RB];
+#pragma unroll
+        for (int a = 0; a < RA; ++a)
+#pragma unroll
+            for (int b = 0; b < RB; ++b)
+                acc[a][b] = 0.0;
+        const int nk = item.k / BKT;
+        issue(0);
+        for (int t = 0; t < nk; ++t) {
+            const int st = t % NST;
+            if (t + 1 < nk) {
+                issue((t + 1) % NST);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+            }
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // every wave's pieces of stage st have landed
+            const double* As = lds + st * STAGE;
+            const double* Bs = As + BKT * SA;
+#pragma unroll
+            for (int ks = 0; ks < BKT; ks += 4) {
+                double af[RA], bf[RB];
+#pragma unroll
+                for (int x = 0; x < RA; ++x)
+                    af[x] = As[(ks + kq) * SA + arow + 16 * x];
+#pragma unroll
+                for (int x = 0; x < RB; ++x)
+                    bf[x] = Bs[(ks + kq) * SB + bcol + 4 * x];
+#pragma unroll
+                for (int n = 0; n < RB; ++n)
+#pragma unroll
+                    for (int m = 0; m < RA; ++m)
+                        acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // stage st may be refilled
+        }
+        if (item.neg) {
+#pragma unroll
+            for (int a = 0; a < RA; ++a)
+#pragma unroll
+                for (int b = 0; b < RB; ++b)
+                    acc[a][b] = -acc[a][b];
+        }
+        {
+            using WT = WaveTileC<RA, RB>;
+            constexpr int SCR = WT::SCRATCH / EPC;
+            static_assert(NWV * SCR <= NST * STAGE, "transposition scratch must fit in the operand stages");
+            // the k loop ended with a barrier: the stages are free, each wave uses a private slice
+            WT::template rmw_chunked<EPC>(acc, lds + wave * SCR, item.C + (int64_t)wn * ld + wm, ld, WT::R, WT::CN, 1, lane);
+        }
+        __syncthreads(); // the next item's prologue overwrites the LDS stages
+    }
+}
+
+void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld)
+{
+    if (nbins <= 0)
+        return;
+    GPE_LAUNCH_NAMED("k_gemm_items", (k_gemm_items<16, 2, 4, 2>), dim3((unsigned)nbins, 1, (unsigned)g_batch.G), dim3(512), 0, s, items, bin_start,
+                     ld, g_batch.bt);
+}
+
 // number of TM x TN tiles that do work (triangular skipping accounted for)
 static int64_t live_tiles(const GemmArgs& g, int TM, int TN)
 {

@@ -1,0 +1,402 @@
+// inv2.hip — K^-1 = L^-T L^-1 (GP::compute_inv_kernel, src/limbo/model/gp.hpp:254-264) by recursion on the factor, as a handful
+// of launches whose products have k = 256 .. N/2 (round 5).  Host code: the plan and its execution; the kernels are
+// gemm.hip: k_gemm_items (lists of 128 x 128 tile products) and inv.hip: k_inv_panels, k_fold_items.
+//
+// Rounds 1-4 built U = L^-T right-looking over 256-column panels: two launches of k = 256 per panel plus the rank-256
+// updates of U U^T — 48 launches at N = 4096, each re-reading its C tiles and most of them under one round of the chip:
+// 1.78 ms = 0.33 of the fp64 matrix-core peak for 2 N^3 / 3 flops.  Here:
+//
+//   leaves   X_p = inv(L_pp) of every 256 x 256 diagonal block (k_inv_panels, one launch): X_p^T into U, X_p into T
+//   node (a | c) of the binary tree over the panels, bottom-up, all nodes of one height in the same launches:
+//        W   = U_a B^T          B = L[c, a]; U_a upper triangular: tile row i has k >= i only
+//        U_b = -W T_c^T         T_c = L_cc^-1 lower triangular: tile column j has k <= j only        -> U[a, c]
+//     (T_c, the untransposed inverse of the right child, is what the second product needs as its B operand — both operands
+//      of the direct-to-LDS kernel are contiguous along their NON-k index.  A node that is itself a right child therefore
+//      leaves its inverse transposed as well: U_b^T by the fold of its tiles, its left child's triangle by tile transposes.)
+//   K^-1     = U U^T, lower triangle: tile (i, j) has k >= i
+//
+// Every product is a list of tiles with its own depth.  A tile's k loop is serial on one CU (17 us per 128 of depth), so
+// the k range of a tile is CUT into chunks where one launch would otherwise wait for its deepest tiles: chunk 0 goes to
+// the destination, chunk c > 0 to partial buffer c, a fold launch adds them in order.  The chunks of a launch are dealt
+// longest-first into `nbins` shares (two resident workgroups per CU), one persistent workgroup each.
+// Algorithmic flops are the minimum, 2 N^3 / 3; no tile of C is ever read by a product, nothing is zero-filled.
+//
+// Buffers (all ld x cap, same leading dimension): L (the factor), U (gpe_ctx::dLinv), K^-1 (dKinv), S = [T-forms and W |
+// partial 1 | partial 2 | partial 3].  W of node (a | c) lies at [a, c] of S's first buffer, strictly above the diagonal
+// blocks that hold the T-forms.
+#include <algorithm>
+#include <cstdlib>
+#include <queue>
+#include <vector>
+
+#include "dev.h"
+
+namespace {
+
+constexpr int TILE = 128, LEAF = 256, NPART = 3;
+enum Buf { B_L = 0, B_U = 1, B_K = 2, B_S0 = 3, B_P1 = 4, B_P2 = 5, B_P3 = 6, B_NONE = -1 };
+
+struct SymRef {
+    int buf = B_NONE;
+    int64_t off = 0;
+};
+struct SymItem {
+    SymRef a, b, c;
+    int k = 0, neg = 0;
+};
+struct SymFold {
+    SymRef d, p[NPART], t;
+};
+struct SymStep {
+    int kind = 0; // 0: tile products, 1: folds
+    int off = 0, count = 0, bins = 0, bin_off = 0;
+    double flops = 0.0;
+};
+struct SymPlan {
+    int prefix_steps = 0; // the first product launch of the lowest tree level (inv2_run, part 1)
+    std::vector<SymItem> items;
+    std::vector<SymFold> folds;
+    std::vector<int32_t> bin_start; // per product step: bins + 1 entries (absolute item indices)
+    std::vector<SymStep> steps;
+};
+
+// an unchunked tile product: depth `units` * 128 from the operands' origins, destination d, optional transposed copy
+struct Prod {
+    SymRef a, b, d, t;
+    int units = 0, neg = 0;
+};
+
+struct Node {
+    int lo = 0, hi = 0, mid = 0, height = 0, left = -1, right = -1;
+    bool is_right = false;
+};
+int make_tree(std::vector<Node>& nodes, int lo, int hi, bool is_right)
+{
+    Node nd;
+    nd.lo = lo;
+    nd.hi = hi;
+    nd.is_right = is_right;
+    const int me = (int)nodes.size();
+    nodes.push_back(nd);
+    if (hi - lo > 1) {
+        const int mid = lo + (hi - lo + 1) / 2;
+        const int l = make_tree(nodes, lo, mid, false);
+        const int r = make_tree(nodes, mid, hi, true);
+        nodes[me].mid = mid;
+        nodes[me].left = l;
+        nodes[me].right = r;
+        nodes[me].height = 1 + std::max(nodes[l].height, nodes[r].height);
+    }
+    return me;
+}
+
+// one launch of products (+ the fold launch behind it when chunks or transposed copies call for one)
+void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extra_folds, int64_t ld, int nbins, double load)
+{
+    if (prods.empty() && extra_folds.empty())
+        return;
+    int64_t total = 0;
+    int lmax = 1;
+    for (const Prod& p : prods) {
+        total += p.units;
+        lmax = std::max(lmax, p.units);
+    }
+    // chunk length (in 128-deep units): no chunk much longer than a share of the launch, at most 1 + NPART chunks per tile,
+    // never below 256 of depth (a fold launch costs more than it saves there)
+    const double avg = (double)total / (double)nbins;
+    int ch = std::max(2, (int)(load * avg + 0.5));
+    ch = std::max(ch, (lmax + NPART) / (NPART + 1));
+    struct Chunk {
+        SymItem it;
+        int units;
+    };
+    std::vector<Chunk> chunks;
+    std::vector<SymFold> folds;
+    double flops = 0.0;
+    for (const Prod& p : prods) {
+        const int nch = (p.units + ch - 1) / ch;
+        const int base = p.units / nch, rem = p.units % nch;
+        SymFold f;
+        f.d = p.d;
+        f.t = p.t;
+        int k0 = 0;
+        for (int c = 0; c < nch; ++c) {
+            const int u = base + (c < rem ? 1 : 0);
+            Chunk q;
+            q.it.a = {p.a.buf, p.a.off + (int64_t)k0 * TILE * ld};
+            q.it.b = {p.b.buf, p.b.off + (int64_t)k0 * TILE * ld};
+            q.it.c = c == 0 ? p.d : SymRef{B_P1 + c - 1, p.d.off};
+            q.it.k = u * TILE;
+            q.it.neg = p.neg;
+            q.units = u;
+            chunks.push_back(q);
+            if (c > 0)
+                f.p[c - 1] = q.it.c;
+            k0 += u;
+        }
+        flops += 2.0 * TILE * TILE * (double)p.units * TILE;
+        if (nch > 1 || p.t.buf != B_NONE)
+            folds.push_back(f);
+    }
+    if (!chunks.empty()) {
+        // Shares: longest chunk first into the least loaded share (ties: the lower share, the earlier chunk — deterministic).
+        // (Measured and dropped: dealing the tiles that read one operand panel to ONE XCD first, so that its 64 resident
+        // workgroups fetch the panel into that XCD's L2 once — U U^T 481 us against 447, the other launches unchanged
+        // (profiles/r05_inv2_ab.log): the products sit at the rate of the LDS-fed inner loop, not at the L2's.)
+        std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& x, const Chunk& y) { return x.units > y.units; });
+        const int nb = (int)std::min<size_t>((size_t)nbins, chunks.size());
+        std::vector<std::vector<int>> bins((size_t)nb);
+        typedef std::pair<double, int> Key;
+        std::priority_queue<Key, std::vector<Key>, std::greater<Key>> heap;
+        for (int b = 0; b < nb; ++b)
+            heap.push(Key(0.0, b));
+        for (size_t i = 0; i < chunks.size(); ++i) {
+            Key k = heap.top();
+            heap.pop();
+            bins[(size_t)k.second].push_back((int)i);
+            heap.push(Key(k.first + chunks[i].units + 0.35, k.second)); // (0.35: prologue + epilogue of a tile, in units)
+        }
+        SymStep st;
+        st.kind = 0;
+        st.off = (int)pl.items.size();
+        st.bins = nb;
+        st.bin_off = (int)pl.bin_start.size();
+        st.flops = flops;
+        for (int b = 0; b < nb; ++b) {
+            pl.bin_start.push_back((int32_t)pl.items.size());
+            for (int i : bins[(size_t)b])
+                pl.items.push_back(chunks[(size_t)i].it);
+        }
+        pl.bin_start.push_back((int32_t)pl.items.size());
+        st.count = (int)pl.items.size() - st.off;
+        pl.steps.push_back(st);
+    }
+    folds.insert(folds.end(), extra_folds.begin(), extra_folds.end());
+    if (!folds.empty()) {
+        SymStep st;
+        st.kind = 1;
+        st.off = (int)pl.folds.size();
+        st.count = (int)folds.size();
+        pl.folds.insert(pl.folds.end(), folds.begin(), folds.end());
+        pl.steps.push_back(st);
+    }
+}
+
+void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load)
+{
+    const int npan = (int)(N / LEAF);
+    std::vector<Node> nodes;
+    make_tree(nodes, 0, npan, false);
+    int H = 0;
+    for (const Node& n : nodes)
+        H = std::max(H, n.height);
+    auto at = [&](int64_t row, int64_t col) { return row + col * ld; };
+    for (int h = 1; h <= H; ++h) {
+        std::vector<Prod> w_prods, u_prods;
+        std::vector<SymFold> t_folds;
+        for (const Node& n : nodes) {
+            if (n.height != h)
+                continue;
+            const int64_t a0 = (int64_t)n.lo * LEAF, am = (int64_t)n.mid * LEAF, ce = (int64_t)n.hi * LEAF;
+            const int ta = (int)((am - a0) / TILE), tc = (int)((ce - am) / TILE);
+            for (int i = 0; i < ta; ++i)
+                for (int j = 0; j < tc; ++j) {
+                    // W[i, j] = sum_{k >= i} U_a[i, k] B[j, k]
+                    Prod w;
+                    w.a = {B_U, at(a0 + (int64_t)i * TILE, a0 + (int64_t)i * TILE)};
+                    w.b = {B_L, at(am + (int64_t)j * TILE, a0 + (int64_t)i * TILE)};
+                    w.d = {B_S0, at(a0 + (int64_t)i * TILE, am + (int64_t)j * TILE)};
+                    w.units = ta - i;
+                    w_prods.push_back(w);
+                    // U_b[i, j] = -sum_{k <= j} W[i, k] T_c[j, k]
+                    Prod u;
+                    u.a = {B_S0, at(a0 + (int64_t)i * TILE, am)};
+                    u.b = {B_S0, at(am + (int64_t)j * TILE, am)};
+                    u.d = {B_U, at(a0 + (int64_t)i * TILE, am + (int64_t)j * TILE)};
+                    u.units = j + 1;
+                    u.neg = 1;
+                    if (n.is_right) // this node's own T-form: T_b = U_b^T
+                        u.t = {B_S0, at(am + (int64_t)j * TILE, a0 + (int64_t)i * TILE)};
+                    u_prods.push_back(u);
+                }
+            if (n.is_right && nodes[(size_t)n.left].height > 0) {
+                // ... and T_a = U_a^T, tile by tile (a leaf has its T-form from k_inv_panels; T_c exists: it was this
+                // node's operand)
+                for (int i = 0; i < ta; ++i)
+                    for (int j = i; j < ta; ++j) {
+                        SymFold f;
+                        f.d = {B_U, at(a0 + (int64_t)i * TILE, a0 + (int64_t)j * TILE)};
+                        f.t = {B_S0, at(a0 + (int64_t)j * TILE, a0 + (int64_t)i * TILE)};
+                        t_folds.push_back(f);
+                    }
+            }
+        }
+        emit(pl, w_prods, {}, ld, nbins, load);
+        if (h == 1)
+            pl.prefix_steps = (int)pl.steps.size();
+        emit(pl, u_prods, t_folds, ld, nbins, load);
+    }
+    // K^-1[i, j] = sum_{k >= i} U[i, k] U[j, k], i >= j
+    std::vector<Prod> k_prods;
+    const int nt = (int)(N / TILE);
+    for (int i = 0; i < nt; ++i)
+        for (int j = 0; j <= i; ++j) {
+            Prod p;
+            p.a = {B_U, at((int64_t)i * TILE, (int64_t)i * TILE)};
+            p.b = {B_U, at((int64_t)j * TILE, (int64_t)i * TILE)};
+            p.d = {B_K, at((int64_t)i * TILE, (int64_t)j * TILE)};
+            p.units = nt - i;
+            k_prods.push_back(p);
+        }
+    emit(pl, k_prods, {}, ld, nbins, load);
+}
+
+// two resident workgroups per CU (74 KB of LDS each); chunks about as long as a share.  Measured around it
+// (profiles/r05_inv2_ab.log): 256 shares 1.305 ms against 1.288 for K^-1 of N = 4096, chunks of half / 0.7 / twice a share
+// 1.270 / 1.283 / 1.446.
+constexpr int PLAN_BINS = 512;
+constexpr double PLAN_LOAD = 1.0;
+
+} // namespace
+
+struct Inv2Plan {
+    int64_t N = 0, ld = 0, pstride = 0;
+    const double* L = nullptr;
+    double *U = nullptr, *K = nullptr, *S = nullptr;
+    std::vector<SymStep> steps;
+    int prefix_steps = 0;
+    char* dev = nullptr;
+    GemmItem* dItems = nullptr;
+    FoldItem* dFolds = nullptr;
+    int32_t* dBins = nullptr;
+    double flops = 0.0;
+};
+
+bool inv2_supported(int64_t N)
+{
+    static const int on = getenv("GPE_INV2") ? atoi(getenv("GPE_INV2")) : 1;
+    static const int64_t min_n = getenv("GPE_INV2_MIN_N") ? atoll(getenv("GPE_INV2_MIN_N")) : 1024;
+    return on && N >= min_n && N % LEAF == 0;
+}
+int inv2_partials() { return NPART; }
+
+void inv2_plan_free(Inv2Plan* p)
+{
+    if (!p)
+        return;
+    if (p->dev)
+        (void)hipFree(p->dev);
+    delete p;
+}
+
+Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride)
+{
+    if (old && old->N == N && old->ld == ld && old->L == L && old->U == U && old->K == Kinv && old->S == S && old->pstride == pstride)
+        return old;
+    inv2_plan_free(old);
+    SymPlan sp;
+    build(sp, N, ld, PLAN_BINS, PLAN_LOAD);
+    Inv2Plan* p = new Inv2Plan;
+    p->N = N;
+    p->ld = ld;
+    p->pstride = pstride;
+    p->L = L;
+    p->U = U;
+    p->K = Kinv;
+    p->S = S;
+    p->steps = sp.steps;
+    p->prefix_steps = sp.prefix_steps;
+    double* base[7] = {const_cast<double*>(L), U, Kinv, S, S + pstride, S + 2 * pstride, S + 3 * pstride};
+    auto res = [&](const SymRef& r) -> double* { return r.buf == B_NONE ? nullptr : base[r.buf] + r.off; };
+    std::vector<GemmItem> gi(sp.items.size());
+    for (size_t i = 0; i < gi.size(); ++i) {
+        gi[i].A = res(sp.items[i].a);
+        gi[i].B = res(sp.items[i].b);
+        gi[i].C = res(sp.items[i].c);
+        gi[i].k = sp.items[i].k;
+        gi[i].neg = sp.items[i].neg;
+    }
+    std::vector<FoldItem> fi(sp.folds.size());
+    for (size_t i = 0; i < fi.size(); ++i) {
+        fi[i].D = res(sp.folds[i].d);
+        for (int q = 0; q < NPART; ++q)
+            fi[i].P[q] = res(sp.folds[i].p[q]);
+        fi[i].T = res(sp.folds[i].t);
+    }
+    const size_t b0 = sizeof(GemmItem) * gi.size(), b1 = sizeof(FoldItem) * fi.size(), b2 = sizeof(int32_t) * sp.bin_start.size();
+    const size_t o1 = (b0 + 255) / 256 * 256, o2 = o1 + (b1 + 255) / 256 * 256;
+    if (hipMalloc(&p->dev, o2 + b2 + 256) != hipSuccess) {
+        delete p;
+        return nullptr;
+    }
+    p->dItems = (GemmItem*)p->dev;
+    p->dFolds = (FoldItem*)(p->dev + o1);
+    p->dBins = (int32_t*)(p->dev + o2);
+    bool ok = hipMemcpy(p->dItems, gi.data(), b0, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && (b1 == 0 || hipMemcpy(p->dFolds, fi.data(), b1, hipMemcpyHostToDevice) == hipSuccess);
+    ok = ok && hipMemcpy(p->dBins, sp.bin_start.data(), b2, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        inv2_plan_free(p);
+        return nullptr;
+    }
+    for (const SymStep& st : p->steps)
+        p->flops += st.flops;
+    return p;
+}
+
+double inv2_flops(const Inv2Plan* p) { return p ? p->flops : 0.0; }
+
+// part 0: everything.  part 1: the leaves and W of the lowest tree level only — they depend on nothing but the factor, are
+// bound by launch latency (128 workgroups, then 32 tile products) and occupy half / an eighth of the chip: gpe_hp_objective
+// runs them on the second stream beside the backward sweep of alpha (110 us against its 116).  part 2: the rest.
+void inv2_run(hipStream_t s, Inv2Plan* p, const double* Xt_all, int part)
+{
+    // X_p = inv(L_pp): as it is into the T-form buffer, transposed into U (zeros on the other side of either diagonal)
+    if (part != 2)
+        launch_inv_panels(s, p->L, p->ld, p->N, LEAF, Xt_all, p->S, p->ld, p->U, p->ld);
+    const size_t first = part == 2 ? (size_t)p->prefix_steps : 0, last = part == 1 ? (size_t)p->prefix_steps : p->steps.size();
+    for (size_t i = first; i < last; ++i) {
+        const SymStep& st = p->steps[i];
+        if (st.kind == 0)
+            launch_gemm_items(s, p->dItems, p->dBins + st.bin_off, st.bins, p->ld);
+        else
+            launch_fold_items(s, p->dFolds + st.off, st.count, p->ld);
+    }
+}
+
+// test hook (gpe_debug_inv_plan): the plan for order N, leading dimension ld; rows of 10 int64:
+//   products: { step, 0, A buf, A off, B buf, B off, C buf, C off, k, neg | share << 1 }   (in launch order, share by share)
+//   folds   : { step, 1, D buf, D off, P1 off | -1, P2 off | -1, P3 off | -1, T buf | -1, T off, 0 }
+// buffers: 0 L, 1 U, 2 K^-1, 3 T-forms / W, 4..6 partials.  Returns the number of rows (also when out is too small).
+int inv2_debug_plan(int64_t N, int64_t ld, int nbins, int load_pct, int64_t* out, int64_t cap_rows)
+{
+    if (N <= 0 || N % LEAF != 0 || ld < N)
+        return -1;
+    SymPlan sp;
+    build(sp, N, ld, nbins > 0 ? nbins : PLAN_BINS, load_pct > 0 ? load_pct / 100.0 : PLAN_LOAD);
+    int64_t row = 0;
+    for (size_t s = 0; s < sp.steps.size(); ++s) {
+        const SymStep& st = sp.steps[s];
+        for (int i = 0; i < st.count; ++i, ++row) {
+            if (row >= cap_rows || !out)
+                continue;
+            int64_t* o = out + row * 10;
+            if (st.kind == 0) {
+                const SymItem& it = sp.items[(size_t)(st.off + i)];
+                int64_t bin = 0; // the share (= workgroup of the launch) this product belongs to
+                while (bin + 1 < st.bins && sp.bin_start[(size_t)(st.bin_off + bin + 1)] <= st.off + i)
+                    ++bin;
+                const int64_t v[10] = {(int64_t)s, 0, it.a.buf, it.a.off, it.b.buf, it.b.off, it.c.buf, it.c.off, it.k, it.neg | (bin << 1)};
+                std::copy(v, v + 10, o);
+            }
+            else {
+                const SymFold& f = sp.folds[(size_t)(st.off + i)];
+                const int64_t v[10] = {(int64_t)s, 1, f.d.buf, f.d.off, f.p[0].buf == B_NONE ? -1 : f.p[0].off,
+                                       f.p[1].buf == B_NONE ? -1 : f.p[1].off, f.p[2].buf == B_NONE ? -1 : f.p[2].off,
+                                       f.t.buf, f.t.off, 0};
+                std::copy(v, v + 10, o);
+            }
+        }
+    }
+    return (int)row;
+}

@@ -1,0 +1,145 @@
+"""The launch plan of the recursive K^-1 (limbo_amd/csrc/inv2.hip; GP::compute_inv_kernel, src/limbo/model/gp.hpp:254-264)
+EXECUTED IN NUMPY — host logic, no device.  gpe_debug_inv_plan hands out every tile product and tile fold of the plan as
+(buffer, offset, depth) rows in launch order; here each is carried out literally on column-major numpy buffers, with the leaf
+inverses (what k_inv_panels leaves) from numpy: U must come out as L^-T, the lower triangle of K^-1 as LAPACK's.  Also held:
+the k range of no tile is cut into more than 1 + 3 chunks, every product launch is dealt into shares whose longest is no
+longer than the mean share + one chunk, every tile a product reads was written before (nothing relies on zero-filled
+memory), and launches of one step never read what the same step writes."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from limbo_amd import _capi
+
+TILE = 128
+
+
+def _plan(n, ld, nbins=512, load_pct=100):
+    lib = ctypes.CDLL(str(_capi.ENGINE_SO))
+    f = lib.gpe_debug_inv_plan
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int64]
+    rows = f(n, ld, nbins, load_pct, None, 0)
+    assert rows > 0
+    out = np.zeros((rows, 10), dtype=np.int64)
+    assert f(n, ld, nbins, load_pct, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), rows) == rows
+    return out
+
+
+def _tile(buf, off, ld, cols=TILE):
+    """view of the 128 x cols block whose origin is at offset `off` of a column-major buffer with leading dimension ld"""
+    r, c = off % ld, off // ld
+    return buf[r:r + TILE, c:c + cols]
+
+
+def _run_plan(n, ld, nbins, load_pct, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(n, n)) / np.sqrt(n)
+    Kmat = A @ A.T + 0.3 * np.eye(n)
+    L = np.linalg.cholesky(Kmat)
+    cap = n
+    NAN = np.nan
+    bufs = [np.full((ld, cap), NAN) for _ in range(7)]  # [row, col] = offset row + col * ld
+    bufs[0][:n, :n] = L
+    # the leaves (k_inv_panels): X_p into the T-form buffer, X_p^T into U, full 256 x 256 squares
+    for p0 in range(0, n, 256):
+        X = np.linalg.inv(L[p0:p0 + 256, p0:p0 + 256])
+        X = np.tril(X)
+        bufs[3][p0:p0 + 256, p0:p0 + 256] = X
+        bufs[1][p0:p0 + 256, p0:p0 + 256] = X.T
+    plan = _plan(n, ld, nbins, load_pct)
+    steps = plan[:, 0]
+    stats = dict(launches=int(steps.max()) + 1, products=0, folds=0, max_chunks=1)
+    for s in range(int(steps.max()) + 1):
+        rows = plan[steps == s]
+        kind = rows[0, 1]
+        assert (rows[:, 1] == kind).all()
+        if kind == 0:
+            stats["products"] += len(rows)
+            results = []
+            written = set()
+            for r in rows:
+                _, _, ab, ao, bb, bo, cb, co, k, neg = (int(v) for v in r)
+                neg &= 1
+                assert k % 128 == 0 and k >= 128
+                At, Bt = _tile(bufs[ab], ao, ld, k), _tile(bufs[bb], bo, ld, k)
+                assert not np.isnan(At).any() and not np.isnan(Bt).any(), "a product reads memory nothing wrote"
+                v = At @ Bt.T
+                results.append((cb, co, -v if neg else v))
+                assert (cb, co) not in written, "two products of one launch write the same tile"
+                written.add((cb, co))
+            reads = {(int(r[2]), int(r[3]) % ld // TILE, (int(r[3]) // ld + kk) // TILE) for r in rows for kk in range(0, int(r[8]), TILE)}
+            reads |= {(int(r[4]), int(r[5]) % ld // TILE, (int(r[5]) // ld + kk) // TILE) for r in rows for kk in range(0, int(r[8]), TILE)}
+            writes = {(cb, co % ld // TILE, co // ld // TILE) for cb, co, _ in results}
+            assert not (reads & writes), "a launch reads a tile it also writes"
+            for cb, co, v in results:
+                _tile(bufs[cb], co, ld)[:, :] = v
+        else:
+            stats["folds"] += len(rows)
+            for r in rows:
+                _, _, db, do, p1, p2, p3, tb, to, _ = (int(v) for v in r)
+                D = _tile(bufs[db], do, ld)
+                nparts = 0
+                for q, po in enumerate((p1, p2, p3)):
+                    if po >= 0:
+                        assert po == do and nparts == q
+                        P = _tile(bufs[4 + q], po, ld)
+                        assert not np.isnan(P).any()
+                        D += P
+                        nparts += 1
+                stats["max_chunks"] = max(stats["max_chunks"], 1 + nparts)
+                assert not np.isnan(D).any()
+                if tb >= 0:
+                    _tile(bufs[tb], to, ld)[:, :] = D.T
+    U = bufs[1][:n, :n]
+    Kinv = bufs[2][:n, :n]
+    return L, Kmat, U, Kinv, stats, plan
+
+
+@pytest.mark.parametrize("n,ld,nbins,load_pct", [(1024, 1024 + 32, 512, 100), (2048, 2048 + 32, 512, 100), (1536, 1536 + 16, 64, 100),
+                                                  (1280, 1280 + 32, 16, 50), (768, 800, 8, 200), (512, 544, 512, 100), (256, 272, 4, 100)])
+def test_inv_plan_executed_in_numpy(n, ld, nbins, load_pct):
+    L, Kmat, U, Kinv, stats, plan = _run_plan(n, ld, nbins, load_pct, seed=n + nbins)
+    Uref = np.linalg.inv(L).T
+    iu = np.triu_indices(n)
+    assert not np.isnan(U[iu]).any()
+    assert np.max(np.abs(U[iu] - Uref[iu])) <= 1e-10 * np.max(np.abs(Uref))
+    il = np.tril_indices(n)
+    Kref = np.linalg.inv(Kmat)
+    assert not np.isnan(Kinv[il]).any()
+    assert np.max(np.abs(Kinv[il] - Kref[il])) <= 1e-9 * np.max(np.abs(Kref))
+    assert stats["max_chunks"] <= 4
+    # algorithmic flops: the products of the plan do 2 n^3 / 3 less what the leaves did, at tile granularity
+    units = plan[plan[:, 1] == 0][:, 8].sum() // TILE
+    t = n // TILE
+    lauum = sum((t - i) * (i + 1) for i in range(t))
+    assert lauum <= units <= 2 * lauum and (units > lauum or n == 256)
+    print(f"n={n}: {stats['launches']} launches after the leaves, {stats['products']} tile products, {stats['folds']} folds")
+
+
+def test_inv_plan_shares_are_balanced():
+    """N = 4096 as config 2 runs it (512 shares = two resident workgroups per CU): per product launch that fills the chip the
+    longest share is within 15 % + one chunk of the mean share."""
+    n, ld = 4096, 4096 + 32
+    plan = _plan(n, ld, 512, 100)
+    steps = plan[:, 0]
+    launches, big = 0, 0
+    for s in range(int(steps.max()) + 1):
+        rows = plan[steps == s]
+        if rows[0, 1] != 0:
+            continue
+        launches += 1
+        units = rows[:, 8] // TILE
+        share = rows[:, 9] >> 1
+        assert share.max() < 512
+        if len(rows) < 256:
+            continue
+        big += 1
+        load = np.bincount(share, weights=units, minlength=512)
+        assert load.max() <= 1.15 * units.sum() / 512 + units.max(), (s, load.max(), units.sum() / 512, units.max())
+    assert big >= 3  # W and U_b of the top node, U U^T
+    last = plan[steps == max(int(s) for s in steps[plan[:, 1] == 0])]
+    assert (last[:, 6] >= 2).all() and last[:, 8].sum() // TILE == 5984 and len(last) >= 512  # U U^T: 528 tiles, 5984 units
+    assert launches == 2 * 4 + 1  # W and U_b of the four heights, then U U^T
+    assert plan[:, 0].max() + 1 <= 2 * launches  # at most one fold launch per product launch
