@@ -1027,16 +1027,34 @@ void enqueue_loglik_terms(gpe_ctx* c)
 }
 
 static void inv2_start_early(gpe_ctx* c); // (below, with ensure_inv)
+// One evaluation's chain on the device (defined with the gate, below).
+struct ChainScope {
+    gpe_ctx* c;
+    bool on;
+    int part = -1; // >= 0: the chain runs on that CU-masked partition's streams
+    hipStream_t own = nullptr, own2 = nullptr;
+    ChainScope(gpe_ctx* c_, bool engage, bool may_partition);
+    ~ChainScope();
+    ChainScope(const ChainScope&) = delete;
+    ChainScope& operator=(const ChainScope&) = delete;
+};
 int compute_enqueue(gpe_ctx* c)
 {
     if (c->N <= 0 || !c->dA)
         return GPE_ERR_STATE;
-    hipStream_t s = c->stream;
     // One evaluation's chain of launches as a unit behind the device's previous data-flow launch (dev.h: FlowGate; the gates of
     // the launches below nest inside this one): two handles evaluated from two threads run chain behind chain — 840
     // evaluations/s in all at N = 4096, where gating launch by launch interleaved their chains at 600.  Not for a batched
     // sequence: the two sub-batches of a batch of 64 overlap on purpose (their data-flow launches are still ordered one by one).
-    FlowGate gate(s, !g_batch.bt);
+    // Round 5: when another chain is in flight on the device, this one goes to one of two CU-masked streams instead — half
+    // of every XCD's CUs each — and the two run side by side (ChainScope, below).
+    bool may_partition = false;
+    if (!g_batch.bt) {
+        const TailPlan pl0 = tail_plan(c, c->N, c->N + c->P);
+        may_partition = pl0.t0 == 0 || (pl0.t0 > 0 && pl0.e0 == 0); // data-flow launches from column 0 on: no 256-column panels
+    }
+    ChainScope gate(c, !g_batch.bt, may_partition);
+    hipStream_t s = c->stream; // (the handle's own stream, or the partition's for the length of this enqueue)
     digest_kernel(c);
     c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
     if (c->handover_off_left > 0 && --c->handover_off_left == 0)
@@ -1645,7 +1663,16 @@ struct GateDev {
     std::recursive_mutex mu;
     int depth = 0, next = 0;
     hipEvent_t ring[64] = {};
-    hipStream_t last_stream = nullptr; // where the device's last data-flow launch went
+    hipStream_t last_stream = nullptr; // where the device's last UNMASKED data-flow launch went
+    // Round 5: two CU-masked stream pairs, half of every XCD's CUs each (mask bit i = XCD i % 8, CU i / 8 of it — measured,
+    // profiles/r05_cumask_probe.log; a mask cannot leave an XCD empty, so "four XCDs each" is not to be had).  A data-flow
+    // launch confined to its half always finds its lowest unfinished workgroup resident there — per XCD the dispatcher hands
+    // a launch's workgroups out in order, and nothing else that WAITS can hold those CUs — so one chain per half runs
+    // deadlock-free beside the other.  An unmasked data-flow launch can hold any CU: it waits for both halves to drain, and
+    // the masked chains that follow wait for it.
+    hipStream_t part[2] = {nullptr, nullptr}, part_aux[2] = {nullptr, nullptr};
+    bool part_tried = false, part_dirty[2] = {false, false};
+    unsigned rr = 0;
 };
 GateDev g_gate[16];
 bool gate_on()
@@ -1668,23 +1695,107 @@ void flow_gate_forget(hipStream_t s)
     if (g.last_stream == s)
         g.last_stream = nullptr; // (gpe_destroy synchronises the stream first: its launches are through)
 }
+// `s` waits for whatever is on `behind` now (an event at that stream's current end)
+static void gate_order(GateDev& g, hipStream_t s, hipStream_t behind)
+{
+    hipEvent_t& e = g.ring[g.next];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+        e = nullptr;
+    if (e && hipEventRecord(e, behind) == hipSuccess) {
+        (void)hipStreamWaitEvent(s, e, 0);
+        g.next = (g.next + 1) % 64;
+    }
+}
+// an unmasked data-flow launch on s: behind the device's previous one on another stream, and behind both masked halves
+static void gate_unmasked(GateDev& g, hipStream_t s)
+{
+    // the previous data-flow launch of the device went to another stream: an event at that stream's current end (behind
+    // that launch; nothing is recorded per launch — a batch of 64 members steps through ~60 gated launches on one stream)
+    if (g.last_stream && g.last_stream != s)
+        gate_order(g, s, g.last_stream);
+    for (int i = 0; i < 2; ++i)
+        if (g.part_dirty[i]) {
+            gate_order(g, s, g.part[i]);
+            g.part_dirty[i] = false;
+        }
+}
 void flow_gate_enter(hipStream_t s)
 {
     if (!gate_on())
         return;
     GateDev& g = gate_dev();
     g.mu.lock(); // (held until flow_gate_leave: the launch in between is a few microseconds of host time)
-    if (g.depth++ == 0 && g.last_stream && g.last_stream != s) {
-        // the previous data-flow launch of the device went to another stream: an event at that stream's current end (behind
-        // that launch; nothing is recorded per launch — a batch of 64 members steps through ~60 gated launches on one stream)
-        hipEvent_t& e = g.ring[g.next];
-        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
-            e = nullptr;
-        if (e && hipEventRecord(e, g.last_stream) == hipSuccess) {
-            (void)hipStreamWaitEvent(s, e, 0);
-            g.next = (g.next + 1) % 64;
+    if (g.depth++ == 0)
+        gate_unmasked(g, s);
+}
+static bool partitions_on()
+{
+    static const bool on = !(getenv("GPE_FLOW_PARTITIONS") && atoi(getenv("GPE_FLOW_PARTITIONS")) == 0);
+    return on;
+}
+static bool partition_streams(GateDev& g)
+{
+    if (!g.part_tried) {
+        g.part_tried = true;
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus == 256) {
+            uint32_t lo[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0}; // CUs 0..15 of every XCD
+            uint32_t hi[8] = {0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; // CUs 16..31
+            bool ok = hipExtStreamCreateWithCUMask(&g.part[0], 8, lo) == hipSuccess && hipExtStreamCreateWithCUMask(&g.part_aux[0], 8, lo) == hipSuccess
+                && hipExtStreamCreateWithCUMask(&g.part[1], 8, hi) == hipSuccess && hipExtStreamCreateWithCUMask(&g.part_aux[1], 8, hi) == hipSuccess;
+            if (!ok)
+                g.part[0] = g.part[1] = nullptr; // (whatever was created stays unused)
         }
     }
+    return g.part[0] != nullptr;
+}
+ChainScope::ChainScope(gpe_ctx* c_, bool engage, bool may_partition) : c(c_), on(engage && gate_on())
+{
+    if (!on)
+        return;
+    GateDev& g = gate_dev();
+    g.mu.lock(); // (held for the enqueue of the evaluation: ~50 us of host time)
+    ++g.depth;   // the gates of the launches inside nest in this one
+    if (g.depth == 1 && may_partition && partitions_on() && !c->prof && partition_streams(g)) {
+        // is another chain in flight on the device?  (A query, not a guarantee: it picks the mode; ORDER comes from the
+        // events below.)
+        const bool full_busy = g.last_stream && g.last_stream != c->stream && hipStreamQuery(g.last_stream) == hipErrorNotReady;
+        bool busy[2];
+        for (int i = 0; i < 2; ++i)
+            busy[i] = g.part_dirty[i] && hipStreamQuery(g.part[i]) == hipErrorNotReady;
+        if (full_busy || busy[0] || busy[1])
+            part = !busy[0] ? 0 : (!busy[1] ? 1 : (int)(g.rr++ & 1));
+    }
+    if (part >= 0) {
+        hipStream_t P = g.part[part];
+        gate_order(g, P, c->stream); // behind the handle's own earlier work (uploads, the previous evaluation's readers)
+        if (g.last_stream && g.last_stream != c->stream)
+            gate_order(g, P, g.last_stream); // behind the device's last unmasked data-flow launch
+        own = c->stream;
+        own2 = c->stream2;
+        c->stream = P;
+        c->stream2 = g.part_aux[part];
+        g.part_dirty[part] = true;
+    }
+    else if (g.depth == 1)
+        gate_unmasked(g, c->stream);
+}
+ChainScope::~ChainScope()
+{
+    if (!on)
+        return;
+    GateDev& g = gate_dev();
+    if (part >= 0) {
+        hipStream_t P = c->stream;
+        c->stream = own;
+        c->stream2 = own2;
+        gate_order(g, c->stream, P); // whatever the handle does next, and its host wait, come behind the chain
+    }
+    else if (g.depth == 1)
+        g.last_stream = c->stream;
+    --g.depth;
+    g.mu.unlock();
 }
 void flow_gate_leave(hipStream_t s)
 {
