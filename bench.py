@@ -573,26 +573,55 @@ def main():
         h15.set_data(X, om)
         ph15 = profiled(h15, 3)
         h15.close()
-        # HBM traffic of the dominant launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-        # runs, FETCH doubled per MI355X_MICROARCH.md): a file under profiles/, not measured in this run (a PMC pass cannot run
-        # inside it) — null when this round's file is absent
-        traffic = None
-        pmc = ROOT / "profiles" / "r04_pmc_trailing_update.json"
-        if pmc.exists() and N == N_C2:
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch_corrected")
-        out["roofline"] = {
-            "bound": "mfma",
+        # HBM traffic from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per
+        # MI355X_MICROARCH.md): a file under profiles/, not measured in this run (a PMC pass cannot run inside it) — null when
+        # the file is absent
+        pmc, pmc_rec = None, {}
+        for cand in ("r05_pmc_bench.json", "r04_pmc_trailing_update.json"):
+            if (ROOT / "profiles" / cand).exists() and N == N_C2:
+                pmc = ROOT / "profiles" / cand
+                pmc_rec = json.loads(pmc.read_text())
+                break
+        upd_roof = {
             "kernel": "k_gemm_glds (Cholesky trailing update A22 -= L21 L21^T, v_mfma_f64_4x4x4_4b): every trailing-update launch of one "
-                      "factorisation, each alone, HIP events on the handle's stream.  Round 4 schedule at N = 4096: ONE update with k = 1280 "
-                      "between the tall data-flow launch (columns 0..1279, all rows) and the closing one (columns 1280..4095); their flops "
-                      "are in `data_flow_launches`, the round-3 accounting (all 15 k = 256 updates) in `all_updates_like_for_like`",
+                      "factorisation, each alone, HIP events on the handle's stream.  At N = 4096: ONE update with k = 1280 between the "
+                      "tall data-flow launch (columns 0..1279, all rows) and the closing one (columns 1280..4095)",
             "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF,
-            "traffic": traffic,
-            "traffic_note": f"bytes of the update launch, PMC (profiles/{pmc.name}: committed, not measured in this run); algorithmic "
-                            "bytes of that launch = 2 x 31.7 MB C tiles (lower triangle of 2816^2) + 28.8 MB panel (2816 x 1280)",
+            "traffic": pmc_rec.get("hbm_bytes_per_launch_corrected"),
+            "traffic_note": f"bytes of the update launch, PMC (profiles/{pmc.name if pmc else '-'}: committed, not measured in this run); "
+                            "algorithmic bytes of that launch = 2 x 31.7 MB C tiles (lower triangle of 2816^2) + 28.8 MB panel (2816 x 1280)",
+            "mfma_busy_percent": pmc_rec.get("mfma_util_percent"),
             "launches_per_step": upd["launches"], "avg_launch_us": upd["us"] / max(upd["launches"], 1),
             "algorithmic_flops_per_step": upd["flops"],
             "share_of_factorisation_flops": upd["flops"] / (float(N) ** 3 / 3.0),
+        }
+        total_us = sum(v["us"] for v in ph.values())
+        if "potrf_tall" in ph and "potrf_tail" in ph:
+            # Round 5: the line's `roofline` is the DOMINANT kernel — k_tail, the two data-flow launches, 70 %
+            # of the GPU time of a step — not the update launch, which follows as `trailing_update`
+            dfl = {"us": ph["potrf_tall"]["us"] + ph["potrf_tail"]["us"], "launches": ph["potrf_tall"]["launches"] + ph["potrf_tail"]["launches"],
+                   "flops": ph["potrf_tall"]["flops"] + ph["potrf_tail"]["flops"]}
+            kt = pmc_rec.get("k_tail") or {}
+            out["roofline"] = {
+                "bound": "mfma",
+                "kernel": "k_tail (potrf.hip): the two data-flow launches of the factorisation — tall (columns 0..1279, every row strip below) "
+                          "and closing (the last 2816 columns); a workgroup per 64 x 64 tile, 64^3 matrix-core products inside a latency "
+                          "chain of 64 diagonal blocks, operands polled between workgroups; each launch alone, HIP events on the handle's "
+                          "stream.  flops = the factorisation flops of the columns each launch covers",
+                "achieved": rate(dfl)["tflops"], "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": rate(dfl)["frac"],
+                "traffic": kt.get("hbm_bytes_per_step_corrected"),
+                "traffic_note": f"bytes of the two launches together, PMC (profiles/{pmc.name if pmc else '-'}: committed, not measured in this "
+                                "run; FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); algorithmic bytes: read + write of the lower triangle "
+                                "each launch covers = 2 x 8 B x (4096^2 - 2816^2) / 2 + 2 x 8 B x 2816^2 / 2 = 134 MB (+ the hand-over slots)",
+                "mfma_busy_percent": {"tall": (kt.get("tall") or {}).get("mfma_util_percent"), "closing": (kt.get("closing") or {}).get("mfma_util_percent")},
+                "launches_per_step": dfl["launches"], "avg_launch_us": dfl["us"] / max(dfl["launches"], 1),
+                "algorithmic_flops_per_step": dfl["flops"], "share_of_gpu_time": dfl["us"] / total_us if total_us > 0 else None,
+                "share_of_factorisation_flops": dfl["flops"] / (float(N) ** 3 / 3.0),
+                "trailing_update": upd_roof,
+            }
+        else:
+            out["roofline"] = dict(upd_roof, bound="mfma", share_of_gpu_time=upd["us"] / total_us if total_us > 0 else None)
+        out["roofline"].update({
             "data_flow_launches": {"tall": rate(ph["potrf_tall"]) if "potrf_tall" in ph else None,
                                    "closing": rate(ph["potrf_tail"]) if "potrf_tail" in ph else None,
                                    "note": "k_tail: a workgroup per 64 x 64 tile, operands polled between workgroups; flops = the "
@@ -604,17 +633,17 @@ def main():
                                               note="GPE_TALL=0 GPE_TAIL_MAX=0: 256-column panels to the end, every one of the 15 trailing updates "
                                                    "(k = 256) alone between two events — rounds 1-3's accounting"),
             "measured_mfma_f64_4x4x4_peak_tflops": pk.value,
-        }
+        })
         out["factorisation_frac"] = out["roofline"]["factorisation"]["frac_over_the_step"]
         out["box_probe"] = box_probe(eng, _capi, O, local_rank)
         out["phases_us_per_step_profiled"] = {k: v["us"] for k, v in ph.items()}
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # R independent evaluations in flight from R host threads (the reference runs hyper-parameter restarts concurrently:
-        # opt/parallel_repeater.hpp:86-105 under tools::par::max).  Round 4: the data-flow launches of different handles no longer
-        # overlap (csrc/dev.h, FlowGate: two of them at once can starve each other's lowest unfinished workgroup — measured: four
-        # threads fell into the bounded polls and the re-run path, 1 evaluation/s), only the other launches do: the figure is the
-        # single-chain rate plus that overlap.  Restarts in lock-step (one batched launch sequence) are `batched_hp_objective`.
+        # opt/parallel_repeater.hpp:86-105 under tools::par::max).  Round 4 ordered the data-flow launches of different handles
+        # chain behind chain (two at once can starve each other's lowest unfinished workgroup); round 5: while another chain
+        # is in flight an evaluation runs on one of two CU-masked streams, half of every XCD's CUs each (csrc/engine.hip:
+        # ChainScope) — two chains side by side.  Restarts in lock-step (one batched launch sequence) are `batched_hp_objective`.
         import threading
 
         conc = {}

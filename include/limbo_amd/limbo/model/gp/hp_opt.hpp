@@ -84,6 +84,114 @@ namespace limbo_amd {
         mutable std::mutex _mu;
         mutable std::map<std::thread::id, std::unique_ptr<GP>> _workers;
     };
+
+    // ---- the hyper-parameter fits, written once ----------------------------------------------------------------------
+    // limbo's four fitting policies (model/gp/kernel_lf_opt.hpp, kernel_loo_opt.hpp, mean_lf_opt.hpp, kernel_mean_lf_opt.hpp)
+    // differ in two things only: WHICH hyper-parameters move — a Subject: read them from a GP, put them into a GP and
+    // refresh what depends on them — and WHAT is maximised — a Score: its value and its gradient pieces.  fit::Objective
+    // is the functor the optimiser calls (one persistent device clone per calling host thread: WorkerClones), fit::run the
+    // policy's operator().  The policy headers instantiate them; the names limbo's users and tests see stay theirs.
+    namespace fit {
+        inline Eigen::VectorXd join(const Eigen::VectorXd& a, const Eigen::VectorXd& b)
+        {
+            Eigen::VectorXd v(a.size() + b.size());
+            for (int i = 0; i < (int)a.size(); ++i)
+                v(i) = a(i);
+            for (int i = 0; i < (int)b.size(); ++i)
+                v(a.size() + i) = b(i);
+            return v;
+        }
+        /// log marginal likelihood (gp.hpp:267-330)
+        struct LogLik {
+            template <typename GP> static double value(GP& gp) { return gp.compute_log_lik(); }
+            template <typename GP> static Eigen::VectorXd wrt_kernel(GP& gp) { return gp.compute_kernel_grad_log_lik(); }
+            template <typename GP> static Eigen::VectorXd wrt_mean(GP& gp) { return gp.compute_mean_grad_log_lik(); }
+        };
+        /// leave-one-out cross-validation log probability (gp.hpp:339-402)
+        struct LogLooCv {
+            template <typename GP> static double value(GP& gp) { return gp.compute_log_loo_cv(); }
+            template <typename GP> static Eigen::VectorXd wrt_kernel(GP& gp) { return gp.compute_kernel_grad_log_loo_cv(); }
+        };
+        /// the kernel's hyper-parameters: a new kernel matrix, same obs_mean (recompute(false))
+        struct KernelParams {
+            static constexpr bool copies_original = false;
+            template <typename GP> static void prepare(GP&) {}
+            template <typename GP> static Eigen::VectorXd read(const GP& gp) { return gp.kernel_function().h_params(); }
+            template <typename GP> static void put(GP& gp, const Eigen::VectorXd& x)
+            {
+                gp.kernel_function().set_h_params(x);
+                gp.recompute(false);
+            }
+            template <typename Score, typename GP> static Eigen::VectorXd gradient(GP& gp) { return Score::wrt_kernel(gp); }
+        };
+        /// the mean function's: same factor, new obs_mean and alpha (recompute(true, false)); K^-1 is formed once on a copy of
+        /// the original that every worker clone then inherits (mean_lf_opt.hpp:78)
+        struct MeanParams {
+            static constexpr bool copies_original = true;
+            template <typename GP> static void prepare(GP& original) { original.compute_inv_kernel(); }
+            template <typename GP> static Eigen::VectorXd read(const GP& gp) { return gp.mean_function().h_params(); }
+            template <typename GP> static void put(GP& gp, const Eigen::VectorXd& x)
+            {
+                gp.mean_function().set_h_params(x);
+                gp.recompute(true, false);
+            }
+            template <typename Score, typename GP> static Eigen::VectorXd gradient(GP& gp) { return Score::wrt_mean(gp); }
+        };
+        /// both, the kernel's first (kernel_mean_lf_opt.hpp:63-66): everything is recomputed
+        struct KernelAndMeanParams {
+            static constexpr bool copies_original = false;
+            template <typename GP> static void prepare(GP&) {}
+            template <typename GP> static Eigen::VectorXd read(const GP& gp) { return join(gp.kernel_function().h_params(), gp.mean_function().h_params()); }
+            template <typename GP> static void put(GP& gp, const Eigen::VectorXd& x)
+            {
+                const int nk = gp.kernel_function().h_params_size(), nm = gp.mean_function().h_params_size();
+                gp.kernel_function().set_h_params(Eigen::VectorXd(x.head(nk)));
+                gp.mean_function().set_h_params(Eigen::VectorXd(x.tail(nm)));
+                gp.recompute(true);
+            }
+            template <typename Score, typename GP> static Eigen::VectorXd gradient(GP& gp) { return join(Score::wrt_kernel(gp), Score::wrt_mean(gp)); }
+        };
+
+        // the original GP by reference, or (Subject::copies_original) by value after Subject::prepare
+        template <typename GP, bool Copy> struct Original {
+            const GP& gp;
+            explicit Original(const GP& g) : gp(g) {}
+        };
+        template <typename GP> struct Original<GP, true> {
+            GP gp;
+            explicit Original(const GP& g) : gp(g) {}
+        };
+
+        template <typename Params, typename GP, typename Subject, typename Score>
+        class Objective {
+        public:
+            explicit Objective(const GP& gp) : _original(gp) { Subject::prepare(const_cast<GP&>(_original.gp)); }
+            limbo::opt::eval_t operator()(const Eigen::VectorXd& x, bool want_gradient) const
+            {
+                GP& worker = _workers.get(_original.gp);
+                Subject::put(worker, x);
+                const double v = Score::value(worker);
+                if (!want_gradient)
+                    return limbo::opt::no_grad(v);
+                return {v, limbo::opt::eval_t::second_type(Subject::template gradient<Score>(worker))};
+            }
+
+        protected:
+            Original<GP, Subject::copies_original> _original;
+            WorkerClones<Params, GP> _workers;
+        };
+
+        /// a policy's operator(): optimise from where the GP stands, leave the GP at the optimum with its score computed
+        template <typename Optimizer, typename Subject, typename Score, typename Obj, typename GP>
+        inline void run(GP& gp)
+        {
+            Obj objective(gp);
+            Optimizer optimizer;
+            const Eigen::VectorXd best = optimizer(objective, Subject::read(gp), false);
+            Subject::put(gp, best);
+            Score::value(gp);
+        }
+    } // namespace fit
 } // namespace limbo_amd
 
 namespace limbo {

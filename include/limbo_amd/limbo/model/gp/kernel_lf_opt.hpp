@@ -6,9 +6,9 @@
 // new theta": each host thread that calls the objective keeps ONE private device clone of the
 // original GP for the lifetime of the optimisation and re-runs build -> factor -> solve on it.
 // The original GP is untouched until the optimiser returns, exactly as in the reference.
-// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
-// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
-// file named above.  The implementation behind the interface is this project's own.
+// Interface attribution: the names of this header (the policy and its nested objective type) are those of resibots/limbo
+// (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info), file named above — a drop-in must keep them.  What they
+// do is written once, in this project's own terms: limbo_amd::fit (hp_opt.hpp).
 #ifndef LIMBO_MODEL_GP_KERNEL_LF_OPT_HPP
 #define LIMBO_MODEL_GP_KERNEL_LF_OPT_HPP
 #include <map>
@@ -28,12 +28,7 @@ namespace limbo {
                 void operator()(GP& gp)
                 {
                     this->_called = true;
-                    KernelLFOptimization<GP> optimization(gp);
-                    Optimizer optimizer;
-                    Eigen::VectorXd params = optimizer(optimization, gp.kernel_function().h_params(), false);
-                    gp.kernel_function().set_h_params(params);
-                    gp.recompute(false);
-                    gp.compute_log_lik();
+                    limbo_amd::fit::run<Optimizer, limbo_amd::fit::KernelParams, limbo_amd::fit::LogLik, KernelLFOptimization<GP>>(gp);
                 }
 
                 /// Addition: the fits of several GPs (the outputs of a MultiGP: multi_gp/parallel_lf_opt.hpp:64-67) in
@@ -76,21 +71,12 @@ namespace limbo {
                 }
 
             protected:
+                /// the objective (kernel_lf_opt.hpp:72-96) = limbo_amd::fit::Objective over (kernel parameters, log-lik), plus the
+                /// batched evaluation below
                 template <typename GP>
-                struct KernelLFOptimization {
-                public:
-                    KernelLFOptimization(const GP& gp) : _original_gp(gp) {}
-
-                    opt::eval_t operator()(const Eigen::VectorXd& params, bool compute_grad) const
-                    {
-                        GP& gp = _workers.get(_original_gp);
-                        gp.kernel_function().set_h_params(params);
-                        gp.recompute(false);
-                        const double lik = gp.compute_log_lik();
-                        if (!compute_grad)
-                            return opt::no_grad(lik);
-                        return {lik, opt::eval_t::second_type(gp.compute_kernel_grad_log_lik())};
-                    }
+                struct KernelLFOptimization : public limbo_amd::fit::Objective<Params, GP, limbo_amd::fit::KernelParams, limbo_amd::fit::LogLik> {
+                    using Base = limbo_amd::fit::Objective<Params, GP, limbo_amd::fit::KernelParams, limbo_amd::fit::LogLik>;
+                    explicit KernelLFOptimization(const GP& gp) : Base(gp), _original_gp(gp) {}
 
                     /// Addition: the objective at params.size() points at once — one private device clone of the original
                     /// GP per point (kept for the lifetime of the optimisation, dealt over the visible devices), all
@@ -127,7 +113,6 @@ namespace limbo {
 
                 protected:
                     const GP& _original_gp;
-                    limbo_amd::WorkerClones<Params, GP> _workers;
                     mutable std::mutex _batch_mu;
                     mutable std::vector<std::unique_ptr<GP>> _batch;
                 };

@@ -1,72 +1,27 @@
-// limbo/model/gp/kernel_mean_lf_opt.hpp — maximise the log marginal likelihood over the kernel AND
-// the mean hyper-parameters (contract: src/limbo/model/gp/kernel_mean_lf_opt.hpp:55-113).
-// Parameter vector = [kernel h_params | mean h_params] (:67-69).  One persistent device clone per
-// calling host thread instead of the reference's deep copy per evaluation (:92).
-// Interface attribution: the template signature / policy shape of this header reproduces, by requirement (drop-in
-// for user code), the public interface of resibots/limbo (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info),
-// file named above.  The implementation behind the interface is this project's own.
+// limbo/model/gp/kernel_mean_lf_opt.hpp — maximise the log marginal likelihood over the kernel's AND the mean
+// function's hyper-parameters, the kernel's first in the parameter vector (contract:
+// src/limbo/model/gp/kernel_mean_lf_opt.hpp:55-118).
+// Interface attribution: the names of this header (the policy and its nested objective type) are those of resibots/limbo
+// (Copyright Inria, 2015-; CeCILL-C licence, http://www.cecill.info), file named above — a drop-in must keep them.  What they
+// do is written once, in this project's own terms: limbo_amd::fit (hp_opt.hpp).
 #ifndef LIMBO_MODEL_GP_KERNEL_MEAN_LF_OPT_HPP
 #define LIMBO_MODEL_GP_KERNEL_MEAN_LF_OPT_HPP
-#include <map>
-#include <memory>
-#include <mutex>
-#include <thread>
 #include <limbo/model/gp/hp_opt.hpp>
 namespace limbo {
     namespace model {
         namespace gp {
             template <typename Params, typename Optimizer = opt::Rprop<Params>>
             struct KernelMeanLFOpt : public HPOpt<Params, Optimizer> {
-            public:
                 template <typename GP>
                 void operator()(GP& gp)
                 {
                     this->_called = true;
-                    KernelMeanLFOptimization<GP> optimization(gp);
-                    Optimizer optimizer;
-                    const int nk = gp.kernel_function().h_params_size(), nm = gp.mean_function().h_params_size();
-                    Eigen::VectorXd init(nk + nm);
-                    const Eigen::VectorXd hk = gp.kernel_function().h_params(), hm = gp.mean_function().h_params();
-                    for (int i = 0; i < nk; ++i)
-                        init(i) = hk(i);
-                    for (int i = 0; i < nm; ++i)
-                        init(nk + i) = hm(i);
-                    Eigen::VectorXd params = optimizer(optimization, init, false);
-                    gp.kernel_function().set_h_params(Eigen::VectorXd(params.head(nk)));
-                    gp.mean_function().set_h_params(Eigen::VectorXd(params.tail(nm)));
-                    gp.recompute(true);
-                    gp.compute_log_lik();
+                    limbo_amd::fit::run<Optimizer, limbo_amd::fit::KernelAndMeanParams, limbo_amd::fit::LogLik, KernelMeanLFOptimization<GP>>(gp);
                 }
 
             protected:
                 template <typename GP>
-                struct KernelMeanLFOptimization {
-                public:
-                    KernelMeanLFOptimization(const GP& gp) : _original_gp(gp) {}
-
-                    opt::eval_t operator()(const Eigen::VectorXd& params, bool compute_grad) const
-                    {
-                        GP& gp = _workers.get(_original_gp);
-                        const int nk = gp.kernel_function().h_params_size(), nm = gp.mean_function().h_params_size();
-                        gp.kernel_function().set_h_params(Eigen::VectorXd(params.head(nk)));
-                        gp.mean_function().set_h_params(Eigen::VectorXd(params.tail(nm)));
-                        gp.recompute(true);
-                        const double lik = gp.compute_log_lik();
-                        if (!compute_grad)
-                            return opt::no_grad(lik);
-                        Eigen::VectorXd grad = Eigen::VectorXd::Zero(nk + nm);
-                        const Eigen::VectorXd gk = gp.compute_kernel_grad_log_lik(), gm = gp.compute_mean_grad_log_lik();
-                        for (int i = 0; i < nk; ++i)
-                            grad(i) = gk(i);
-                        for (int i = 0; i < nm; ++i)
-                            grad(nk + i) = gm(i);
-                        return {lik, opt::eval_t::second_type(grad)};
-                    }
-
-                protected:
-                    const GP& _original_gp;
-                    limbo_amd::WorkerClones<Params, GP> _workers;
-                };
+                using KernelMeanLFOptimization = limbo_amd::fit::Objective<Params, GP, limbo_amd::fit::KernelAndMeanParams, limbo_amd::fit::LogLik>;
             };
         } // namespace gp
     } // namespace model

@@ -120,10 +120,10 @@ struct gpe_ctx {
     bool stop_events = true;    // next-panel update signals through its own dispatch (hipExtLaunchKernel stop event)
     bool fuse_diag = true;      // next diagonal block factored inside the next-panel update launch (k_upd_fused)
     bool lookahead = true;             // GPE_LOOKAHEAD=0 disables
-    int bulk_wgs = 192;                // physical workgroups of a look-ahead bulk update (GPE_BULK_WGS)
+    int bulk_wgs = 192;                // physical workgroups of a look-ahead bulk update
     int near_wgs = 0;                  // workgroups of the "near" part of a look-ahead update (0: unrestricted — it is what the
-                                       // next panel's update waits for; -1: bulk_wgs; GPE_NEAR_WGS)
-    int64_t bulk_free_tiles = 0;       // ... unless it has at least this many 128 x 128 tiles (GPE_BULK_FREE_TILES).  250 (the
+                                       // next panel's update waits for; -1: bulk_wgs)
+    int64_t bulk_free_tiles = 0;       // ... unless it has at least this many 128 x 128 tiles.  250 (the
                                        // first three far updates at N = 4096) while the panels ran step by step; with the
                                        // one-launch panels (64 CUs for ~55 us) every far update is better off unrestricted:
                                        // 640 -> 651/s at N = 4096 for 0..100, round 3
@@ -194,17 +194,7 @@ namespace {
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-int ld_pad()
-{
-    static int pad = -1;
-    if (pad < 0) {
-        const char* e = getenv("GPE_LD_PAD");
-        pad = e ? atoi(e) : 16; // break power-of-two column strides (HBM channel camping)
-        if (pad < 0 || (pad & 1))
-            pad = 16;
-    }
-    return pad;
-}
+int ld_pad() { return 16; } // break power-of-two column strides (HBM channel camping)
 
 // leading dimension: cap rows + room for the P right-hand-side rows + a pad that breaks
 // power-of-two column strides
@@ -1866,15 +1856,9 @@ int gpe_create(int device_id, gpe_handle* out)
     if (const char* f = getenv("GPE_SMALL"))
         c->small_path = atoi(f) != 0;
     c->dInfo = c->hInfo; // mapped pinned memory: same address on the device (unified addressing)
-    if (const char* f = getenv("GPE_BULK_WGS"))
-        c->bulk_wgs = atoi(f);
-    if (const char* f = getenv("GPE_NEAR_WGS"))
-        c->near_wgs = atoi(f);
     if (const char* f = getenv("GPE_PANEL_HANDOVER"))
         c->panel_handover = atoi(f) != 0;
     c->panel_handover_cfg = c->panel_handover;
-    if (const char* f = getenv("GPE_BULK_FREE_TILES"))
-        c->bulk_free_tiles = atoll(f);
     if (const char* f = getenv("GPE_FUSE_DIAG"))
         c->fuse_diag = atoi(f) != 0;
     if (const char* f = getenv("GPE_PANEL256"))
@@ -2965,7 +2949,6 @@ int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out)
             gpe_destroy(c);
             return rc;
         }
-        // alloc_dev may round differently only if GPE_LD_PAD changed mid-run; same process => same ld
         c->N = src->N;
         c->D = src->D;
         c->P = src->P;

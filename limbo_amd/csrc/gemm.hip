@@ -753,16 +753,7 @@ void launch_gemm_sub(hipStream_t s, const GemmArgs& g0)
         return;
     if (g0.k <= 0 && !g0.overwrite)
         return;
-    static int use_glds64 = -1;
-    if (use_glds64 < 0) {
-        const char* e = getenv("GPE_GLDS64");
-        use_glds64 = e ? atoi(e) : 1;
-    }
-    static int force = -1;
-    if (force < 0) {
-        const char* e = getenv("GPE_GEMM_TILE"); // debug/tuning: 128, 64 or 32
-        force = e ? atoi(e) : 0;
-    }
+    const int use_glds64 = 1, force = 0; // (the tile is picked by problem size below; GemmArgs::tile forces one)
     if (g0.rhs_rows > 0) {
         // Right-hand-side rows as FMAs inside the kernel (gemm_glds64.h) instead of a row of tiles: the FMAs cost every
         // workgroup ~4 us before its first tile, the tile row costs n / 128 extra workgroups — which only matters when
@@ -800,7 +791,7 @@ static void launch_gemm_sub_impl(hipStream_t s, const GemmArgs& g, int use_glds6
         // LDS-fed MFMA rate (~48 us per tile); below ~200 live tiles too many CUs idle and the
         // 64 x 64 tile (4x the workgroups) wins; the 32 x 64 tile serves the tiny panel steps
         const int64_t GB = g_batch.G; // a batched launch runs GB problems of this shape at once
-        static const int64_t t128_min = getenv("GPE_TILE128_MIN") ? atoll(getenv("GPE_TILE128_MIN")) : 200;
+        const int64_t t128_min = 200;
         if (glds_ok(g) && GB * live_tiles(g, 128, 128) >= t128_min)
             tile = 128;
         else if (glds_ok(g) && !g.ktri && use_glds64 && GB * live_tiles(g, 64, 64) >= 96) // (the 64 x 64 body has no ktri form)

@@ -177,102 +177,19 @@ static void launch_build(hipStream_t s, const double* Xt, int64_t ldx, int64_t N
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_build_lower<KIND, BATCH> — the training matrix's lower triangle, tuned for the HBM-write roofline
-// (N (N + 1) / 2 * 8 B out, N * D * 8 B in).  Differences from the generic k_build above:
+// The training matrix's lower triangle, tuned for the HBM-write roofline (N (N + 1) / 2 * 8 B out, N * D * 8 B in).
+// Differences of k_build_wide from the generic k_build above:
 //   * specialised on the kernel functor: no switch inside the pair loop;
-//   * a wave's 16 columns are wave-uniform, so the column sample's coordinates come through the SCALAR unit
-//     (s_load, SGPR operands of the VALU ops) — no LDS staging, no ds_read per dimension and pair, no barrier;
 //   * branch-free pair loop: out-of-range rows/columns are clamped for the loads and masked at the store (diagonal
 //     tiles compute the few upper-triangle pairs and drop them);
-//   * exp(-h), h >= 0, without libm's special cases: n = rint(x log2 e), r = x - n ln 2 (two-term), degree-13 Taylor
-//     polynomial on |r| <= 0.347 (remainder 4e-18 relative), ldexp.  < 1 ulp from the correctly rounded value.
+//   * exp(-h), h >= 0, without libm's special cases (kfun_fast.h): < 1 ulp from the correctly rounded value.
 // Same pair formula and summation order as k_build: z = sum_d ((x_i,d - x_j,d) / ell_d)^2, d ascending, fma.
+// (Round 2 measured a third form between the two — 64 x 64 tiles, column samples through the scalar unit, 8-byte stores:
+// 32 us at N = 4096 like the other two, profiles/r02_kernel_build_trace.txt; removed in round 5 with its switch.)
 // ---------------------------------------------------------------------------------------------------------------------
 #include "kfun_fast.h"
 
-template <int KIND, int DMAX, bool BATCH>
-__global__ __launch_bounds__(256) void k_build_lower(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp_,
-                                                      double* __restrict__ A, int64_t lda, const BatchTab* __restrict__ bt)
-{
-    if (BATCH) {
-        Xt = bt_rebase(bt, (int)blockIdx.z, Xt);
-        A = bt_rebase(bt, (int)blockIdx.z, A);
-    }
-#define KPF(field) (BATCH ? bt->kp[blockIdx.z].field : kp_.field)
-    const int D = KPF(D);
-    const double sf2 = KPF(sf2), diag_add = KPF(diag_add);
-    int ti, tj;
-    {
-        long long b = blockIdx.x;
-        long long t = (long long)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-        while ((t + 1) * (t + 2) / 2 <= b)
-            ++t;
-        while (t * (t + 1) / 2 > b)
-            --t;
-        ti = (int)t;
-        tj = (int)(b - t * (t + 1) / 2);
-    }
-    const int tx = threadIdx.x & 63;
-    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t i = (int64_t)ti * TILE + tx;
-    const int64_t ic = i < N ? i : N - 1;
-    const int64_t j0 = (int64_t)tj * TILE + 16 * ty;
-    double xi[DMAX], ie[DMAX];
-#pragma unroll
-    for (int d = 0; d < DMAX; ++d) {
-        ie[d] = d < D ? KPF(inv_ell[d]) : 0.0;
-        xi[d] = d < D ? Xt[(int64_t)d * ldx + ic] : 0.0;
-    }
-#undef KPF
-#pragma unroll 4
-    for (int c = 0; c < 16; ++c) {
-        const int64_t j = j0 + c; // wave-uniform
-        if (j >= N)
-            break; // uniform
-        double z = 0.0;
-#pragma unroll
-        for (int d = 0; d < DMAX; ++d) {
-            if (d < D) { // uniform
-                const double xj = Xt[(int64_t)d * ldx + j]; // uniform address: scalar load
-                const double q = (xi[d] - xj) * ie[d];
-                z = fma(q, q, z);
-            }
-        }
-        double v = kfun_fast<KIND>(z, sf2);
-        if (i == j)
-            v += diag_add;
-        if (i < N && j <= i)
-            A[i + j * lda] = v;
-    }
-}
-
-template <int KIND>
-static void launch_build_lower_kind(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A, int64_t lda)
-{
-    const int64_t nt = (N + TILE - 1) / TILE;
-    dim3 grid((unsigned)(nt * (nt + 1) / 2), 1, (unsigned)g_batch.G);
-    const BatchTab* bt = g_batch.bt;
-#define LBL(DM)                                                                                                   \
-    do {                                                                                                          \
-        if (bt)                                                                                                   \
-            GPE_LAUNCH((k_build_lower<KIND, DM, true>), grid, dim3(256), 0, s, Xt, ldx, N, kp, A, lda, bt);  \
-        else                                                                                                      \
-            GPE_LAUNCH((k_build_lower<KIND, DM, false>), grid, dim3(256), 0, s, Xt, ldx, N, kp, A, lda, bt); \
-    } while (0)
-    if (kp.D <= 4)
-        LBL(4);
-    else if (kp.D <= 8)
-        LBL(8);
-    else if (kp.D <= 16)
-        LBL(16);
-    else if (kp.D <= 32)
-        LBL(32);
-    else
-        LBL(64);
-#undef LBL
-}
-
-// k_build_wide<KIND, DMAX, BATCH> — as k_build_lower, but shaped for the memory side: a workgroup owns 128 rows x 64
+// k_build_wide<KIND, DMAX, BATCH> — shaped for the memory side: a workgroup owns 128 rows x 64
 // columns, a lane owns TWO consecutive rows and stores them as one 16-byte double2 (1 KiB contiguous per wave store
 // instead of 512 B), the 64 column samples are staged once through LDS (wave-uniform LDS reads: broadcasts).
 // rt (single-GP launches): the workgroups from rt.first on do what k_cols_to_rows (solve.hip) does — obs_mean^T into the rows
@@ -340,26 +257,14 @@ __global__ __launch_bounds__(256) void k_build_wide(const double* __restrict__ X
         double za = 0.0, zb = 0.0;
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
-            if (KIND == 9) {
-                za = xa[0] + smem[cc];
-                zb = xb[0] + smem[cc];
-            }
-            else if (d < D) {
+            if (d < D) {
                 const double xj = smem[d * TILE + cc];
                 const double qa = (xa[d] - xj) * ie[d], qb = (xb[d] - xj) * ie[d];
                 za = fma(qa, qa, za);
                 zb = fma(qb, qb, zb);
             }
         }
-        double va, vb;
-        if (KIND == 9) { // measurement only (GPE_KBUILD=9): the store pattern without the arithmetic
-            va = za;
-            vb = zb;
-        }
-        else {
-            va = kfun_fast<KIND>(za, sf2);
-            vb = kfun_fast<KIND>(zb, sf2);
-        }
+        double va = kfun_fast<KIND>(za, sf2), vb = kfun_fast<KIND>(zb, sf2);
         if (i0 == j)
             va += diag_add;
         if (i0 + 1 == j)
@@ -417,34 +322,19 @@ bool launch_build_K(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, con
     BuildRowsTail rt{};
     if (tail && !g_batch.bt && tail->P > 0)
         rt = *tail;
-    // GPE_KBUILD: 0 = the generic tile kernel (k_build), 1 = k_build_lower (scalar-unit column samples), 2 = k_build_wide
-    static const int variant = getenv("GPE_KBUILD") ? atoi(getenv("GPE_KBUILD")) : 2;
-    const bool fast = variant != 0;
-    if (!fast || N <= 0 || (lda & 1)) {
+    if (N <= 0 || (lda & 1)) { // (the wide kernel stores pairs of rows: an odd leading dimension takes the generic one)
         launch_build<0>(s, Xt, ldx, N, nullptr, 0, 0, kp, A, lda);
         return false;
     }
-    if (variant == 9) {
-        launch_build_wide_kind<9>(s, Xt, ldx, N, kp, A, lda, rt);
-        return rt.V != nullptr;
-    }
-    if (variant == 2) {
-        switch (kp.kind) {
-        case 0:
-        case 3: launch_build_wide_kind<0>(s, Xt, ldx, N, kp, A, lda, rt); break;
-        case 1: launch_build_wide_kind<1>(s, Xt, ldx, N, kp, A, lda, rt); break;
-        default: launch_build_wide_kind<2>(s, Xt, ldx, N, kp, A, lda, rt); break;
-        }
-        return rt.V != nullptr;
-    }
     switch (kp.kind) {
     case 0:
-    case 3: launch_build_lower_kind<0>(s, Xt, ldx, N, kp, A, lda); break;
-    case 1: launch_build_lower_kind<1>(s, Xt, ldx, N, kp, A, lda); break;
-    default: launch_build_lower_kind<2>(s, Xt, ldx, N, kp, A, lda); break;
+    case 3: launch_build_wide_kind<0>(s, Xt, ldx, N, kp, A, lda, rt); break;
+    case 1: launch_build_wide_kind<1>(s, Xt, ldx, N, kp, A, lda, rt); break;
+    default: launch_build_wide_kind<2>(s, Xt, ldx, N, kp, A, lda, rt); break;
     }
-    return false;
+    return rt.V != nullptr;
 }
+
 void launch_build_K_full(hipStream_t s, const double* Xt, int64_t ldx, int64_t N, const KParams& kp, double* A,
                          int64_t lda)
 {

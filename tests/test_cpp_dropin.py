@@ -53,6 +53,7 @@ def test_dropin_cases_on_device(virtual_devices, min_n):
         env["LIMBO_AMD_MIN_N_FOR_GPU"] = str(min_n)
     if virtual_devices:
         env["GPE_VIRTUAL_DEVICES"] = str(virtual_devices)
+        env["LIMBO_AMD_HOST_BATCH_CROSSOVER"] = "64"  # host-resident models answer query_batch from their device shadow much earlier
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -501,15 +501,24 @@ def test_gpu_alternate_schedules(engine_lib, oracle_lib, monkeypatch, env):
 
 @pytest.mark.parametrize("env", [{"GPE_QUERY_SWEEP": "0", "GPE_INV_PANELS": "0"}, {"GPE_QUERY_T": "0", "GPE_INV_OVERLAP": "0"},
                                  {"GPE_RHS_FMA": "2"}, {"GPE_RHS_FMA": "0"}, {"GPE_PANEL256": "0", "GPE_TAIL_MAX": "0"}, {"GPE_TAIL_MAX": "0"},
-                                 {"GPE_EARLY_BULK_TILES": "0", "GPE_ROWS_TAIL": "0"}],
+                                 {"GPE_EARLY_BULK_TILES": "0", "GPE_ROWS_TAIL": "0"},
+                                 {"GPE_INV2": "0"}, {"GPE_HP_FUSED": "0", "GPE_INV2_MIN_N": "256"},
+                                 {"GPE_FLOW_PARTITIONS": "0", "GPE_FLOW_XCD": "0", "GPE_FLOW_GATE": "0"},
+                                 {"GPE_STREAM_PRIO": "0", "GPE_TAIL_GEN": "0", "GPE_TRACE": "1", "GPE_ROCTX": "1"},
+                                 {"GPE_BATCH_SPLIT": "0", "GPE_BATCH_TAIL_TILES": "0", "GPE_BATCH_TAIL_MAX": "512"}, {"GPE_BATCH": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_process_wide_switches(env):
     """Switches that are read once per process (the blocked point-query solve, the in-panel substitution chain for K^-1; round 3:
     the sample-contiguous batched queries, K^-1's product after its chain, right-hand-side rows always / never as FMAs,
     the look-ahead stream released by every panel and obs_mean's rows by a launch of their own; round 4: 256-column panels to
     the end — one-launch (GPE_TAIL_MAX=0) or step by step (+ GPE_PANEL256=0): the schedules the data-flow launches replaced and
-    what a hand-over timeout falls back to): the same parity checks in a child, at a size
-    with seven outer panels (N = 1700: ragged last panel) and, for the hyper-parameter objective, through gpe_hp_objective."""
+    what a hand-over timeout falls back to; round 5: K^-1 in its panel form instead of the recursion, the objective as
+    separate calls instead of one enqueue, no CU-masked chain partitions / XCD-local sweeps / gate, default stream priorities
+    with K built in front of the one-launch factorisation and the launch trace on, batched sequences unsplit / with the
+    data-flow launches at any size / member by member): the same parity checks in a child, at a size with seven outer
+    panels (N = 1700: ragged last panel), for the hyper-parameter objective through gpe_hp_objective (N = 1792: seven panels,
+    the recursion's tree is unbalanced), and a batched factorisation (3 x N = 700) and objective (2 x N = 1024) — every
+    switch of SWITCHES.md that is not a handle-creation switch (test_gpu_alternate_schedules) is set by one of these."""
     import os
     import subprocess
     import sys
@@ -529,6 +538,19 @@ def test_gpu_process_wide_switches(env):
             "    h = _capi.Handle(lib); h.set_data(X, om)\n"
             "    res.append(h.hp_objective(0, rng.uniform(-0.2, 0.2, 6) * 0 + 0.1, 0.01, optimize_noise=True, want_grad=True)); h.close()\n"
             "assert abs(res[0][0] - res[1][0]) <= 1e-10 * abs(res[1][0]) and relerr_norm(res[0][1], res[1][1]) < 1e-6\n"
+            "hs = [_capi.Handle(eng) for _ in range(3)]\n"
+            "for q, h in enumerate(hs): h.set_data(X[:700] + 0.01 * q, om[:700]); h.set_kernel(0, np.full(6, 0.05 * q), 0.01)\n"
+            "st, bl = _capi.batch_compute(hs), _capi.batch_log_lik(hs)\n"
+            "for q, h in enumerate(hs):\n"
+            "    o = _capi.Handle(orc); o.set_data(X[:700] + 0.01 * q, om[:700]); o.set_kernel(0, np.full(6, 0.05 * q), 0.01); assert o.compute() == 0\n"
+            "    assert st[q] == 0 and abs(bl[q] - o.log_lik()) <= 1e-10 * abs(o.log_lik()); o.close(); h.close()\n"
+            "hb = [_capi.Handle(eng) for _ in range(2)]\n"
+            "for h in hb: h.set_data(X[:1024], om[:1024])\n"
+            "thb = np.array([np.full(6, 0.05), np.full(6, -0.05)])\n"
+            "lik, grad, st = _capi.batch_hp_objective(hb, 0, thb, np.full(2, 0.01), optimize_noise=False, want_grad=True)\n"
+            "for q in range(2):\n"
+            "    o = _capi.Handle(orc); o.set_data(X[:1024], om[:1024]); r = o.hp_objective(0, thb[q], 0.01, optimize_noise=False, want_grad=True)\n"
+            "    assert st[q] == 0 and abs(lik[q] - r[0]) <= 1e-10 * abs(r[0]) and relerr_norm(grad[q], r[1]) < 1e-6; o.close()\n"
             "print('child ok')\n") % str(ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr

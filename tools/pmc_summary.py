@@ -49,4 +49,42 @@ out["duration_us_under_pmc"] = dur
 if mops is not None:
     out["MOPS_F64"] = mops
     out["mfma_flops"] = mops * 512.0
+
+
+# Round 5: the DOMINANT kernel of a step is k_tail (two launches: tall = the larger grid, closing), 70 % of the GPU time —
+# its traffic and matrix-core busy time beside the update's (bench.py: roofline.traffic)
+def by_kernel(db, counter, match):
+    g_, a_ = per_dispatch(db, counter)
+    ids_ = [d for d in a_ if match in g_[d][1]]
+    return g_, a_, ids_
+
+
+def tail_entry(which):
+    ent = {}
+    for key, db, cnt in (("FETCH_SIZE_KiB", sys.argv[1], "FETCH_SIZE"), ("WRITE_SIZE_KiB", sys.argv[2], "WRITE_SIZE")):
+        g_, a_, ids_ = by_kernel(db, cnt, "k_tail")
+        if not ids_:
+            return None
+        grids = sorted({g_[d][0] for d in ids_})
+        want = grids[-1] if which == "tall" else grids[0]
+        sel = [d for d in ids_ if g_[d][0] == want]
+        ent[key] = sum(sum(v for v, _ in a_[d]) for d in sel) / len(sel)
+        ent["grid_threads"] = want
+    ent["hbm_bytes_per_launch_corrected"] = 1024.0 * (2.0 * ent["FETCH_SIZE_KiB"] + ent["WRITE_SIZE_KiB"])
+    g_, a_, ids_ = by_kernel(sys.argv[3], "SQ_VALU_MFMA_BUSY_CYCLES", "k_tail")
+    sel = [d for d in ids_ if g_[d][0] == ent["grid_threads"]]
+    busy_ = sum(sum(v for v, _ in a_[d]) for d in sel) / len(sel)
+    g2_, a2_, _ = by_kernel(sys.argv[3], "GRBM_GUI_ACTIVE", "k_tail")
+    gui_ = sum(sum(v for v, _ in a2_[d]) / len(a2_[d]) for d in sel) / len(sel)
+    ent["mfma_util_percent"] = 100.0 * busy_ / (gui_ * 1024.0)
+    ent["duration_us_under_pmc"] = sum(a_[d][0][1] for d in sel) / len(sel) / 1e3
+    return ent
+
+
+tall, closing = tail_entry("tall"), tail_entry("closing")
+if tall and closing and tall["grid_threads"] != closing["grid_threads"]:
+    out["k_tail"] = {"tall": tall, "closing": closing,
+                     "hbm_bytes_per_step_corrected": tall["hbm_bytes_per_launch_corrected"] + closing["hbm_bytes_per_launch_corrected"],
+                     "note": "the two data-flow launches of an N = 4096 factorisation (tall: columns 0..1279 with every row strip below; closing: "
+                             "the last 2816 columns); bytes include the polled hand-over slots and the polling itself"}
 print(json.dumps(out, indent=1))
