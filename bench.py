@@ -151,8 +151,7 @@ def box_probe(eng, _capi, O, local_rank):
 
 
 def extras(eng, _capi, O, local_rank, steps):
-    """Secondary objects of the bench line, N=1 only, outside the headline's timed region (driver-run versions of what
-    bench_extra.py measures): BASELINE configs[1] as written (the gradient objective of one KernelLFOpt iteration),
+    """Secondary objects of the bench line, N=1 only, outside the headline's timed region: BASELINE configs[1] as written (the gradient objective of one KernelLFOpt iteration),
     configs[2] (N=16384 factorisation + 100k batched queries), configs[3] on one GPU (64 GPs), configs[4] (BO inner loop)."""
     import torch
 

@@ -608,6 +608,8 @@ namespace limbo {
             bool _host_mode = false;            // the host matrices are the model (the device holds nothing current)
             bool _host_off = false;             // this object has needed the device for something with no host form: it stays there
             mutable bool _dev_shadow_ok = false; // (host mode) the device copy that serves large query_batch() calls is current
+            mutable Eigen::VectorXd _shadow_hp;   // ... and the kernel hyper-parameters / noise it was given
+            mutable double _shadow_noise = -1.0;
 
             bool _use_host(int64_t n) const { return !_host_off && n < (int64_t)limbo_amd::min_n_for_gpu<Params>(); }
             /// everything without a host form: the model moves to the device and stays there
@@ -782,35 +784,44 @@ namespace limbo {
             void _sync_device_shadow() const
             {
                 std::lock_guard<std::mutex> lk(_mirror_mu);
-                if (_dev_shadow_ok)
+                // the shadow is the HOST model on the device — its factor and alpha as they are (uploaded, not
+                // re-factored) and the kernel's CURRENT hyper-parameters for k*.  After kernel_function().set_h_params()
+                // without recompute() the reference answers queries with the old L / alpha and the new k* (gp.hpp:613-632);
+                // so do the host loop and, now, this copy — whichever side of host_batch_crossover a batch falls on.
+                const Eigen::VectorXd hp = _kernel_function.h_params();
+                const double nz = _kernel_function.noise();
+                const bool same_kernel = _shadow_noise == nz && _shadow_hp.size() == hp.size()
+                    && std::equal(hp.data(), hp.data() + hp.size(), _shadow_hp.data());
+                if (_dev_shadow_ok && same_kernel)
                     return;
                 const int64_t n = _samples.size();
-                std::vector<double> X((size_t)(n * _dim_in));
-                for (int64_t i = 0; i < n; ++i)
-                    for (int d = 0; d < _dim_in; ++d)
-                        X[(size_t)(i * _dim_in + d)] = _samples[i](d);
-                _eng.check(gpe_set_data(_eng.get(), X.data(), n, _dim_in, _obs_mean.data(), _dim_out), "gpe_set_data");
                 constexpr int kind = limbo_amd::device_kernel<KernelFunction>::kind;
-                if (kind == limbo_amd::KIND_HOST_K) {
-                    _eng.check(gpe_set_kernel(_eng.get(), kind, nullptr, 0, _kernel_function.noise()), "gpe_set_kernel");
-                    Eigen::MatrixXd K(n, n);
-                    for (int64_t i = 0; i < n; i++)
-                        for (int64_t j = 0; j <= i; ++j) {
-                            K(i, j) = _kernel_function(_samples[i], _samples[j], i, j);
-                            K(j, i) = K(i, j);
-                        }
-                    _eng.check(gpe_set_K_host(_eng.get(), K.data(), n), "gpe_set_K_host");
+                if (!_dev_shadow_ok) {
+                    std::vector<double> X((size_t)(n * _dim_in));
+                    for (int64_t i = 0; i < n; ++i)
+                        for (int d = 0; d < _dim_in; ++d)
+                            X[(size_t)(i * _dim_in + d)] = _samples[i](d);
+                    _eng.check(gpe_set_data(_eng.get(), X.data(), n, _dim_in, _obs_mean.data(), _dim_out), "gpe_set_data");
                 }
+                if (kind == limbo_amd::KIND_HOST_K)
+                    _eng.check(gpe_set_kernel(_eng.get(), kind, nullptr, 0, nz), "gpe_set_kernel");
                 else {
-                    Eigen::VectorXd hp = _kernel_function.h_params();
                     const int nk = (int)hp.size() - (Params::kernel::optimize_noise() ? 1 : 0);
-                    _eng.check(gpe_set_kernel(_eng.get(), kind, hp.data(), nk, _kernel_function.noise()), "gpe_set_kernel");
+                    _eng.check(gpe_set_kernel(_eng.get(), kind, hp.data(), nk, nz), "gpe_set_kernel");
                 }
-                _eng.check(gpe_compute(_eng.get()), "gpe_compute");
+                // (the factor goes up with every kernel change too: gpe_set_L also refreshes the Lambda^T x rows of SE-ARD with
+                // Lambda columns, which depend on the hyper-parameters — n < min_n_for_gpu: a few hundred KB)
+                _eng.check(gpe_set_L(_eng.get(), _matrixL.data(), _matrixL.rows()), "gpe_set_L");
+                _eng.check(gpe_set_alpha(_eng.get(), _alpha.data()), "gpe_set_alpha");
+                _shadow_hp = hp;
+                _shadow_noise = nz;
                 _dev_shadow_ok = true;
             }
 
         public:
+            /// Addition: this model lives on the host (below Params::gpu::min_n_for_gpu samples, nothing device-only asked yet)
+            bool host_resident() const { return _host_mode && _use_host((int64_t)_samples.size()); }
+
             /// Additions: the two halves of `_compute_full_kernel` around the device factorisation, so that a caller
             /// holding several independent GPs (model::MultiGP: one per output, multi_gp.hpp:124-126) can run all their
             /// factorisations as ONE batched launch sequence (`compute_full_kernels_batched` -> gpe_batch_compute).

@@ -59,14 +59,23 @@ namespace limbo {
                         return out;
                     };
                     auto res = opt::rprop_lockstep<typename opt::rprop_params_of<Optimizer, Params>::type>(fb, inits, false); // (Rprop<P>: P's settings)
+                    // recompute(false) + compute_log_lik() of operator(): batched for the models that live on the device; a model
+                    // that lives on the host stays there (the batched call would move it to the device for good, and
+                    // every later add_sample() / query() of a small output model with it)
                     std::vector<GP*> orig;
                     for (size_t i = 0; i < gps.size(); ++i) {
                         gps[i].kernel_function().set_h_params(res[i].first);
-                        orig.push_back(&gps[i]);
+                        if (gps[i].host_resident()) {
+                            gps[i].recompute(false);
+                            gps[i].compute_log_lik();
+                        }
+                        else
+                            orig.push_back(&gps[i]);
                     }
-                    std::vector<double> liks; // recompute(false) + compute_log_lik() of operator(), batched
+                    std::vector<double> liks;
                     std::vector<Eigen::VectorXd> none;
-                    GP::hp_objectives_batched(orig, false, liks, none);
+                    if (!orig.empty())
+                        GP::hp_objectives_batched(orig, false, liks, none);
                     return true;
                 }
 

@@ -1,4 +1,4 @@
-"""Mint tests/golden/mp_c5_n200_noise1e-10.npz: 50-digit ground truth for BASELINE configs[4] at the benchmark's own
+"""Mint tests/golden/c5_truth_n200_noise1e-10.npz: 50-digit ground truth for BASELINE configs[4] at the benchmark's own
 noise (src/benchmarks/limbo/bench.cpp:70: noise 1e-10; :66-67,:83-84: 10 random samples + 190 add_sample calls, Hartmann6).
 
 Why: at noise 1e-10 cond(K) ~ sigma_f^2 n / (noise + 1e-8) ~ 2e10, and two correct fp64 implementations that sum in a
@@ -22,7 +22,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from limbo_amd import synth  # noqa: E402
 
-OUT = ROOT / "tests" / "golden" / "mp_c5_n200_noise1e-10.npz"
+OUT = ROOT / "tests" / "golden" / "c5_truth_n200_noise1e-10.npz"
 
 
 def main():

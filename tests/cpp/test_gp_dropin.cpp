@@ -679,6 +679,29 @@ CASE(test_host_path_threshold)
     double s0;
     std::tie(m0, s0) = small.query(pts[7]);
     CHECK(std::abs(m0(0) - mu(7, 0)) < 1e-9 && std::abs(s0 - s2(7)) < 1e-8 * s0);
+    // new kernel hyper-parameters WITHOUT recompute() — the reference then answers with the old L / alpha and the
+    // new k* (gp.hpp:613-632).  Host loop (single points, small batches) and device copy (large batches) must agree on that.
+    {
+        VectorXd hp = small.kernel_function().h_params();
+        for (int i = 0; i < (int)hp.size(); ++i)
+            hp(i) += 0.2 * (i % 2 ? 1.0 : -1.0);
+        small.kernel_function().set_h_params(hp);
+        small.query_batch(pts, mu, s2); // device copy: must carry the host's factor, not one of its own for the new kernel
+        double e1 = 0, e2 = 0;
+        for (int m = 0; m < 400; m += 37) {
+            VectorXd mm;
+            double ss;
+            std::tie(mm, ss) = small.query(pts[m]);
+            e1 = std::max(e1, std::abs(mm(0) - mu(m, 0)) + std::abs(mm(1) - mu(m, 1)));
+            e2 = std::max(e2, std::abs(ss - s2(m)) / ss);
+        }
+        CHECK(e1 < 1e-9);
+        CHECK(e2 < 1e-8);
+        small.recompute(false); // and back in step
+        small.query_batch(pts, mu, s2);
+        std::tie(m0, s0) = small.query(pts[11]);
+        CHECK(std::abs(m0(0) - mu(11, 0)) < 1e-9 && std::abs(s0 - s2(11)) < 1e-8 * s0);
+    }
     // what has no host form moves the model to the device
     GP_d dev50;
     dev50.compute(std::vector<VectorXd>(X.begin(), X.begin() + 51), std::vector<VectorXd>(Y.begin(), Y.begin() + 51));

@@ -59,6 +59,13 @@ def test_two_ranks_agree_on_argmax():
     assert '"ok": true' in _run(2, 64)
 
 
+def test_eight_ranks_agree_on_argmax():
+    """the world size of the driver's scaling run (one rank per GPU of an 8-GPU node): 64 units = configs[3]'s 64 GPs dealt
+    8 per rank, and 5 units over 8 ranks (three idle ranks)."""
+    assert '"ok": true' in _run(8, 64)
+    assert '"ok": true' in _run(8, 5)
+
+
 def test_ragged_shards_and_idle_rank():
     # 3 units over 2 ranks (2 + 1) and 1 unit over 2 ranks (rank 1 idle)
     assert '"ok": true' in _run(2, 3)
