@@ -515,7 +515,10 @@ static void debug_tail_plan(int64_t N, int P, int G, int64_t tail_max, int64_t t
 }
 // The hand-over buffers of handle c for this plan, on stream s (ordered in front of the launches that poll them).
 // like != nullptr (a batched launch built from `like`'s pointers): same capacities and the same armed parity as that handle.
-static bool prepare_tail(gpe_ctx* c, const TailPlan& pl, hipStream_t s, const gpe_ctx* like = nullptr)
+// ... the allocation part: a stream synchronisation, a free and a malloc when the buffers must grow.  compute_enqueue calls it
+// BEFORE it enters the device's gate (the gate's mutex must not be held across a device synchronisation — every
+// other host thread launching on the device would stall behind it); prepare_tail calls it again, then a no-op.
+static bool reserve_tail(gpe_ctx* c, const TailPlan& pl, hipStream_t s, const gpe_ctx* like = nullptr)
 {
     if (pl.t0 < 0)
         return true;
@@ -541,6 +544,14 @@ static bool prepare_tail(gpe_ctx* c, const TailPlan& pl, hipStream_t s, const gp
         c->tall_cap = want_tall;
         c->tail_lay = c->tall_lay = -1;
     }
+    return true;
+}
+static bool prepare_tail(gpe_ctx* c, const TailPlan& pl, hipStream_t s, const gpe_ctx* like = nullptr)
+{
+    if (pl.t0 < 0)
+        return true;
+    if (!reserve_tail(c, pl, s, like))
+        return false;
     const int64_t lay_tail = pl.nt_tail * 65536 + pl.nb_tail, lay_tall = pl.e0 >= 0 ? pl.nt_tall * 65536 + pl.nb_tall : -1;
     if (c->tail_lay == -2 || (c->tail_lay >= 0 && c->tail_lay != lay_tail)
         || (like && c->tail_lay >= 0 && ((c->tail_count ^ like->tail_count) & 1))) {
@@ -1042,6 +1053,7 @@ int compute_enqueue(gpe_ctx* c)
     if (!g_batch.bt) {
         const TailPlan pl0 = tail_plan(c, c->N, c->N + c->P);
         may_partition = pl0.t0 == 0 || (pl0.t0 > 0 && pl0.e0 == 0); // data-flow launches from column 0 on: no 256-column panels
+        (void)reserve_tail(c, pl0, c->stream); // (a failure shows again, and is handled, where the buffers are prepared)
     }
     ChainScope gate(c, !g_batch.bt, may_partition);
     hipStream_t s = c->stream; // (the handle's own stream, or the partition's for the length of this enqueue)

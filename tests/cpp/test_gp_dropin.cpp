@@ -682,7 +682,8 @@ CASE(test_host_path_threshold)
     // new kernel hyper-parameters WITHOUT recompute() — the reference then answers with the old L / alpha and the
     // new k* (gp.hpp:613-632).  Host loop (single points, small batches) and device copy (large batches) must agree on that.
     {
-        VectorXd hp = small.kernel_function().h_params();
+        const VectorXd hp0 = small.kernel_function().h_params();
+        VectorXd hp = hp0;
         for (int i = 0; i < (int)hp.size(); ++i)
             hp(i) += 0.2 * (i % 2 ? 1.0 : -1.0);
         small.kernel_function().set_h_params(hp);
@@ -701,6 +702,8 @@ CASE(test_host_path_threshold)
         small.query_batch(pts, mu, s2);
         std::tie(m0, s0) = small.query(pts[11]);
         CHECK(std::abs(m0(0) - mu(11, 0)) < 1e-9 && std::abs(s0 - s2(11)) < 1e-8 * s0);
+        small.kernel_function().set_h_params(hp0); // (the checks below compare with a model at the default hyper-parameters)
+        small.recompute(false);
     }
     // what has no host form moves the model to the device
     GP_d dev50;

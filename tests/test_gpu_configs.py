@@ -594,6 +594,34 @@ def test_gpu_data_flow_buffers_across_sizes_on_one_handle(engine_lib):
     h.close()
 
 
+def test_gpu_cached_first_look_never_sees_a_stale_slot(engine_lib):
+    """the first look at a polled hand-over slot is a cacheable (workgroup-scope) load (potrf.hip: POLL_CACHED):
+    sound as long as every kernel boundary writes back / invalidates the L2 lines of the slots, so that a word which is not
+    the all-ones pattern is this launch's final value — never a leftover of the launch that used the same buffer TWO launches
+    ago.  One handle at N = 4096, hyper-parameters cycling through three settings (so the launch two evaluations back
+    always had OTHER values in every slot), 12 evaluations back to back: every log-likelihood and every 16th factor must be
+    bitwise what a fresh handle (clean buffers) gives for that setting."""
+    X, Y = synth.make_problem("c2", N=4096)
+    om, _ = synth.obs_mean_data(Y)
+    thetas = [np.zeros(7), np.full(7, 0.15), np.linspace(-0.2, 0.2, 7)]
+    fresh = []
+    for th in thetas:
+        f = new_gp(engine_lib, O.SE_ARD, X, om, th, 0.01)
+        assert f.compute() == 0
+        fresh.append((f.log_lik(), f.get_L()[::16, ::16].copy()))
+        f.close()
+    h = new_gp(engine_lib, O.SE_ARD, X, om, thetas[0], 0.01)
+    for k in range(12):
+        i = k % 3
+        h.set_kernel(O.SE_ARD, thetas[i], 0.01)
+        assert h.compute() == 0
+        assert h.log_lik() == fresh[i][0], (k, i)
+        if k >= 9:
+            assert np.array_equal(h.get_L()[::16, ::16], fresh[i][1]), (k, i)
+    assert h.flow_retries() == 0 and h.handover_reruns() == 0
+    h.close()
+
+
 def test_gpu_tall_pair_survives_a_batch_without_a_tall_launch(engine_lib):
     """ADVICE r4 (medium).  Two handles at N = 4096 whose tall hand-over pairs are armed with DIFFERENT parities (one and two
     single evaluations), then batched together at a size whose plan has no tall launch (N = 1024), then evaluated singly at
