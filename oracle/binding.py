@@ -110,6 +110,7 @@ def load_ref():
             "ref_kernel_eval": ([_vp, _dp, _dp, C.c_int, C.c_int, C.c_int], C.c_double),
             "ref_kernel_grad": ([_vp, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp], None),
             "ref_save": ([_vp, C.c_char_p, C.c_int], None),
+            "ref_acqui": ([_vp, C.c_int, C.c_int, _dp, i64, C.c_int, _dp], None),
             "ref_load": ([_vp, C.c_char_p, C.c_int, C.c_int], None),
         }
         for name, (args, res) in sig.items():
@@ -187,6 +188,13 @@ class RefGP:
 
     def recompute(self, update_obs_mean=True, update_full_kernel=True):
         self.lib.ref_recompute(self.h, int(update_obs_mean), int(update_full_kernel))
+
+    def acqui(self, which, Xq, iteration=0):
+        """limbo's own acquisition functors over this model (acqui/ucb.hpp, gp_ucb.hpp, ei.hpp): 0 UCB, 1 GP_UCB, 2 EI; first output."""
+        Xq = _c(np.atleast_2d(Xq))
+        out = np.zeros(Xq.shape[0])
+        self.lib.ref_acqui(self.h, int(which), int(iteration), _p(Xq), Xq.shape[0], Xq.shape[1], _p(out))
+        return out
 
     def save(self, directory, binary):
         """GP::save<TextArchive | BinaryArchive>(directory) of the reference (gp.hpp:439-460): real files."""

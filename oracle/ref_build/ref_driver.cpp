@@ -10,6 +10,9 @@
 #include <memory>
 #include <tuple>
 
+#include <limbo/acqui/ei.hpp>
+#include <limbo/acqui/gp_ucb.hpp>
+#include <limbo/acqui/ucb.hpp>
 #include <limbo/kernel/exp.hpp>
 #include <limbo/kernel/matern_five_halves.hpp>
 #include <limbo/kernel/matern_three_halves.hpp>
@@ -53,6 +56,12 @@ struct Params {
         BO_DYN_PARAM(double, eps_stop);
     };
     struct opt_parallelrepeater : public defaults::opt_parallelrepeater {
+    };
+    struct acqui_ucb : public defaults::acqui_ucb {
+    };
+    struct acqui_gpucb : public defaults::acqui_gpucb {
+    };
+    struct acqui_ei : public defaults::acqui_ei {
     };
 };
 BO_DECLARE_DYN_PARAM(double, Params::kernel, noise);
@@ -116,6 +125,7 @@ namespace {
         virtual void optimize(int which) = 0;               // 0 KernelLFOpt, 1 KernelLooOpt, 2 MeanLFOpt, 3 KernelMeanLFOpt
         virtual double kernel_eval(const double* a, const double* b, int D, int i, int j) = 0;
         virtual void kernel_grad(const double* a, const double* b, int D, int i, int j, double* g) = 0;
+        virtual void acqui(int which, int iteration, const double* Xq, int64_t M, int D, double* out) = 0; // acqui/*.hpp
         virtual void save(const char* dir, bool binary) = 0;                 // gp.hpp:439-460
         virtual void load(const char* dir, bool binary, bool recompute) = 0; // gp.hpp:462-511
     };
@@ -231,6 +241,27 @@ namespace {
             for (int q = 0; q < v.size(); ++q)
                 g[q] = v(q);
         }
+        // the reference's own acquisition functors over its own model, first output as the aggregator (bo_base.hpp: FirstElem):
+        // 0 UCB (acqui/ucb.hpp:83-90), 1 GP_UCB (acqui/gp_ucb.hpp:86-103), 2 EI (acqui/ei.hpp:85-116)
+        void acqui(int which, int iteration, const double* Xq, int64_t npts, int D, double* out) override
+        {
+            auto first = [](const Eigen::VectorXd& v) { return v(0); };
+            if (which == 0) {
+                limbo::acqui::UCB<Params, G> a(gp, iteration);
+                for (int64_t m = 0; m < npts; ++m)
+                    out[m] = opt::fun(a(vec(Xq + m * D, D), first, false));
+            }
+            else if (which == 1) {
+                limbo::acqui::GP_UCB<Params, G> a(gp, iteration);
+                for (int64_t m = 0; m < npts; ++m)
+                    out[m] = opt::fun(a(vec(Xq + m * D, D), first, false));
+            }
+            else {
+                limbo::acqui::EI<Params, G> a(gp, iteration);
+                for (int64_t m = 0; m < npts; ++m)
+                    out[m] = opt::fun(a(vec(Xq + m * D, D), first, false));
+            }
+        }
         // the reference's own archives, writing / reading real files (serialize/text_archive.hpp, binary_archive.hpp)
         void save(const char* dir, bool binary) override
         {
@@ -334,6 +365,8 @@ void ref_get_matrix(void* h, int which, double* out) { Scope s(G); G->get_matrix
 void ref_optimize_hyperparams(void* h, int which) { Scope s(G); G->optimize(which); }
 double ref_kernel_eval(void* h, const double* a, const double* b, int D, int i, int j) { Scope s(G); return G->kernel_eval(a, b, D, i, j); }
 void ref_kernel_grad(void* h, const double* a, const double* b, int D, int i, int j, double* g) { Scope s(G); G->kernel_grad(a, b, D, i, j, g); }
+// acquisition values at M points (which: 0 UCB, 1 GP_UCB, 2 EI; aggregator = first output)
+void ref_acqui(void* h, int which, int iteration, const double* Xq, int64_t M, int D, double* out) { Scope s(G); G->acqui(which, iteration, Xq, M, D, out); }
 // GP::save<TextArchive / BinaryArchive>(directory) and GP::load<...>(directory, recompute) of the reference (gp.hpp:439-511)
 void ref_save(void* h, const char* dir, int binary) { Scope s(G); G->save(dir, binary != 0); }
 void ref_load(void* h, const char* dir, int binary, int recompute) { Scope s(G); G->load(dir, binary != 0, recompute != 0); }

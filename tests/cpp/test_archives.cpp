@@ -10,6 +10,9 @@
 //       then GP::save<TextArchive>(dir_out/text) and GP::save<BinaryArchive>(dir_out/bin)
 //   test_archives compute <kind> <mean> <data file> <dir_out>
 //       data file: P D n M, n rows of X (D) Y (P), M query points; compute(), print as above, save both formats
+//   test_archives acqui <kind> <mean> <dir_in> <text|bin> <query file> <iteration>
+//       GP::load<A>(dir_in, false); print acqui::UCB / GP_UCB / EI ::batch() at the query points — the
+//       batched acquisition layer against limbo's own functors over limbo's own model (tests/test_archives.py)
 // kind: 0 SquaredExpARD, 1 MaternFiveHalves; mean: 0 Data, 2 Constant
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +20,9 @@
 #include <string>
 #include <vector>
 
+#include <limbo/acqui/ei.hpp>
+#include <limbo/acqui/gp_ucb.hpp>
+#include <limbo/acqui/ucb.hpp>
 #include <limbo/kernel/matern_five_halves.hpp>
 #include <limbo/kernel/squared_exp_ard.hpp>
 #include <limbo/mean/constant.hpp>
@@ -37,6 +43,12 @@ struct Params {
         BO_PARAM(double, constant, 1.0);
     };
     struct opt_rprop : public limbo::defaults::opt_rprop {
+    };
+    struct acqui_ucb : public limbo::defaults::acqui_ucb {
+    };
+    struct acqui_gpucb : public limbo::defaults::acqui_gpucb {
+    };
+    struct acqui_ei : public limbo::defaults::acqui_ei {
     };
 };
 
@@ -123,8 +135,41 @@ static int run_compute(char** a)
 }
 
 template <typename Kernel, typename Mean>
+static int run_acqui(char** a)
+{
+    using GP_t = limbo::model::GP<Params, Kernel, Mean>;
+    GP_t gp;
+    if (std::strcmp(a[1], "bin") == 0)
+        gp.template load<limbo::serialize::BinaryArchive>(std::string(a[0]), false);
+    else
+        gp.template load<limbo::serialize::TextArchive>(std::string(a[0]), false);
+    FILE* f = std::fopen(a[2], "r");
+    int M = 0;
+    std::vector<Eigen::VectorXd> Q;
+    if (!f || std::fscanf(f, "%d", &M) != 1 || !read_points(f, M, gp.dim_in(), Q))
+        return 2;
+    std::fclose(f);
+    const int iteration = std::atoi(a[3]);
+    auto first = [](const Eigen::VectorXd& v) { return v(0); };
+    limbo::acqui::UCB<Params, GP_t> ucb(gp, iteration);
+    limbo::acqui::GP_UCB<Params, GP_t> gpucb(gp, iteration);
+    limbo::acqui::EI<Params, GP_t> ei(gp, iteration);
+    const std::vector<double> vals[3] = {ucb.batch(Q, first), gpucb.batch(Q, first), ei.batch(Q, first)};
+    const char* names[3] = {"ucb", "gp_ucb", "ei"};
+    for (int k = 0; k < 3; ++k) {
+        std::printf("%s", names[k]);
+        for (double v : vals[k])
+            std::printf(" %.17g", v);
+        std::printf("\n");
+    }
+    return 0;
+}
+
+template <typename Kernel, typename Mean>
 static int dispatch(const char* cmd, char** rest)
 {
+    if (std::strcmp(cmd, "acqui") == 0)
+        return run_acqui<Kernel, Mean>(rest);
     return std::strcmp(cmd, "load") == 0 ? run_load<Kernel, Mean>(rest) : run_compute<Kernel, Mean>(rest);
 }
 
@@ -134,7 +179,7 @@ int main(int argc, char** argv)
         return 1;
     const char* cmd = argv[1];
     const int kind = std::atoi(argv[2]), mean = std::atoi(argv[3]);
-    if ((std::strcmp(cmd, "load") == 0 && argc != 9) || (std::strcmp(cmd, "compute") == 0 && argc != 6))
+    if ((std::strcmp(cmd, "load") == 0 && argc != 9) || (std::strcmp(cmd, "compute") == 0 && argc != 6) || (std::strcmp(cmd, "acqui") == 0 && argc != 8))
         return 1;
     using namespace limbo;
     if (kind == 0 && mean == 0)

@@ -38,7 +38,7 @@ def _driver(*args, env=None):
     out = {}
     for ln in r.stdout.splitlines():
         w = ln.split()
-        if w and w[0] in ("h_params", "log_lik", "mu", "sigma"):
+        if w and w[0] in ("h_params", "log_lik", "mu", "sigma", "ucb", "gp_ucb", "ei"):
             out[w[0]] = np.array([float(v) for v in w[1:]])
         elif w and w[0] == "n":
             out["n"], out["dim_in"], out["dim_out"] = int(w[1]), int(w[3]), int(w[5])
@@ -144,6 +144,43 @@ def _cross(tmp_path, kind, mean, n, D, P, env=None):
                 assert np.max(np.abs(r2.matrixL() - L_own)) <= (0.0 if fmt2 == "bin" else 1e-14 * np.max(np.abs(L_own)))
             r2.close()
     rc.close()
+
+
+def _acqui_cross(tmp_path, kind, mean, n, D, P, M, env=None):
+    """SURVEY 8f N1 (VERDICT r4: "the acquisition layer itself is only self-compared"): limbo's own acqui::UCB / GP_UCB / EI
+    functors (acqui/ucb.hpp:83-90, gp_ucb.hpp:86-103, ei.hpp:85-116) over limbo's own model, point by point, against the
+    drop-in's batch() over the SAME model — handed over through limbo's binary archive (recompute = false: the same factor
+    and alpha bit for bit).  1e-10 on UCB / GP_UCB (of the value), 1e-9 absolute on EI (values ~1e-2 .. 1e-1)."""
+    X, Y, _, theta = _problem(kind, mean, n, D, P, seed=900 + n)
+    rng = np.random.default_rng(n)
+    Q = np.concatenate([rng.uniform(-1, 1, size=(M - 3, D)), X[:3]])  # three AT training points (sigma ~ noise: EI's small-sigma branch)
+    qf = tmp_path / "q.txt"
+    qf.write_text(f"{len(Q)}\n" + "\n".join(" ".join(repr(float(v)) for v in q) for q in Q) + "\n")
+    r = _ref(kind, mean, D, P)
+    r.compute(X, Y)
+    r.set_h_params(theta)
+    r.recompute(True, True)
+    r.save(tmp_path / "model", True)
+    got = _driver("acqui", kind, mean, tmp_path / "model", "bin", qf, 7, env=env)
+    for which, name, tol in ((0, "ucb", 1e-10), (1, "gp_ucb", 1e-10), (2, "ei", None)):
+        want = r.acqui(which, Q, iteration=7)
+        assert got[name].shape == want.shape
+        if tol is not None:
+            assert np.max(np.abs(got[name] - want) / np.maximum(np.abs(want), 1.0)) <= tol, name
+        else:
+            assert np.max(np.abs(got[name] - want)) <= 1e-9 and (got[name] >= 0).all() and got[name].max() > 0, name
+    r.close()
+
+
+def test_acquisition_batch_vs_limbos_functors_host_model(tmp_path):
+    _acqui_cross(tmp_path, 0, 0, 60, 3, 1, M=40)        # 40 x 60 products: the drop-in's host loop
+    _acqui_cross(tmp_path, 1, 0, 45, 2, 2, M=20)
+
+
+@pytest.mark.gpu
+def test_gpu_acquisition_batch_vs_limbos_functors(tmp_path):
+    _acqui_cross(tmp_path, 0, 0, 300, 6, 1, M=500, env={"LIMBO_AMD_MIN_N_FOR_GPU": "0"})   # one device batch (query_batch)
+    _acqui_cross(tmp_path, 0, 0, 200, 3, 1, M=300)                                          # host model, batch from its device shadow
 
 
 @pytest.mark.parametrize("kind,mean,n,D,P", [(0, 0, 60, 3, 1), (1, 2, 45, 2, 2), (1, 0, 33, 4, 1)])
