@@ -317,13 +317,13 @@ struct GemmItem {
     int32_t neg;     // 1: C = -A B^T
 };
 struct FoldItem {
-    double* D;          // 128 x 128 tile: D += P[0] + P[1] + P[2] (null entries skipped; D is not rewritten without any)
+    double* D;          // tile (128 x 128, or 64 x 64): D += P[0] + P[1] + P[2] (null entries skipped; D is not rewritten without any)
     const double* P[3];
     double* T;          // optional: the resulting tile transposed, T[c + r * ld] = D[r + c * ld]
 };
 // (batched launches, g_batch: the lists hold member 0's pointers, workgroup z rebases them — dev.h: bt_rebase)
-void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld);
-void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld);
+void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld, int tile = 128); // tile: 128 or 64
+void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld, int tile = 128);
 // the plan of one inversion (inv2.hip): host-built once per (N, ld, buffers), resident on the device
 struct Inv2Plan;
 Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride);

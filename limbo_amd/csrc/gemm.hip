@@ -721,8 +721,121 @@ __global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __rest
     }
 }
 
-void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld)
+// The same for 64 x 64 tiles: the low levels of the recursion have a few dozen 128 x 128 tiles per launch, each a serial k
+// loop on one CU (17 us per 128 of depth) — four times as many tiles of a quarter the work each finish in a third of the time
+// (a launch of 32 tile products of k = 256: 38 us with 128 x 128 tiles).  The k loop is gemm_glds64_body's with eight waves
+// on the tile (2 x 4 waves of 32 x 16: two per SIMD cover each other's fragment reads), BKT 16, four LDS stages (74 KB).
+template <int BKT, int NST, int NWV>
+__global__ __launch_bounds__(64 * NWV, 1) void k_gemm_items64(const GemmItem* __restrict__ items, const int32_t* __restrict__ bin_start,
+                                                               int64_t ld, const BatchTab* __restrict__ bt)
 {
+    static_assert(NWV == 8, "2 x 4 waves of 32 x 16");
+    constexpr int PAIR = 144, OPER = (BKT / 2) * PAIR, STAGE = 2 * OPER;
+    constexpr int RA = 2, RB = 64 / (NWV / 2) / 4;
+    constexpr int LPW = 2 * (BKT / 2) / NWV;
+    __shared__ __attribute__((aligned(16))) double lds[NST * STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * (4 * RB);
+    const int arow = wm + (lane & 15), bcol = wn + (lane & 3);
+    const int kq = lane >> 4, kperm = ((kq & 1) << 1) | (kq >> 1); // 0,2,1,3
+    const int r2 = 2 * (lane & 31), khalf = lane >> 5;
+    const int i0 = bin_start[blockIdx.x], i1 = bin_start[blockIdx.x + 1];
+    const int64_t step8 = (int64_t)(2 * NWV) * ld;
+    for (int it = i0; it < i1; ++it) {
+        GemmItem item = items[it];
+        if (bt) {
+            item.A = bt_rebase(bt, (int)blockIdx.z, item.A);
+            item.B = bt_rebase(bt, (int)blockIdx.z, item.B);
+            item.C = bt_rebase(bt, (int)blockIdx.z, item.C);
+        }
+        // this lane's 16-byte piece: rows (2 l', 2 l' + 1) of k-row kk + (lane >> 5), l' = lane & 31; wave w moves k-row pairs w, w + NWV, ..
+        const double* pa = item.A + r2 + (int64_t)(2 * wave + khalf) * ld;
+        const double* pb = item.B + r2 + (int64_t)(2 * wave + khalf) * ld;
+        auto issue = [&](int stage) {
+            double* sa = lds + stage * STAGE + wave * PAIR;
+            double* sb = sa + OPER;
+#pragma unroll
+            for (int q = 0; q < BKT / 2 / NWV; ++q) {
+                __builtin_amdgcn_global_load_lds(pa, (lds_void_t*)(sa + NWV * q * PAIR), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(pb, (lds_void_t*)(sb + NWV * q * PAIR), 16, 0, 0);
+                pa += step8;
+                pb += step8;
+            }
+        };
+        double acc[RA][RB];
+#pragma unroll
+        for (int a = 0; a < RA; ++a)
+#pragma unroll
+            for (int b = 0; b < RB; ++b)
+                acc[a][b] = 0.0;
+        const int nk = item.k / BKT;
+        for (int t = 0; t < NST - 1 && t < nk; ++t)
+            issue(t);
+        for (int t = 0; t < nk; ++t) {
+            const int st = t % NST;
+            if (t + NST - 1 < nk)
+                issue((t + NST - 1) % NST);
+            const int ahead = nk - 1 - t < NST - 1 ? nk - 1 - t : NST - 1; // stages still allowed in flight once stage t has landed
+            if (ahead >= 3)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPW) : "memory");
+            else if (ahead == 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+            else if (ahead == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * LPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // every wave's pieces of stage st have landed
+            const double* As = lds + st * STAGE;
+            const double* Bs = As + OPER;
+#pragma unroll
+            for (int ks = 0; ks < BKT; ks += 4) {
+                const int k = ks + kperm;
+                const int off = (k >> 1) * PAIR + (k & 1) * 64;
+                double af[RA], bf[RB];
+#pragma unroll
+                for (int x = 0; x < RA; ++x)
+                    af[x] = As[off + arow + 16 * x];
+#pragma unroll
+                for (int x = 0; x < RB; ++x)
+                    bf[x] = Bs[off + bcol + 4 * x];
+#pragma unroll
+                for (int n = 0; n < RB; ++n)
+#pragma unroll
+                    for (int m = 0; m < RA; ++m)
+                        acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // stage st may be refilled
+        }
+        if (item.neg) {
+#pragma unroll
+            for (int a = 0; a < RA; ++a)
+#pragma unroll
+                for (int b = 0; b < RB; ++b)
+                    acc[a][b] = -acc[a][b];
+        }
+        {
+            using WT = WaveTileC<RA, RB>;
+            static_assert(NWV * WT::SCRATCH <= NST * STAGE, "transposition scratch must fit in the operand stages");
+            double cv[WT::NIT];
+#pragma unroll
+            for (int q = 0; q < WT::NIT; ++q)
+                cv[q] = 0.0; // (overwrite: C is not read)
+            WT::store(acc, cv, lds + wave * WT::SCRATCH, item.C + (int64_t)wn * ld + wm, ld, WT::R, WT::CN, 1, lane);
+        }
+        __syncthreads(); // the next item's prologue overwrites the LDS stages
+    }
+}
+
+void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld, int tile)
+{
+    if (nbins > 0 && tile == 64) {
+        GPE_LAUNCH_NAMED("k_gemm_items64", (k_gemm_items64<16, 4, 8>), dim3((unsigned)nbins, 1, (unsigned)g_batch.G), dim3(512), 0, s, items,
+                         bin_start, ld, g_batch.bt);
+        return;
+    }
+
     if (nbins <= 0)
         return;
     GPE_LAUNCH_NAMED("k_gemm_items", (k_gemm_items<16, 2, 4, 2>), dim3((unsigned)nbins, 1, (unsigned)g_batch.G), dim3(512), 0, s, items, bin_start,

@@ -179,6 +179,7 @@ void launch_zero2d(hipStream_t s, double* A, int64_t lda, int64_t rows, int64_t 
 // One workgroup per 128 x 128 tile: D += P[0] + P[1] + P[2] in that order (the chunks of a product whose k range was cut:
 // bitwise reproducible), and / or the tile transposed into T through LDS (both sides coalesced: lanes along the rows of D
 // when reading, along the rows of T when writing).  A bandwidth kernel: four 64 x 64 quarters, 16 elements per thread each.
+template <int QUARTERS> // 4: a 128 x 128 tile, 1: a 64 x 64 tile
 __global__ __launch_bounds__(256) void k_fold_items(const FoldItem* __restrict__ items, int64_t ld, const BatchTab* __restrict__ bt)
 {
     __shared__ double sh[64 * 65];
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void k_fold_items(const FoldItem* __restrict__
     const int r = threadIdx.x & 63, c4 = threadIdx.x >> 6;
     const bool sum = it.P[0] != nullptr;
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QUARTERS; ++q) {
         const int r0 = (q & 1) * 64, c0 = (q >> 1) * 64;
         double v[16];
 #pragma unroll
@@ -229,9 +230,12 @@ __global__ __launch_bounds__(256) void k_fold_items(const FoldItem* __restrict__
         }
     }
 }
-void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld)
+void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld, int tile)
 {
     if (n <= 0)
         return;
-    GPE_LAUNCH(k_fold_items, dim3((unsigned)n, 1, (unsigned)g_batch.G), dim3(256), 0, s, items, ld, g_batch.bt);
+    if (tile == 64)
+        GPE_LAUNCH_NAMED("k_fold_items64", (k_fold_items<1>), dim3((unsigned)n, 1, (unsigned)g_batch.G), dim3(256), 0, s, items, ld, g_batch.bt);
+    else
+        GPE_LAUNCH_NAMED("k_fold_items", (k_fold_items<4>), dim3((unsigned)n, 1, (unsigned)g_batch.G), dim3(256), 0, s, items, ld, g_batch.bt);
 }

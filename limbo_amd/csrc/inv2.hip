@@ -33,7 +33,9 @@
 
 namespace {
 
-constexpr int TILE = 128, LEAF = 256, NPART = 3;
+constexpr int LEAF = 256, NPART = 3;
+// tile edge of a launch: 128 where the launch fills the chip with 128 x 128 tiles, 64 below that (the low levels of the tree)
+constexpr int TILES128_MIN = 200;
 enum Buf { B_L = 0, B_U = 1, B_K = 2, B_S0 = 3, B_P1 = 4, B_P2 = 5, B_P3 = 6, B_NONE = -1 };
 
 struct SymRef {
@@ -49,6 +51,7 @@ struct SymFold {
 };
 struct SymStep {
     int kind = 0; // 0: tile products, 1: folds
+    int te = 128; // tile edge of the launch (128 or 64)
     int off = 0, count = 0, bins = 0, bin_off = 0;
     double flops = 0.0;
 };
@@ -60,7 +63,7 @@ struct SymPlan {
     std::vector<SymStep> steps;
 };
 
-// an unchunked tile product: depth `units` * 128 from the operands' origins, destination d, optional transposed copy
+// an unchunked tile product: depth `units` * (tile edge) from the operands' origins, destination d, optional transposed copy
 struct Prod {
     SymRef a, b, d, t;
     int units = 0, neg = 0;
@@ -91,7 +94,7 @@ int make_tree(std::vector<Node>& nodes, int lo, int hi, bool is_right)
 }
 
 // one launch of products (+ the fold launch behind it when chunks or transposed copies call for one)
-void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extra_folds, int64_t ld, int nbins, double load)
+void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extra_folds, int64_t ld, int nbins, double load, int te)
 {
     if (prods.empty() && extra_folds.empty())
         return;
@@ -101,10 +104,10 @@ void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extr
         total += p.units;
         lmax = std::max(lmax, p.units);
     }
-    // chunk length (in 128-deep units): no chunk much longer than a share of the launch, at most 1 + NPART chunks per tile,
-    // never below 256 of depth (a fold launch costs more than it saves there)
+    // chunk length (in units of one tile edge of depth): no chunk much longer than a share of the launch, at most 1 + NPART
+    // chunks per tile, never below 256 of depth (a fold launch costs more than it saves there)
     const double avg = (double)total / (double)nbins;
-    int ch = std::max(2, (int)(load * avg + 0.5));
+    int ch = std::max(256 / te, (int)(load * avg + 0.5));
     ch = std::max(ch, (lmax + NPART) / (NPART + 1));
     struct Chunk {
         SymItem it;
@@ -123,10 +126,10 @@ void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extr
         for (int c = 0; c < nch; ++c) {
             const int u = base + (c < rem ? 1 : 0);
             Chunk q;
-            q.it.a = {p.a.buf, p.a.off + (int64_t)k0 * TILE * ld};
-            q.it.b = {p.b.buf, p.b.off + (int64_t)k0 * TILE * ld};
+            q.it.a = {p.a.buf, p.a.off + (int64_t)k0 * te * ld};
+            q.it.b = {p.b.buf, p.b.off + (int64_t)k0 * te * ld};
             q.it.c = c == 0 ? p.d : SymRef{B_P1 + c - 1, p.d.off};
-            q.it.k = u * TILE;
+            q.it.k = u * te;
             q.it.neg = p.neg;
             q.units = u;
             chunks.push_back(q);
@@ -134,7 +137,7 @@ void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extr
                 f.p[c - 1] = q.it.c;
             k0 += u;
         }
-        flops += 2.0 * TILE * TILE * (double)p.units * TILE;
+        flops += 2.0 * te * te * (double)p.units * te;
         if (nch > 1 || p.t.buf != B_NONE)
             folds.push_back(f);
     }
@@ -154,10 +157,11 @@ void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extr
             Key k = heap.top();
             heap.pop();
             bins[(size_t)k.second].push_back((int)i);
-            heap.push(Key(k.first + chunks[i].units + 0.35, k.second)); // (0.35: prologue + epilogue of a tile, in units)
+            heap.push(Key(k.first + chunks[i].units + (te == 128 ? 0.35 : 1.5), k.second)); // (prologue + epilogue of a tile, in units)
         }
         SymStep st;
         st.kind = 0;
+        st.te = te;
         st.off = (int)pl.items.size();
         st.bins = nb;
         st.bin_off = (int)pl.bin_start.size();
@@ -175,6 +179,7 @@ void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extr
     if (!folds.empty()) {
         SymStep st;
         st.kind = 1;
+        st.te = te;
         st.off = (int)pl.folds.size();
         st.count = (int)folds.size();
         pl.folds.insert(pl.folds.end(), folds.begin(), folds.end());
@@ -192,6 +197,11 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load)
         H = std::max(H, n.height);
     auto at = [&](int64_t row, int64_t col) { return row + col * ld; };
     for (int h = 1; h <= H; ++h) {
+        int64_t tiles128 = 0;
+        for (const Node& n : nodes)
+            if (n.height == h)
+                tiles128 += (int64_t)(n.mid - n.lo) * (n.hi - n.mid) * (LEAF / 128) * (LEAF / 128);
+        const int TILE = tiles128 >= TILES128_MIN ? 128 : 64;
         std::vector<Prod> w_prods, u_prods;
         std::vector<SymFold> t_folds;
         for (const Node& n : nodes) {
@@ -231,13 +241,14 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load)
                     }
             }
         }
-        emit(pl, w_prods, {}, ld, nbins, load);
+        emit(pl, w_prods, {}, ld, nbins, load, TILE);
         if (h == 1)
             pl.prefix_steps = (int)pl.steps.size();
-        emit(pl, u_prods, t_folds, ld, nbins, load);
+        emit(pl, u_prods, t_folds, ld, nbins, load, TILE);
     }
     // K^-1[i, j] = sum_{k >= i} U[i, k] U[j, k], i >= j
     std::vector<Prod> k_prods;
+    constexpr int TILE = 128;
     const int nt = (int)(N / TILE);
     for (int i = 0; i < nt; ++i)
         for (int j = 0; j <= i; ++j) {
@@ -248,7 +259,7 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load)
             p.units = nt - i;
             k_prods.push_back(p);
         }
-    emit(pl, k_prods, {}, ld, nbins, load);
+    emit(pl, k_prods, {}, ld, nbins, load, TILE);
 }
 
 // two resident workgroups per CU (74 KB of LDS each); chunks about as long as a share.  Measured around it
@@ -358,15 +369,16 @@ void inv2_run(hipStream_t s, Inv2Plan* p, const double* Xt_all, int part)
     for (size_t i = first; i < last; ++i) {
         const SymStep& st = p->steps[i];
         if (st.kind == 0)
-            launch_gemm_items(s, p->dItems, p->dBins + st.bin_off, st.bins, p->ld);
+            launch_gemm_items(s, p->dItems, p->dBins + st.bin_off, st.bins, p->ld, st.te);
         else
-            launch_fold_items(s, p->dFolds + st.off, st.count, p->ld);
+            launch_fold_items(s, p->dFolds + st.off, st.count, p->ld, st.te);
     }
 }
 
 // test hook (gpe_debug_inv_plan): the plan for order N, leading dimension ld; rows of 10 int64:
-//   products: { step, 0, A buf, A off, B buf, B off, C buf, C off, k, neg | share << 1 }   (in launch order, share by share)
-//   folds   : { step, 1, D buf, D off, P1 off | -1, P2 off | -1, P3 off | -1, T buf | -1, T off, 0 }
+//   products: { step, 0 | 2, A buf, A off, B buf, B off, C buf, C off, k, neg | share << 1 }   (in launch order, share by share;
+//             0: 128 x 128 tiles, 2: 64 x 64 tiles)
+//   folds   : { step, 1 | 3, D buf, D off, P1 off | -1, P2 off | -1, P3 off | -1, T buf | -1, T off, 0 }
 // buffers: 0 L, 1 U, 2 K^-1, 3 T-forms / W, 4..6 partials.  Returns the number of rows (also when out is too small).
 int inv2_debug_plan(int64_t N, int64_t ld, int nbins, int load_pct, int64_t* out, int64_t cap_rows)
 {
@@ -386,12 +398,12 @@ int inv2_debug_plan(int64_t N, int64_t ld, int nbins, int load_pct, int64_t* out
                 int64_t bin = 0; // the share (= workgroup of the launch) this product belongs to
                 while (bin + 1 < st.bins && sp.bin_start[(size_t)(st.bin_off + bin + 1)] <= st.off + i)
                     ++bin;
-                const int64_t v[10] = {(int64_t)s, 0, it.a.buf, it.a.off, it.b.buf, it.b.off, it.c.buf, it.c.off, it.k, it.neg | (bin << 1)};
+                const int64_t v[10] = {(int64_t)s, st.te == 64 ? 2 : 0, it.a.buf, it.a.off, it.b.buf, it.b.off, it.c.buf, it.c.off, it.k, it.neg | (bin << 1)};
                 std::copy(v, v + 10, o);
             }
             else {
                 const SymFold& f = sp.folds[(size_t)(st.off + i)];
-                const int64_t v[10] = {(int64_t)s, 1, f.d.buf, f.d.off, f.p[0].buf == B_NONE ? -1 : f.p[0].off,
+                const int64_t v[10] = {(int64_t)s, st.te == 64 ? 3 : 1, f.d.buf, f.d.off, f.p[0].buf == B_NONE ? -1 : f.p[0].off,
                                        f.p[1].buf == B_NONE ? -1 : f.p[1].off, f.p[2].buf == B_NONE ? -1 : f.p[2].off,
                                        f.t.buf, f.t.off, 0};
                 std::copy(v, v + 10, o);

@@ -27,10 +27,10 @@ def _plan(n, ld, nbins=512, load_pct=100):
     return out
 
 
-def _tile(buf, off, ld, cols=TILE):
-    """view of the 128 x cols block whose origin is at offset `off` of a column-major buffer with leading dimension ld"""
+def _tile(buf, off, ld, te, cols=None):
+    """view of the te x cols block whose origin is at offset `off` of a column-major buffer with leading dimension ld"""
     r, c = off % ld, off // ld
-    return buf[r:r + TILE, c:c + cols]
+    return buf[r:r + te, c:c + (te if cols is None else cols)]
 
 
 def _run_plan(n, ld, nbins, load_pct, seed):
@@ -55,43 +55,45 @@ def _run_plan(n, ld, nbins, load_pct, seed):
         rows = plan[steps == s]
         kind = rows[0, 1]
         assert (rows[:, 1] == kind).all()
-        if kind == 0:
+        te = 64 if kind & 2 else 128  # tile edge of the launch
+        stats["tile_edges"] = stats.get("tile_edges", set()) | {te}
+        if kind & 1 == 0:
             stats["products"] += len(rows)
             results = []
             written = set()
             for r in rows:
                 _, _, ab, ao, bb, bo, cb, co, k, neg = (int(v) for v in r)
                 neg &= 1
-                assert k % 128 == 0 and k >= 128
-                At, Bt = _tile(bufs[ab], ao, ld, k), _tile(bufs[bb], bo, ld, k)
+                assert k % te == 0 and k >= te and k % 32 == 0
+                At, Bt = _tile(bufs[ab], ao, ld, te, k), _tile(bufs[bb], bo, ld, te, k)
                 assert not np.isnan(At).any() and not np.isnan(Bt).any(), "a product reads memory nothing wrote"
                 v = At @ Bt.T
                 results.append((cb, co, -v if neg else v))
                 assert (cb, co) not in written, "two products of one launch write the same tile"
                 written.add((cb, co))
-            reads = {(int(r[2]), int(r[3]) % ld // TILE, (int(r[3]) // ld + kk) // TILE) for r in rows for kk in range(0, int(r[8]), TILE)}
-            reads |= {(int(r[4]), int(r[5]) % ld // TILE, (int(r[5]) // ld + kk) // TILE) for r in rows for kk in range(0, int(r[8]), TILE)}
-            writes = {(cb, co % ld // TILE, co // ld // TILE) for cb, co, _ in results}
+            reads = {(int(r[2]), int(r[3]) % ld // te, (int(r[3]) // ld + kk) // te) for r in rows for kk in range(0, int(r[8]), te)}
+            reads |= {(int(r[4]), int(r[5]) % ld // te, (int(r[5]) // ld + kk) // te) for r in rows for kk in range(0, int(r[8]), te)}
+            writes = {(cb, co % ld // te, co // ld // te) for cb, co, _ in results}
             assert not (reads & writes), "a launch reads a tile it also writes"
             for cb, co, v in results:
-                _tile(bufs[cb], co, ld)[:, :] = v
+                _tile(bufs[cb], co, ld, te)[:, :] = v
         else:
             stats["folds"] += len(rows)
             for r in rows:
                 _, _, db, do, p1, p2, p3, tb, to, _ = (int(v) for v in r)
-                D = _tile(bufs[db], do, ld)
+                D = _tile(bufs[db], do, ld, te)
                 nparts = 0
                 for q, po in enumerate((p1, p2, p3)):
                     if po >= 0:
                         assert po == do and nparts == q
-                        P = _tile(bufs[4 + q], po, ld)
+                        P = _tile(bufs[4 + q], po, ld, te)
                         assert not np.isnan(P).any()
                         D += P
                         nparts += 1
                 stats["max_chunks"] = max(stats["max_chunks"], 1 + nparts)
                 assert not np.isnan(D).any()
                 if tb >= 0:
-                    _tile(bufs[tb], to, ld)[:, :] = D.T
+                    _tile(bufs[tb], to, ld, te)[:, :] = D.T
     U = bufs[1][:n, :n]
     Kinv = bufs[2][:n, :n]
     return L, Kmat, U, Kinv, stats, plan
@@ -111,10 +113,9 @@ def test_inv_plan_executed_in_numpy(n, ld, nbins, load_pct):
     assert np.max(np.abs(Kinv[il] - Kref[il])) <= 1e-9 * np.max(np.abs(Kref))
     assert stats["max_chunks"] <= 4
     # algorithmic flops: the products of the plan do 2 n^3 / 3 less what the leaves did, at tile granularity
-    units = plan[plan[:, 1] == 0][:, 8].sum() // TILE
-    t = n // TILE
-    lauum = sum((t - i) * (i + 1) for i in range(t))
-    assert lauum <= units <= 2 * lauum and (units > lauum or n == 256)
+    prods = plan[plan[:, 1] & 1 == 0]
+    flops = float(np.sum(np.where(prods[:, 1] & 2, 64.0 * 64.0, 128.0 * 128.0) * 2.0 * prods[:, 8]))
+    assert 0.55 * 2 * n ** 3 / 3 <= flops <= 1.4 * 2 * n ** 3 / 3 + 2.0 * 128 ** 3 * 3  # 2 n^3 / 3 less the leaves, whole tiles on the diagonals
     print(f"n={n}: {stats['launches']} launches after the leaves, {stats['products']} tile products, {stats['folds']} folds")
 
 
@@ -127,10 +128,10 @@ def test_inv_plan_shares_are_balanced():
     launches, big = 0, 0
     for s in range(int(steps.max()) + 1):
         rows = plan[steps == s]
-        if rows[0, 1] != 0:
+        if rows[0, 1] & 1:
             continue
         launches += 1
-        units = rows[:, 8] // TILE
+        units = rows[:, 8] // (64 if rows[0, 1] & 2 else 128)
         share = rows[:, 9] >> 1
         assert share.max() < 512
         if len(rows) < 256:
@@ -139,7 +140,9 @@ def test_inv_plan_shares_are_balanced():
         load = np.bincount(share, weights=units, minlength=512)
         assert load.max() <= 1.15 * units.sum() / 512 + units.max(), (s, load.max(), units.sum() / 512, units.max())
     assert big >= 3  # W and U_b of the top node, U U^T
-    last = plan[steps == max(int(s) for s in steps[plan[:, 1] == 0])]
+    kinds = {int(k) for k in plan[:, 1]}
+    assert 0 in kinds and 2 in kinds  # 128 x 128 tiles where a launch fills the chip, 64 x 64 at the low levels of the tree
+    last = plan[steps == max(int(s) for s in steps[plan[:, 1] & 1 == 0])]
     assert (last[:, 6] >= 2).all() and last[:, 8].sum() // TILE == 5984 and len(last) >= 512  # U U^T: 528 tiles, 5984 units
     assert launches == 2 * 4 + 1  # W and U_b of the four heights, then U U^T
     assert plan[:, 0].max() + 1 <= 2 * launches  # at most one fold launch per product launch
