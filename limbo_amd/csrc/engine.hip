@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <atomic>
 #include <chrono>
 #include <map>
@@ -149,6 +150,8 @@ struct gpe_ctx {
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     double* dInvS = nullptr; // the recursive K^-1's scratch (inv2.hip): T-forms / W | three partial buffers, ld x cap each
     Inv2Plan* inv2 = nullptr; // ... and its plan, rebuilt when N, ld or a buffer changes
+    hipEvent_t chain_ev = nullptr; // the end of this handle's last evaluation chain when that ran on a CU-masked stream (ChainScope) ...
+    bool chain_pending = false;    // ... and nobody has waited for it yet: the HOST does (wait_chain), never the handle's own stream
     bool inv_early = false;   // set by gpe_hp_objective around compute_enqueue: start K^-1's lowest level beside the sweep
     bool inv_prefix_done = false; // ... done on stream2 for the factor at hand; inv_ev completes behind it
     hipEvent_t inv_ev = nullptr, inv_ev0 = nullptr;
@@ -1057,6 +1060,8 @@ int compute_enqueue(gpe_ctx* c)
     }
     ChainScope gate(c, !g_batch.bt, may_partition);
     hipStream_t s = c->stream; // (the handle's own stream, or the partition's for the length of this enqueue)
+    if (gate.part >= 0)
+        c->inv_early = false; // (its events would make the own stream wait for a masked one: see ChainScope's destructor)
     digest_kernel(c);
     c->hInfo[0] = c->hInfo[1] = 0; // nothing of this handle is in flight here
     if (c->handover_off_left > 0 && --c->handover_off_left == 0)
@@ -1155,6 +1160,35 @@ static hipError_t wait_stream(hipStream_t s)
     }
 }
 
+// A data-flow launch that ran into its bounded poll while the device was split into the two CU-masked halves (ChainScope): whatever
+// the cause — a runtime that stopped honouring the masks, a queue mapping nobody has seen yet — the halves are given up for the
+// rest of the process and evaluations go chain behind chain again (round 4's gate), which needs no assumption about masks.
+std::atomic<bool> g_partitions_broken{false};
+std::atomic<int> g_masked_chains{0}; // chains enqueued on a masked stream so far
+static void partitions_give_up(const char* why)
+{
+    if (g_masked_chains.load() > 0 && !g_partitions_broken.exchange(true))
+        fprintf(stderr, "limbo_amd: %s while evaluations shared the device in CU-masked halves: back to one chain at a time\n", why);
+}
+
+// host wait for the end of this handle's chain on a CU-masked stream (ChainScope): polls like wait_stream
+static hipError_t wait_chain(gpe_ctx* c)
+{
+    if (!c->chain_pending)
+        return hipSuccess;
+    c->chain_pending = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int i = 0; i < 64; ++i) {
+            hipError_t e = hipEventQuery(c->chain_ev);
+            if (e != hipErrorNotReady)
+                return e;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+            return hipEventSynchronize(c->chain_ev);
+    }
+}
+
 // after a stream sync: did a data-flow sweep give up waiting for a producer?  With the dispatch-ordered block
 // mapping (dev.h, flow_block_of) that is not a reachable state; the bounded poll stays as a backstop, and the host
 // answers it by running the same work again with one launch per block (GPE_FLOW_FAULT=1 forces that path in tests).
@@ -1162,6 +1196,8 @@ static bool flow_failed(gpe_ctx* c)
 {
     static const bool fault = getenv("GPE_FLOW_FAULT") && atoi(getenv("GPE_FLOW_FAULT")) != 0;
     const bool bad = c->hInfo[1] != 0 || (fault && c->flow_solve);
+    if (c->hInfo[1] != 0)
+        partitions_give_up("a sweep's hand-off timed out");
     c->hInfo[1] = 0;
     if (bad)
         ++c->flow_retries;
@@ -1193,6 +1229,7 @@ static void sum_ll_partials(gpe_ctx* c)
 // redo: re-enqueues, with the one-launch sweeps off, everything that depended on a sweep of this call
 template <class Redo> int compute_finish(gpe_ctx* c, Redo redo)
 {
+    HIPCHK(c, wait_chain(c));
     HIPCHK(c, wait_stream(c->stream));
     HIPCHK(c, hipGetLastError());
     drain_phases(c);
@@ -1206,12 +1243,14 @@ template <class Redo> int compute_finish(gpe_ctx* c, Redo redo)
         c->tail_lay = c->tall_lay = -2; // the data-flow launches' buffers are in an unknown state: all-ones again before their next use
         ++c->flow_retries;
         ++c->handover_reruns;
+        partitions_give_up("a hand-over of the factorisation timed out");
         const BatchLaunch saved = g_batch;
         g_batch = BatchLaunch{};
         const int e = compute_enqueue(c);
         g_batch = saved;
         if (e != GPE_OK)
             return e;
+        HIPCHK(c, wait_chain(c));
         HIPCHK(c, wait_stream(c->stream));
         HIPCHK(c, hipGetLastError());
         drain_phases(c);
@@ -1675,7 +1714,10 @@ struct GateDev {
     hipStream_t part[2] = {nullptr, nullptr}, part_aux[2] = {nullptr, nullptr};
     bool part_tried = false, part_dirty[2] = {false, false};
     unsigned rr = 0;
-    int conc_score = 0; // > 0: a chain found another one in flight within the last few evaluations (ChainScope)
+    unsigned char* d_owner = nullptr; // device: owner[xcd * 256 + place] = the half (0 / 1) that (XCD, CU) place belongs to, 255 unknown
+    int* h_violation = nullptr;       // pinned: set by a workgroup of a masked chain that found itself in the OTHER half
+    std::chrono::steady_clock::time_point last_busy{}; // when a chain last found another one in flight (ChainScope)
+    bool ever_busy = false;
 };
 GateDev g_gate[16];
 bool gate_on()
@@ -1718,7 +1760,7 @@ static void gate_unmasked(GateDev& g, hipStream_t s)
         gate_order(g, s, g.last_stream);
     for (int i = 0; i < 2; ++i)
         if (g.part_dirty[i]) {
-            gate_order(g, s, g.part[i]);
+            (void)hipStreamSynchronize(g.part[i]); // (a host wait, not an event the stream waits for: ChainScope's destructor says why)
             g.part_dirty[i] = false;
         }
 }
@@ -1734,7 +1776,68 @@ void flow_gate_enter(hipStream_t s)
 static bool partitions_on()
 {
     static const bool on = !(getenv("GPE_FLOW_PARTITIONS") && atoi(getenv("GPE_FLOW_PARTITIONS")) == 0);
-    return on;
+    return on && !g_partitions_broken.load(std::memory_order_relaxed);
+}
+// where a workgroup runs: XCD and (shader engine, array, CU) of it
+__global__ void k_partition_probe(unsigned* __restrict__ out, int spin)
+{
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        out[blockIdx.x] = ((xcc & 15u) << 16) | (hw & 0xFF00u); // CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+    }
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < spin) { // stay resident for a moment so that the launch spreads over every CU it may use
+    }
+}
+// do the two masked streams really confine their launches to disjoint halves of every XCD, here, in this process?
+// (owner, optional: the half every place seen belongs to)
+static bool partition_masks_hold(hipStream_t a, hipStream_t b, unsigned char* owner = nullptr)
+{
+    constexpr int G = 2048;
+    unsigned* d = nullptr;
+    if (hipMalloc(&d, sizeof(unsigned) * 2 * G) != hipSuccess)
+        return false;
+    hipLaunchKernelGGL(k_partition_probe, dim3(G), dim3(64), 0, a, d, 300);
+    hipLaunchKernelGGL(k_partition_probe, dim3(G), dim3(64), 0, b, d + G, 300);
+    std::vector<unsigned> h(2 * G);
+    bool ok = hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess
+        && hipMemcpy(h.data(), d, sizeof(unsigned) * 2 * G, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok)
+        return false;
+    std::vector<unsigned> pa(h.begin(), h.begin() + G), pb(h.begin() + G, h.end());
+    std::sort(pa.begin(), pa.end());
+    pa.erase(std::unique(pa.begin(), pa.end()), pa.end());
+    std::sort(pb.begin(), pb.end());
+    pb.erase(std::unique(pb.begin(), pb.end()), pb.end());
+    std::vector<unsigned> both;
+    std::set_intersection(pa.begin(), pa.end(), pb.begin(), pb.end(), std::back_inserter(both));
+    unsigned xa = 0, xb = 0; // XCDs seen
+    for (unsigned v : pa)
+        xa |= 1u << (v >> 16);
+    for (unsigned v : pb)
+        xb |= 1u << (v >> 16);
+    if (owner) {
+        for (unsigned v : pa)
+            owner[(v >> 16) * 256 + ((v >> 8) & 255)] = 0;
+        for (unsigned v : pb)
+            owner[(v >> 16) * 256 + ((v >> 8) & 255)] = 1;
+    }
+    return both.empty() && !pa.empty() && !pb.empty() && pa.size() <= 128 && pb.size() <= 128 && xa == 0xFFu && xb == 0xFFu;
+}
+// at the head of every masked chain: 64 single-wave workgroups look where they are; one that sits in the other half's CUs says so
+__global__ void k_partition_check(const unsigned char* __restrict__ owner, int half, int* __restrict__ violation)
+{
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const unsigned char o = owner[(xcc & 15u) * 256 + ((hw >> 8) & 255u)];
+        if (o != 255 && o != (unsigned char)half)
+            *violation = 1;
+    }
 }
 static bool partition_streams(GateDev& g)
 {
@@ -1749,6 +1852,30 @@ static bool partition_streams(GateDev& g)
                 && hipExtStreamCreateWithCUMask(&g.part[1], 8, hi) == hipSuccess && hipExtStreamCreateWithCUMask(&g.part_aux[1], 8, hi) == hipSuccess;
             if (!ok)
                 g.part[0] = g.part[1] = nullptr; // (whatever was created stays unused)
+            else {
+                // the runtime creates a stream's hardware queue at its FIRST launch (tens of milliseconds for a masked one):
+                // here, not inside the first evaluation that meets another one
+                void* word = nullptr;
+                if (hipMalloc(&word, 64) == hipSuccess) {
+                    for (hipStream_t st : {g.part[0], g.part_aux[0], g.part[1], g.part_aux[1]}) {
+                        (void)hipMemsetAsync(word, 0, 64, st);
+                        (void)hipStreamSynchronize(st);
+                    }
+                    (void)hipFree(word);
+                }
+                // ... and the assumption everything rests on is CHECKED, in this process, on these streams: launches on the two
+                // halves land on disjoint sets of at most 128 (XCD, CU) places, all eight XCDs each.  If not: no partitions.
+                std::vector<unsigned char> owner(16 * 256, 255);
+                if (!partition_masks_hold(g.part[0], g.part[1], owner.data()) || !partition_masks_hold(g.part_aux[0], g.part_aux[1])
+                    || hipMalloc(&g.d_owner, owner.size()) != hipSuccess
+                    || hipMemcpy(g.d_owner, owner.data(), owner.size(), hipMemcpyHostToDevice) != hipSuccess
+                    || hipHostMalloc(&g.h_violation, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+                    fprintf(stderr, "limbo_amd: the CU masks of the chain partitions are not honoured here: one chain at a time\n");
+                    g.part[0] = g.part[1] = nullptr;
+                }
+                else
+                    *g.h_violation = 0;
+            }
         }
     }
     return g.part[0] != nullptr;
@@ -1760,6 +1887,11 @@ ChainScope::ChainScope(gpe_ctx* c_, bool engage, bool may_partition) : c(c_), on
     GateDev& g = gate_dev();
     g.mu.lock(); // (held for the enqueue of the evaluation: ~50 us of host time)
     ++g.depth;   // the gates of the launches inside nest in this one
+    if (g.h_violation && *g.h_violation) { // a masked chain saw one of its workgroups in the other half's CUs
+        *g.h_violation = 0;
+        g_masked_chains.fetch_add(1);
+        partitions_give_up("a CU mask was not honoured");
+    }
     if (g.depth == 1 && may_partition && partitions_on() && !c->prof && partition_streams(g)) {
         // is another chain in flight on the device?  (A query, not a guarantee: it picks the mode; ORDER comes from the
         // events below.)
@@ -1769,14 +1901,15 @@ ChainScope::ChainScope(gpe_ctx* c_, bool engage, bool may_partition) : c(c_), on
             busy[i] = g.part_dirty[i] && hipStreamQuery(g.part[i]) == hipErrorNotReady;
         // Hysteresis: with R threads in flight a chain now and then finds the device idle for a moment (the others are between
         // evaluations on the host); were it to take the whole chip, both halves would have to drain for it and the next
-        // masked chains to wait behind it — measured: 701 evaluations/s with four threads instead of 970.  So the device
-        // stays in two halves until eight evaluations in a row have found it idle (a caller that alternates handles from
-        // ONE thread never finds a chain in flight: always the whole chip).
-        if (full_busy || busy[0] || busy[1])
-            g.conc_score = 8;
-        else if (g.conc_score > 0)
-            --g.conc_score;
-        if (g.conc_score > 0)
+        // masked chains to wait behind it — measured: 701 evaluations/s with four threads instead of 930.  So the device
+        // stays in two halves for 3 ms after a chain last found another one in flight (a caller that alternates handles from
+        // ONE thread never finds a chain in flight: always the whole chip; so does whoever comes 3 ms after the threads).
+        const auto now = std::chrono::steady_clock::now();
+        if (full_busy || busy[0] || busy[1]) {
+            g.last_busy = now;
+            g.ever_busy = true;
+        }
+        if (g.ever_busy && now - g.last_busy < std::chrono::milliseconds(3))
             part = !busy[0] ? 0 : (!busy[1] ? 1 : (int)(g.rr++ & 1));
     }
     if (part >= 0) {
@@ -1789,6 +1922,9 @@ ChainScope::ChainScope(gpe_ctx* c_, bool engage, bool may_partition) : c(c_), on
         c->stream = P;
         c->stream2 = g.part_aux[part];
         g.part_dirty[part] = true;
+        g_masked_chains.fetch_add(1, std::memory_order_relaxed);
+        static const bool fault = getenv("GPE_PARTITION_FAULT") && atoi(getenv("GPE_PARTITION_FAULT")) != 0; // (test hook: claims the other half)
+        hipLaunchKernelGGL(k_partition_check, dim3(64), dim3(64), 0, P, g.d_owner, fault ? 1 - part : part, g.h_violation);
     }
     else if (g.depth == 1)
         gate_unmasked(g, c->stream);
@@ -1802,7 +1938,19 @@ ChainScope::~ChainScope()
         hipStream_t P = c->stream;
         c->stream = own;
         c->stream2 = own2;
-        gate_order(g, c->stream, P); // whatever the handle does next, and its host wait, come behind the chain
+        // Whatever the handle does next comes behind the chain — by a HOST wait (wait_chain, in compute_finish), not by making
+        // the handle's own stream wait for an event of the masked one: own streams are high-priority queues (create_main_stream),
+        // masked ones cannot be (hipExtStreamCreateWithCUMask takes no priority), and a high-priority queue that sits on a
+        // barrier packet keeps the scheduler from the normal-priority queue it is waiting for once the process has more
+        // hardware queues than the chip maps at a time — measured with GPU_MAX_HW_QUEUES=8, torch in the process and eight
+        // threads: masked chains got no service for seconds, their bounded polls fired (3 evaluations/s, re-runs); with the
+        // own streams at the default priority, or with this, 950 evaluations/s.
+        if (!c->chain_ev && hipEventCreateWithFlags(&c->chain_ev, hipEventDisableTiming) != hipSuccess)
+            c->chain_ev = nullptr;
+        if (c->chain_ev && hipEventRecord(c->chain_ev, P) == hipSuccess)
+            c->chain_pending = true;
+        else
+            (void)hipStreamSynchronize(P);
     }
     else if (g.depth == 1)
         g.last_stream = c->stream;
@@ -1867,6 +2015,16 @@ int gpe_create(int device_id, gpe_handle* out)
         return GPE_ERR_HIP;
     }
     c->dHead = c->dScal + 1024;
+    {
+        // the CU-masked stream pairs of the chain partitions (ChainScope) are created when a device gets its SECOND live handle:
+        // creating them takes tens of milliseconds, which must not fall into the first evaluation that meets another one
+        static std::atomic<int> live[16];
+        if (c->device < 16 && live[c->device].fetch_add(1) + 1 >= 2 && gate_on() && partitions_on()) {
+            GateDev& gd = gate_dev();
+            std::lock_guard<std::recursive_mutex> lk(gd.mu);
+            (void)partition_streams(gd);
+        }
+    }
     // the polled X22 copies of k_panel256 (both buffers: a block from the pool may have been left in either state)
     hipMemsetAsync(c->dHead + GPE_S22_TILE * (NB * NB), 0xFF, sizeof(double) * GPE_S22_TILES * NB * NB, c->stream);
     hipMemsetAsync(c->dHead + (32 + GPE_S22_TILE) * (NB * NB), 0xFF, sizeof(double) * GPE_S22_TILES * NB * NB, c->stream);
@@ -1923,6 +2081,10 @@ int gpe_destroy(gpe_handle c)
     if (c->inv_ev) {
         hipEventDestroy(c->inv_ev);
         hipEventDestroy(c->inv_ev0);
+    }
+    if (c->chain_ev) {
+        (void)wait_chain(c);
+        hipEventDestroy(c->chain_ev);
     }
     drain_phases(c);
     for (auto e : c->pool)
@@ -2382,6 +2544,8 @@ int gpe_hp_objective(gpe_handle c, int kind, const double* th, int n_theta, doub
         c->inv_early = true;
         rc = compute_enqueue(c);
         c->inv_early = false;
+        if (rc == GPE_OK && c->chain_pending) // (the chain ran on a masked stream: K^-1 and the gradient follow it by a host wait)
+            rc = wait_chain(c) == hipSuccess ? GPE_OK : GPE_ERR_HIP;
         if (rc == GPE_OK)
             rc = grad_enqueue(c, n_grad, optimize_noise, false);
         if (c->inv_prefix_done) { // (not consumed: an error on the way) nothing may outlive this call on the second stream

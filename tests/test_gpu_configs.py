@@ -570,6 +570,35 @@ def test_gpu_concurrent_handles_do_not_starve_each_other(engine_lib, threads, pe
     assert threads * per / dt > 100.0, dt
 
 
+def test_gpu_chain_partitions_give_up_when_a_mask_is_not_honoured():
+    """Round 5 safety net of the CU-masked chain partitions (engine.hip: ChainScope).  They rest on ONE assumption — a launch
+    on a masked stream stays inside its half of every XCD — which is checked when the streams are created (a probe launch per
+    stream: disjoint sets of at most 128 places, all eight XCDs) and AGAIN at the head of every masked chain (64 workgroups
+    look up where they sit).  GPE_PARTITION_FAULT=1 makes that check claim the other half: the first masked chain reports a
+    violation, the process goes back to one chain at a time (a line on stderr), every result stays bitwise the sequential one."""
+    code = ("import sys, threading; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from limbo_amd import _capi, synth\n"
+            "eng = _capi.load_engine()\n"
+            "X, Y = synth.make_problem('c2', N=2048); om, _ = synth.obs_mean_data(Y)\n"
+            "hs, ref = [], []\n"
+            "for r in range(3):\n"
+            "    h = _capi.Handle(eng); h.set_kernel(0, np.zeros(7) + 1e-3 * r, 0.01); h.set_data(X, om); assert h.compute() == 0; ref.append(h.log_lik()); hs.append(h)\n"
+            "bad = [0]\n"
+            "def work(i):\n"
+            "    for _ in range(40):\n"
+            "        if hs[i].compute() != 0 or hs[i].log_lik() != ref[i]: bad[0] += 1\n"
+            "ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]\n"
+            "[t.start() for t in ts]; [t.join() for t in ts]\n"
+            "assert bad[0] == 0 and all(h.flow_retries() == 0 for h in hs)\n"
+            "print('child ok')\n") % str(ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPE_PARTITION_FAULT="1"), capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
+    assert "a CU mask was not honoured" in r.stderr and "one chain at a time" in r.stderr, r.stderr
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert r.returncode == 0 and "child ok" in r.stdout and "limbo_amd:" not in r.stderr, r.stdout + r.stderr
+
+
 def test_gpu_data_flow_buffers_across_sizes_on_one_handle(engine_lib):
     """the data-flow launches (k_tail) hand tiles over through buffers that must hold an all-ones pattern
     where the launch polls, and a launch only re-arms ITS OWN slot layout of the other buffer.  One handle whose N and P change

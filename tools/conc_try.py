@@ -19,6 +19,11 @@ def child(per):
     from limbo_amd import _capi
     from limbo_amd import synth as O
 
+    if os.environ.get("CONC_TORCH"):
+        import torch
+
+        torch.zeros(4, device="cuda:0")
+        torch.cuda.synchronize()
     eng = _capi.load_engine()
     X, Y = O.make_problem("c2", N=4096)
     om, _ = O.obs_mean_data(Y)
@@ -35,7 +40,7 @@ def child(per):
     single = per / (time.perf_counter() - t0)
     one.close()
     line = [f"{tag}: one handle {single:.0f}/s"]
-    for R in (2, 4, 8):
+    for R in [int(v) for v in os.environ.get("CONC_R", "2,4,8").split(",")]:
         hs, ref = [], []
         for r in range(R):
             h = _capi.Handle(eng, 0)
