@@ -540,7 +540,7 @@ def test_gpu_concurrent_handles_do_not_starve_each_other(engine_lib, threads, pe
     side, each launch's lowest unfinished workgroup always resident in its own half (the reference runs independent GPs
     truly in parallel: multi_gp.hpp:124-126, parallel_repeater.hpp:86-103).  4 threads x 6 and 8 threads x 200 evaluations:
     no re-run, every log-likelihood bitwise the handle's own sequential one, and not slower than 100 evaluations/s
-    (measured: 970/s with four in flight against 795 chain behind chain, profiles/r05_concurrent_chains.log)."""
+    (measured: 1120/s with four or eight in flight against 795 chain behind chain, profiles/r05_concurrent_chains.log)."""
     import threading
     import time
     X, Y = synth.make_problem("c2", N=4096)
