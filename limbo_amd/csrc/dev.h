@@ -326,7 +326,8 @@ void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_
 void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld, int tile = 128);
 // the plan of one inversion (inv2.hip): host-built once per (N, ld, buffers), resident on the device
 struct Inv2Plan;
-Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride);
+Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride,
+                        int members = 1); // members: GPs stepped by the launches (a batched sequence: another plan from four on)
 void inv2_plan_free(Inv2Plan* p);
 bool inv2_supported(int64_t N);
 int inv2_partials();                // N x N partial buffers behind the W / T-form buffer in S (S holds 1 + this many)

@@ -150,6 +150,7 @@ struct gpe_ctx {
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     double* dInvS = nullptr; // the recursive K^-1's scratch (inv2.hip): T-forms / W | three partial buffers, ld x cap each
     Inv2Plan* inv2 = nullptr; // ... and its plan, rebuilt when N, ld or a buffer changes
+    Inv2Plan* inv2_batched = nullptr; // ... the plan of a batched sequence of >= 4 members led by this handle (no chunked k ranges)
     hipEvent_t chain_ev = nullptr; // the end of this handle's last evaluation chain when that ran on a CU-masked stream (ChainScope) ...
     bool chain_pending = false;    // ... and nobody has waited for it yet: the HOST does (wait_chain), never the handle's own stream
     bool inv_early = false;   // set by gpe_hp_objective around compute_enqueue: start K^-1's lowest level beside the sweep
@@ -321,7 +322,8 @@ void free_dev(gpe_ctx* c)
         hipFree(c->dInvS);
     c->dInvS = nullptr;
     inv2_plan_free(c->inv2);
-    c->inv2 = nullptr;
+    inv2_plan_free(c->inv2_batched);
+    c->inv2 = c->inv2_batched = nullptr;
     c->grad_partial_cap = 0;
     c->cap = c->ld = 0;
 }
@@ -1325,8 +1327,9 @@ static int inv2_prepare(gpe_ctx* c)
         HIPCHK(c, hipMalloc(&c->dKinv, sizeof(double) * (size_t)(ld * c->cap)));
     if (!c->dInvS)
         HIPCHK(c, hipMalloc(&c->dInvS, sizeof(double) * (size_t)(ld * c->cap) * (size_t)(1 + inv2_partials())));
-    c->inv2 = inv2_plan_get(c->inv2, c->N, ld, c->dA, c->dLinv, c->dKinv, c->dInvS, ld * c->cap);
-    if (!c->inv2) {
+    Inv2Plan*& slot = g_batch.G >= 4 ? c->inv2_batched : c->inv2;
+    slot = inv2_plan_get(slot, c->N, ld, c->dA, c->dLinv, c->dKinv, c->dInvS, ld * c->cap, g_batch.G);
+    if (!slot) {
         c->err = "K^-1: no memory for the plan of the recursion";
         return GPE_ERR_NOMEM;
     }
@@ -1371,14 +1374,15 @@ int ensure_inv(gpe_ctx* c)
         if (rc)
             return rc;
         {
-            PhaseScope ps(c, GPE_PH_INV, inv2_flops(c->inv2));
-            if (c->inv_prefix_done) { // (inv2_start_early: the lowest level ran beside the sweep)
+            Inv2Plan* plan = g_batch.G >= 4 ? c->inv2_batched : c->inv2;
+            PhaseScope ps(c, GPE_PH_INV, inv2_flops(plan));
+            if (c->inv_prefix_done) { // (inv2_start_early — single handles only: the lowest level ran beside the sweep)
                 hipStreamWaitEvent(s, c->inv_ev, 0);
-                inv2_run(s, c->inv2, c->dXinv, 2);
+                inv2_run(s, plan, c->dXinv, 2);
                 c->inv_prefix_done = false;
             }
             else
-                inv2_run(s, c->inv2, c->dXinv, 0);
+                inv2_run(s, plan, c->dXinv, 0);
         }
         HIPCHK(c, hipGetLastError());
         c->inv_ok = true; // gp.hpp:263

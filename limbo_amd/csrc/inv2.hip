@@ -187,8 +187,14 @@ void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extr
     }
 }
 
-void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load)
+void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load, int members)
 {
+    // A batched sequence of at least four members fills the chip with whole tiles: no k range is cut (no partial buffers, no
+    // fold launches but the transposed copies) and every tile product is a workgroup of its own.
+    if (members >= 4) {
+        load = 1e9;
+        nbins = 1 << 20;
+    }
     const int npan = (int)(N / LEAF);
     std::vector<Node> nodes;
     make_tree(nodes, 0, npan, false);
@@ -272,6 +278,7 @@ constexpr double PLAN_LOAD = 1.0;
 
 struct Inv2Plan {
     int64_t N = 0, ld = 0, pstride = 0;
+    int members = 1;
     const double* L = nullptr;
     double *U = nullptr, *K = nullptr, *S = nullptr;
     std::vector<SymStep> steps;
@@ -300,17 +307,19 @@ void inv2_plan_free(Inv2Plan* p)
     delete p;
 }
 
-Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride)
+Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride, int members)
 {
-    if (old && old->N == N && old->ld == ld && old->L == L && old->U == U && old->K == Kinv && old->S == S && old->pstride == pstride)
+    if (old && old->N == N && old->ld == ld && old->L == L && old->U == U && old->K == Kinv && old->S == S && old->pstride == pstride
+        && (old->members >= 4) == (members >= 4))
         return old;
     inv2_plan_free(old);
     SymPlan sp;
-    build(sp, N, ld, PLAN_BINS, PLAN_LOAD);
+    build(sp, N, ld, PLAN_BINS, PLAN_LOAD, members);
     Inv2Plan* p = new Inv2Plan;
     p->N = N;
     p->ld = ld;
     p->pstride = pstride;
+    p->members = members;
     p->L = L;
     p->U = U;
     p->K = Kinv;
@@ -385,7 +394,7 @@ int inv2_debug_plan(int64_t N, int64_t ld, int nbins, int load_pct, int64_t* out
     if (N <= 0 || N % LEAF != 0 || ld < N)
         return -1;
     SymPlan sp;
-    build(sp, N, ld, nbins > 0 ? nbins : PLAN_BINS, load_pct > 0 ? load_pct / 100.0 : PLAN_LOAD);
+    build(sp, N, ld, nbins > 0 ? nbins : PLAN_BINS, load_pct > 0 ? load_pct / 100.0 : PLAN_LOAD, 1);
     int64_t row = 0;
     for (size_t s = 0; s < sp.steps.size(); ++s) {
         const SymStep& st = sp.steps[s];

@@ -499,6 +499,15 @@ def test_gpu_alternate_schedules(engine_lib, oracle_lib, monkeypatch, env):
     _small_parity(engine_lib, oracle_lib, N=520, seed=len(env))
 
 
+_SWITCH_MEMO = []
+
+
+def _switch_memo_dir(tmp_path_factory):
+    if not _SWITCH_MEMO:
+        _SWITCH_MEMO.append(tmp_path_factory.mktemp("switches"))
+    return _SWITCH_MEMO[0]
+
+
 @pytest.mark.parametrize("env", [{"GPE_QUERY_SWEEP": "0", "GPE_INV_PANELS": "0"}, {"GPE_QUERY_T": "0", "GPE_INV_OVERLAP": "0"},
                                  {"GPE_RHS_FMA": "2"}, {"GPE_RHS_FMA": "0"}, {"GPE_PANEL256": "0", "GPE_TAIL_MAX": "0"}, {"GPE_TAIL_MAX": "0"},
                                  {"GPE_EARLY_BULK_TILES": "0", "GPE_ROWS_TAIL": "0"},
@@ -507,7 +516,7 @@ def test_gpu_alternate_schedules(engine_lib, oracle_lib, monkeypatch, env):
                                  {"GPE_STREAM_PRIO": "0", "GPE_TAIL_GEN": "0", "GPE_TRACE": "1", "GPE_ROCTX": "1"},
                                  {"GPE_BATCH_SPLIT": "0", "GPE_BATCH_TAIL_TILES": "0", "GPE_BATCH_TAIL_MAX": "512"}, {"GPE_BATCH": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
-def test_gpu_process_wide_switches(env):
+def test_gpu_process_wide_switches(env, tmp_path_factory):
     """Switches that are read once per process (the blocked point-query solve, the in-panel substitution chain for K^-1; round 3:
     the sample-contiguous batched queries, K^-1's product after its chain, right-hand-side rows always / never as FMAs,
     the look-ahead stream released by every panel and obs_mean's rows by a launch of their own; round 4: 256-column panels to
@@ -527,32 +536,34 @@ def test_gpu_process_wide_switches(env):
             "from limbo_amd import _capi\n"
             "from oracle import binding as OB\n"
             "from tests.test_gpu_parity import _small_parity\n"
-            "from tests.util import relerr_norm\n"
-            "eng, orc = _capi.load_engine(), OB.load_oracle()\n"
+            "from tests.util import relerr_norm, MemoLib\n"
+            "eng, orc = _capi.load_engine(), MemoLib(OB.load_oracle(), sys.argv[1])  # (the oracle's answers are the same in every child)\n"
             "_small_parity(eng, orc, N=520, seed=7)\n"
             "_small_parity(eng, orc, N=1700, D=4, P=1, seed=8)\n"
             "_small_parity(eng, orc, N=150, D=3, P=1, seed=9)\n"
             "rng = np.random.default_rng(3); X = rng.uniform(0, 1, (1792, 5)); om = np.cos(X.sum(1))[:, None] - 0.1\n"
             "res = []\n"
             "for lib in (eng, orc):\n"
-            "    h = _capi.Handle(lib); h.set_data(X, om)\n"
+            "    h = lib.handle() if isinstance(lib, MemoLib) else _capi.Handle(lib); h.set_data(X, om)\n"
             "    res.append(h.hp_objective(0, rng.uniform(-0.2, 0.2, 6) * 0 + 0.1, 0.01, optimize_noise=True, want_grad=True)); h.close()\n"
             "assert abs(res[0][0] - res[1][0]) <= 1e-10 * abs(res[1][0]) and relerr_norm(res[0][1], res[1][1]) < 1e-6\n"
             "hs = [_capi.Handle(eng) for _ in range(3)]\n"
             "for q, h in enumerate(hs): h.set_data(X[:700] + 0.01 * q, om[:700]); h.set_kernel(0, np.full(6, 0.05 * q), 0.01)\n"
             "st, bl = _capi.batch_compute(hs), _capi.batch_log_lik(hs)\n"
             "for q, h in enumerate(hs):\n"
-            "    o = _capi.Handle(orc); o.set_data(X[:700] + 0.01 * q, om[:700]); o.set_kernel(0, np.full(6, 0.05 * q), 0.01); assert o.compute() == 0\n"
+            "    o = orc.handle(); o.set_data(X[:700] + 0.01 * q, om[:700]); o.set_kernel(0, np.full(6, 0.05 * q), 0.01); assert o.compute() == 0\n"
             "    assert st[q] == 0 and abs(bl[q] - o.log_lik()) <= 1e-10 * abs(o.log_lik()); o.close(); h.close()\n"
             "hb = [_capi.Handle(eng) for _ in range(2)]\n"
             "for h in hb: h.set_data(X[:1024], om[:1024])\n"
             "thb = np.array([np.full(6, 0.05), np.full(6, -0.05)])\n"
             "lik, grad, st = _capi.batch_hp_objective(hb, 0, thb, np.full(2, 0.01), optimize_noise=False, want_grad=True)\n"
             "for q in range(2):\n"
-            "    o = _capi.Handle(orc); o.set_data(X[:1024], om[:1024]); r = o.hp_objective(0, thb[q], 0.01, optimize_noise=False, want_grad=True)\n"
+            "    o = orc.handle(); o.set_data(X[:1024], om[:1024]); r = o.hp_objective(0, thb[q], 0.01, optimize_noise=False, want_grad=True)\n"
             "    assert st[q] == 0 and abs(lik[q] - r[0]) <= 1e-10 * abs(r[0]) and relerr_norm(grad[q], r[1]) < 1e-6; o.close()\n"
+            "orc.save()\n"
             "print('child ok')\n") % str(ROOT)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    memo = _switch_memo_dir(tmp_path_factory) / "oracle_memo.pkl"
+    r = subprocess.run([sys.executable, "-c", code, str(memo)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
 
 

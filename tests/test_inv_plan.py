@@ -100,7 +100,8 @@ def _run_plan(n, ld, nbins, load_pct, seed):
 
 
 @pytest.mark.parametrize("n,ld,nbins,load_pct", [(1024, 1024 + 32, 512, 100), (2048, 2048 + 32, 512, 100), (1536, 1536 + 16, 64, 100),
-                                                  (1280, 1280 + 32, 16, 50), (768, 800, 8, 200), (512, 544, 512, 100), (256, 272, 4, 100)])
+                                                  (1280, 1280 + 32, 16, 50), (768, 800, 8, 200), (512, 544, 512, 100), (256, 272, 4, 100),
+                                                  (1536, 1536 + 32, 1 << 20, 10 ** 8)])  # the last: what a batched sequence runs — no k range is cut
 def test_inv_plan_executed_in_numpy(n, ld, nbins, load_pct):
     L, Kmat, U, Kinv, stats, plan = _run_plan(n, ld, nbins, load_pct, seed=n + nbins)
     Uref = np.linalg.inv(L).T
@@ -112,6 +113,8 @@ def test_inv_plan_executed_in_numpy(n, ld, nbins, load_pct):
     assert not np.isnan(Kinv[il]).any()
     assert np.max(np.abs(Kinv[il] - Kref[il])) <= 1e-9 * np.max(np.abs(Kref))
     assert stats["max_chunks"] <= 4
+    if load_pct >= 10 ** 8:
+        assert stats["max_chunks"] == 1 and (plan[plan[:, 1] & 1 == 1][:, 4] == -1).all()  # folds only where a transposed copy is asked for
     # algorithmic flops: the products of the plan do 2 n^3 / 3 less what the leaves did, at tile granularity
     prods = plan[plan[:, 1] & 1 == 0]
     flops = float(np.sum(np.where(prods[:, 1] & 2, 64.0 * 64.0, 128.0 * 128.0) * 2.0 * prods[:, 8]))
