@@ -19,6 +19,7 @@
 // i.e. one symmetric N^3 product (MFMA GEMM, gemm.hip) + this kernel with (u, alpha, M) in place of
 // (alpha, alpha, K^-1) and a factor 2 (the pair sum visits the lower triangle once).
 #include "dev.h"
+#include "kfun_fast.h" // exp(-h), h >= 0, branch-free (< 1 ulp): the pair loop is arithmetic-bound, libm's exp was a third of it
 
 #define TILE 64
 
@@ -114,14 +115,14 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
                 zs += q * q;
             }
             if (LAM) { // squared_exp_ard.hpp:118-121
-                const double k = kp.sf2 * exp(-0.5 * zs);
+                const double k = kp.sf2 * exp_nonpos(-0.5 * zs);
                 const double wkf = -(w * k) * (fi - xj[lrow * TILE + cc]);
 #pragma unroll
                 for (int d = 0; d < DMAX; ++d)
                     acc[d] = fma(wkf, z[d], acc[d]);
             }
             else if (kp.kind == 0) { // squared_exp_ard.hpp:127-135 (k = 0 branch; k > 0: :114-116, :123)
-                const double k = kp.sf2 * exp(-0.5 * zs);
+                const double k = kp.sf2 * exp_nonpos(-0.5 * zs);
                 const double wk = w * k;
 #pragma unroll
                 for (int d = 0; d < DMAX; ++d)
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
                 const double r_ = sqrt(zs);
                 const double term1 = 2.23606797749978969641 * r_;
                 const double term2 = (5.0 / 3.0) * zs;
-                const double r = exp(-term1);
+                const double r = exp_nonpos(-term1);
                 const double g0 = kp.sf2 * (r * term1 * (1 + term1 + term2) + (-term1 - 2. * term2) * r);
                 const double g1 = 2 * kp.sf2 * (1 + term1 + term2) * r;
                 acc[0] = fma(w, g0, acc[0]);
@@ -140,14 +141,14 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
             }
             else if (kp.kind == 2) { // matern_three_halves.hpp:109-121
                 const double term = 1.73205080756887729353 * sqrt(zs);
-                const double r = exp(-term);
+                const double r = exp_nonpos(-term);
                 const double g0 = kp.sf2 * (-term * r + (1 + term) * term * r);
                 const double g1 = 2 * kp.sf2 * (1 + term) * r;
                 acc[0] = fma(w, g0, acc[0]);
                 acc[1] = fma(w, g1, acc[1]);
             }
             else { // exp.hpp:104-113
-                const double k = kp.sf2 * exp(-0.5 * zs);
+                const double k = kp.sf2 * exp_nonpos(-0.5 * zs);
                 acc[0] = fma(w * k, zs, acc[0]);
                 acc[1] = fma(w * k, 2.0, acc[1]);
             }
