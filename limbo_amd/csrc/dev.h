@@ -312,14 +312,15 @@ double gemm_flops(const GemmArgs& g);
 struct GemmItem {
     const double* A; // tile row origin at the first k of the chunk: A[r + kk * ld]
     const double* B; // tile column origin likewise: B[c + kk * ld]
-    double* C;       // tile origin, overwritten
-    int32_t k;       // multiple of 32
-    int32_t neg;     // 1: C = -A B^T
+    double* C;       // tile origin, overwritten (its first mr rows x nc columns: a ragged last tile stores nothing else)
+    int32_t k;       // multiple of 16
+    int32_t flags;   // bit 0: C = -A B^T; bits 8..15: mr, bits 16..23: nc — valid rows / columns of the tile (1 .. tile edge)
 };
 struct FoldItem {
     double* D;          // tile (128 x 128, or 64 x 64): D += P[0] + P[1] + P[2] (null entries skipped; D is not rewritten without any)
     const double* P[3];
     double* T;          // optional: the resulting tile transposed, T[c + r * ld] = D[r + c * ld]
+    int32_t mr, nc;     // valid rows / columns of D's tile
 };
 // (batched launches, g_batch: the lists hold member 0's pointers, workgroup z rebases them — dev.h: bt_rebase)
 void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld, int tile = 128); // tile: 128 or 64
@@ -327,7 +328,8 @@ void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld, 
 // the plan of one inversion (inv2.hip): host-built once per (N, ld, buffers), resident on the device
 struct Inv2Plan;
 Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride,
-                        int members = 1); // members: GPs stepped by the launches (a batched sequence: another plan from four on)
+                        int members = 1, bool* rebuilt = nullptr); // members: GPs stepped by the launches (a batched sequence: another
+                                                                   // plan from four on); rebuilt: the caller zero-fills U and S then
 void inv2_plan_free(Inv2Plan* p);
 bool inv2_supported(int64_t N);
 int inv2_partials();                // N x N partial buffers behind the W / T-form buffer in S (S holds 1 + this many)

@@ -150,6 +150,7 @@ struct gpe_ctx {
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     double* dInvS = nullptr; // the recursive K^-1's scratch (inv2.hip): T-forms / W | three partial buffers, ld x cap each
     Inv2Plan* inv2 = nullptr; // ... and its plan, rebuilt when N, ld or a buffer changes
+    int64_t inv_pad_n = -1;           // U and the T-form / W buffer read as zero beyond the inv_pad_n x inv_pad_n part (-1: unknown)
     Inv2Plan* inv2_batched = nullptr; // ... the plan of a batched sequence of >= 4 members led by this handle (no chunked k ranges)
     hipEvent_t chain_ev = nullptr; // the end of this handle's last evaluation chain when that ran on a CU-masked stream (ChainScope) ...
     bool chain_pending = false;    // ... and nobody has waited for it yet: the HOST does (wait_chain), never the handle's own stream
@@ -321,6 +322,7 @@ void free_dev(gpe_ctx* c)
     if (c->dInvS)
         hipFree(c->dInvS);
     c->dInvS = nullptr;
+    c->inv_pad_n = -1;
     inv2_plan_free(c->inv2);
     inv2_plan_free(c->inv2_batched);
     c->inv2 = c->inv2_batched = nullptr;
@@ -387,6 +389,7 @@ int grow_dev(gpe_ctx* c, int64_t need)
     c->dY = nY;
     c->dXinv = nXi;
     c->dLinv = c->dKinv = c->dLooS = c->dLooV = nullptr;
+    c->inv_pad_n = -1;
     c->inv_ok = false;
     c->cap = ncap;
     c->ld = nld;
@@ -1317,18 +1320,40 @@ static LamParams lam_params(const gpe_ctx* c)
     return lp;
 }
 
+// What lies beyond the N x N part of U and of the T-form / W buffer must read as zero — the k ranges of a ragged order run to N
+// rounded up to 64, and no launch ever writes there (every tile stores its valid part only).  Once per order and allocation.
+static void inv2_zero_pads(gpe_ctx* c, hipStream_t s)
+{
+    if (!c->dLinv || !c->dInvS)
+        return;
+    if (c->inv_pad_n >= 0 && c->N >= c->inv_pad_n) { // (a larger N: its pads lie inside the pads that are zero already)
+        c->inv_pad_n = c->N;
+        return;
+    }
+    hipMemsetAsync(c->dLinv, 0, sizeof(double) * (size_t)(c->ld * c->cap), s);
+    hipMemsetAsync(c->dInvS, 0, sizeof(double) * (size_t)(c->ld * c->cap), s);
+    c->inv_pad_n = c->N;
+}
+
 // buffers and plan of the recursive K^-1 (inv2.hip) for the factor at hand
 static int inv2_prepare(gpe_ctx* c)
 {
     const int64_t ld = c->ld;
-    if (!c->dLinv)
+    if (!c->dLinv) {
         HIPCHK(c, hipMalloc(&c->dLinv, sizeof(double) * (size_t)(ld * c->cap)));
+        c->inv_pad_n = -1; // (fresh memory: the pads of the recursive K^-1 are to be zero-filled)
+    }
     if (!c->dKinv)
         HIPCHK(c, hipMalloc(&c->dKinv, sizeof(double) * (size_t)(ld * c->cap)));
-    if (!c->dInvS)
+    if (!c->dInvS) {
         HIPCHK(c, hipMalloc(&c->dInvS, sizeof(double) * (size_t)(ld * c->cap) * (size_t)(1 + inv2_partials())));
+        c->inv_pad_n = -1; // (fresh memory: the pads of the recursive K^-1 are to be zero-filled)
+    }
     Inv2Plan*& slot = g_batch.G >= 4 ? c->inv2_batched : c->inv2;
-    slot = inv2_plan_get(slot, c->N, ld, c->dA, c->dLinv, c->dKinv, c->dInvS, ld * c->cap, g_batch.G);
+    bool rebuilt = false;
+    slot = inv2_plan_get(slot, c->N, ld, c->dA, c->dLinv, c->dKinv, c->dInvS, ld * c->cap, g_batch.G, &rebuilt);
+    (void)rebuilt;
+    inv2_zero_pads(c, c->stream);
     if (!slot) {
         c->err = "K^-1: no memory for the plan of the recursion";
         return GPE_ERR_NOMEM;
@@ -1362,13 +1387,15 @@ int ensure_inv(gpe_ctx* c)
         return GPE_ERR_STATE;
     hipStream_t s = c->stream;
     const int64_t N = c->N, ld = c->ld;
-    if (!c->dLinv)
+    if (!c->dLinv) {
         HIPCHK(c, hipMalloc(&c->dLinv, sizeof(double) * (size_t)(ld * c->cap)));
+        c->inv_pad_n = -1; // (fresh memory: the pads of the recursive K^-1 are to be zero-filled)
+    }
     if (!c->dKinv)
         HIPCHK(c, hipMalloc(&c->dKinv, sizeof(double) * (size_t)(ld * c->cap)));
     if (inv2_supported(N)) {
         // Round 5: the recursion of inv2.hip — a dozen launches of tile-product lists with k = 256 .. N / 2 instead of 48
-        // launches of k = 256 (N a multiple of 256; everything else keeps the panel form below).  A batched sequence runs the
+        // launches of k = 256 (N >= 1024, ragged orders included; smaller ones keep the panel form below).  A batched sequence runs the
         // same lists for every member (gridDim.z; batch_enqueue_fused allocated every member's scratch).
         int rc = inv2_prepare(c);
         if (rc)
@@ -1389,6 +1416,7 @@ int ensure_inv(gpe_ctx* c)
         return GPE_OK;
     }
     static const bool inv_panels = !(getenv("GPE_INV_PANELS") && atoi(getenv("GPE_INV_PANELS")) == 0);
+    c->inv_pad_n = -1; // (the forms below write whole tiles of the U buffer)
     if (inv_panels && c->nbo % 128 == 0 && c->nbo <= 256) {
         // Transposed formulation: U = L^-T (upper triangular) is built in dLinv, K^-1 = U U^T.  Every product below
         // is C (-/+)= A B^T with A and B contiguous along their non-k index — the operand layout of the LDS-direct
@@ -1561,8 +1589,10 @@ static int loo_weights(gpe_ctx* c)
         return rc;
     hipStream_t s = c->stream;
     const int64_t N = c->N, ld = c->ld;
-    if (!c->dLinv) // a clone that inherited K^-1 never ran ensure_inv's allocation
+    if (!c->dLinv) { // a clone that inherited K^-1 never ran ensure_inv's allocation
         HIPCHK(c, hipMalloc(&c->dLinv, sizeof(double) * (size_t)(ld * c->cap)));
+        c->inv_pad_n = -1; // (fresh memory: the pads of the recursive K^-1 are to be zero-filled)
+    }
     double *v = c->dLooV, *sc = c->dLooV + ld * c->P, *val = sc + ld, *outp = c->dLooV + ld * (c->P + 2);
     {
         PhaseScope ps(c, GPE_PH_GRAD, 0.0);
@@ -3226,12 +3256,18 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
         for (int q = 0; q < Gc; ++q) {
             gpe_ctx* c = cs[q];
             const size_t mat = sizeof(double) * (size_t)(c->ld * c->cap);
-            if (!c->dLinv)
+            if (!c->dLinv) {
                 HIPCHK(c, hipMalloc(&c->dLinv, mat));
+                c->inv_pad_n = -1; // (fresh memory: the pads of the recursive K^-1 are to be zero-filled)
+            }
             if (!c->dKinv)
                 HIPCHK(c, hipMalloc(&c->dKinv, mat));
-            if (!c->dInvS && inv2_supported(c->N)) // the recursive K^-1's scratch (inv2.hip)
+            if (!c->dInvS && inv2_supported(c->N)) { // the recursive K^-1's scratch (inv2.hip)
                 HIPCHK(c, hipMalloc(&c->dInvS, mat * (size_t)(1 + inv2_partials())));
+                c->inv_pad_n = -1; // (fresh memory: the pads of the recursive K^-1 are to be zero-filled)
+            }
+            if (inv2_supported(c->N))
+                inv2_zero_pads(c, c0->stream); // (every member's, on the stream the batch runs on)
             int rc = ensure_grad_partial(c, want->n_grad);
             if (rc)
                 return rc;

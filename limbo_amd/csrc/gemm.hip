@@ -652,9 +652,17 @@ __global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __rest
             item.B = bt_rebase(bt, (int)blockIdx.z, item.B);
             item.C = bt_rebase(bt, (int)blockIdx.z, item.C);
         }
-        // this lane's 16-byte piece of every k-row: rows (2 lane, 2 lane + 1); wave w moves k-rows w, w + 8, ..
-        const double* pa = item.A + 2 * lane + (int64_t)wave * ld;
-        const double* pb = item.B + 2 * lane + (int64_t)wave * ld;
+        // this lane's 16-byte piece of every k-row: rows (2 lane, 2 lane + 1), clamped into the tile's valid rows (copies of
+        // valid rows only feed outputs the epilogue does not store); wave w moves k-rows w, w + 8, ..
+        const int mr = (item.flags >> 8) & 255, nc = (item.flags >> 16) & 255;
+        int ra = 2 * lane, rb = 2 * lane;
+        {
+            const int ma = (mr - 1) & ~1, mb = (nc - 1) & ~1;
+            ra = ra < ma ? ra : ma;
+            rb = rb < mb ? rb : mb;
+        }
+        const double* pa = item.A + ra + (int64_t)wave * ld;
+        const double* pb = item.B + rb + (int64_t)wave * ld;
         auto issue = [&](int stage) {
             double* sa = lds + stage * STAGE + wave * SA;
             double* sb = lds + stage * STAGE + BKT * SA + wave * SB;
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __rest
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier(); // stage st may be refilled
         }
-        if (item.neg) {
+        if (item.flags & 1) {
 #pragma unroll
             for (int a = 0; a < RA; ++a)
 #pragma unroll
@@ -715,7 +723,9 @@ __global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __rest
             constexpr int SCR = WT::SCRATCH / EPC;
             static_assert(NWV * SCR <= NST * STAGE, "transposition scratch must fit in the operand stages");
             // the k loop ended with a barrier: the stages are free, each wave uses a private slice
-            WT::template rmw_chunked<EPC>(acc, lds + wave * SCR, item.C + (int64_t)wn * ld + wm, ld, WT::R, WT::CN, 1, lane);
+            const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
+            if (rlim > 0 && clim > 0)
+                WT::template rmw_chunked<EPC>(acc, lds + wave * SCR, item.C + (int64_t)wn * ld + wm, ld, rlim, clim, 1, lane);
         }
         __syncthreads(); // the next item's prologue overwrites the LDS stages
     }
@@ -749,9 +759,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_gemm_items64(const GemmItem* __
             item.B = bt_rebase(bt, (int)blockIdx.z, item.B);
             item.C = bt_rebase(bt, (int)blockIdx.z, item.C);
         }
-        // this lane's 16-byte piece: rows (2 l', 2 l' + 1) of k-row kk + (lane >> 5), l' = lane & 31; wave w moves k-row pairs w, w + NWV, ..
-        const double* pa = item.A + r2 + (int64_t)(2 * wave + khalf) * ld;
-        const double* pb = item.B + r2 + (int64_t)(2 * wave + khalf) * ld;
+        // this lane's 16-byte piece: rows (2 l', 2 l' + 1) of k-row kk + (lane >> 5), l' = lane & 31, clamped into the tile's valid
+        // rows; wave w moves k-row pairs w, w + NWV, ..
+        const int mr = (item.flags >> 8) & 255, nc = (item.flags >> 16) & 255;
+        const int ma = (mr - 1) & ~1, mb = (nc - 1) & ~1;
+        const double* pa = item.A + (r2 < ma ? r2 : ma) + (int64_t)(2 * wave + khalf) * ld;
+        const double* pb = item.B + (r2 < mb ? r2 : mb) + (int64_t)(2 * wave + khalf) * ld;
         auto issue = [&](int stage) {
             double* sa = lds + stage * STAGE + wave * PAIR;
             double* sb = sa + OPER;
@@ -808,7 +821,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_gemm_items64(const GemmItem* __
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier(); // stage st may be refilled
         }
-        if (item.neg) {
+        if (item.flags & 1) {
 #pragma unroll
             for (int a = 0; a < RA; ++a)
 #pragma unroll
@@ -822,7 +835,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_gemm_items64(const GemmItem* __
 #pragma unroll
             for (int q = 0; q < WT::NIT; ++q)
                 cv[q] = 0.0; // (overwrite: C is not read)
-            WT::store(acc, cv, lds + wave * WT::SCRATCH, item.C + (int64_t)wn * ld + wm, ld, WT::R, WT::CN, 1, lane);
+            const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
+            if (rlim > 0 && clim > 0)
+                WT::store(acc, cv, lds + wave * WT::SCRATCH, item.C + (int64_t)wn * ld + wm, ld, rlim, clim, 1, lane);
         }
         __syncthreads(); // the next item's prologue overwrites the LDS stages
     }

@@ -17,6 +17,7 @@
 // kernel is plain FMA from LDS, one workgroup per 32-column strip of a panel (8 x npanels
 // workgroups), the strip's tiles of the result staying in LDS as the right-hand operand of the
 // later ones:   Y_ss = X_s,   Y_is = -X_i * sum_{k=s}^{i-1} L_ik Y_ks   (i > s, 64-row blocks).
+#include <type_traits>
 #include "dev.h"
 
 #define NB 64
@@ -195,13 +196,15 @@ __global__ __launch_bounds__(256) void k_fold_items(const FoldItem* __restrict__
     }
     const int r = threadIdx.x & 63, c4 = threadIdx.x >> 6;
     const bool sum = it.P[0] != nullptr;
-#pragma unroll 1
-    for (int q = 0; q < QUARTERS; ++q) {
-        const int r0 = (q & 1) * 64, c0 = (q >> 1) * 64;
+    // one 64 x 64 quarter; MASKED (a ragged last tile: block-uniform) guards every element, the full form keeps its 16 loads in flight
+    auto quarter = [&](int r0, int c0, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+        const bool rok = !MASKED || r0 + r < it.mr;
+        auto ok = [&](int j) { return !MASKED || (rok && c0 + c4 + 4 * j < it.nc); };
         double v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            v[j] = it.D[(int64_t)(c0 + c4 + 4 * j) * ld + r0 + r];
+            v[j] = ok(j) ? it.D[(int64_t)(c0 + c4 + 4 * j) * ld + r0 + r] : 0.0;
         if (sum) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
@@ -209,11 +212,13 @@ __global__ __launch_bounds__(256) void k_fold_items(const FoldItem* __restrict__
                     break;
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    v[j] += it.P[p][(int64_t)(c0 + c4 + 4 * j) * ld + r0 + r];
+                    if (ok(j))
+                        v[j] += it.P[p][(int64_t)(c0 + c4 + 4 * j) * ld + r0 + r];
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                it.D[(int64_t)(c0 + c4 + 4 * j) * ld + r0 + r] = v[j];
+                if (ok(j))
+                    it.D[(int64_t)(c0 + c4 + 4 * j) * ld + r0 + r] = v[j];
         }
         if (it.T) {
 #pragma unroll
@@ -224,10 +229,21 @@ __global__ __launch_bounds__(256) void k_fold_items(const FoldItem* __restrict__
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int y = c4 + 4 * j;
-                it.T[(int64_t)(r0 + y) * ld + c0 + r] = sh[r * 65 + y];
+                if (!MASKED || (r0 + y < it.mr && c0 + r < it.nc))
+                    it.T[(int64_t)(r0 + y) * ld + c0 + r] = sh[r * 65 + y];
             }
             __syncthreads();
         }
+    };
+#pragma unroll 1
+    for (int q = 0; q < QUARTERS; ++q) {
+        const int r0 = (q & 1) * 64, c0 = (q >> 1) * 64;
+        if (r0 >= it.mr || c0 >= it.nc)
+            continue;
+        if (r0 + 64 <= it.mr && c0 + 64 <= it.nc)
+            quarter(r0, c0, std::false_type{});
+        else
+            quarter(r0, c0, std::true_type{});
     }
 }
 void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld, int tile)

@@ -44,10 +44,11 @@ struct SymRef {
 };
 struct SymItem {
     SymRef a, b, c;
-    int k = 0, neg = 0;
+    int k = 0, neg = 0, mr = 0, nc = 0;
 };
 struct SymFold {
     SymRef d, p[NPART], t;
+    int mr = 0, nc = 0;
 };
 struct SymStep {
     int kind = 0; // 0: tile products, 1: folds
@@ -63,10 +64,11 @@ struct SymPlan {
     std::vector<SymStep> steps;
 };
 
-// an unchunked tile product: depth `units` * (tile edge) from the operands' origins, destination d, optional transposed copy
+// an unchunked tile product: depth klen from the operands' origins (a multiple of 64; the last tile of a ragged order may end
+// short of a whole tile edge), destination d with mr x nc valid entries, optional transposed copy
 struct Prod {
     SymRef a, b, d, t;
-    int units = 0, neg = 0;
+    int klen = 0, neg = 0, mr = 0, nc = 0;
 };
 
 struct Node {
@@ -98,11 +100,12 @@ void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extr
 {
     if (prods.empty() && extra_folds.empty())
         return;
+    auto units_of = [&](const Prod& p) { return (p.klen + te - 1) / te; };
     int64_t total = 0;
     int lmax = 1;
     for (const Prod& p : prods) {
-        total += p.units;
-        lmax = std::max(lmax, p.units);
+        total += units_of(p);
+        lmax = std::max(lmax, units_of(p));
     }
     // chunk length (in units of one tile edge of depth): no chunk much longer than a share of the launch, at most 1 + NPART
     // chunks per tile, never below 256 of depth (a fold launch costs more than it saves there)
@@ -117,27 +120,33 @@ void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extr
     std::vector<SymFold> folds;
     double flops = 0.0;
     for (const Prod& p : prods) {
-        const int nch = (p.units + ch - 1) / ch;
-        const int base = p.units / nch, rem = p.units % nch;
+        const int units = units_of(p);
+        const int nch = (units + ch - 1) / ch;
+        const int base = units / nch, rem = units % nch;
         SymFold f;
         f.d = p.d;
         f.t = p.t;
-        int k0 = 0;
+        f.mr = p.mr;
+        f.nc = p.nc;
+        int u0 = 0;
         for (int c = 0; c < nch; ++c) {
             const int u = base + (c < rem ? 1 : 0);
+            const int k0 = u0 * te, k1 = std::min((u0 + u) * te, p.klen);
             Chunk q;
-            q.it.a = {p.a.buf, p.a.off + (int64_t)k0 * te * ld};
-            q.it.b = {p.b.buf, p.b.off + (int64_t)k0 * te * ld};
+            q.it.a = {p.a.buf, p.a.off + (int64_t)k0 * ld};
+            q.it.b = {p.b.buf, p.b.off + (int64_t)k0 * ld};
             q.it.c = c == 0 ? p.d : SymRef{B_P1 + c - 1, p.d.off};
-            q.it.k = u * te;
+            q.it.k = k1 - k0;
             q.it.neg = p.neg;
+            q.it.mr = p.mr;
+            q.it.nc = p.nc;
             q.units = u;
             chunks.push_back(q);
             if (c > 0)
                 f.p[c - 1] = q.it.c;
-            k0 += u;
+            u0 += u;
         }
-        flops += 2.0 * te * te * (double)p.units * te;
+        flops += 2.0 * p.mr * p.nc * (double)p.klen;
         if (nch > 1 || p.t.buf != B_NONE)
             folds.push_back(f);
     }
@@ -195,13 +204,17 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load, int membe
         load = 1e9;
         nbins = 1 << 20;
     }
-    const int npan = (int)(N / LEAF);
+    const int npan = (int)((N + LEAF - 1) / LEAF);
+    const int64_t N64 = (N + 63) / 64 * 64; // how far a k range may run: the buffers hold zeros between N and their capacity
     std::vector<Node> nodes;
     make_tree(nodes, 0, npan, false);
     int H = 0;
     for (const Node& n : nodes)
         H = std::max(H, n.height);
     auto at = [&](int64_t row, int64_t col) { return row + col * ld; };
+    // A ragged order: the last panel is the only partial one and always sits in a RIGHT child, so every left block is whole
+    // panels; tiles of the last row / column strip carry fewer valid rows / columns (mr, nc), k ranges over the right block end
+    // at N rounded up to 64.
     for (int h = 1; h <= H; ++h) {
         int64_t tiles128 = 0;
         for (const Node& n : nodes)
@@ -213,24 +226,30 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load, int membe
         for (const Node& n : nodes) {
             if (n.height != h)
                 continue;
-            const int64_t a0 = (int64_t)n.lo * LEAF, am = (int64_t)n.mid * LEAF, ce = (int64_t)n.hi * LEAF;
-            const int ta = (int)((am - a0) / TILE), tc = (int)((ce - am) / TILE);
+            const int64_t a0 = (int64_t)n.lo * LEAF, am = (int64_t)n.mid * LEAF;
+            const int64_t ce = std::min<int64_t>((int64_t)n.hi * LEAF, N), ce64 = std::min<int64_t>((int64_t)n.hi * LEAF, N64);
+            const int ta = (int)((am - a0) / TILE), tc = (int)((ce - am + TILE - 1) / TILE);
             for (int i = 0; i < ta; ++i)
                 for (int j = 0; j < tc; ++j) {
+                    const int ncj = (int)std::min<int64_t>(TILE, ce - (am + (int64_t)j * TILE)); // valid columns of the strip
                     // W[i, j] = sum_{k >= i} U_a[i, k] B[j, k]
                     Prod w;
                     w.a = {B_U, at(a0 + (int64_t)i * TILE, a0 + (int64_t)i * TILE)};
                     w.b = {B_L, at(am + (int64_t)j * TILE, a0 + (int64_t)i * TILE)};
                     w.d = {B_S0, at(a0 + (int64_t)i * TILE, am + (int64_t)j * TILE)};
-                    w.units = ta - i;
+                    w.klen = (ta - i) * TILE;
+                    w.mr = TILE;
+                    w.nc = ncj;
                     w_prods.push_back(w);
                     // U_b[i, j] = -sum_{k <= j} W[i, k] T_c[j, k]
                     Prod u;
                     u.a = {B_S0, at(a0 + (int64_t)i * TILE, am)};
                     u.b = {B_S0, at(am + (int64_t)j * TILE, am)};
                     u.d = {B_U, at(a0 + (int64_t)i * TILE, am + (int64_t)j * TILE)};
-                    u.units = j + 1;
+                    u.klen = (int)std::min<int64_t>((int64_t)(j + 1) * TILE, ce64 - am);
                     u.neg = 1;
+                    u.mr = TILE;
+                    u.nc = ncj;
                     if (n.is_right) // this node's own T-form: T_b = U_b^T
                         u.t = {B_S0, at(am + (int64_t)j * TILE, a0 + (int64_t)i * TILE)};
                     u_prods.push_back(u);
@@ -243,6 +262,7 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load, int membe
                         SymFold f;
                         f.d = {B_U, at(a0 + (int64_t)i * TILE, a0 + (int64_t)j * TILE)};
                         f.t = {B_S0, at(a0 + (int64_t)j * TILE, a0 + (int64_t)i * TILE)};
+                        f.mr = f.nc = TILE;
                         t_folds.push_back(f);
                     }
             }
@@ -255,14 +275,16 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load, int membe
     // K^-1[i, j] = sum_{k >= i} U[i, k] U[j, k], i >= j
     std::vector<Prod> k_prods;
     constexpr int TILE = 128;
-    const int nt = (int)(N / TILE);
+    const int nt = (int)((N + TILE - 1) / TILE);
     for (int i = 0; i < nt; ++i)
         for (int j = 0; j <= i; ++j) {
             Prod p;
             p.a = {B_U, at((int64_t)i * TILE, (int64_t)i * TILE)};
             p.b = {B_U, at((int64_t)j * TILE, (int64_t)i * TILE)};
             p.d = {B_K, at((int64_t)i * TILE, (int64_t)j * TILE)};
-            p.units = nt - i;
+            p.klen = (int)(N64 - (int64_t)i * TILE);
+            p.mr = (int)std::min<int64_t>(TILE, N - (int64_t)i * TILE);
+            p.nc = (int)std::min<int64_t>(TILE, N - (int64_t)j * TILE);
             k_prods.push_back(p);
         }
     emit(pl, k_prods, {}, ld, nbins, load, TILE);
@@ -294,7 +316,7 @@ bool inv2_supported(int64_t N)
 {
     static const int on = getenv("GPE_INV2") ? atoi(getenv("GPE_INV2")) : 1;
     static const int64_t min_n = getenv("GPE_INV2_MIN_N") ? atoll(getenv("GPE_INV2_MIN_N")) : 1024;
-    return on && N >= min_n && N % LEAF == 0;
+    return on && N >= min_n;
 }
 int inv2_partials() { return NPART; }
 
@@ -307,11 +329,16 @@ void inv2_plan_free(Inv2Plan* p)
     delete p;
 }
 
-Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride, int members)
+Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride, int members,
+                        bool* rebuilt)
 {
+    if (rebuilt)
+        *rebuilt = false;
     if (old && old->N == N && old->ld == ld && old->L == L && old->U == U && old->K == Kinv && old->S == S && old->pstride == pstride
         && (old->members >= 4) == (members >= 4))
         return old;
+    if (rebuilt)
+        *rebuilt = true;
     inv2_plan_free(old);
     SymPlan sp;
     build(sp, N, ld, PLAN_BINS, PLAN_LOAD, members);
@@ -334,7 +361,7 @@ Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, d
         gi[i].B = res(sp.items[i].b);
         gi[i].C = res(sp.items[i].c);
         gi[i].k = sp.items[i].k;
-        gi[i].neg = sp.items[i].neg;
+        gi[i].flags = (sp.items[i].neg & 1) | (sp.items[i].mr << 8) | (sp.items[i].nc << 16);
     }
     std::vector<FoldItem> fi(sp.folds.size());
     for (size_t i = 0; i < fi.size(); ++i) {
@@ -342,6 +369,8 @@ Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, d
         for (int q = 0; q < NPART; ++q)
             fi[i].P[q] = res(sp.folds[i].p[q]);
         fi[i].T = res(sp.folds[i].t);
+        fi[i].mr = sp.folds[i].mr;
+        fi[i].nc = sp.folds[i].nc;
     }
     const size_t b0 = sizeof(GemmItem) * gi.size(), b1 = sizeof(FoldItem) * fi.size(), b2 = sizeof(int32_t) * sp.bin_start.size();
     const size_t o1 = (b0 + 255) / 256 * 256, o2 = o1 + (b1 + 255) / 256 * 256;
@@ -384,14 +413,15 @@ void inv2_run(hipStream_t s, Inv2Plan* p, const double* Xt_all, int part)
     }
 }
 
-// test hook (gpe_debug_inv_plan): the plan for order N, leading dimension ld; rows of 10 int64:
+// test hook (gpe_debug_inv_plan): the plan for order N, leading dimension ld; rows of 12 int64 (the last two: valid rows and
+// columns of the tile):
 //   products: { step, 0 | 2, A buf, A off, B buf, B off, C buf, C off, k, neg | share << 1 }   (in launch order, share by share;
 //             0: 128 x 128 tiles, 2: 64 x 64 tiles)
 //   folds   : { step, 1 | 3, D buf, D off, P1 off | -1, P2 off | -1, P3 off | -1, T buf | -1, T off, 0 }
 // buffers: 0 L, 1 U, 2 K^-1, 3 T-forms / W, 4..6 partials.  Returns the number of rows (also when out is too small).
 int inv2_debug_plan(int64_t N, int64_t ld, int nbins, int load_pct, int64_t* out, int64_t cap_rows)
 {
-    if (N <= 0 || N % LEAF != 0 || ld < N)
+    if (N <= 0 || ld < (N + 63) / 64 * 64)
         return -1;
     SymPlan sp;
     build(sp, N, ld, nbins > 0 ? nbins : PLAN_BINS, load_pct > 0 ? load_pct / 100.0 : PLAN_LOAD, 1);
@@ -401,21 +431,21 @@ int inv2_debug_plan(int64_t N, int64_t ld, int nbins, int load_pct, int64_t* out
         for (int i = 0; i < st.count; ++i, ++row) {
             if (row >= cap_rows || !out)
                 continue;
-            int64_t* o = out + row * 10;
+            int64_t* o = out + row * 12;
             if (st.kind == 0) {
                 const SymItem& it = sp.items[(size_t)(st.off + i)];
                 int64_t bin = 0; // the share (= workgroup of the launch) this product belongs to
                 while (bin + 1 < st.bins && sp.bin_start[(size_t)(st.bin_off + bin + 1)] <= st.off + i)
                     ++bin;
-                const int64_t v[10] = {(int64_t)s, st.te == 64 ? 2 : 0, it.a.buf, it.a.off, it.b.buf, it.b.off, it.c.buf, it.c.off, it.k, it.neg | (bin << 1)};
-                std::copy(v, v + 10, o);
+                const int64_t v[12] = {(int64_t)s, st.te == 64 ? 2 : 0, it.a.buf, it.a.off, it.b.buf, it.b.off, it.c.buf, it.c.off, it.k, it.neg | (bin << 1), it.mr, it.nc};
+                std::copy(v, v + 12, o);
             }
             else {
                 const SymFold& f = sp.folds[(size_t)(st.off + i)];
-                const int64_t v[10] = {(int64_t)s, st.te == 64 ? 3 : 1, f.d.buf, f.d.off, f.p[0].buf == B_NONE ? -1 : f.p[0].off,
+                const int64_t v[12] = {(int64_t)s, st.te == 64 ? 3 : 1, f.d.buf, f.d.off, f.p[0].buf == B_NONE ? -1 : f.p[0].off,
                                        f.p[1].buf == B_NONE ? -1 : f.p[1].off, f.p[2].buf == B_NONE ? -1 : f.p[2].off,
-                                       f.t.buf, f.t.off, 0};
-                std::copy(v, v + 10, o);
+                                       f.t.buf, f.t.off, 0, f.mr, f.nc};
+                std::copy(v, v + 12, o);
             }
         }
     }

@@ -929,6 +929,30 @@ def test_gpu_c2_full_size_gradient_objective_vs_lapack(engine_lib, on):
     h.close()
 
 
+@pytest.mark.parametrize("N", [1025, 1700, 2944])
+def test_gpu_kinv_recursion_at_ragged_orders_vs_lapack(engine_lib, N):
+    """K^-1 (gp.hpp:254-264) and d log-lik / d theta (gp.hpp:285-311) where the recursion of csrc/inv2.hip meets a partial last
+    panel and partial last tiles (N = 1025: one sample beyond a tile edge; 1700; 2944 = 11.5 panels): the whole matrix against
+    dpotrf / dpotri-style LAPACK on the host 1e-9, the gradient 1e-6; then the same handle with 37 samples fewer (the k ranges of a
+    ragged order run over the pads of the recursion's buffers, which must read as zero again) and with the samples back."""
+    X, Y = synth.make_problem("c2", N=N)
+    om, _ = synth.obs_mean_data(Y)
+    rng = np.random.default_rng(N)
+    th = rng.uniform(-0.3, 0.3, size=7)
+    noise = 0.01
+    h = new_gp(engine_lib, O.SE_ARD, X, om, th, noise)
+    for Xs, oms in ((X, om), (X[:N - 37], om[:N - 37]), (X, om)):
+        h.set_data(Xs, oms)
+        assert h.compute() == 0
+        g = h.log_lik_grad(True)
+        Kinv = h.get_Kinv()
+        _, g_r, Kinv_r, _ = _lapack_grad_se_ard(Xs, th, noise, oms, True)
+        e_ki, e_g = relerr_norm(Kinv, Kinv_r), relerr_norm(g, g_r)
+        print(f"N = {len(Xs)}: K^-1 {e_ki:.2e}  grad {e_g:.2e}")
+        assert not np.isnan(Kinv).any() and e_ki < 1e-9 and e_g < PC.TOL_GRAD and np.max(np.abs(Kinv - Kinv.T)) == 0.0
+    h.close()
+
+
 def test_gpu_c2_full_size_fit_lockstep_vs_lapack(engine_lib):
     """BASELINE configs[1] end to end at its own size: a KernelLFOpt fit (model/gp/kernel_lf_opt.hpp:60-69 -> opt/rprop.hpp:84-144)
     at N = 4096 with 4 restarts (parallel_repeater.hpp:84-105) advanced in lock-step, every iteration ONE

@@ -1,10 +1,13 @@
 """The launch plan of the recursive K^-1 (limbo_amd/csrc/inv2.hip; GP::compute_inv_kernel, src/limbo/model/gp.hpp:254-264)
 EXECUTED IN NUMPY — host logic, no device.  gpe_debug_inv_plan hands out every tile product and tile fold of the plan as
-(buffer, offset, depth) rows in launch order; here each is carried out literally on column-major numpy buffers, with the leaf
-inverses (what k_inv_panels leaves) from numpy: U must come out as L^-T, the lower triangle of K^-1 as LAPACK's.  Also held:
+(buffer, offset, depth, valid rows, valid columns) rows in launch order; here each is carried out literally on column-major
+numpy buffers, with the leaf inverses (what k_inv_panels leaves) from numpy: U must come out as L^-T, the lower triangle of K^-1
+as LAPACK's — for any order N, ragged ones included (the last panel and the last tiles are partial: a tile stores its valid part
+only, k ranges run to N rounded up to 64 over the zero-filled pads of U and of the T-form / W buffer).  Also held:
 the k range of no tile is cut into more than 1 + 3 chunks, every product launch is dealt into shares whose longest is no
 longer than the mean share + one chunk, every tile a product reads was written before (nothing relies on zero-filled
-memory), and launches of one step never read what the same step writes."""
+memory inside the N x N part, nothing reads the other buffers' pads at all), and launches of one step never read what the same
+step writes."""
 import ctypes
 
 import numpy as np
@@ -22,15 +25,16 @@ def _plan(n, ld, nbins=512, load_pct=100):
     f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int64]
     rows = f(n, ld, nbins, load_pct, None, 0)
     assert rows > 0
-    out = np.zeros((rows, 10), dtype=np.int64)
+    out = np.zeros((rows, 12), dtype=np.int64)
     assert f(n, ld, nbins, load_pct, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), rows) == rows
     return out
 
 
-def _tile(buf, off, ld, te, cols=None):
-    """view of the te x cols block whose origin is at offset `off` of a column-major buffer with leading dimension ld"""
+def _tile(buf, off, ld, rows, cols):
+    """view of the rows x cols block whose origin is at offset `off` of a column-major buffer with leading dimension ld"""
     r, c = off % ld, off // ld
-    return buf[r:r + te, c:c + (te if cols is None else cols)]
+    assert r + rows <= buf.shape[0] and c + cols <= buf.shape[1], "a tile reaches beyond its buffer"
+    return buf[r:r + rows, c:c + cols]
 
 
 def _run_plan(n, ld, nbins, load_pct, seed):
@@ -38,16 +42,20 @@ def _run_plan(n, ld, nbins, load_pct, seed):
     A = rng.normal(size=(n, n)) / np.sqrt(n)
     Kmat = A @ A.T + 0.3 * np.eye(n)
     L = np.linalg.cholesky(Kmat)
-    cap = n
+    cap = (n + 63) // 64 * 64  # (engine.hip, alloc_dev: the capacity is a multiple of 64)
     NAN = np.nan
     bufs = [np.full((ld, cap), NAN) for _ in range(7)]  # [row, col] = offset row + col * ld
     bufs[0][:n, :n] = L
-    # the leaves (k_inv_panels): X_p into the T-form buffer, X_p^T into U, full 256 x 256 squares
+    for b in (1, 3):  # U and the T-form / W buffer: zero-filled beyond the N x N part (engine.hip, inv2_zero_pads)
+        bufs[b][:, :] = 0.0
+        bufs[b][:n, :n] = NAN
+    # the leaves (k_inv_panels): X_p into the T-form buffer, X_p^T into U, full squares (the last one partial)
     for p0 in range(0, n, 256):
         X = np.linalg.inv(L[p0:p0 + 256, p0:p0 + 256])
         X = np.tril(X)
-        bufs[3][p0:p0 + 256, p0:p0 + 256] = X
-        bufs[1][p0:p0 + 256, p0:p0 + 256] = X.T
+        pw = X.shape[0]
+        bufs[3][p0:p0 + pw, p0:p0 + pw] = X
+        bufs[1][p0:p0 + pw, p0:p0 + pw] = X.T
     plan = _plan(n, ld, nbins, load_pct)
     steps = plan[:, 0]
     stats = dict(launches=int(steps.max()) + 1, products=0, folds=0, max_chunks=1)
@@ -62,38 +70,44 @@ def _run_plan(n, ld, nbins, load_pct, seed):
             results = []
             written = set()
             for r in rows:
-                _, _, ab, ao, bb, bo, cb, co, k, neg = (int(v) for v in r)
+                _, _, ab, ao, bb, bo, cb, co, k, neg, mr, nc = (int(v) for v in r)
                 neg &= 1
-                assert k % te == 0 and k >= te and k % 32 == 0
-                At, Bt = _tile(bufs[ab], ao, ld, te, k), _tile(bufs[bb], bo, ld, te, k)
+                assert k % 64 == 0 and k >= 64 and 1 <= mr <= te and 1 <= nc <= te
+                assert ao % ld + mr <= n and bo % ld + nc <= n and co % ld + mr <= n and co // ld + nc <= n  # valid parts lie inside N
+                At, Bt = _tile(bufs[ab], ao, ld, mr, k), _tile(bufs[bb], bo, ld, nc, k)
                 assert not np.isnan(At).any() and not np.isnan(Bt).any(), "a product reads memory nothing wrote"
                 v = At @ Bt.T
-                results.append((cb, co, -v if neg else v))
+                results.append((cb, co, mr, nc, -v if neg else v))
                 assert (cb, co) not in written, "two products of one launch write the same tile"
                 written.add((cb, co))
-            reads = {(int(r[2]), int(r[3]) % ld // te, (int(r[3]) // ld + kk) // te) for r in rows for kk in range(0, int(r[8]), te)}
-            reads |= {(int(r[4]), int(r[5]) % ld // te, (int(r[5]) // ld + kk) // te) for r in rows for kk in range(0, int(r[8]), te)}
-            writes = {(cb, co % ld // te, co // ld // te) for cb, co, _ in results}
+            reads = {(int(r[2]), int(r[3]) % ld // te, (int(r[3]) // ld + kk) // te) for r in rows for kk in range(0, int(r[8]), 64)}
+            reads |= {(int(r[4]), int(r[5]) % ld // te, (int(r[5]) // ld + kk) // te) for r in rows for kk in range(0, int(r[8]), 64)}
+            writes = {(cb, co % ld // te, co // ld // te) for cb, co, _, _, _ in results}
             assert not (reads & writes), "a launch reads a tile it also writes"
-            for cb, co, v in results:
-                _tile(bufs[cb], co, ld, te)[:, :] = v
+            for cb, co, mr, nc, v in results:
+                _tile(bufs[cb], co, ld, mr, nc)[:, :] = v
         else:
             stats["folds"] += len(rows)
             for r in rows:
-                _, _, db, do, p1, p2, p3, tb, to, _ = (int(v) for v in r)
-                D = _tile(bufs[db], do, ld, te)
+                _, _, db, do, p1, p2, p3, tb, to, _, mr, nc = (int(v) for v in r)
+                assert 1 <= mr <= te and 1 <= nc <= te
+                D = _tile(bufs[db], do, ld, mr, nc)
                 nparts = 0
                 for q, po in enumerate((p1, p2, p3)):
                     if po >= 0:
                         assert po == do and nparts == q
-                        P = _tile(bufs[4 + q], po, ld, te)
+                        P = _tile(bufs[4 + q], po, ld, mr, nc)
                         assert not np.isnan(P).any()
                         D += P
                         nparts += 1
                 stats["max_chunks"] = max(stats["max_chunks"], 1 + nparts)
                 assert not np.isnan(D).any()
                 if tb >= 0:
-                    _tile(bufs[tb], to, ld, te)[:, :] = D.T
+                    _tile(bufs[tb], to, ld, nc, mr)[:, :] = D.T
+    for b in (1, 3):  # the pads are as they were: no launch wrote there
+        Z = bufs[b].copy()
+        Z[:n, :n] = 0.0
+        assert not Z.any()
     U = bufs[1][:n, :n]
     Kinv = bufs[2][:n, :n]
     return L, Kmat, U, Kinv, stats, plan
@@ -101,7 +115,10 @@ def _run_plan(n, ld, nbins, load_pct, seed):
 
 @pytest.mark.parametrize("n,ld,nbins,load_pct", [(1024, 1024 + 32, 512, 100), (2048, 2048 + 32, 512, 100), (1536, 1536 + 16, 64, 100),
                                                   (1280, 1280 + 32, 16, 50), (768, 800, 8, 200), (512, 544, 512, 100), (256, 272, 4, 100),
-                                                  (1536, 1536 + 32, 1 << 20, 10 ** 8)])  # the last: what a batched sequence runs — no k range is cut
+                                                  (1536, 1536 + 32, 1 << 20, 10 ** 8),  # what a batched sequence runs — no k range is cut
+                                                  (1100, 1152 + 32, 512, 100), (1700, 1728 + 16, 512, 100), (1025, 1088 + 32, 512, 100),
+                                                  (1344, 1344 + 32, 64, 100), (2047, 2048 + 32, 512, 100), (1281, 1344 + 16, 1 << 20, 10 ** 8),
+                                                  (300, 320 + 16, 8, 100), (65, 128 + 16, 4, 100)])
 def test_inv_plan_executed_in_numpy(n, ld, nbins, load_pct):
     L, Kmat, U, Kinv, stats, plan = _run_plan(n, ld, nbins, load_pct, seed=n + nbins)
     Uref = np.linalg.inv(L).T
@@ -118,7 +135,8 @@ def test_inv_plan_executed_in_numpy(n, ld, nbins, load_pct):
     # algorithmic flops: the products of the plan do 2 n^3 / 3 less what the leaves did, at tile granularity
     prods = plan[plan[:, 1] & 1 == 0]
     flops = float(np.sum(np.where(prods[:, 1] & 2, 64.0 * 64.0, 128.0 * 128.0) * 2.0 * prods[:, 8]))
-    assert 0.55 * 2 * n ** 3 / 3 <= flops <= 1.4 * 2 * n ** 3 / 3 + 2.0 * 128 ** 3 * 3  # 2 n^3 / 3 less the leaves, whole tiles on the diagonals
+    nn = (n + 127) // 128 * 128  # (a ragged order pays for whole tiles)
+    assert 0.55 * 2 * n ** 3 / 3 - 2.0 * 256 ** 3 <= flops <= 1.4 * 2 * nn ** 3 / 3 + 2.0 * 128 ** 3 * 3  # 2 n^3 / 3 less the leaves, whole tiles on the diagonals
     print(f"n={n}: {stats['launches']} launches after the leaves, {stats['products']} tile products, {stats['folds']} folds")
 
 
