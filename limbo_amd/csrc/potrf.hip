@@ -490,7 +490,7 @@ void launch_diag(hipStream_t s, double* A, int64_t lda, int jb, double* Xt, int*
 //   wave tile: 32 rows x (4 RBN) columns starting at column wn
 //   BKM = true : B stored k-contiguous, B(col, k) = Bop[col * XS + k]     (X or L blocks, [c][k])
 //   BKM = false: B stored [kk][n],      B(col, k) = Bop[k * PS + col]
-template <bool BKM, int KLEN, int RBN>
+template <bool BKM, int KLEN, int RBN, int BS = XS> // BS: row stride of a k-contiguous B
 static __device__ __forceinline__ void mmk(const double* __restrict__ Aop, int ak0, const double* __restrict__ Bop,
                                            int bk0, int wm, int wn, int lane, double (&acc)[2][RBN])
 {
@@ -503,7 +503,7 @@ static __device__ __forceinline__ void mmk(const double* __restrict__ Aop, int a
             af[x] = Aop[(ak0 + ks + kq) * PS + ar + 16 * x];
 #pragma unroll
         for (int x = 0; x < RBN; ++x)
-            bf[x] = BKM ? Bop[(bc + 4 * x) * XS + bk0 + ks + kq] : Bop[(bk0 + ks + kq) * PS + bc + 4 * x];
+            bf[x] = BKM ? Bop[(bc + 4 * x) * BS + bk0 + ks + kq] : Bop[(bk0 + ks + kq) * PS + bc + 4 * x];
 #pragma unroll
         for (int n = 0; n < RBN; ++n)
 #pragma unroll
@@ -1497,6 +1497,361 @@ static __device__ __forceinline__ void tail_gen_tile(const TailArgs& a, const KP
         out[it] = kfun_fast_rt(kind, z[it], sf2) + (I == J0 + 2 * it ? da : 0.0);
 }
 
+// ---- k_tail's chain workgroup (round 5) ----------------------------------------------------------------------------------------
+// Stamps (tools/kbench_t, profiles/r05_chain_stamps.log) showed that a hop of the chain is NOT "panel wave, then the crossing":
+// three loops of about the same length go round at once —
+//   (1) panel wave of block c-1 ends -> X22 visible -> phase B of block c's crossing -> first pivot -> panel wave of block c ends
+//   (2) second half of L(c-1, c-2) published -> the LAST update step of workgroup c (it needs that tile) -> phase A -> phase B up to
+//       the publication of L(c, c-1)'s second half
+//   (3) X11 / L21 of block c-1 visible -> phase A -> phase B -> first pivot -> ... -> X11 / L21 of block c
+// and every stage in them is tens of matrix-core instructions between barriers: two waves share a SIMD's matrix pipe, a
+// 64 x 64 x 32 product is 0.85 us of it, the five products of a crossing 3 us.  So, here:
+//  * products only over what is not zero and not thrown away: Y Y^T and L L^T feed the LOWER triangle of the diagonal block —
+//    40 of its 64 units of 16 x 4, five per wave (syrk40) —, X11 and X22 are triangular (tri_solve32 stops at the diagonal and
+//    pairs the waves of a SIMD so that their k ranges add up to the same);
+//  * no layout conversions and no staging on the path: the diagonal block sits in LDS in the factorisation's layout, the sum of
+//    ALL its updates (the loop's and the crossing's) stays in the matrix-core accumulators and is subtracted in place, once; the
+//    tile (c, c-1) likewise ([kk][i], what the solve multiplies);
+//  * the last update step is split: L(c, c-2) L(c, c-2)^T does not need the late tile and runs before it arrives, one product
+//    is left behind it;
+//  * results go to a scratch block nobody is reading (no write-after-read barriers); the chain workgroup watches ITS OWN words of
+//    the polled quarters without a pause (one workgroup at a time is there, and the launch is waiting for it).
+//    (Measured and dropped: diag_flow reading the block from one buffer and publishing L into another, which saves the barrier
+//    behind its waves' first loads — the panel wave then runs 0.5 us longer per block, 6.97 against 6.44 us, 1.160 against 1.154 ms.)
+// LDS (doubles), two halves of 10240 = the two operand pairs of the update loop; the LAST step uses pair 0:
+//   pair 1: T [kk][i] (5120) | X11 (stride 34, 1088) | L21 (stride 34, 1088)
+//   pair 0: opA | opB of the last step; behind barrier A1: D (64 x XS) | H | invd | sy | Xw (Ys = Y1 / Y2 lies inside Xw) | X22
+#define CH_T 10240
+#define CH_X11 (CH_T + NB * PS)
+#define CH_LD (CH_X11 + 32 * 34)
+#define CH_D 0
+#define CH_AUX (NB * XS)
+#define CH_YS (CH_AUX + 1096)
+#define CH_X22 (CH_AUX + 1096 + DIAG_XW_DOUBLES)
+static_assert(CH_X22 + 32 * 34 <= CH_T && CH_YS + 32 * PS <= CH_X22 && CH_LD + 32 * 34 <= 4 * NB * PS, "chain workgroup LDS carve");
+
+// acc[u] += the wave's five 16 x 4 units of the lower triangle of Aop Aop^T over k in [ak0, ak0 + KLEN)  (Aop: [kk][i], stride PS)
+//   waves 0..3: column block j1 = w (columns 4w ..), row blocks 0..3 -> u = 0..3;  column block 15 - w, row block 3 -> u = 4
+//   waves 4..7: column block j1 = w, row blocks 1..3 -> u = 0..2;  column block 15 - w, row blocks 2, 3 -> u = 3, 4
+template <int KLEN>
+static __device__ __forceinline__ void syrk40(const double* __restrict__ Aop, int ak0, int wave, int lane, double (&acc)[5])
+{
+    const int r16 = lane & 15, kq = lane >> 4, c4 = lane & 3;
+    const int j1 = wave, j2 = 15 - wave;
+    if (wave < 4) {
+#pragma unroll
+        for (int ks = 0; ks < KLEN; ks += 4) {
+            const double* row = Aop + (ak0 + ks + kq) * PS;
+            const double a0 = row[r16], a1 = row[16 + r16], a2 = row[32 + r16], a3 = row[48 + r16];
+            const double b1 = row[4 * j1 + c4], b2 = row[4 * j2 + c4];
+            acc[0] = mfma4(a0, b1, acc[0]);
+            acc[1] = mfma4(a1, b1, acc[1]);
+            acc[2] = mfma4(a2, b1, acc[2]);
+            acc[3] = mfma4(a3, b1, acc[3]);
+            acc[4] = mfma4(a3, b2, acc[4]);
+        }
+    }
+    else {
+#pragma unroll
+        for (int ks = 0; ks < KLEN; ks += 4) {
+            const double* row = Aop + (ak0 + ks + kq) * PS;
+            const double a1 = row[16 + r16], a2 = row[32 + r16], a3 = row[48 + r16];
+            const double b1 = row[4 * j1 + c4], b2 = row[4 * j2 + c4];
+            acc[0] = mfma4(a1, b1, acc[0]);
+            acc[1] = mfma4(a2, b1, acc[1]);
+            acc[2] = mfma4(a3, b1, acc[2]);
+            acc[3] = mfma4(a2, b2, acc[3]);
+            acc[4] = mfma4(a3, b2, acc[4]);
+        }
+    }
+}
+// y[m][n] = sum_{k <= column} Aop[ak0 + k][wm + 16 m + ..] X[column][k] for the wave's columns hn + 4 n + ..: X (32 x 32, row-major,
+// stride 34) is lower triangular, the k loop stops at the wave's last column
+static __device__ __forceinline__ void tri_solve32(const double* __restrict__ Aop, int ak0, const double* __restrict__ X, int wm,
+                                                   int hn, int lane, double (&y)[2][2])
+{
+    const int ar = wm + (lane & 15), bc = hn + (lane & 3), kq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 32; ks += 4) {
+        if (ks >= hn + 8) // (wave-uniform)
+            break;
+        double af[2], bf[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            af[m] = Aop[(ak0 + ks + kq) * PS + ar + 16 * m];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            bf[n] = X[(bc + 4 * n) * 34 + ks + kq];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                y[m][n] = mfma4(af[m], bf[n], y[m][n]);
+    }
+}
+
+// The chain workgroup watches ITS OWN words of a polled block (device scope, no pause) until none shows the pattern: one look at
+// poll_one's word, a pause and a second fetch of the own words are 0.5 us between "visible" and "seen" — on the chain.
+template <int NW, int STRIDE = 512> // word q of a thread lies STRIDE words behind word q - 1
+static __device__ __forceinline__ void chain_watch(const unsigned long long* __restrict__ p, unsigned long long (&b)[NW], int spin_limit,
+                                                   int* __restrict__ info)
+{
+    static_assert(NW == 2 || NW == 4, "written out: the words stay in registers");
+    const unsigned long long SENT = ~0ull;
+    int spins = 0;
+    if constexpr (NW == 4) {
+        while (b[0] == SENT || b[1] == SENT || b[2] == SENT || b[3] == SENT) {
+            if (++spins > spin_limit) {
+                info[2] = 1;
+                break;
+            }
+            if (b[0] == SENT) b[0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[1] == SENT) b[1] = __hip_atomic_load(p + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[2] == SENT) b[2] = __hip_atomic_load(p + 2 * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[3] == SENT) b[3] = __hip_atomic_load(p + 3 * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    else {
+        while (b[0] == SENT || b[1] == SENT) {
+            if (++spins > spin_limit) {
+                info[2] = 1;
+                break;
+            }
+            if (b[0] == SENT) b[0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b[1] == SENT) b[1] = __hip_atomic_load(p + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+// acc = -(the wave's units of a 64 x 64 block held row-major with stride XS) / the block's units = -acc  (syrk40's layout)
+static __device__ __forceinline__ void syrk40_units(int wave, int q, int& i, int& j)
+{
+    if (wave < 4) {
+        i = q < 4 ? q : 3;
+        j = q < 4 ? wave : 15 - wave;
+    }
+    else {
+        i = q < 3 ? q + 1 : q - 1;
+        j = q < 3 ? wave : 15 - wave;
+    }
+}
+static __device__ __forceinline__ void syrk40_load_neg(const double* __restrict__ Dl, int wave, int lane, double (&acc)[5])
+{
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        int i, j;
+        syrk40_units(wave, q, i, j);
+        acc[q] = -Dl[(16 * i + drow) * XS + 4 * j + dcol];
+    }
+}
+static __device__ __forceinline__ void syrk40_store_neg(double* __restrict__ Dl, int wave, int lane, const double (&acc)[5])
+{
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        int i, j;
+        syrk40_units(wave, q, i, j);
+        Dl[(16 * i + drow) * XS + 4 * j + dcol] = -acc[q];
+    }
+}
+
+// The chain workgroup of column c >= 1 from "tiles (c, c-1) and (c, c) loaded" (cl, cv: lane = row layout) to "the diagonal block is
+// complete in lds + CH_D" (a barrier away from the factorisation); L(c, c-1) is left in lds + CH_T for the matrix.
+static __device__ __forceinline__ void tail_chain_updates_and_crossing(const TailArgs& a, const P256& x, double* __restrict__ lds,
+                                                                       const int c, const double (&cl)[8], const double (&cv)[8])
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16; // a 64 x 64 product's wave tile
+    // the half-block products' eight columns: the waves of one SIMD (w, w + 4) get 0 | 24 and 8 | 16 — their k ranges add up to 40
+    const int hq = wave >> 1, hn = hq == 0 ? 0 : (hq == 1 ? 8 : (hq == 2 ? 24 : 16));
+    const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+    double* const T = lds + CH_T;
+    double* const X11 = lds + CH_X11;
+    double* const Ld = lds + CH_LD;
+    double* const Dl = lds + CH_D;
+    double* const Ys = lds + CH_YS;
+    double* const X22 = lds + CH_X22;
+    const double* Sq = a.SP + (int64_t)(c - 1) * 3072;
+    double* pub = a.LP + (int64_t)tail_tile_id(a.nb, c, c - 1) * (NB * NB);
+    const unsigned long long* Sp = reinterpret_cast<const unsigned long long*>(Sq) + threadIdx.x;
+    // The diagonal block's lower triangle lives in the matrix-core accumulators from here to the factorisation: a2v = -(tile) now,
+    // + every product of the loop and of the crossing, and -a2v is what the factorisation reads.  (Through LDS once, here, where
+    // nothing is waiting: the tile was loaded / generated in the lane = row layout.)
+    double a2v[5];
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        lds[crow * XS + ccol + 2 * it] = cv[it];
+    __syncthreads();
+    syrk40_load_neg(lds, wave, lane, a2v);
+    __syncthreads(); // (the loop's first operands land in the same place)
+    unsigned long long xb[4]; // X11: e, e + 512; L21: 1024 + e, 1024 + e + 512
+    if (c > 1) {
+        // Steps s < c-1: tile (c, c-1) -= L(c, s) L(c-1, s)^T, tile (c, c) -= L(c, s) L(c, s)^T.  Software-pipelined over two pairs of
+        // operand buffers (the operands of step s+1 are on their way under the products of step s: one barrier a step); the pair
+        // alternates so that the LAST step uses pair 0.
+        PolledTile pa, pb;
+        pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
+        pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, 0) * (NB * NB));
+        double a2l[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll 1
+        for (int s = 0; s < c - 2; ++s) {
+            double* const opA = lds + ((c - 2 - s) & 1) * (2 * NB * PS);
+            double* const opB = opA + NB * PS;
+            pa.finish(a.LP + (int64_t)tail_tile_id(a.nb, c, s) * (NB * NB), x.spin_limit, x.info);
+            pa.store(opA);
+            pb.finish(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s) * (NB * NB), x.spin_limit, x.info);
+            pb.store(opB);
+            pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, s + 1) * (NB * NB));
+            pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s + 1) * (NB * NB));
+            __syncthreads(); // this step's operands are in LDS (and every wave is through with the pair of step s-1)
+            mm64<false>(opA, opB, wm, wn, lane, a2l);
+            syrk40<NB>(opA, 0, wave, lane, a2v);
+        }
+        // The last step, s = c-2.  BOTH of its tiles are late: L(c-1, c-2) is what the chain workgroup before this one has only just
+        // solved, L(c, c-2) what the tile below it has — each published in two halves, columns 0..31 behind phase A of its solve,
+        // 32..63 behind phase B some 3 us later.  Each half's products as it comes (k = 0..31, then 32..63: the order of the whole
+        // product), this workgroup's own words watched without a pause: 1.4 us of matrix-core time behind the second halves
+        // instead of 2.8.
+        double* const opA = lds;
+        double* const opB = lds + NB * PS;
+        {
+            const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+            const unsigned long long* ga = reinterpret_cast<const unsigned long long*>(a.LP + (int64_t)tail_tile_id(a.nb, c, c - 2) * (NB * NB)) + i + kk0 * NB;
+            const unsigned long long* gb = reinterpret_cast<const unsigned long long*>(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, c - 2) * (NB * NB)) + i + kk0 * NB;
+            unsigned long long ha[4] = {pa.b[0], pa.b[1], pa.b[2], pa.b[3]}, hb[4] = {pb.b[0], pb.b[1], pb.b[2], pb.b[3]};
+            chain_watch<4, 8 * NB>(ga, ha, x.spin_limit, x.info);
+            chain_watch<4, 8 * NB>(gb, hb, x.spin_limit, x.info);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                opA[(kk0 + 8 * q) * PS + i] = __longlong_as_double((long long)ha[q]);
+                opB[(kk0 + 8 * q) * PS + i] = __longlong_as_double((long long)hb[q]);
+            }
+            __syncthreads(); // columns 0..31 of both tiles in LDS; every wave is through with pair 1
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                T[(ccol + 2 * it) * PS + crow] = cl[it];
+            mmk<false, 32, 4>(opA, 0, opB, 0, wm, wn, lane, a2l);
+            syrk40<32>(opA, 0, wave, lane, a2v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) // first look at X11 / L21 of block c-1 (cacheable, see PolledTile)
+                xb[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
+            unsigned long long ka[4] = {pa.b[4], pa.b[5], pa.b[6], pa.b[7]}, kb[4] = {pb.b[4], pb.b[5], pb.b[6], pb.b[7]};
+            chain_watch<4, 8 * NB>(ga + 32 * NB, ka, x.spin_limit, x.info);
+            chain_watch<4, 8 * NB>(gb + 32 * NB, kb, x.spin_limit, x.info);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                opA[(32 + kk0 + 8 * q) * PS + i] = __longlong_as_double((long long)ka[q]);
+                opB[(32 + kk0 + 8 * q) * PS + i] = __longlong_as_double((long long)kb[q]);
+            }
+            __syncthreads(); // columns 32..63 (and T)
+            mmk<false, 32, 4>(opA, 32, opB, 32, wm, wn, lane, a2l);
+            syrk40<32>(opA, 32, wave, lane, a2v);
+        }
+        // T -= all the loop's products, in place: a lane's own elements
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                double* t = T + (wn + 4 * n + dcol) * PS + wm + 16 * m + drow;
+                *t = *t - a2l[m][n];
+            }
+    }
+    else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            T[(ccol + 2 * it) * PS + crow] = cl[it];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            xb[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
+    }
+    TTS(c, 0);
+    // ---- phase A: X11 and L21 of block c-1, polled value by value (diag_flow.h: DiagEarly) ----
+    {
+        chain_watch<4>(Sp, xb, x.spin_limit, x.info);
+        TTS2(x, true, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = threadIdx.x + 512 * q; // X11: e = k + 32 c ; L21: e = c + 32 k
+            X11[(e >> 5) * 34 + (e & 31)] = __longlong_as_double((long long)xb[q]);
+            Ld[(e & 31) * 34 + (e >> 5)] = __longlong_as_double((long long)xb[2 + q]); // Ld[c][k] = L21[c][k]
+        }
+    }
+    __syncthreads(); // (A1) T, X11, L21 in LDS; pair 0 is free
+    diag_flow_init(reinterpret_cast<DiagSync*>(lds + CH_AUX + DIAG_LTB + NB));
+    double y1[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    tri_solve32(T, 0, X11, wm, hn, lane, y1); // Y1 = T1 X11^T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            Ys[(hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y1[m][n];
+    __syncthreads(); // (A2) Y1 in Ys; every wave is through with T[:, 0:32]
+    TTS2(x, true, 6);
+    double u[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    mmk<true, 32, 2, 34>(Ys, 0, Ld, 0, wm, hn, lane, u); // Y1 L21^T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            double* t = T + (32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow; // (a lane's own elements)
+            *t = *t - u[m][n];
+            T[(hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y1[m][n]; // the first half of L(c, c-1), for the matrix
+        }
+    { // columns 0..31 of L(c, c-1) are final: the polled copy starts its way now
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = kk0 + 8 * q;
+            __hip_atomic_store(pub + i + NB * col, Ys[col * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    TTS2(x, true, 7);
+    // first look at X22 (in steady state it is there by now: the load's latency passes under the product)
+    unsigned long long xc[2];
+    xc[0] = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xc[1] = __hip_atomic_load(Sp + 2048 + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    syrk40<32>(Ys, 0, wave, lane, a2v); // + Y1 Y1^T
+    TTS2(x, true, 1);
+    // ---- phase B: X22 ----
+    {
+        chain_watch<2>(Sp + 2048, xc, x.spin_limit, x.info);
+        TTS2(x, true, 2);
+        const int e0 = threadIdx.x, e1 = threadIdx.x + 512; // e = k + 32 c
+        X22[(e0 >> 5) * 34 + (e0 & 31)] = __longlong_as_double((long long)xc[0]);
+        X22[(e1 >> 5) * 34 + (e1 & 31)] = __longlong_as_double((long long)xc[1]);
+    }
+    __syncthreads(); // (B1) X22 in LDS, T[:, 32:64] complete, Ys free
+    TTS2(x, true, 3);
+    double y2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    tri_solve32(T, 32, X22, wm, hn, lane, y2); // Y2 = T2 X22^T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            Ys[(hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
+    __syncthreads(); // (B2) Y2 in Ys; every wave is through with T[:, 32:64]
+    TTS2(x, true, 4);
+    { // the other 32 columns of L(c, c-1) leave at once: the NEXT chain workgroup's last update step waits for them (loop (2))
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = kk0 + 8 * q;
+            __hip_atomic_store(pub + i + NB * (32 + col), Ys[col * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    syrk40<32>(Ys, 0, wave, lane, a2v);    // + Y2 Y2^T
+    syrk40_store_neg(Dl, wave, lane, a2v); // the diagonal block's lower triangle, where the factorisation reads it
+    // (off the chain: the second half of L(c, c-1) for the matrix)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
+    TTS2(x, true, 5);
+}
+
 static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wgid, double* __restrict__ lds,
                                                  const KParams* __restrict__ kp = nullptr)
 {
@@ -1717,10 +2072,14 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
     }
     if (b == c) {
         // ---- a diagonal tile's workgroup: the chain.  It also owns the tile to the left, (c, c-1): L(c, c-1) never has to
-        // travel to reach the block it completes, and its product with itself is accumulated inside its two-phase solve
-        // (k_panel256's factoring strip).  Steps s < c-1 update both tiles with the same polled L(c, s).
-        double cl[8]; // tile (c, c-1)
+        // travel to reach the block it completes (k_panel256's factoring strip).  Steps s < c-1 update both tiles with the same
+        // polled L(c, s); step c-1 is the crossing (tail_chain_updates_and_crossing).
+        double* const Dl = lds + CH_D;
+        double* const Ltb = lds + CH_AUX;
+        double* const invd = Ltb + DIAG_LTB;
+        DiagSync* const sy = reinterpret_cast<DiagSync*>(invd + NB);
         if (c > 0) {
+            double cl[8]; // tile (c, c-1)
             if (kp)
                 tail_gen_tile(a, kp, x.R0 + crow, a.t0 + (int64_t)NB * (c - 1) + ccol, cl);
             else {
@@ -1728,82 +2087,32 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
                 for (int it = 0; it < 8; ++it)
                     cl[it] = a.A[x.R0 + crow + (a.t0 + (int64_t)NB * (c - 1) + ccol + 2 * it) * a.lda];
             }
-            // Steps s < c-1, software-pipelined over two pairs of operand buffers ([A0 | B0 | A1 | B1] re-carved over the whole
-            // LDS block): the operands of step s+1 are on their way (registers) under the products of step s and land in the
-            // other pair, so a step has ONE barrier, and the products accumulate in the matrix-core layout — one conversion to
-            // the lane = row layout behind the loop, not one per step.
-            PolledTile pa, pb;
-            if (c > 1) {
-                pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
-                pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, 0) * (NB * NB));
-            }
-            double a2l[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, a2v[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-#pragma unroll 1
-            for (int s = 0; s < c - 1; ++s) {
-                double* const opA = lds + (s & 1) * (2 * NB * PS);
-                double* const opB = opA + NB * PS;
-                pa.finish(a.LP + (int64_t)tail_tile_id(a.nb, c, s) * (NB * NB), x.spin_limit, x.info);
-                pa.store(opA);
-                pb.finish(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s) * (NB * NB), x.spin_limit, x.info);
-                pb.store(opB);
-                if (s + 1 < c - 1) {
-                    pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, s + 1) * (NB * NB));
-                    pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s + 1) * (NB * NB));
-                }
-                __syncthreads(); // this step's operands are in LDS (and every wave is through with the pair of step s-1)
-                mm64<false>(opA, opB, wm, wn, lane, a2l);
-                mm64<false>(opA, opA, wm, wn, lane, a2v);
-            }
-            if (c > 1) {
-                double a2r[8];
-                wave_tile_to_rows(a2l, a2r, lane);
-#pragma unroll
-                for (int it = 0; it < 8; ++it)
-                    cl[it] -= a2r[it];
-                wave_tile_to_rows(a2v, a2r, lane);
-#pragma unroll
-                for (int it = 0; it < 8; ++it)
-                    cv[it] -= a2r[it];
-                __syncthreads(); // the operand buffers are free again: [Bx | T0 | T1 | T2] from here on
-            }
-            TTS(c, 0);
-            // step c-1: L(c, c-1) = tile X_{c-1}^T in two phases (T1 keeps it: the factorisation re-carves [Bx | T0]), its product
-            // with itself accumulated on the way, published in two halves for the tiles below
-            double a2c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            p256_half_solve<0, true>(x, x.T1, x.T0, cl, a2c, true, a.SP + (int64_t)(c - 1) * 3072,
-                                     a.LP + (int64_t)tail_tile_id(a.nb, c, c - 1) * (NB * NB));
-            double a2r[8];
-            wave_tile_to_rows(a2c, a2r, lane);
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                cv[it] -= a2r[it];
-            __syncthreads(); // [Bx | T0] have no readers left
+            tail_chain_updates_and_crossing(a, x, lds, c, cl, cv);
             TTS(c, 1);
         }
-        double* Ls = x.Bx;
-        double* Ltb = Ls + NB * XS;
-        double* invd = Ltb + DIAG_LTB;
+        else {
 #pragma unroll
-        for (int it = 0; it < 8; ++it)
-            Ls[crow * XS + ccol + 2 * it] = cv[it];
-        DiagSync* sy = reinterpret_cast<DiagSync*>(invd + NB);
-        diag_flow_init(sy);
-        __syncthreads();
+            for (int it = 0; it < 8; ++it)
+                Dl[crow * XS + ccol + 2 * it] = cv[it];
+            diag_flow_init(sy);
+        }
+        __syncthreads(); // the diagonal block is complete in Dl (and nobody reads the crossing's scratch any more)
         DiagEarly ea;
         ea.mute = mute;
         ea.S = a.SP + (int64_t)c * 3072;
         TTS(c, 2);
-        diag_flow(Ls, Ltb, invd, sy, a.A + x.R0 + x.R0 * a.lda, a.lda, a.Xt + (int64_t)c * (NB * NB), a.info, x.R0, wave, lane,
+        diag_flow(Dl, Ltb, invd, sy, a.A + x.R0 + x.R0 * a.lda, a.lda, a.Xt + (int64_t)c * (NB * NB), a.info, x.R0, wave, lane,
                   invd + NB + 8, &ea);
         TTS(c, 3);
         if (c > 0) { // L(c, c-1) into the matrix: nobody reads it there before the launch ends
             __syncthreads();
             const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
             double* Ag = a.A + x.R0 + (a.t0 + (int64_t)NB * (c - 1)) * a.lda;
+            const double* T = lds + CH_T;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int col = kk0 + 8 * q;
-                Ag[i + (int64_t)col * a.lda] = x.T1[col * PS + i];
+                Ag[i + (int64_t)col * a.lda] = T[col * PS + i];
             }
         }
         return;
@@ -2180,8 +2489,9 @@ void dump_tail_timing(int nt)
     printf("  between two blocks, us after the panel wave of column c-1 is through: X11/L21 seen | phase A done | X22 seen | X22 in LDS | Y2 written | second half product done | block complete | factoring\n");
     for (int c = 1; c < nt && c < 64; ++c) {
         const long long p = h[c - 1][3];
-        printf("  %2d | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f\n", c, (g[c][0] - p) * 0.01, (g[c][1] - p) * 0.01, (g[c][2] - p) * 0.01,
-               (g[c][3] - p) * 0.01, (g[c][4] - p) * 0.01, (g[c][5] - p) * 0.01, (h[c][1] - p) * 0.01, (h[c][2] - p) * 0.01);
+        printf("  %2d | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f   (updates done %6.2f; inside phase A: Y1 in LDS %6.2f, T2 updated + first half out %6.2f)\n", c, (g[c][0] - p) * 0.01, (g[c][1] - p) * 0.01, (g[c][2] - p) * 0.01,
+               (g[c][3] - p) * 0.01, (g[c][4] - p) * 0.01, (g[c][5] - p) * 0.01, (h[c][1] - p) * 0.01, (h[c][2] - p) * 0.01, (h[c][0] - p) * 0.01,
+               (g[c][6] - p) * 0.01, (g[c][7] - p) * 0.01);
     }
 }
 void dump_p256_timing()

@@ -444,8 +444,10 @@ def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, mon
     env = dict(os.environ, GPE_HANDOVER_FAULT="1")  # (GPE_TAIL_MAX: inherited from the monkeypatched environment)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    # the re-run factorises without the hand-over (step-by-step panels): the same factor to rounding (N eps ~ 5e-13 at N = 4096)
-    assert abs(float(r.stdout.split("child ok")[1]) - ll) <= 1e-12 * abs(ll)
+    # the re-run factorises without the hand-over (step-by-step panels): the same factor to rounding (N eps ~ 5e-13 at N = 4096; the
+    # data-flow launches keep a diagonal block's updates in ONE accumulator chain since round 5, the panels subtract them in two
+    # pieces: 1.0e-12 apart at N = 4096, with LAPACK's value between them)
+    assert abs(float(r.stdout.split("child ok")[1]) - ll) <= 3e-12 * abs(ll)
 
 
 @pytest.mark.parametrize("N,P,tail,tall", [(128, 1, None, None), (320, 2, None, None), (704, 3, None, None), (1344, 1, None, None),
