@@ -52,7 +52,7 @@ __device__ long long g_panel_ts[64];
 #define PTS(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_panel_ts[(blockIdx.x == 0 ? 0 : 32) + (i)] = clock64(); } while (0)
 __device__ long long g_tail_ts[64][4]; // k_tail, the diagonal workgroup of column c: updates done | solved | factoring | factored
 #define TTS(c, i) do { if (threadIdx.x == 0 && (c) < 64) g_tail_ts[(c)][(i)] = wall_clock64(); } while (0)
-__device__ long long g_tail_ts2[64][8]; // ... inside its two-phase solve: X11/L21 seen | phase A done | X22 seen | X22 in LDS | Y2 written | done
+__device__ long long g_tail_ts2[64][12]; // ... inside its two-phase solve: X11/L21 seen | phase A done | X22 seen | X22 in LDS | Y2 written | done
 #define TTS2(x, on, i) do { if ((on) && threadIdx.x == 0 && ((x).R0 - (x).p0) / NB < 64) g_tail_ts2[((x).R0 - (x).p0) / NB][(i)] = wall_clock64(); } while (0)
 __device__ long long g_p256_ts[5][32]; // k_panel256: strips 0..3 and the last one; [6 S + i] = stamp i of step S, [30] start, [31] end
 #define P2TS(i) do { if (threadIdx.x == 0 && (blockIdx.x < 4 || blockIdx.x == gridDim.x - 1)) g_p256_ts[blockIdx.x < 4 ? blockIdx.x : 4][(i)] = wall_clock64(); } while (0)
@@ -1623,6 +1623,30 @@ static __device__ __forceinline__ void chain_watch(const unsigned long long* __r
     }
     asm volatile("" ::: "memory");
 }
+// ... two blocks at once (four words of each): one round trip covers both
+static __device__ __forceinline__ void chain_watch2(const unsigned long long* __restrict__ pa, unsigned long long (&a)[4],
+                                                    const unsigned long long* __restrict__ pb, unsigned long long (&b)[4], int spin_limit,
+                                                    int* __restrict__ info)
+{
+    const unsigned long long SENT = ~0ull;
+    constexpr int STRIDE = 8 * NB;
+    int spins = 0;
+    while (a[0] == SENT || a[1] == SENT || a[2] == SENT || a[3] == SENT || b[0] == SENT || b[1] == SENT || b[2] == SENT || b[3] == SENT) {
+        if (++spins > spin_limit) {
+            info[2] = 1;
+            break;
+        }
+        if (a[0] == SENT) a[0] = __hip_atomic_load(pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a[1] == SENT) a[1] = __hip_atomic_load(pa + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a[2] == SENT) a[2] = __hip_atomic_load(pa + 2 * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a[3] == SENT) a[3] = __hip_atomic_load(pa + 3 * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b[0] == SENT) b[0] = __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b[1] == SENT) b[1] = __hip_atomic_load(pb + STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b[2] == SENT) b[2] = __hip_atomic_load(pb + 2 * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b[3] == SENT) b[3] = __hip_atomic_load(pb + 3 * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" ::: "memory");
+}
 // acc = -(the wave's units of a 64 x 64 block held row-major with stride XS) / the block's units = -acc  (syrk40's layout)
 static __device__ __forceinline__ void syrk40_units(int wave, int q, int& i, int& j)
 {
@@ -1721,8 +1745,8 @@ static __device__ __forceinline__ void tail_chain_updates_and_crossing(const Tai
             const unsigned long long* ga = reinterpret_cast<const unsigned long long*>(a.LP + (int64_t)tail_tile_id(a.nb, c, c - 2) * (NB * NB)) + i + kk0 * NB;
             const unsigned long long* gb = reinterpret_cast<const unsigned long long*>(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, c - 2) * (NB * NB)) + i + kk0 * NB;
             unsigned long long ha[4] = {pa.b[0], pa.b[1], pa.b[2], pa.b[3]}, hb[4] = {pb.b[0], pb.b[1], pb.b[2], pb.b[3]};
-            chain_watch<4, 8 * NB>(ga, ha, x.spin_limit, x.info);
-            chain_watch<4, 8 * NB>(gb, hb, x.spin_limit, x.info);
+            chain_watch2(ga, ha, gb, hb, x.spin_limit, x.info);
+            TTS2(x, true, 8);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 opA[(kk0 + 8 * q) * PS + i] = __longlong_as_double((long long)ha[q]);
@@ -1734,20 +1758,22 @@ static __device__ __forceinline__ void tail_chain_updates_and_crossing(const Tai
                 T[(ccol + 2 * it) * PS + crow] = cl[it];
             mmk<false, 32, 4>(opA, 0, opB, 0, wm, wn, lane, a2l);
             syrk40<32>(opA, 0, wave, lane, a2v);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) // first look at X11 / L21 of block c-1 (cacheable, see PolledTile)
-                xb[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
             unsigned long long ka[4] = {pa.b[4], pa.b[5], pa.b[6], pa.b[7]}, kb[4] = {pb.b[4], pb.b[5], pb.b[6], pb.b[7]};
-            chain_watch<4, 8 * NB>(ga + 32 * NB, ka, x.spin_limit, x.info);
-            chain_watch<4, 8 * NB>(gb + 32 * NB, kb, x.spin_limit, x.info);
+            chain_watch2(ga + 32 * NB, ka, gb + 32 * NB, kb, x.spin_limit, x.info);
+            TTS2(x, true, 9);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 opA[(32 + kk0 + 8 * q) * PS + i] = __longlong_as_double((long long)ka[q]);
                 opB[(32 + kk0 + 8 * q) * PS + i] = __longlong_as_double((long long)kb[q]);
             }
             __syncthreads(); // columns 32..63 (and T)
+            TTS2(x, true, 10);
             mmk<false, 32, 4>(opA, 32, opB, 32, wm, wn, lane, a2l);
             syrk40<32>(opA, 32, wave, lane, a2v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) // first look at X11 / L21 of block c-1, device scope: in steady state they have just become
+                                        // visible, and the load's way passes under the products' tail and the update of T below
+                xb[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // T -= all the loop's products, in place: a lane's own elements
 #pragma unroll
@@ -1808,7 +1834,7 @@ static __device__ __forceinline__ void tail_chain_updates_and_crossing(const Tai
         }
     }
     TTS2(x, true, 7);
-    // first look at X22 (in steady state it is there by now: the load's latency passes under the product)
+    // first look at X22 (in steady state it arrives about now: the load's way passes under the product)
     unsigned long long xc[2];
     xc[0] = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     xc[1] = __hip_atomic_load(Sp + 2048 + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1833,7 +1859,11 @@ static __device__ __forceinline__ void tail_chain_updates_and_crossing(const Tai
             Ys[(hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
     __syncthreads(); // (B2) Y2 in Ys; every wave is through with T[:, 32:64]
     TTS2(x, true, 4);
-    { // the other 32 columns of L(c, c-1) leave at once: the NEXT chain workgroup's last update step waits for them (loop (2))
+    syrk40<32>(Ys, 0, wave, lane, a2v);    // + Y2 Y2^T
+    syrk40_store_neg(Dl, wave, lane, a2v); // the diagonal block's lower triangle, where the factorisation reads it
+    // (off the chain: the other 32 columns of L(c, c-1) for the tiles below — the next chain workgroup's last update step has
+    // a few microseconds of slack — and for the matrix)
+    {
         const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1841,15 +1871,143 @@ static __device__ __forceinline__ void tail_chain_updates_and_crossing(const Tai
             __hip_atomic_store(pub + i + NB * (32 + col), Ys[col * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    syrk40<32>(Ys, 0, wave, lane, a2v);    // + Y2 Y2^T
-    syrk40_store_neg(Dl, wave, lane, a2v); // the diagonal block's lower triangle, where the factorisation reads it
-    // (off the chain: the second half of L(c, c-1) for the matrix)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
             T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
     TTS2(x, true, 5);
+}
+
+// The solve of any other tile (b, c), b > c + 1: L(b, c) = tile X_c^T in the half-block form, two phases, with the chain
+// workgroup's means — triangular products (tri_solve32), results through a scratch block (no write-after-read barriers: four
+// barriers instead of seven), the tile's second half updated by each lane in place.  `near` (b - c <= 3: the tiles whose L the
+// chain's next workgroups wait for, loop (2) above) watch their own words of the block's quarters without a pause; the others —
+// hundreds in a tall launch — keep the one-word look with a pause (poll_one: their polling is memory traffic for everybody).
+// own: the tile with every earlier step applied (lane = row layout).  L(b, c) is left in lds + CH_T ([kk][i]) behind a barrier.
+static __device__ __forceinline__ void tail_tile_solve(const P256& x, double* __restrict__ lds, const double (&own)[8],
+                                                       const double* __restrict__ Sq, double* __restrict__ pub, const bool near)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
+    const int hq = wave >> 1, hn = hq == 0 ? 0 : (hq == 1 ? 8 : (hq == 2 ? 24 : 16)); // (tail_chain_updates_and_crossing)
+    const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
+    const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+    double* const T = lds + CH_T;
+    double* const X11 = lds + CH_X11;
+    double* const Ld = lds + CH_LD;
+    double* const Ys = lds + CH_YS;
+    double* const X22 = lds + CH_X22;
+    const unsigned long long SENT = ~0ull;
+    const unsigned long long* Sp = reinterpret_cast<const unsigned long long*>(Sq) + threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        T[(ccol + 2 * it) * PS + crow] = own[it];
+    // ---- phase A: X11 and L21 ----
+    {
+        unsigned long long xb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) // (first look: cacheable, see PolledTile)
+            xb[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
+        if (near)
+            chain_watch<4>(Sp, xb, x.spin_limit, x.info);
+        else {
+            int spins = 0;
+            while (xb[0] == SENT || xb[1] == SENT || xb[2] == SENT || xb[3] == SENT) {
+                if (++spins > x.spin_limit) {
+                    x.info[2] = 1;
+                    break;
+                }
+                poll_one(Sq + 1023, x.spin_limit, x.info);            // X11's last row
+                poll_one(Sq + 1024 + 32 * 31, x.spin_limit, x.info);  // L21's last column
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (xb[q] == SENT)
+                        xb[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = threadIdx.x + 512 * q; // X11: e = k + 32 c ; L21: e = c + 32 k
+            X11[(e >> 5) * 34 + (e & 31)] = __longlong_as_double((long long)xb[q]);
+            Ld[(e & 31) * 34 + (e >> 5)] = __longlong_as_double((long long)xb[2 + q]);
+        }
+    }
+    __syncthreads(); // (A1)
+    double y1[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    tri_solve32(T, 0, X11, wm, hn, lane, y1); // Y1 = T1 X11^T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            Ys[(hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y1[m][n];
+    __syncthreads(); // (A2) Y1 in Ys; every wave is through with T[:, 0:32]
+    double u[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    mmk<true, 32, 2, 34>(Ys, 0, Ld, 0, wm, hn, lane, u); // Y1 L21^T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            double* t = T + (32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow; // (a lane's own elements)
+            *t = *t - u[m][n];
+            T[(hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y1[m][n];
+        }
+    { // columns 0..31 of L(b, c) are final: the polled copy starts its way
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = kk0 + 8 * q;
+            __hip_atomic_store(pub + i + NB * col, Ys[col * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- phase B: X22 ----
+    {
+        unsigned long long xc[2];
+        xc[0] = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
+        xc[1] = __hip_atomic_load(Sp + 2048 + 512, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
+        if (near)
+            chain_watch<2>(Sp + 2048, xc, x.spin_limit, x.info);
+        else {
+            int spins = 0;
+            while (xc[0] == SENT || xc[1] == SENT) {
+                if (++spins > x.spin_limit) {
+                    x.info[2] = 1;
+                    break;
+                }
+                poll_one(Sq + 2048 + 1023, x.spin_limit, x.info); // X22's last row
+                if (xc[0] == SENT)
+                    xc[0] = __hip_atomic_load(Sp + 2048, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (xc[1] == SENT)
+                    xc[1] = __hip_atomic_load(Sp + 2048 + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        const int e0 = threadIdx.x, e1 = threadIdx.x + 512; // e = k + 32 c
+        X22[(e0 >> 5) * 34 + (e0 & 31)] = __longlong_as_double((long long)xc[0]);
+        X22[(e1 >> 5) * 34 + (e1 & 31)] = __longlong_as_double((long long)xc[1]);
+    }
+    __syncthreads(); // (B1) X22 in LDS, T[:, 32:64] complete, Ys free
+    double y2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    tri_solve32(T, 32, X22, wm, hn, lane, y2); // Y2 = T2 X22^T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            Ys[(hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
+    __syncthreads(); // (B2) Y2 in Ys; every wave is through with T[:, 32:64]
+    {
+        const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = kk0 + 8 * q;
+            __hip_atomic_store(pub + i + NB * (32 + col), Ys[col * PS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            T[(32 + hn + 4 * n + dcol) * PS + wm + 16 * m + drow] = y2[m][n];
+    __syncthreads(); // L(b, c) complete in T
 }
 
 static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wgid, double* __restrict__ lds,
@@ -2147,16 +2305,16 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
             cv[it] -= a2r[it];
         __syncthreads(); // the operand buffers are free again
     }
-    double unused[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    p256_half_solve<0, true>(x, x.T0, x.T2, cv, unused, false, a.SP + (int64_t)c * 3072, myslot);
+    tail_tile_solve(x, lds, cv, a.SP + (int64_t)c * 3072, myslot, b - c <= 3);
     { // L(b, c) into the matrix
         const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
         double* Ag = a.A + x.R0 + (a.t0 + (int64_t)NB * c) * a.lda;
+        const double* T = lds + CH_T;
         if (i < x.nrows) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int col = kk0 + 8 * q;
-                Ag[i + (int64_t)col * a.lda] = x.T0[col * PS + i];
+                Ag[i + (int64_t)col * a.lda] = T[col * PS + i];
             }
         }
     }
@@ -2484,7 +2642,7 @@ void dump_tail_timing(int nt)
     for (int c = 0; c < nt && c < 64; ++c)
         printf("  %2d | %7.2f | %7.2f | %7.2f | %7.2f   (step %5.2f)\n", c, c ? (h[c][0] - t0) * 0.01 : 0.0, c ? (h[c][1] - t0) * 0.01 : 0.0,
                (h[c][2] - t0) * 0.01, (h[c][3] - t0) * 0.01, c ? (h[c][2] - h[c - 1][2]) * 0.01 : 0.0);
-    long long g[64][8];
+    long long g[64][12];
     hipMemcpyFromSymbol(g, HIP_SYMBOL(g_tail_ts2), sizeof(g));
     printf("  between two blocks, us after the panel wave of column c-1 is through: X11/L21 seen | phase A done | X22 seen | X22 in LDS | Y2 written | second half product done | block complete | factoring\n");
     for (int c = 1; c < nt && c < 64; ++c) {
@@ -2492,6 +2650,9 @@ void dump_tail_timing(int nt)
         printf("  %2d | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f   (updates done %6.2f; inside phase A: Y1 in LDS %6.2f, T2 updated + first half out %6.2f)\n", c, (g[c][0] - p) * 0.01, (g[c][1] - p) * 0.01, (g[c][2] - p) * 0.01,
                (g[c][3] - p) * 0.01, (g[c][4] - p) * 0.01, (g[c][5] - p) * 0.01, (h[c][1] - p) * 0.01, (h[c][2] - p) * 0.01, (h[c][0] - p) * 0.01,
                (g[c][6] - p) * 0.01, (g[c][7] - p) * 0.01);
+        if (c >= 2)
+            printf("       the last update step: first halves of L(c, c-2), L(c-1, c-2) seen %6.2f | second halves seen %6.2f | in LDS %6.2f\n",
+                   (g[c][8] - p) * 0.01, (g[c][9] - p) * 0.01, (g[c][10] - p) * 0.01);
     }
 }
 void dump_p256_timing()
