@@ -215,6 +215,11 @@ int gpe_trace_dump(const char* path);
  * tiles in which every workgroup waits for lower-numbered ones only (what makes the launch deadlock-free), 0: not, -1: bad
  * arguments.  The engine runs the same check before it uses a table. */
 int gpe_debug_tail_order(int nt, int nb, int lag, int pair);
+/* Test hook, host only: how the eight waves of k_tail's chain workgroup split its products (csrc/potrf.hip: syrk40, tri_solve32).
+ * units10 = five { row block i of 16, column block j of 4 } pairs: the wave's units of the LOWER triangle of the 64 x 64 diagonal
+ * block (40 in all, every one needed exactly once); *cols = the first of the wave's eight columns of a 32-column triangular product
+ * (its k loop runs to cols + 8).  0: ok, -1: bad arguments. */
+int gpe_debug_chain_split(int wave, int* units10, int* cols);
 /* ... and the schedule the engine picks for n samples, p outputs and a batched sequence of g members (g <= 1: one handle) under
  * the given widths (<= 0: the defaults GPE_TAIL_MAX / GPE_TALL / GPE_BATCH_TAIL_MAX): out8 = { t0 (first column of the closing
  * data-flow launch; -1: panels to the end), e0 (first column of the tall launch in front of it; -1: none), tile columns and row

@@ -233,6 +233,7 @@ struct FlowGate {
     FlowGate& operator=(const FlowGate&) = delete;
 };
 int debug_tail_order(int nt, int nb, int lag, int pair); // potrf.hip (host only)
+void debug_chain_split(int wave, int* units10, int* cols); // potrf.hip (host only): the chain workgroup's work split
 static inline int64_t tail_tiles(int64_t nt, int64_t nb) { return nt * nb - nt * (nt - 1) / 2; }
 static inline int64_t tail_buf_doubles(int64_t nt, int64_t nb) { return nt * 3072 + tail_tiles(nt, nb) * 4096; }
 // gen (optional): the launch generates its tiles of K from the samples (and obs_mean's rows from Om) instead of reading A,

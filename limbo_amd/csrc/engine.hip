@@ -3696,6 +3696,13 @@ int gpe_trace_dump(const char* path)
 }
 
 int gpe_debug_tail_order(int nt, int nb, int lag, int pair) { return debug_tail_order(nt, nb, lag, pair); }
+int gpe_debug_chain_split(int wave, int* units10, int* cols)
+{
+    if (wave < 0 || wave > 7 || !units10 || !cols)
+        return -1;
+    debug_chain_split(wave, units10, cols);
+    return 0;
+}
 int gpe_debug_inv_plan(int64_t n, int64_t ld, int nbins, int load_pct, int64_t* out, int64_t cap_rows)
 {
     return inv2_debug_plan(n, ld, nbins, load_pct, out, cap_rows);

@@ -1423,7 +1423,8 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
 //   steps s = 0 .. c-1:  tile -= L(b, s) L(c, s)^T, both operands polled from the owners of those tiles (PolledTile; the next
 //                        step's operands are asked for before this step's product)
 //   step c, b == c:      the diagonal block is complete: factor it (diag_flow), its inverse leaves in polled quarters
-//   step c, b >  c:      L(b, c) = tile X_c^T in the half-block form, in two phases (p256_half_solve), published in two halves
+//   step c, b >  c:      L(b, c) = tile X_c^T in the half-block form, in two phases (tail_tile_solve; the chain workgroup:
+//                        tail_chain_updates_and_crossing; the pair form: p256_half_solve), published in two halves
 // Workgroups are numbered column by column, the diagonal tile first: every wait is for a lower-numbered workgroup.  The chain
 // diag(c) -> X_c -> L(c+1, c) -> last update of tile (c+1, c+1) -> diag(c+1) is what k_panel256's is, without the fused
 // updates and launch boundaries in between.  Polled buffers: LP (a 4096-double slot per tile, blockIdx order) and SP (3072 doubles
@@ -1459,8 +1460,9 @@ struct TailArgs {
     int64_t ldal;
     int P;
 };
-// LDS of a k_tail workgroup: [Bx | T0 | T1 | T2] for the solves and the factorisation, re-carved as two pairs of operand tiles
-// [A0 | B0 | A1 | B1] (40 KB each: all of the CU's 160 KB) for the pipelined products in front of them
+// LDS of a k_tail workgroup: two pairs of operand tiles [A0 | B0 | A1 | B1] (40 KB each: all of the CU's 160 KB) for the pipelined
+// products of the update loop; behind it the carve of the solve and the factorisation (CH_*, further down; the pair form of
+// diag_flow2.h keeps round 4's [Bx | T0 | T1 | T2])
 #define TAIL_LDS_DOUBLES (4 * NB * PS)
 static_assert(TAIL_LDS_DOUBLES >= NB * XS + 3 * NB * PS && TAIL_LDS_DOUBLES >= D2_LDS_DOUBLES && TAIL_LDS_DOUBLES * 8 <= 160 * 1024, "k_tail LDS carve");
 static __device__ __forceinline__ int tail_tile_id(int nb, int b, int c) { return c * nb - (c * (c - 1)) / 2 + (b - c); }
@@ -1565,6 +1567,13 @@ static __device__ __forceinline__ void syrk40(const double* __restrict__ Aop, in
         }
     }
 }
+// The eight columns (of a 32-column half) a wave's triangular products compute: waves w and w + 4 share a SIMD (dev.h) and get
+// 0 | 24 and 8 | 16 — their k ranges, hn + 8 each, add up to 40 on every SIMD
+static __host__ __device__ __forceinline__ int tri_solve_cols(int wave)
+{
+    const int hq = wave >> 1;
+    return hq == 0 ? 0 : (hq == 1 ? 8 : (hq == 2 ? 24 : 16));
+}
 // y[m][n] = sum_{k <= column} Aop[ak0 + k][wm + 16 m + ..] X[column][k] for the wave's columns hn + 4 n + ..: X (32 x 32, row-major,
 // stride 34) is lower triangular, the k loop stops at the wave's last column
 static __device__ __forceinline__ void tri_solve32(const double* __restrict__ Aop, int ak0, const double* __restrict__ X, int wm,
@@ -1648,7 +1657,7 @@ static __device__ __forceinline__ void chain_watch2(const unsigned long long* __
     asm volatile("" ::: "memory");
 }
 // acc = -(the wave's units of a 64 x 64 block held row-major with stride XS) / the block's units = -acc  (syrk40's layout)
-static __device__ __forceinline__ void syrk40_units(int wave, int q, int& i, int& j)
+static __host__ __device__ __forceinline__ void syrk40_units(int wave, int q, int& i, int& j)
 {
     if (wave < 4) {
         i = q < 4 ? q : 3;
@@ -1687,8 +1696,7 @@ static __device__ __forceinline__ void tail_chain_updates_and_crossing(const Tai
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16; // a 64 x 64 product's wave tile
-    // the half-block products' eight columns: the waves of one SIMD (w, w + 4) get 0 | 24 and 8 | 16 — their k ranges add up to 40
-    const int hq = wave >> 1, hn = hq == 0 ? 0 : (hq == 1 ? 8 : (hq == 2 ? 24 : 16));
+    const int hn = tri_solve_cols(wave);
     const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
     const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
     double* const T = lds + CH_T;
@@ -1890,7 +1898,7 @@ static __device__ __forceinline__ void tail_tile_solve(const P256& x, double* __
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 16;
-    const int hq = wave >> 1, hn = hq == 0 ? 0 : (hq == 1 ? 8 : (hq == 2 ? 24 : 16)); // (tail_chain_updates_and_crossing)
+    const int hn = tri_solve_cols(wave);
     const int crow = wm + (lane & 31), ccol = wn + (lane >> 5);
     const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
     double* const T = lds + CH_T;
@@ -2461,6 +2469,13 @@ static const int* tail_order(int nt, int nb, int W, int lag, int pair)
         fprintf(stderr, "gpe: tail_order(%d, %d, W %d, lag %d, pair %d) violates a dependency — column-by-column order used\n", nt, nb, W, lag, pair);
     cache[key] = d;
     return d;
+}
+// test hook: the work split of the chain workgroup's products (syrk40 / tri_solve32) as the device code has it
+void debug_chain_split(int wave, int* units10, int* cols)
+{
+    for (int q = 0; q < 5; ++q)
+        syrk40_units(wave, q, units10[2 * q], units10[2 * q + 1]);
+    *cols = tri_solve_cols(wave);
 }
 // test hook (include/gpe.h: gpe_debug_tail_order): 1 if the dispatch table of a data-flow launch of nt tile columns x nb row
 // strips is a permutation of its tiles in which every wait is for a lower-numbered workgroup, 0 if not; host only

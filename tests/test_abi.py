@@ -78,7 +78,7 @@ def test_engine_is_independent_of_the_oracle():
 def test_oracle_mirrors_the_abi(oracle_lib):
     skip = {"gpe_get_stream", "gpe_set_profiling", "gpe_get_phase_ms", "gpe_reset_phase_ms", "gpe_mfma_f64_peak",
             "gpe_hbm_stream_peak", "gpe_flow_retries", "gpe_small_calls", "gpe_handover_reruns", "gpe_trace", "gpe_trace_dump",
-            "gpe_debug_tail_order", "gpe_debug_tail_plan", "gpe_debug_inv_plan"}
+            "gpe_debug_tail_order", "gpe_debug_tail_plan", "gpe_debug_inv_plan", "gpe_debug_chain_split"}
     for s in declared_symbols():
         if s in skip:
             continue
@@ -115,6 +115,37 @@ def test_dispatch_tables_of_the_data_flow_launches_are_deadlock_free():
                     if f(nt, nb, lag, pair) != 1:
                         bad.append((nt, nb, lag, pair))
     assert not bad, bad[:10]
+
+
+def test_chain_workgroup_splits_its_products_evenly_and_completely():
+    """csrc/potrf.hip: syrk40 / tri_solve32 (round 5).  The chain workgroup of a data-flow launch multiplies only what is kept: of
+    the 64 units of 16 x 4 of a diagonal block's update Y Y^T, the 40 that touch the LOWER triangle — five per wave, every unit once —
+    and, against the triangular 32 x 32 block inverses, k ranges that stop at a wave's last column, dealt so that the two waves of a
+    SIMD (w and w + 4) add up to the same.  The device code's own mapping functions, called on the host."""
+    from limbo_amd import _capi
+
+    lib = ctypes.CDLL(str(_capi.ENGINE_SO))
+    f = lib.gpe_debug_chain_split
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    units, cols = {}, []
+    for w in range(8):
+        u10, c = (ctypes.c_int * 10)(), ctypes.c_int()
+        assert f(w, u10, ctypes.byref(c)) == 0
+        mine = [(u10[2 * q], u10[2 * q + 1]) for q in range(5)]
+        assert len(set(mine)) == 5
+        for ij in mine:
+            assert ij not in units, "a unit computed twice"
+            units[ij] = w
+        cols.append(c.value)
+    assert f(8, (ctypes.c_int * 10)(), ctypes.byref(ctypes.c_int())) == -1
+    # exactly the units (row block i of 16, column block j of 4) with an element on or below the diagonal: 16 i + 15 >= 4 j
+    want = {(i, j) for i in range(4) for j in range(16) if 16 * i + 15 >= 4 * j}
+    assert set(units) == want and len(want) == 40
+    # the triangular products: the four column blocks of eight are all there, each for both row halves (waves 2 q, 2 q + 1), and the
+    # k loops (cols + 8 steps of one) of the two waves of a SIMD add up to 40
+    assert sorted(cols) == [0, 0, 8, 8, 16, 16, 24, 24] and all(cols[2 * q] == cols[2 * q + 1] for q in range(4))
+    assert all((cols[w] + 8) + (cols[w + 4] + 8) == 40 for w in range(4))
 
 
 def test_schedule_of_the_factorisation_by_size():
