@@ -145,9 +145,10 @@ def box_probe(eng, _capi, O, local_rank):
         per.append(time.perf_counter() - t0)
     h.close()
     ms = 1e3 * float(np.median(per))
-    return {"n1024_compute_loglik_ms": ms, "usual_ms": 0.25, "slow_box": bool(ms > 0.31),
-            "note": "compute()+log_lik at N = 1024 (ONE data-flow launch + the sweep: pure chain latency); boxes that read > 0.31 ms "
-                    "here ran every latency-bound figure of this line at about half speed in rounds 3-4, with `roofline` unaffected"}
+    return {"n1024_compute_loglik_ms": ms, "usual_ms": 0.22, "slow_box": bool(ms > 0.28),
+            "note": "compute()+log_lik at N = 1024 (ONE data-flow launch + the sweep: pure chain latency; 0.215-0.222 ms on the usual "
+                    "boxes since the chain work of round 5, 0.245 before); boxes that read > 0.28 ms here ran every latency-bound figure "
+                    "of this line at about half speed in rounds 3-5 (one box in ten of the pool), with `roofline.trailing_update` unaffected"}
 
 
 def extras(eng, _capi, O, local_rank, steps):
