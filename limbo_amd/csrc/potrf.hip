@@ -1511,13 +1511,15 @@ static __device__ __forceinline__ void tail_gen_tile(const TailArgs& a, const KP
 //  * products only over what is not zero and not thrown away: Y Y^T and L L^T feed the LOWER triangle of the diagonal block —
 //    40 of its 64 units of 16 x 4, five per wave (syrk40) —, X11 and X22 are triangular (tri_solve32 stops at the diagonal and
 //    pairs the waves of a SIMD so that their k ranges add up to the same);
-//  * no layout conversions and no staging on the path: the diagonal block sits in LDS in the factorisation's layout, the sum of
-//    ALL its updates (the loop's and the crossing's) stays in the matrix-core accumulators and is subtracted in place, once; the
-//    tile (c, c-1) likewise ([kk][i], what the solve multiplies);
-//  * the last update step is split: L(c, c-2) L(c, c-2)^T does not need the late tile and runs before it arrives, one product
-//    is left behind it;
+//  * no layout conversions and no staging on the path: the diagonal block's lower triangle lives in the matrix-core accumulators
+//    from the moment the workgroup starts (a2v = -tile) to the factorisation — every update of the loop and both halves of the
+//    crossing add to that ONE chain, and what the factorisation reads is its negative, stored once (syrk40_store_neg); the tile
+//    (c, c-1) sits in LDS in the layout the solve multiplies ([kk][i]) and the loop's sum is subtracted from it in place;
+//  * the last update step half by half: BOTH of its tiles, L(c-1, c-2) and L(c, c-2), are published in two halves 3 us apart —
+//    the k = 0..31 halves of both products run before the second halves arrive, 1.4 us of matrix-core time is left behind them;
 //  * results go to a scratch block nobody is reading (no write-after-read barriers); the chain workgroup watches ITS OWN words of
-//    the polled quarters without a pause (one workgroup at a time is there, and the launch is waiting for it).
+//    the polled quarters and tiles without a pause (chain_watch; the last step's two tiles in ONE round trip: chain_watch2) —
+//    one workgroup at a time is there, and the launch is waiting for it.
 //    (Measured and dropped: diag_flow reading the block from one buffer and publishing L into another, which saves the barrier
 //    behind its waves' first loads — the panel wave then runs 0.5 us longer per block, 6.97 against 6.44 us, 1.160 against 1.154 ms.)
 // LDS (doubles), two halves of 10240 = the two operand pairs of the update loop; the LAST step uses pair 0:
