@@ -671,7 +671,11 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 g.grow0 = N64;
                 g.gcol0 = N64;
                 PhaseScope ps(c, GPE_PH_POTRF_UPDATE, gemm_flops(g));
-                launch_gemm_sub(s, g);
+                // ONE tile with k up to 2816: dealt to up to 32 workgroups + an ordered fold (potrf.hip); its scratch is the pair of polled
+                // buffers the closing launch has just used — dead until the next launch arms all of them again
+                double* const used = c->dTail + ((c->tail_count - 1) & 1) * c->tail_cap;
+                if (!launch_ragged_update(s, g.C, ld, g.A, ld, g.m, g.n, g.k, used, pl.need_tail))
+                    launch_gemm_sub(s, g);
             }
             p0 = N64;
             next_diag_done = false;

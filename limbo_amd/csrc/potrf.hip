@@ -2362,6 +2362,102 @@ __global__ __launch_bounds__(512) void k_tail_b(TailArgs a, const BatchTab* __re
     tail_body(a, (int)blockIdx.x / G, lds, a.Xg ? &bt->kp[gp] : nullptr);
 }
 
+// ---- the update of a ragged order's last block, behind the data-flow launch ------------------------------------------------------
+// C[0:m, 0:n] -= A[0:m, 0:k] A[0:n, 0:k]^T (lower part: i >= j) with m <= 64 rows (the ragged rows of the order + the
+// right-hand-side rows), n < 64 columns and k = everything the data-flow launch factored, up to 2816: ONE tile.  Its k loop on one
+// compute unit is bound by that unit's load rate — 46 us at k = 1088, 69 us at k = 1664 (profiles/r05_tail_sizes.log: N = 1700 took
+// longer than N = 2048).  Here the k range is dealt to up to 32 workgroups, each leaves its partial product in a scratch slot, and
+// a second launch adds the slots IN ORDER (bitwise reproducible) and subtracts the sum.
+// The scratch is the pair of polled buffers the data-flow launch has just used: dead until the NEXT launch arms them again, all of
+// them (tail_body: every workgroup arms its own slots of the other pair).
+__global__ __launch_bounds__(256) void k_ragged_partial(const double* __restrict__ A, int64_t ld, int m, int n, int64_t k, int kc,
+                                                        double* __restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) double As[32][NB];
+    const int li = threadIdx.x & 63, lk = threadIdx.x >> 6; // loading: row li, k rows lk, lk + 4, ..
+    const int ti = threadIdx.x & 15, tj = threadIdx.x >> 4; // computing: a 4 x 4 block, rows 4 ti .., columns 4 tj ..
+    const int64_t k0 = (int64_t)blockIdx.x * kc, k1 = k0 + kc < k ? k0 + kc : k;
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            acc[r][c] = 0.0;
+    double nx[8]; // the next 32 k rows, on their way under this block's products
+    auto fetch = [&](int64_t kb) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { // (rows >= m read as zero; the B operand is the first n rows of the same strip)
+            const int kk = lk + 4 * q;
+            nx[q] = (kb + kk < k1 && li < m) ? A[li + (kb + kk) * ld] : 0.0;
+        }
+    };
+    fetch(k0);
+    for (int64_t kb = k0; kb < k1; kb += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            As[lk + 4 * q][li] = nx[q];
+        if (kb + 32 < k1)
+            fetch(kb + 32);
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = As[kk][4 * ti + r];
+                b[r] = As[kk][4 * tj + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[r][c] = fma(a[r], b[c], acc[r][c]);
+        }
+    }
+    double* out = part + (int64_t)blockIdx.x * (NB * NB);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            out[4 * ti + r + NB * (4 * tj + c)] = acc[r][c];
+}
+#define RAGGED_MAX_G 32
+__global__ __launch_bounds__(256) void k_ragged_fold(double* __restrict__ C, int64_t ldc, int m, int n, int G, const double* __restrict__ part)
+{
+    const int i = threadIdx.x & 63, j = 4 * (int)blockIdx.x + (threadIdx.x >> 6); // one element a thread, 16 workgroups
+    if (i >= m || j >= n || i < j)
+        return;
+    // every slot's value requested before the first is added (written out to RAGGED_MAX_G: one after the other the loads cost a
+    // trip to memory each — 62 us for 13 slots in one workgroup), then the sum in slot order
+    double v[RAGGED_MAX_G];
+#pragma unroll
+    for (int g = 0; g < RAGGED_MAX_G; ++g)
+        v[g] = g < G ? part[(int64_t)g * (NB * NB) + i + NB * j] : 0.0;
+    double sum = 0.0;
+#pragma unroll
+    for (int g = 0; g < RAGGED_MAX_G; ++g)
+        sum += v[g]; // (slots >= G add +0.0)
+    C[i + (int64_t)j * ldc] -= sum;
+}
+// false: not this shape (the caller takes the general product)
+bool launch_ragged_update(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t ld, int64_t m, int64_t n, int64_t k,
+                          double* scratch, int64_t scratch_doubles)
+{
+    if (g_batch.bt || g_batch.G != 1 || m < 1 || m > NB || n < 1 || n > NB || k < 256 || !scratch)
+        return false;
+    int64_t G = k / 64;
+    G = G > RAGGED_MAX_G ? RAGGED_MAX_G : G;
+    G = G > scratch_doubles / (NB * NB) ? scratch_doubles / (NB * NB) : G;
+    if (G < 2)
+        return false;
+    const int kc = (int)(((k + G - 1) / G + 31) / 32 * 32);
+    G = (k + kc - 1) / kc;
+    GPE_LAUNCH(k_ragged_partial, dim3((unsigned)G), dim3(256), 0, s, A, ld, (int)m, (int)n, k, kc, scratch);
+    GPE_LAUNCH(k_ragged_fold, dim3(NB / 4), dim3(256), 0, s, C, ldc, (int)m, (int)n, (int)G, (const double*)scratch);
+    return true;
+}
+
 // ---- dispatch order of a data-flow launch ----------------------------------------------------------------------------
 // Workgroups are handed out in index order and each holds a CU from its dispatch to its last store, so WHEN a tile's
 // workgroup becomes resident decides whether it spends its residency working or waiting — and 256 resident workgroups are all
