@@ -220,6 +220,10 @@ int gpe_debug_tail_order(int nt, int nb, int lag, int pair);
  * block (40 in all, every one needed exactly once); *cols = the first of the wave's eight columns of a 32-column triangular product
  * (its k loop runs to cols + 8).  0: ok, -1: bad arguments. */
 int gpe_debug_chain_split(int wave, int* units10, int* cols);
+/* Test hook, host only: how the update of a ragged order's last block behind a data-flow launch deals its k range (csrc/potrf.hip:
+ * launch_ragged_update): returns the number of workgroups (0: the general product runs instead — k < 256 or no room for two
+ * 64 x 64 slots in scratch_doubles) and *kc = the k rows of each; -1: bad arguments. */
+int gpe_debug_ragged_split(int64_t k, int64_t scratch_doubles, int* kc);
 /* ... and the schedule the engine picks for n samples, p outputs and a batched sequence of g members (g <= 1: one handle) under
  * the given widths (<= 0: the defaults GPE_TAIL_MAX / GPE_TALL / GPE_BATCH_TAIL_MAX): out8 = { t0 (first column of the closing
  * data-flow launch; -1: panels to the end), e0 (first column of the tall launch in front of it; -1: none), tile columns and row

@@ -248,6 +248,7 @@ struct TailGen {
     int P;
     const KParams* kp; // host copy (single launches pass it by value; batched ones read the batch table)
 };
+int ragged_split(int64_t k, int64_t scratch_doubles, int* kc_out); // potrf.hip (host only)
 bool launch_ragged_update(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t ld, int64_t m, int64_t n, int64_t k,
                           double* scratch, int64_t scratch_doubles); // potrf.hip: a ragged order's last block behind k_tail
 void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, int64_t N64, int64_t M, double* Xt_all, int* info,

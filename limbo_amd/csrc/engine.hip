@@ -3700,6 +3700,13 @@ int gpe_trace_dump(const char* path)
 }
 
 int gpe_debug_tail_order(int nt, int nb, int lag, int pair) { return debug_tail_order(nt, nb, lag, pair); }
+int gpe_debug_ragged_split(int64_t k, int64_t scratch_doubles, int* kc)
+{
+    if (!kc)
+        return -1;
+    *kc = 0;
+    return ragged_split(k, scratch_doubles, kc);
+}
 int gpe_debug_chain_split(int wave, int* units10, int* cols)
 {
     if (wave < 0 || wave > 7 || !units10 || !cols)

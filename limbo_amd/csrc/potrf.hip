@@ -2440,21 +2440,32 @@ __global__ __launch_bounds__(256) void k_ragged_fold(double* __restrict__ C, int
         sum += v[g]; // (slots >= G add +0.0)
     C[i + (int64_t)j * ldc] -= sum;
 }
+// how the k range is dealt: G workgroups (0: not worth it / no room) of kc rows each, kc a multiple of the kernel's 32-row blocks,
+// the last one not empty; also the test hook gpe_debug_ragged_split (host only)
+int ragged_split(int64_t k, int64_t scratch_doubles, int* kc_out)
+{
+    if (k < 256 || scratch_doubles < 2 * NB * NB)
+        return 0;
+    int64_t G = k / 64;
+    G = G > RAGGED_MAX_G ? RAGGED_MAX_G : G;
+    G = G > scratch_doubles / (NB * NB) ? scratch_doubles / (NB * NB) : G;
+    const int64_t kc = ((k + G - 1) / G + 31) / 32 * 32;
+    G = (k + kc - 1) / kc;
+    *kc_out = (int)kc;
+    return (int)G;
+}
 // false: not this shape (the caller takes the general product)
 bool launch_ragged_update(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t ld, int64_t m, int64_t n, int64_t k,
                           double* scratch, int64_t scratch_doubles)
 {
-    if (g_batch.bt || g_batch.G != 1 || m < 1 || m > NB || n < 1 || n > NB || k < 256 || !scratch)
+    if (g_batch.bt || g_batch.G != 1 || m < 1 || m > NB || n < 1 || n > NB || !scratch)
         return false;
-    int64_t G = k / 64;
-    G = G > RAGGED_MAX_G ? RAGGED_MAX_G : G;
-    G = G > scratch_doubles / (NB * NB) ? scratch_doubles / (NB * NB) : G;
+    int kc = 0;
+    const int G = ragged_split(k, scratch_doubles, &kc);
     if (G < 2)
         return false;
-    const int kc = (int)(((k + G - 1) / G + 31) / 32 * 32);
-    G = (k + kc - 1) / kc;
     GPE_LAUNCH(k_ragged_partial, dim3((unsigned)G), dim3(256), 0, s, A, ld, (int)m, (int)n, k, kc, scratch);
-    GPE_LAUNCH(k_ragged_fold, dim3(NB / 4), dim3(256), 0, s, C, ldc, (int)m, (int)n, (int)G, (const double*)scratch);
+    GPE_LAUNCH(k_ragged_fold, dim3(NB / 4), dim3(256), 0, s, C, ldc, (int)m, (int)n, G, (const double*)scratch);
     return true;
 }
 

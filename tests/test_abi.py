@@ -78,7 +78,7 @@ def test_engine_is_independent_of_the_oracle():
 def test_oracle_mirrors_the_abi(oracle_lib):
     skip = {"gpe_get_stream", "gpe_set_profiling", "gpe_get_phase_ms", "gpe_reset_phase_ms", "gpe_mfma_f64_peak",
             "gpe_hbm_stream_peak", "gpe_flow_retries", "gpe_small_calls", "gpe_handover_reruns", "gpe_trace", "gpe_trace_dump",
-            "gpe_debug_tail_order", "gpe_debug_tail_plan", "gpe_debug_inv_plan", "gpe_debug_chain_split"}
+            "gpe_debug_tail_order", "gpe_debug_tail_plan", "gpe_debug_inv_plan", "gpe_debug_chain_split", "gpe_debug_ragged_split"}
     for s in declared_symbols():
         if s in skip:
             continue
@@ -146,6 +146,28 @@ def test_chain_workgroup_splits_its_products_evenly_and_completely():
     # k loops (cols + 8 steps of one) of the two waves of a SIMD add up to 40
     assert sorted(cols) == [0, 0, 8, 8, 16, 16, 24, 24] and all(cols[2 * q] == cols[2 * q + 1] for q in range(4))
     assert all((cols[w] + 8) + (cols[w + 4] + 8) == 40 for w in range(4))
+
+
+def test_ragged_block_update_deals_its_k_range_completely():
+    """csrc/potrf.hip: launch_ragged_update (round 5).  The last block of a ragged order is updated over everything the data-flow
+    launch factored (k = 256 .. 2816) by up to 32 workgroups of kc rows each + an ordered fold: the chunks cover [0, k) exactly,
+    the last one is not empty, kc is a multiple of the kernel's 32-row blocks, the slots fit the scratch, and small k / small
+    scratch fall back to the general product."""
+    from limbo_amd import _capi
+
+    lib = ctypes.CDLL(str(_capi.ENGINE_SO))
+    f = lib.gpe_debug_ragged_split
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int)]
+    kc = ctypes.c_int()
+    assert f(192, 1 << 20, ctypes.byref(kc)) == 0 and f(2048, 4096, ctypes.byref(kc)) == 0 and f(2048, 1 << 20, None) == -1
+    for k in range(256, 2816 + 1, 64):
+        for scratch in (2 * 4096, 5 * 4096 + 17, 14 * 4096 + 4 * 3072, 1 << 22):
+            G = f(k, scratch, ctypes.byref(kc))
+            assert 1 <= G <= 32 and G * 4096 <= scratch, (k, scratch, G)
+            assert kc.value % 32 == 0 and G * kc.value >= k and (G - 1) * kc.value < k, (k, scratch, G, kc.value)
+    G = f(1664, 1 << 22, ctypes.byref(kc))  # N = 1700: 26 workgroups of 64 rows
+    assert (G, kc.value) == (26, 64)
 
 
 def test_schedule_of_the_factorisation_by_size():
