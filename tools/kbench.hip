@@ -171,7 +171,7 @@ int main(int argc, char** argv)
 #endif
 #ifdef DIAG_TIMING
     { // the first 1024 x 1024 block of K as one tiled data-flow launch (k_tail)
-        const int64_t T = 1024;
+        const int64_t T = getenv("KB_TAIL_T") ? atoll(getenv("KB_TAIL_T")) : 1024; // (2816: the closing launch's shape)
         const int64_t need = tail_buf_doubles(T / 64, T / 64 + 1);
         double* tb;
         CHK(hipMalloc(&tb, sizeof(double) * 2 * need));
@@ -191,9 +191,9 @@ int main(int argc, char** argv)
             hipEventElapsedTime(&ms, e0, e1);
             best = ms < best ? ms : best;
         }
-        printf("k_tail, the leading 1024 x 1024 block of K (16 tile columns + one right-hand-side row): %.2f us (events)\n", 1e3 * best);
+        printf("k_tail, the leading %lld x %lld block of K (%lld tile columns + one right-hand-side row): %.2f us (events)\n", (long long)T, (long long)T, (long long)(T / 64), 1e3 * best);
         extern void dump_tail_timing(int);
-        dump_tail_timing(16);
+        dump_tail_timing((int)(T / 64));
     }
 #endif
     printf("kbench done\n");
