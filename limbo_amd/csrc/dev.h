@@ -252,11 +252,7 @@ int ragged_split(int64_t k, int64_t scratch_doubles, int* kc_out); // potrf.hip 
 bool launch_ragged_update(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t ld, int64_t m, int64_t n, int64_t k,
                           double* scratch, int64_t scratch_doubles); // potrf.hip: a ragged order's last block behind k_tail
 void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, int64_t N64, int64_t M, double* Xt_all, int* info,
-                 double* buf_cur, double* buf_next, const TailGen* gen = nullptr, int64_t pre0 = -1);
-// pre0 >= 0 (round 6, "fold"): columns [pre0, t0) are factored but NOT yet applied to the launch's tiles — the launch applies them
-// itself (TailArgs::npre); the caller must not have run the k = t0 - pre0 update.  Ignored (false returned by tail_can_fold) for the
-// pair form, generated tiles and batched launches.
-bool tail_can_fold(const TailGen* gen);
+                 double* buf_cur, double* buf_next, const TailGen* gen = nullptr);
 // S22 / S22_next: the polled hand-over buffers (block inverses + head tiles), 33,792 doubles each, holding the all-ones
 // pattern when the launch starts (the launch arms S22_next)
 #define GPE_S22_TILE 20 // the two buffers sit in tiles 20..28 of either half of gpe_ctx::dHead

@@ -229,103 +229,6 @@ struct FlowP<-1> {
     static __device__ __forceinline__ void run(double (&)[4], double (&)[4], double*, const double*, double*, DiagSync*, int) {}
 };
 
-// The same sixteen rounds as ONE loop body (round 6).  FlowP<15> is 16 unrolled copies of a ~130-instruction round: ~17 KB of
-// straight-line code that every chain workgroup executes exactly once — each line of it a cold miss of the instruction cache
-// (64 KB, shared by two CUs; the block's other waves stream another ~30 KB of single-use code through it meanwhile), fetched
-// from an L2 that hundreds of polling workgroups keep busy.  Stamps (profiles/r06_closing_stamps.log): the panel wave takes
-// 14.3-15 k cycles when the chip is quiet and 16-19 k in the first thirty columns of a closing launch.  As a loop the body is
-// fetched once and runs from the cache fifteen times; what was constexpr (lane indices of the broadcasts, buffer parities) is
-// wave-uniform scalar arithmetic.
-#ifndef FLOWP_LOOP
-#define FLOWP_LOOP 1
-#endif
-// one round; FETCH: the next group comes from the update waves' hand-over (rounds 1..14), NEXT: there is a next group (0..14)
-template <bool FETCH, bool NEXT>
-static __device__ __forceinline__ void flow_p_round(const int G, double (&c)[4], double (&n)[4], double* Ls, const double* H,
-                                                    double* invd, DiagSync* sy, int r)
-{
-    const int c0 = 4 * G;
-    const double* h = H + ((G + 1) & 1) * (NB * 4) + r * 4;
-    int seen = 0;
-    if (FETCH) {
-        seen = lds_peek(&sy->hflag[(G + 1) & 1]);
-        asm volatile("" ::: "memory");
-        n[0] = h[0];
-        n[1] = h[1];
-        n[2] = h[2];
-        n[3] = h[3];
-    }
-    const double b00 = bcast_lane(c[0], c0), b10 = bcast_lane(c[0], c0 + 1), b20 = bcast_lane(c[0], c0 + 2),
-                 b30 = bcast_lane(c[0], c0 + 3);
-    const double b11 = bcast_lane(c[1], c0 + 1), b21 = bcast_lane(c[1], c0 + 2), b31 = bcast_lane(c[1], c0 + 3);
-    const double b22 = bcast_lane(c[2], c0 + 2), b32 = bcast_lane(c[2], c0 + 3);
-    const double b33 = bcast_lane(c[3], c0 + 3);
-    const double y0 = rsq_newton(b00);
-    const double l10 = b10 * y0, l20 = b20 * y0, l30 = b30 * y0;
-    const double x0 = c[0] * y0;
-    const double y1 = rsq_newton(fma(-l10, l10, b11));
-    const double l21 = fma(-l20, l10, b21) * y1, l31 = fma(-l30, l10, b31) * y1;
-    const double x1 = fma(-x0, l10, c[1]) * y1;
-    double* dst = Ls + r * XS + c0;
-    dst[0] = x0;
-    dst[1] = x1;
-    const double y2 = rsq_newton(fma(-l21, l21, fma(-l20, l20, b22)));
-    const double l32 = fma(-l31, l21, fma(-l30, l20, b32)) * y2;
-    const double x2 = fma(-x1, l21, fma(-x0, l20, c[2])) * y2;
-    dst[2] = x2;
-    double m0[4], m1[4], m2[4];
-    if (NEXT) {
-        const double* mrow = Ls + (c0 + 4) * XS + c0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            m0[e] = mrow[e * XS + 0];
-            m1[e] = mrow[e * XS + 1];
-            m2[e] = mrow[e * XS + 2];
-        }
-    }
-    const double y3 = rsq_newton(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, b33))));
-    const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, c[3]))) * y3;
-    dst[3] = x3;
-    if (r == 0) {
-        invd[c0 + 0] = y0;
-        invd[c0 + 1] = y1;
-        invd[c0 + 2] = y2;
-        invd[c0 + 3] = y3;
-        lds_post(&sy->prog, G + 1);
-    }
-    if (FETCH && seen < G + 1) { // the hand-over was not there at the top of the round: wait for it where it is needed
-        lds_await(&sy->hflag[(G + 1) & 1], G + 1);
-        n[0] = h[0];
-        n[1] = h[1];
-        n[2] = h[2];
-        n[3] = h[3];
-    }
-    if (NEXT) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            n[e] = fma(-x0, m0[e], n[e]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            n[e] = fma(-x1, m1[e], n[e]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            n[e] = fma(-x2, m2[e], n[e]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            c[e] = fma(-x3, bcast_lane(x3, c0 + 4 + e), n[e]);
-    }
-    FTS(0, G);
-}
-static __device__ __forceinline__ void flow_p_loop(double (&c)[4], double (&n)[4], double* Ls, const double* H, double* invd,
-                                                   DiagSync* sy, int r)
-{
-    flow_p_round<false, true>(0, c, n, Ls, H, invd, sy, r); // (groups 0 and 1 were read from Ls at the start)
-#pragma unroll FLOWP_LOOP
-    for (int G = 1; G < 15; ++G)
-        flow_p_round<true, true>(G, c, n, Ls, H, invd, sy, r);
-    flow_p_round<false, false>(15, c, n, Ls, H, invd, sy, r);
-}
-
 // ---- U ---------------------------------------------------------------------------------------------------------------------
 // acc[bi][n]: element (row 16 bi + 4 ((lane >> 2) & 3) + (lane >> 4), column 16 BJ + 4 n + (lane & 3)) — st16's layout
 template <int BJ, int T>
@@ -667,11 +570,7 @@ static __device__ __forceinline__ void diag_flow(double* Ls, double* H, double* 
             n[e] = Ls[lane * XS + 4 + e];
         }
         __syncthreads();
-#if FLOWP_LOOP
-        flow_p_loop(c, n, Ls, H, invd, sy, lane);
-#else
         FlowP<15>::run(c, n, Ls, H, invd, sy, lane);
-#endif
         return;
     }
     __syncthreads();

@@ -101,8 +101,6 @@ struct gpe_ctx {
     int64_t tall_max = 1536;           // ... and up to this many columns in FRONT of them as one tall data-flow launch (all rows
                                        // below ride along) followed by ONE update with k = its width (GPE_TALL=0: 256-column panels
                                        // with look-ahead all the way to the closing launch, the round-3 schedule)
-    int tail_fold = 0;                 // GPE_TAIL_FOLD=1 (round 6): no update launch between the tall and the closing launch — the closing
-                                       // launch's tiles apply the tall columns themselves (potrf.hip: TailArgs::npre)
     int64_t batch_tail_max = 1536;     // tail_max of a batched launch sequence (GPE_BATCH_TAIL_MAX): G members share the chip, so
                                        // more of the work belongs in the one update between the two data-flow launches (measured,
                                        // profiles/r04_batch_split_ab.log: 8 x N = 2048 1.29 ms per batch at 1536 against 1.48 at 2560)
@@ -606,7 +604,6 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
     TailGen gen{c->dXt, ld, N, c->dOm, ld, (c->flow_solve && (N + NB - 1) / NB <= 256) ? c->dAl : nullptr, ld, c->P, &c->kp};
     const int64_t t0 = pl.t0, e0 = pl.e0, N64 = pl.N64;
     const int64_t stop0 = e0 >= 0 ? e0 : t0; // where the panels end: the panel in front of it updates everything left in one piece
-    int64_t fold0 = -1; // >= 0: the closing launch applies the columns [fold0, t0) itself (no update launch in front of it)
     for (int64_t p0 = 0; p0 < N; p0 += nbo) {
         if (e0 >= 0 && p0 == e0) {
             if (la_pending) {
@@ -624,8 +621,7 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 ++c->tall_count;
                 c->tall_lay = pl.nt_tall * 65536 + pl.nb_tall;
             }
-            fold0 = (c->tail_fold && tail_can_fold(c->gen_mode == 1 ? &gen : nullptr)) ? e0 : -1;
-            if (fold0 < 0) { // everything behind t0 -= L[t0:M, e0:t0] L[t0:N, e0:t0]^T: one launch, k = t0 - e0
+            { // everything behind t0 -= L[t0:M, e0:t0] L[t0:N, e0:t0]^T: one launch, k = t0 - e0
                 GemmArgs g{};
                 g.C = A + t0 + t0 * ld;
                 g.ldc = ld;
@@ -652,10 +648,9 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 la_pending = false;
             }
             {
-                const double wt = (double)(N64 - t0), kf = fold0 >= 0 ? (double)(t0 - fold0) : 0.0;
-                PhaseScope ps(c, GPE_PH_POTRF_TAIL, wt * wt * wt / 3.0 + kf * ((double)(N - t0) * (N - t0) + 2.0 * (M - N) * (N - t0)));
+                PhaseScope ps(c, GPE_PH_POTRF_TAIL, (double)(N64 - t0) * (N64 - t0) * (N64 - t0) / 3.0);
                 launch_tail(s, A, ld, t0, N64, N64, M, c->dXinv, c->dInfo, c->dTail + (c->tail_count & 1) * c->tail_cap,
-                            c->dTail + ((c->tail_count + 1) & 1) * c->tail_cap, c->gen_mode == 1 ? &gen : nullptr, fold0);
+                            c->dTail + ((c->tail_count + 1) & 1) * c->tail_cap, c->gen_mode == 1 ? &gen : nullptr);
                 ++c->tail_count;
                 c->tail_lay = pl.nt_tail * 65536 + pl.nb_tail;
             }
@@ -665,14 +660,13 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 GemmArgs g{};
                 g.C = A + N64 + N64 * ld;
                 g.ldc = ld;
-                const int64_t k0 = fold0 >= 0 ? fold0 : t0; // (fold: nobody applied the tall columns to the ragged block either)
-                g.A = A + N64 + k0 * ld;
+                g.A = A + N64 + t0 * ld;
                 g.lda = ld;
-                g.B = A + N64 + k0 * ld;
+                g.B = A + N64 + t0 * ld;
                 g.ldb = ld;
                 g.m = M - N64;
                 g.n = N - N64;
-                g.k = N64 - k0;
+                g.k = N64 - t0;
                 g.tri = 1;
                 g.grow0 = N64;
                 g.gcol0 = N64;
@@ -2093,8 +2087,6 @@ int gpe_create(int device_id, gpe_handle* out)
         c->tail_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), GPE_TAIL_MAX);
     if (const char* f = getenv("GPE_TALL"))
         c->tall_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), GPE_TAIL_MAX);
-    if (const char* f = getenv("GPE_TAIL_FOLD"))
-        c->tail_fold = atoi(f);
     c->batch_tail_max = std::min(c->batch_tail_max, c->tail_max);
     if (const char* f = getenv("GPE_BATCH_TAIL_MAX"))
         c->batch_tail_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), c->tail_max);

@@ -1460,13 +1460,6 @@ struct TailArgs {
     double* Al;       // optional: the backward sweep's output, pre-filled with its sentinel here (what the build launch does)
     int64_t ldal;
     int P;
-    // fold (round 6, npre > 0): the npre tile columns [pre0, t0) in front of this launch are factored (L in A, final: an earlier
-    // launch) but their update of this launch's tiles has NOT been applied — every tile takes those npre products itself,
-    // operands by ordinary loads from A, in front of its polled steps ("left-looking" across the launch boundary: the k = t0 - pre0
-    // trailing update of the three-launch schedule runs inside the closing launch, under its latency chain)
-    int64_t pre0;
-    int npre;
-    int dbg; // TEMP experiment: 1 = every tile's fold operands from the same rows (perfect L2 locality; wrong numbers)
 };
 // LDS of a k_tail workgroup: two pairs of operand tiles [A0 | B0 | A1 | B1] (40 KB each: all of the CU's 160 KB) for the pipelined
 // products of the update loop; behind it the carve of the solve and the factorisation (CH_*, further down; the pair form of
@@ -1729,31 +1722,6 @@ static __device__ __forceinline__ void tail_chain_updates_and_crossing(const Tai
     syrk40_load_neg(lds, wave, lane, a2v);
     __syncthreads(); // (the loop's first operands land in the same place)
     unsigned long long xb[4]; // X11: e, e + 512; L21: 1024 + e, 1024 + e + 512
-    double a2l[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    if (a.npre > 0) {
-        // fold: the columns in front of the launch, L(c, j) and L(c-1, j) from A by ordinary loads (final: an earlier launch wrote
-        // them).  Same pipeline as the polled steps below; the pair alternates INTO theirs (the last of these uses pair
-        // (c - 1) & 1, the first polled step (c - 2) & 1, the last step of all pair 0).
-        const double* Ga = a.A + x.R0 + a.pre0 * a.lda;
-        const double* Gb = Ga - NB;
-        TileRegs ta, tb;
-        ta.load(Ga, a.lda, NB);
-        tb.load(Gb, a.lda, NB);
-#pragma unroll 1
-        for (int j = 0; j < a.npre; ++j) {
-            double* const opA = lds + ((c - 2 + a.npre - j) & 1) * (2 * NB * PS);
-            double* const opB = opA + NB * PS;
-            ta.store(opA);
-            tb.store(opB);
-            if (j + 1 < a.npre) {
-                ta.load(Ga + (int64_t)(j + 1) * NB * a.lda, a.lda, NB);
-                tb.load(Gb + (int64_t)(j + 1) * NB * a.lda, a.lda, NB);
-            }
-            __syncthreads();
-            mm64<false>(opA, opB, wm, wn, lane, a2l);
-            syrk40<NB>(opA, 0, wave, lane, a2v);
-        }
-    }
     if (c > 1) {
         // Steps s < c-1: tile (c, c-1) -= L(c, s) L(c-1, s)^T, tile (c, c) -= L(c, s) L(c, s)^T.  Software-pipelined over two pairs of
         // operand buffers (the operands of step s+1 are on their way under the products of step s: one barrier a step); the pair
@@ -1761,6 +1729,7 @@ static __device__ __forceinline__ void tail_chain_updates_and_crossing(const Tai
         PolledTile pa, pb;
         pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
         pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, 0) * (NB * NB));
+        double a2l[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll 1
         for (int s = 0; s < c - 2; ++s) {
             double* const opA = lds + ((c - 2 - s) & 1) * (2 * NB * PS);
@@ -1827,20 +1796,9 @@ static __device__ __forceinline__ void tail_chain_updates_and_crossing(const Tai
             }
     }
     else {
-        // (c == 1; with a fold its last step used pair 0 and every wave is through with pair 1, where T lies)
 #pragma unroll
         for (int it = 0; it < 8; ++it)
             T[(ccol + 2 * it) * PS + crow] = cl[it];
-        if (a.npre > 0) {
-            __syncthreads();
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    double* t = T + (wn + 4 * n + dcol) * PS + wm + 16 * m + drow;
-                    *t = *t - a2l[m][n];
-                }
-        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             xb[q] = __hip_atomic_load(Sp + 512 * q, __ATOMIC_RELAXED, POLL_FIRST_SCOPE);
@@ -2301,31 +2259,6 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
             tail_chain_updates_and_crossing(a, x, lds, c, cl, cv);
             TTS(c, 1);
         }
-        else if (a.npre > 0) {
-            // fold, the launch's first diagonal block: -= sum_j L(0, j) L(0, j)^T over the columns in front of the launch (the chain
-            // workgroup's accumulator form: syrk40; pairs alternate so that the last step reads pair 1 — Dl lies in pair 0)
-            double a2v[5];
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                lds[crow * XS + ccol + 2 * it] = cv[it];
-            __syncthreads();
-            syrk40_load_neg(lds, wave, lane, a2v);
-            __syncthreads();
-            const double* Ga = a.A + x.R0 + a.pre0 * a.lda;
-            TileRegs ta;
-            ta.load(Ga, a.lda, NB);
-#pragma unroll 1
-            for (int j = 0; j < a.npre; ++j) {
-                double* const opA = lds + ((a.npre - j) & 1) * (2 * NB * PS);
-                ta.store(opA);
-                if (j + 1 < a.npre)
-                    ta.load(Ga + (int64_t)(j + 1) * NB * a.lda, a.lda, NB);
-                __syncthreads();
-                syrk40<NB>(opA, 0, wave, lane, a2v);
-            }
-            syrk40_store_neg(Dl, wave, lane, a2v);
-            diag_flow_init(sy);
-        }
         else {
 #pragma unroll
             for (int it = 0; it < 8; ++it)
@@ -2355,41 +2288,14 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
     }
     // ---- any other tile: steps 0 .. c-1, then its solve ----
     PolledTile pa, pb;
-    double a2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    const int par = a.npre & 1; // (the pairs go on alternating behind the fold's steps)
-    if (a.npre > 0) {
-        // fold: tile -= L(b, j) L(c, j)^T over the npre tile columns in front of the launch, operands by ordinary loads from A
-        // (final: an earlier launch wrote them), the next step's on their way under this step's product
-        const double* Ga = a.A + (a.dbg == 1 ? a.t0 : x.R0) + a.pre0 * a.lda;
-        const double* Gb = a.A + a.t0 + (a.dbg == 1 ? 0 : (int64_t)NB * c) + a.pre0 * a.lda;
-        TileRegs ta, tb;
-        ta.load(Ga, a.lda, x.nrows);
-        tb.load(Gb, a.lda, NB);
-#pragma unroll 1
-        for (int j = 0; j < a.npre; ++j) {
-            double* const opA = lds + (j & 1) * (2 * NB * PS);
-            double* const opB = opA + NB * PS;
-            ta.store(opA);
-            tb.store(opB);
-            if (j + 1 < a.npre) {
-                ta.load(Ga + (int64_t)(j + 1) * NB * a.lda, a.lda, x.nrows);
-                tb.load(Gb + (int64_t)(j + 1) * NB * a.lda, a.lda, NB);
-            }
-            else if (c > 0) {
-                pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, b, 0) * (NB * NB));
-                pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
-            }
-            __syncthreads();
-            mm64<false>(opA, opB, wm, wn, lane, a2);
-        }
-    }
-    else if (c > 0) {
+    if (c > 0) {
         pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, b, 0) * (NB * NB));
         pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
     }
+    double a2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll 1
     for (int s = 0; s < c; ++s) { // (pipelined over two pairs of operand buffers, one barrier a step: see the diagonal workgroup's loop)
-        double* const opA = lds + ((s + par) & 1) * (2 * NB * PS);
+        double* const opA = lds + (s & 1) * (2 * NB * PS);
         double* const opB = opA + NB * PS;
         pa.finish(a.LP + (int64_t)tail_tile_id(a.nb, b, s) * (NB * NB), x.spin_limit, x.info);
         pa.store(opA);
@@ -2402,7 +2308,7 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
         __syncthreads();
         mm64<false>(opA, opB, wm, wn, lane, a2);
     }
-    if (c > 0 || a.npre > 0) {
+    if (c > 0) {
         double a2r[8];
         wave_tile_to_rows(a2, a2r, lane);
 #pragma unroll
@@ -2706,15 +2612,8 @@ int debug_tail_order(int nt, int nb, int lag, int pair)
 // to 64; t1 == N64: the closing launch) and, as one more row strip, the M - N64 <= 64 rows below them — right-hand-side rows and
 // the rows of a ragged last block the caller finishes.  Fully updated by everything in front of t0.  buf_cur / buf_next:
 // tail_buf_doubles(nt, nb) each, all-ones (this launch arms buf_next)
-// GPE_TAIL_PAIR=1: two diagonal blocks per chain workgroup (diag_flow2.h)
-static int tail_pair_mode()
-{
-    static const int pair = getenv("GPE_TAIL_PAIR") ? atoi(getenv("GPE_TAIL_PAIR")) : 0;
-    return pair;
-}
-bool tail_can_fold(const TailGen* gen) { return !tail_pair_mode() && !gen && !g_batch.bt; }
 void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, int64_t N64, int64_t M, double* Xt_all, int* info,
-                 double* buf_cur, double* buf_next, const TailGen* gen, int64_t pre0)
+                 double* buf_cur, double* buf_next, const TailGen* gen)
 {
     TailArgs a{};
     a.A = A;
@@ -2736,12 +2635,9 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
     // just-in-time window W > 0 LOSES (6: 675, 8: 694, 12: 738, 16: 770): a tile dispatched late has its catch-up products still
     // to do when its row's diagonal workgroup asks for it; waiting workgroups are not what limits the closing launch
     static const int ord_lag = getenv("GPE_TAIL_LAG") ? atoi(getenv("GPE_TAIL_LAG")) : 3;
-    a.pair = tail_pair_mode() && a.nt >= 2 ? 1 : 0;
-    if (pre0 >= 0 && pre0 < t0 && tail_can_fold(gen)) { // fold: the update by columns [pre0, t0) runs inside the launch
-        a.pre0 = pre0;
-        a.npre = (int)((t0 - pre0) / NB);
-        a.dbg = getenv("GPE_TAIL_DBG") ? atoi(getenv("GPE_TAIL_DBG")) : 0;
-    }
+    // GPE_TAIL_PAIR=1: two diagonal blocks per chain workgroup (diag_flow2.h)
+    static const int pair = getenv("GPE_TAIL_PAIR") ? atoi(getenv("GPE_TAIL_PAIR")) : 0;
+    a.pair = pair && a.nt >= 2 ? 1 : 0;
     a.order = tail_order(a.nt, a.nb, 0, ord_lag, a.pair); // (W: the just-in-time window of the table, measured as a loss — kept in tail_order for the record)
     const int64_t tiles = tail_tiles(a.nt, a.nb);
     if (gen) {
