@@ -2663,6 +2663,11 @@ static int query_transposed(gpe_ctx* c, const double* Xq, int64_t M, double* kta
     double* dVar = dKta + n_kta;
     double* dKvv = dVar + mc_max;
     int rc = GPE_OK;
+    // The tile of every product below is picked from N alone, never from the batch: the 128 x 128 and the 64 x 64 kernels round
+    // differently in the last bit (measured, round 6: a point's variance moved by 1.5e-15 with the size of the batch it was asked
+    // in, because launch_gemm_sub picks the tile from the live-tile count = from mc).  A point's answer must not depend on the
+    // batch around it (tests/test_gpu_configs.py: the 100 000-point batch of configs[2] bitwise equal to chunks of 4096).
+    const int qtile = N >= 1024 ? 128 : 64;
     if (var) {
         PhaseScope ps(c, GPE_PH_QUERY, 0.0);
         launch_inv_panels(s, c->dA, ld, N, (int)nbo, c->dXinv, dXp, 0, nullptr, 0); // X_p of every panel, compact
@@ -2699,11 +2704,13 @@ static int query_transposed(gpe_ctx* c, const double* Xq, int64_t M, double* kta
                     g.n = pw;
                     g.k = pw;
                     g.overwrite = 1;
+                    g.tile = qtile;
                     PhaseScope ps(c, GPE_PH_QUERY, gemm_flops(g));
                     launch_gemm_sub(s, g);
                 }
                 if (oe < N) {
                     GemmArgs g{};
+                    g.tile = qtile;
                     g.C = dKst + oe * ldq;
                     g.ldc = ldq;
                     g.A = dZt + o0 * ldq;
