@@ -349,6 +349,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="profiling runs: only the N=4096 evaluation loop (no H2D variant, no config 4)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (hp_objective, config3, config4_g64, config5)")
+    ap.add_argument("--c3-n", type=int, default=16384, help="config3_sharded: samples (debug / tests: a reduced N)")
+    ap.add_argument("--c3-m", type=int, default=100000, help="config3_sharded: query points in all")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group (and run barrier / all_gather / all_reduce) even with ONE rank: the RCCL "
                          "branch rehearsed on a one-GPU box (tests/test_gpu_configs.py::test_gpu_bench_one_rank_rccl)")
@@ -506,6 +508,54 @@ def main():
                    "value": world * G4 * reps4 / dt4, "unit": "evaluations/s", "gps_total": G4 * world, "ms_per_batch": 1e3 * dt4 / reps4,
                    "tflops": world * G4 * reps4 / dt4 * (N4 ** 3 / 3.0 + 2.0 * N4 * N4) / 1e12, "best_log_lik": float(best4[0])}
 
+    config3_sharded = None
+    if not args.headline_only and dist is not None:
+        # BASELINE configs[2] across ranks — SURVEY §8(e)'s second shard axis (multi_gp.hpp:191-195, tools/parallel.hpp:138-201: the
+        # reference's parallel query): every rank factors its OWN replica of the N = 16384 Matern-5/2 GP (31 ms — cheaper than
+        # broadcasting a 2 GiB factor over xGMI), answers row_slice(M, rank, world) of the 100 000 points with one
+        # gpe_query_batch, ONE all-gather of (P + 1) doubles per point reassembles mu / sigma^2 on every rank.  Strong scaling:
+        # the M points are fixed, the per-rank share shrinks.  Rank 0 then asks 512 points of the LAST rank's slice itself:
+        # replicas and batch-invariant queries make the gathered answer bitwise its own.
+        N3, M3 = args.c3_n, args.c3_m
+        X3, Y3 = O.make_problem("c3", N=N3)
+        om3, mean3 = O.obs_mean_data(Y3)
+        h3 = _capi.Handle(eng, local_rank)
+        h3.set_kernel(O.MATERN52, np.zeros(2), 0.01)
+        h3.set_data(X3, om3)
+        assert h3.compute() == 0  # warm (allocations, hand-over buffers)
+        Xq3 = np.random.default_rng(20260928).uniform(0.0, 1.0, size=(M3, X3.shape[1]))  # the same points on every rank
+        h3.query_batch(Xq3[: min(M3, 4096)])
+        sync()
+        t0 = time.perf_counter()
+        info3 = h3.compute()
+        ll3 = h3.log_lik()
+        sync()
+        dt3_fact = max_over_ranks(time.perf_counter() - t0)
+        st3 = {}
+        t0 = time.perf_counter()
+        kta3, var3 = PAR.query_sharded(h3.query_batch, Xq3, dist, device=coll_dev, force=args.force_dist, stats=st3)
+        sync()
+        dt3_q = max_over_ranks(time.perf_counter() - t0)
+        gather3 = max_over_ranks(st3["gather_s"])
+        local3 = max_over_ranks(st3["local_s"])
+        assert info3 == 0 and np.isfinite(ll3) and kta3.shape == (M3, 1) and var3.shape == (M3,) and np.all(np.isfinite(var3))
+        sl_last = PAR.row_slice(M3, world - 1, world)
+        chk = slice(sl_last.start, min(sl_last.stop, sl_last.start + 512))
+        k_own, v_own = h3.query_batch(Xq3[chk])
+        same = bool(np.array_equal(np.asarray(k_own).reshape(-1), kta3[chk, 0]) and np.array_equal(np.asarray(v_own).reshape(-1), var3[chk]))
+        h3.close()
+        config3_sharded = {
+            "workload": f"configs[2] sharded over the query points: Matern5/2 GP, N={N3}, D={X3.shape[1]}, fp64, a replica per rank (each rank "
+                        f"factors its own), {M3} query points dealt in contiguous slices over {world} rank(s) (row_slice), one all-gather of "
+                        "(mu, sigma^2); strong scaling in M",
+            "value": M3 / dt3_q, "unit": "query points/s (whole job, incl. the all-gather)", "points": M3, "points_per_rank": int(st3["points_local"]),
+            "query_s": dt3_q, "local_query_s_max_over_ranks": local3, "gather_s_max_over_ranks": gather3,
+            "replica_compute_loglik_ms": 1e3 * dt3_fact, "log_lik": float(ll3),
+            "gathered_equals_own_answer_bitwise": same,
+            "query_tflops": M3 / dt3_q * (float(N3) * N3 + 2.0 * N3) / 1e12,
+        }
+        assert same, "config3_sharded: the gathered answer of another rank's slice differs from this rank's own answer"
+
     out = {
         "metric": "GP compute()+log_lik evaluations/sec at N=4096 D=6 fp64",
         "value": value,
@@ -528,6 +578,7 @@ def main():
         "value_incl_h2d": value_incl_h2d,
         "value_incl_h2d_note": "same step with gpe_set_data (X: 196 KB, obs_mean: 32 KB, host -> HBM) inside the timed region",
         "config4": config4,
+        "config3_sharded": config3_sharded,
         "collectives": {"backend": args.dist_backend if dist is not None else None, "world": world,
                         "tensors_on": coll_dev if dist is not None else None, "executed": executed,
                         "note": "barrier + max-over-ranks all_reduce around every timed region, all_gather arg-max of (log_lik, theta) "

@@ -59,15 +59,22 @@ def row_slice(n_rows: int, rank: int, world: int) -> slice:
     return slice(lo, lo + q + (1 if rank < r else 0))
 
 
-def query_sharded(query_fn, Xq, dist=None, device="cpu"):
+def query_sharded(query_fn, Xq, dist=None, device="cpu", force=False, stats=None):
     """query_fn(points) -> (kta [m x P], var [m]) on this rank's replica of the GP (e.g.
-    Handle.query_batch).  Returns the full (kta [M x P], var [M]) on every rank."""
+    Handle.query_batch).  Returns the full (kta [M x P], var [M]) on every rank.
+    force: run the collectives even in a group of one rank (bench.py --force-dist).
+    stats (a dict, optional): this rank's seconds in its own slice ("local_s") and in the collectives ("gather_s")."""
+    import time
+
     import torch
 
     Xq = np.ascontiguousarray(Xq, dtype=np.float64)
     M = Xq.shape[0]
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    t0 = time.perf_counter()
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         kta, var = query_fn(Xq)
+        if stats is not None:
+            stats.update(local_s=time.perf_counter() - t0, gather_s=0.0, points_local=M)
         return np.asarray(kta, float).reshape(M, -1), np.asarray(var, float).reshape(M)
     rank, world = dist.get_rank(), dist.get_world_size()
     sl = row_slice(M, rank, world)
@@ -77,6 +84,7 @@ def query_sharded(query_fn, Xq, dist=None, device="cpu"):
         kta = np.asarray(kta, float).reshape(m, -1)
     else:  # more ranks than points: nothing to answer, P learnt from the others
         kta, var = np.zeros((0, 0)), np.zeros(0)
+    t1 = time.perf_counter()
     P = torch.tensor([kta.shape[1]], dtype=torch.int64, device=device)
     dist.all_reduce(P, op=dist.ReduceOp.MAX)  # a rank with an empty slice does not know P
     P = int(P.item())
@@ -90,4 +98,6 @@ def query_sharded(query_fn, Xq, dist=None, device="cpu"):
     dist.all_gather(parts, t)
     out = np.concatenate([parts[r].cpu().numpy()[: row_slice(M, r, world).stop - row_slice(M, r, world).start]
                           for r in range(world)])
+    if stats is not None:
+        stats.update(local_s=t1 - t0, gather_s=time.perf_counter() - t1, points_local=m)
     return out[:, :P].copy(), out[:, P].copy()

@@ -1263,7 +1263,8 @@ def test_gpu_bench_ranks_on_one_gpu(ranks):
     (--dist-backend gloo; the driver's runs use RCCL).  The 8-rank rehearsal takes the schedules without data-flow launches
     (GPE_TAIL_MAX=0 GPE_PANEL256=0 GPE_FLOW_SOLVE=0): eight PROCESSES on one GPU would otherwise starve each other's
     chains (the gate that orders data-flow launches is per process, DESIGN 3.12) — on the node every rank has its own GPU;
-    what is rehearsed here is the distributed plumbing: n_gpus, the 64 GPs of configs[3] dealt 8 per rank, the arg-max owner."""
+    what is rehearsed here is the distributed plumbing: n_gpus, the 64 GPs of configs[3] dealt 8 per rank, the arg-max owner,
+    and (round 6) configs[2]'s query points dealt over the ranks with every rank factoring its replica (`config3_sharded`)."""
     import json
     import socket
 
@@ -1275,7 +1276,7 @@ def test_gpu_bench_ranks_on_one_gpu(ranks):
         env.update(GPE_TAIL_MAX="0", GPE_PANEL256="0", GPE_FLOW_SOLVE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
-           "--dist-backend", "gloo"]
+           "--dist-backend", "gloo", "--c3-n", "2048", "--c3-m", "5003"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -1287,6 +1288,10 @@ def test_gpu_bench_ranks_on_one_gpu(ranks):
     assert out["argmax"]["owner_rank"] in range(ranks) and np.isfinite(out["argmax"]["best_log_lik"])
     assert set(out["collectives"]["executed"]) >= {"barrier", "all_gather", "all_reduce"} and out["collectives"]["world"] == ranks
     assert "roofline" in out and "cpu_baseline" not in out  # rank 0 at N = 1 only
+    # round 6: configs[2] sharded over the query points (a replica per rank, row_slice of the points, one all-gather) at a reduced N
+    c3 = out["config3_sharded"]
+    assert c3["points"] == 5003 and c3["points_per_rank"] == 5003 // ranks + (1 if 5003 % ranks else 0) and c3["value"] > 0
+    assert c3["gathered_equals_own_answer_bitwise"] is True and np.isfinite(c3["log_lik"]) and c3["gather_s_max_over_ranks"] >= 0
     print(f"{ranks} ranks on one GPU: {out['value']:.1f} evaluations/s in all, config4 {out['config4']['value']:.0f}/s, arg-max owner rank {out['argmax']['owner_rank']}")
 
 
@@ -1304,7 +1309,7 @@ def test_gpu_bench_one_rank_rccl():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     common = ["--gpus", "1", "--steps", "20", "--warmup", "3", "--no-extras", "--no-cpu-baseline", "--no-roofline"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "bench.py"), "--force-dist"] + common
+           "--master-port", str(port), str(ROOT / "bench.py"), "--force-dist", "--c3-n", "2048", "--c3-m", "3000"] + common
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -1314,6 +1319,7 @@ def test_gpu_bench_one_rank_rccl():
     assert {"barrier", "all_gather", "all_reduce"} <= set(out["collectives"]["executed"])
     assert out["argmax"]["owner_rank"] == 0 and np.isfinite(out["argmax"]["best_log_lik"])
     assert out["config4"]["gps_total"] == 8 and out["config4"]["value"] > 0
+    assert out["config3_sharded"]["points_per_rank"] == 3000 and out["config3_sharded"]["gathered_equals_own_answer_bitwise"] is True
     r2 = subprocess.run([sys.executable, str(ROOT / "bench.py")] + common, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     plain = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][0])
