@@ -76,6 +76,11 @@ int gpe_clone(gpe_handle src, gpe_handle* out);
 int gpe_clone_to(gpe_handle src, int device_id, gpe_handle* out);
 int gpe_device_count(int* n);
 int gpe_get_device(gpe_handle h, int* device_id);
+/* A counter that moves with every call that can change what a query answers (set_data, set_kernel, compute, add_sample,
+ * update_alpha, set_L, set_alpha, the batched entry points ...): a clone made at epoch e answers like its source for as long as
+ * the source's epoch is still e.  The C++ drop-in keeps one query replica per device on it (model/gp.hpp: query_batch over
+ * the visible devices — the reference's parallel query, multi_gp.hpp:191-195 / tools/parallel.hpp:138-201). */
+int gpe_epoch(gpe_handle h, uint64_t* epoch);
 int gpe_destroy(gpe_handle h);
 const char* gpe_last_error(gpe_handle h);
 const char* gpe_version(void);

@@ -42,6 +42,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -154,7 +155,11 @@ namespace limbo {
 
             /// device this GP lives on / move it (additions)
             int device() const { return _eng.device(); }
-            void set_device(int device) { _eng.set_device(device); }
+            void set_device(int device)
+            {
+                _eng.set_device(device);
+                release_query_replicas(); // (they were dealt around the old home)
+            }
 
             GP& operator=(const GP& o)
             {
@@ -610,6 +615,11 @@ namespace limbo {
             mutable bool _dev_shadow_ok = false; // (host mode) the device copy that serves large query_batch() calls is current
             mutable Eigen::VectorXd _shadow_hp;   // ... and the kernel hyper-parameters / noise it was given
             mutable double _shadow_noise = -1.0;
+            // ---- query replicas (round 6): one deep copy of the device model per OTHER visible device, made lazily by the first
+            // large query_batch() and valid while the engine's epoch (gpe_epoch) stands still; never copied with the GP
+            mutable std::vector<limbo_amd::Engine> _replicas;
+            mutable uint64_t _replica_epoch = 0;
+            mutable std::mutex _replica_mu;
 
             bool _use_host(int64_t n) const { return !_host_off && n < (int64_t)limbo_amd::min_n_for_gpu<Params>(); }
             /// everything without a host form: the model moves to the device and stays there
@@ -654,6 +664,11 @@ namespace limbo {
                 std::swap(_host_mode, o._host_mode);
                 std::swap(_host_off, o._host_off);
                 std::swap(_dev_shadow_ok, o._dev_shadow_ok);
+                std::swap(_shadow_hp, o._shadow_hp); // (the flag never travels without what it vouches for)
+                std::swap(_shadow_noise, o._shadow_noise);
+                _replicas.clear(); // (replicas belong to a handle; both handles changed hands)
+                o._replicas.clear();
+                _replica_epoch = o._replica_epoch = 0;
             }
 
             void _status_or(int rc)
@@ -1035,7 +1050,12 @@ namespace limbo {
                         for (int d = 0; d < _dim_in; ++d)
                             Xq[(size_t)(m * _dim_in + d)] = pts[m](d);
                     }
-                    _eng.check(gpe_query_batch(_eng.get(), Xq.data(), M, kta, var), "gpe_query_batch");
+                if (!_host_mode && limbo_amd::multi_device_query_min() > 0 && M >= (int64_t)limbo_amd::multi_device_query_min()
+                    && limbo_amd::visible_devices() > 1 && limbo_amd::param_device<Params>::get() < 0) {
+                    _query_over_devices(Xq.data(), M, kta, var);
+                    return;
+                }
+                _eng.check(gpe_query_batch(_eng.get(), Xq.data(), M, kta, var), "gpe_query_batch");
                     return;
                 }
                 // functor-built cross kernel (gp.hpp:626-632), solves on the device
@@ -1048,6 +1068,73 @@ namespace limbo {
                     for (int64_t m = 0; m < M; ++m)
                         var[m] = _kernel_function(pts[m], pts[m]) - zz[(size_t)m];
             }
+            /// One GP's batch over ALL visible devices (missing 3; the reference's parallel query: multi_gp.hpp:191-195,
+            /// tools/parallel.hpp:138-201 — TBB tasks over host cores there): device d answers a contiguous slice of the points
+            /// on its own replica of the model (gpe_clone_to: a peer copy over xGMI, made once per state of the model — the
+            /// engine's epoch — and kept), one host thread per device, no collective: every slice lands in the caller's
+            /// arrays.  Batched queries pick their kernels from N alone, so a point's answer does not depend on the slice it
+            /// fell into: the result is bitwise the one-device answer.  Not used when Params::gpu::device() pins the model.
+            void _query_over_devices(const double* Xq, int64_t M, double* kta, double* var) const
+            {
+                std::lock_guard<std::mutex> lk(_replica_mu);
+                const int ndev = limbo_amd::visible_devices(), own = _eng.device();
+                uint64_t ep = 0;
+                _eng.check(gpe_epoch(_eng.get(), &ep), "gpe_epoch");
+                if ((int)_replicas.size() != ndev - 1 || _replica_epoch != ep) {
+                    _replicas.clear();
+                    _replicas.reserve((size_t)(ndev - 1));
+                    for (int d = 0; d < ndev; ++d)
+                        if (d != own)
+                            _replicas.emplace_back(_eng, d);
+                    _replica_epoch = ep;
+                }
+                const int P = _dim_out, D = _dim_in;
+                auto lo_of = [&](int k) { return (int64_t)k * (M / ndev) + std::min<int64_t>(k, M % ndev); }; // (parallel.py: row_slice)
+                std::vector<std::string> errs((size_t)ndev);
+                auto work = [&](int k, limbo_amd::Engine* e) {
+                    try {
+                        const int64_t lo = lo_of(k), m = lo_of(k + 1) - lo;
+                        if (m <= 0)
+                            return;
+                        if (P == 1 || !kta) {
+                            e->check(gpe_query_batch(e->get(), Xq + lo * D, m, kta ? kta + lo : nullptr, var ? var + lo : nullptr), "gpe_query_batch");
+                            return;
+                        }
+                        std::vector<double> kl((size_t)(m * P)); // kta is [point + M output]: a slice is not contiguous in it
+                        e->check(gpe_query_batch(e->get(), Xq + lo * D, m, kl.data(), var ? var + lo : nullptr), "gpe_query_batch");
+                        for (int p = 0; p < P; ++p)
+                            std::copy(kl.begin() + (size_t)(m * p), kl.begin() + (size_t)(m * (p + 1)), kta + lo + M * p);
+                    }
+                    catch (const std::exception& ex) {
+                        errs[(size_t)k] = ex.what();
+                    }
+                };
+                std::vector<std::thread> th;
+                int slot = 1; // slice 0 is the model's own device (this thread), slices 1.. the replicas in device order
+                for (auto& r : _replicas)
+                    th.emplace_back(work, slot++, &r);
+                work(0, &_eng);
+                for (auto& t : th)
+                    t.join();
+                for (auto& e : errs)
+                    if (!e.empty())
+                        throw std::runtime_error(e);
+            }
+        public:
+            /// Addition: give the per-device query replicas back (device memory: one copy of the model on every other device)
+            void release_query_replicas() const
+            {
+                std::lock_guard<std::mutex> lk(_replica_mu);
+                _replicas.clear();
+                _replica_epoch = 0;
+            }
+            /// Addition (tests): how many devices the last large query_batch() was dealt over (1 + replicas alive)
+            int query_devices() const
+            {
+                std::lock_guard<std::mutex> lk(_replica_mu);
+                return 1 + (int)_replicas.size();
+            }
+        protected:
             void _query_one(const Eigen::VectorXd& v, Eigen::VectorXd* kta, double* var) const
             {
                 if (_host_mode) {

@@ -62,6 +62,18 @@ namespace limbo_amd {
         return v;
     }
 
+    /// query_batch() of a device-resident model is dealt over ALL visible devices (one replica each, a host thread per
+    /// device) from this many points on (LIMBO_AMD_MULTI_DEVICE_QUERY_MIN; 0: never) — the reference's parallel query
+    /// (multi_gp.hpp:191-195, tools/parallel.hpp:138-201) with GPUs in place of cores
+    inline long multi_device_query_min()
+    {
+        static const long v = [] {
+            const char* e = std::getenv("LIMBO_AMD_MULTI_DEVICE_QUERY_MIN");
+            return e ? std::atol(e) : 16384L;
+        }();
+        return v;
+    }
+
     namespace host_small {
         /// A (n x n, column-major, leading dimension lda): lower triangle in, L out; the strict upper triangle is zeroed
         /// (gp.hpp:565: `Eigen::LLT<MatrixXd>(K).matrixL()` is dense with a zero upper part).  Returns 0, or the 1-based

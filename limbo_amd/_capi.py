@@ -98,6 +98,7 @@ def _sig(lib, prefix):
             "trace": [C.c_int],
             "trace_dump": [C.c_char_p],
             "hbm_stream_peak": [C.c_int, _dp],
+            "epoch": [_vp, C.POINTER(C.c_uint64)],
         }
         for name, args in G.items():
             f = getattr(lib, prefix + name)
@@ -189,6 +190,12 @@ class Handle:
         d = C.c_int()
         self._chk(self.lib.fn("get_device")(self._h, C.byref(d)), "get_device")
         return d.value
+
+    def epoch(self) -> int:
+        """Moves with every call that can change what a query answers (include/gpe.h: gpe_epoch)."""
+        e = C.c_uint64()
+        self._chk(self.lib.fn("epoch")(self._h, C.byref(e)), "epoch")
+        return e.value
 
     def flow_retries(self) -> int:
         n = _i64()

@@ -90,6 +90,8 @@ struct PhaseRec {
 } // namespace
 
 struct gpe_ctx {
+    std::atomic<uint64_t> epoch{1}; // bumped by every call that can change what a query answers (gpe_epoch: round 6 — the C++ drop-in's
+                                    // per-device query replicas are valid exactly as long as this has not moved)
     int device = 0;  // physical HIP device
     int ldevice = 0; // the device id the caller used (differs from `device` only under GPE_VIRTUAL_DEVICES)
     hipStream_t stream = nullptr;
@@ -2160,6 +2162,8 @@ const char* gpe_last_error(gpe_handle c) { return c ? c->err.c_str() : "null han
 
 int gpe_set_data(gpe_handle c, const double* X, int64_t N, int D, const double* obs_mean, int P)
 {
+    if (c)
+        ++c->epoch;
     if (!c || !X || !obs_mean || N <= 0 || D <= 0 || D > GPE_MAX_THETA - 2 || P <= 0)
         return GPE_ERR_ARG;
     DevGuard g(c);
@@ -2199,6 +2203,8 @@ int gpe_set_data(gpe_handle c, const double* X, int64_t N, int D, const double* 
 
 int gpe_set_data_device(gpe_handle c, const double* dX, int64_t N, int D, const double* dOm, int P)
 {
+    if (c)
+        ++c->epoch;
     if (!c || !dX || !dOm || N <= 0 || D <= 0 || D > GPE_MAX_THETA - 2 || P <= 0)
         return GPE_ERR_ARG;
     DevGuard g(c);
@@ -2221,6 +2227,8 @@ int gpe_set_data_device(gpe_handle c, const double* dX, int64_t N, int D, const 
 
 int gpe_set_kernel(gpe_handle c, int kind, const double* th, int n_theta, double noise)
 {
+    if (c)
+        ++c->epoch;
     if (!c || kind < 0 || kind > GPE_KERNEL_HOST_K || n_theta < 0 || n_theta > GPE_MAX_THETA)
         return GPE_ERR_ARG;
     if (n_theta > 0 && !th)
@@ -2236,6 +2244,8 @@ int gpe_set_kernel(gpe_handle c, int kind, const double* th, int n_theta, double
 
 int gpe_set_K_host(gpe_handle c, const double* K, int64_t ldk)
 {
+    if (c)
+        ++c->epoch;
     if (!c || !K || c->N <= 0 || ldk < c->N)
         return GPE_ERR_ARG;
     DevGuard g(c);
@@ -2253,6 +2263,8 @@ int gpe_set_K_host(gpe_handle c, const double* K, int64_t ldk)
 
 int gpe_compute(gpe_handle c)
 {
+    if (c)
+        ++c->epoch;
     if (!c)
         return GPE_ERR_ARG;
     DevGuard g(c);
@@ -2271,6 +2283,8 @@ int gpe_compute(gpe_handle c)
 
 int gpe_update_alpha(gpe_handle c, const double* obs_mean)
 {
+    if (c)
+        ++c->epoch;
     if (!c)
         return GPE_ERR_ARG;
     if (!c->have_L)
@@ -2338,6 +2352,8 @@ __global__ void k_knn(const double* __restrict__ kcol, int64_t n, double diag_ad
 
 int gpe_add_sample(gpe_handle c, const double* x, int D, const double* obs_mean, int P)
 {
+    if (c)
+        ++c->epoch;
     if (!c || !x || !obs_mean || D <= 0 || P <= 0)
         return GPE_ERR_ARG;
     DevGuard g(c);
@@ -2922,6 +2938,8 @@ int gpe_query_batch_cross(gpe_handle c, const double* Ks, int64_t M, double* kta
 
 int gpe_set_obs_mean(gpe_handle c, const double* obs_mean)
 {
+    if (c)
+        ++c->epoch;
     if (!c || !obs_mean || c->N <= 0 || !c->dOm)
         return GPE_ERR_ARG;
     DevGuard g(c);
@@ -2960,6 +2978,8 @@ int gpe_get_L(gpe_handle c, double* L, int64_t ldh)
 
 int gpe_set_L(gpe_handle c, const double* L, int64_t ldh)
 {
+    if (c)
+        ++c->epoch;
     if (!c || !L || c->N <= 0 || ldh < c->N)
         return GPE_ERR_ARG;
     DevGuard g(c);
@@ -2996,6 +3016,8 @@ int gpe_get_alpha(gpe_handle c, double* a)
 
 int gpe_set_alpha(gpe_handle c, const double* a)
 {
+    if (c)
+        ++c->epoch;
     if (!c || !a || c->N <= 0)
         return GPE_ERR_ARG;
     DevGuard g(c);
@@ -3108,6 +3130,13 @@ int gpe_device_count(int* n)
     return *n > 0 ? GPE_OK : GPE_ERR_HIP;
 }
 
+int gpe_epoch(gpe_handle c, uint64_t* epoch)
+{
+    if (!c || !epoch)
+        return GPE_ERR_ARG;
+    *epoch = c->epoch.load();
+    return GPE_OK;
+}
 int gpe_get_device(gpe_handle c, int* device_id)
 {
     if (!c || !device_id)
@@ -3403,6 +3432,9 @@ static int batch_finish_fused(gpe_ctx** cs, int Gc, int* rc, const BatchWant* wa
 
 static int batch_compute_impl(gpe_handle* hs, int G, int* status, const BatchWant* want)
 {
+    for (int g_ = 0; hs && g_ < G; ++g_)
+        if (hs[g_])
+            ++hs[g_]->epoch;
     if (!hs || G < 0)
         return GPE_ERR_ARG;
     std::vector<int> rc(G, 0);

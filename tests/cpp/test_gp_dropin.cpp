@@ -1038,6 +1038,84 @@ CASE(test_sparse_gp_accuracy)
 // Restarts / outputs in lock-step (opt/batched_rprop.hpp, gpe_batch_hp_objective): the same iterates as limbo's
 // sequential Rprop (opt/rprop.hpp:82-145) run per restart (opt/parallel_repeater.hpp:84-105) or per output
 // (model/multi_gp/parallel_lf_opt.hpp:64-67)
+struct ParamsPinned : public Params {
+    struct gpu {
+        BO_PARAM(int, device, 0);
+    };
+};
+// One GP's query_batch over ALL visible devices (missing 3 / next 3b): a replica per device made once per state of
+// the model, contiguous slices, a host thread per device.  Under GPE_VIRTUAL_DEVICES=4 the four logical devices share the
+// physical one — the plumbing (gpe_clone_to, gpe_epoch, slices, scatter of a P = 2 result) is what is exercised; the answer must
+// be BITWISE the one-device answer (queries pick their kernels from N alone), before and after the model changes.
+CASE(test_multi_device_query_batch)
+{
+    int ndev = 0;
+    CHECK(gpe_device_count(&ndev) == GPE_OK && ndev >= 1);
+    using GP_t = model::GP<Params, kernel::SquaredExpARD<Params>, mean::Data<Params>>;
+    using GPpin_t = model::GP<ParamsPinned, kernel::SquaredExpARD<ParamsPinned>, mean::Data<ParamsPinned>>;
+    std::vector<VectorXd> X, Y;
+    make_problem(700, 4, 2, X, Y); // (above min_n_for_gpu: device-resident; P = 2: a slice of kta is not contiguous)
+    GP_t gp;
+    gp.compute(X, Y);
+    GPpin_t one; // pinned to device 0: never dealt
+    one.compute(X, Y);
+    const int M = 20011; // >= LIMBO_AMD_MULTI_DEVICE_QUERY_MIN (16384), not a multiple of anything
+    std::vector<VectorXd> pts;
+    for (int m = 0; m < M; ++m)
+        pts.push_back(rand_vec(4, 0, 1));
+    MatrixXd mu, mu1;
+    VectorXd s2, s21;
+    gp.query_batch(pts, mu, s2);
+    one.query_batch(pts, mu1, s21);
+    std::printf("    %d visible device(s): the batch of %d points was dealt over %d\n", ndev, M, gp.query_devices());
+    CHECK(gp.query_devices() == ndev && one.query_devices() == 1);
+    bool same = true;
+    for (int m = 0; m < M && same; ++m)
+        same = mu(m, 0) == mu1(m, 0) && mu(m, 1) == mu1(m, 1) && s2(m) == s21(m);
+    CHECK(same);
+    // a small batch stays on the model's own device and equals the big one point by point
+    std::vector<VectorXd> few(pts.begin() + 5000, pts.begin() + 5300);
+    MatrixXd muf;
+    VectorXd s2f;
+    gp.query_batch(few, muf, s2f);
+    same = true;
+    for (int m = 0; m < 300 && same; ++m)
+        same = muf(m, 0) == mu(5000 + m, 0) && muf(m, 1) == mu(5000 + m, 1) && s2f(m) == s2(5000 + m);
+    CHECK(same);
+    // the model changes (one more sample): the replicas must follow — answers again bitwise the pinned model's
+    const VectorXd xn = rand_vec(4, 0, 1);
+    VectorXd yn(2);
+    yn << 0.3, -0.2;
+    gp.add_sample(xn, yn);
+    one.add_sample(xn, yn);
+    gp.query_batch(pts, mu, s2);
+    one.query_batch(pts, mu1, s21);
+    same = true;
+    for (int m = 0; m < M && same; ++m)
+        same = mu(m, 0) == mu1(m, 0) && mu(m, 1) == mu1(m, 1) && s2(m) == s21(m);
+    CHECK(same);
+    // ... and new hyper-parameters + recompute
+    VectorXd hp = gp.kernel_function().h_params();
+    hp(0) += 0.2;
+    gp.kernel_function().set_h_params(hp);
+    one.kernel_function().set_h_params(hp);
+    gp.recompute(false);
+    one.recompute(false);
+    gp.query_batch(pts, mu, s2);
+    one.query_batch(pts, mu1, s21);
+    same = true;
+    for (int m = 0; m < M && same; ++m)
+        same = mu(m, 0) == mu1(m, 0) && mu(m, 1) == mu1(m, 1) && s2(m) == s21(m);
+    CHECK(same);
+    // a copy has no replicas of its own until it asks; releasing them is harmless
+    GP_t cp(gp);
+    CHECK(cp.query_devices() == 1);
+    gp.release_query_replicas();
+    CHECK(gp.query_devices() == 1);
+    gp.query_batch(pts, mu, s2);
+    CHECK(gp.query_devices() == ndev && mu(17, 1) == mu1(17, 1) && s2(M - 1) == s21(M - 1));
+}
+
 CASE(test_lockstep_restarts)
 {
     using Opt_t = model::gp::KernelLFOpt<Params, opt::ParallelRepeater<Params, opt::Rprop<Params>>>;
@@ -1095,11 +1173,6 @@ CASE(test_lockstep_restarts)
 // (parallel_repeater.hpp:84-105).  With one visible device everything stays on it; GPE_VIRTUAL_DEVICES=n (the
 // pytest wrapper runs the whole binary again with 4) deals n logical devices over the physical ones, so the
 // placement logic and gpe_clone_to run on a one-GPU box too.
-struct ParamsPinned : public Params {
-    struct gpu {
-        BO_PARAM(int, device, 0);
-    };
-};
 CASE(test_multi_device_placement)
 {
     int ndev = 0;
@@ -1245,6 +1318,7 @@ int main()
     test_batch_search_run();
     test_sparse_gp_accuracy_run();
     test_multi_device_placement_run();
+    test_multi_device_query_batch_run();
     test_lockstep_restarts_run();
     test_host_path_threshold_run();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
