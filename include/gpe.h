@@ -81,6 +81,12 @@ int gpe_get_device(gpe_handle h, int* device_id);
  * the source's epoch is still e.  The C++ drop-in keeps one query replica per device on it (model/gp.hpp: query_batch over
  * the visible devices — the reference's parallel query, multi_gp.hpp:191-195 / tools/parallel.hpp:138-201). */
 int gpe_epoch(gpe_handle h, uint64_t* epoch);
+/* Several PROCESSES on one GPU (an ordinary way to run limbo experiments; the reference's gp.hpp:565 is re-entrant across
+ * processes): the engine's data-flow launches wait for each other inside a launch and must not share the device with another
+ * process's.  While another process of this library has a handle on the GPU (a byte of /dev/shm/limbo_amd.gpu-<bus id>.users
+ * locked), every data-flow launch scope runs — launch AND host wait — under flock(.lock); alone, nothing is locked.
+ * gpe_xproc_waits: how many scopes of this process ran under the lock so far. */
+int gpe_xproc_waits(int64_t* n);
 int gpe_destroy(gpe_handle h);
 const char* gpe_last_error(gpe_handle h);
 const char* gpe_version(void);

@@ -99,6 +99,7 @@ def _sig(lib, prefix):
             "trace_dump": [C.c_char_p],
             "hbm_stream_peak": [C.c_int, _dp],
             "epoch": [_vp, C.POINTER(C.c_uint64)],
+            "xproc_waits": [C.POINTER(_i64)],
         }
         for name, args in G.items():
             f = getattr(lib, prefix + name)

@@ -27,6 +27,11 @@
 #include <chrono>
 #include <map>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1250,7 +1255,16 @@ template <class Redo> int compute_finish(gpe_ctx* c, Redo redo)
         // whole evaluation again, from K on, with every workgroup deriving the head tiles itself.
         c->hInfo[0] = c->hInfo[1] = c->hInfo[2] = 0;
         c->panel_handover = false;
-        c->handover_off_left = 16 + 1; // this re-run and the next 16 evaluations re-derive the tiles, then hand over again
+        // this re-run and the next 16 evaluations re-derive the tiles, then hand over again — twice as many after every further
+        // event in the process (a fixed back-off that re-arms for ever is a silent 1000x slowdown when the cause
+        // persists), and ONE line on stderr the first time
+        static std::atomic<int> events{0};
+        const int ev = events.fetch_add(1);
+        c->handover_off_left = (16 << std::min(ev, 14)) + 1;
+        if (ev == 0)
+            fprintf(stderr, "limbo_amd: a hand-over inside a data-flow launch timed out (another process on this GPU that does not take part in "
+                            "/dev/shm/limbo_amd.gpu-*.lock, or a runtime that no longer dispatches workgroups in order): the evaluation was run again "
+                            "without them; they stay off for 16 evaluations, twice as long after every further event (gpe_handover_reruns counts)\n");
         c->tail_lay = c->tall_lay = -2; // the data-flow launches' buffers are in an unknown state: all-ones again before their next use
         ++c->flow_retries;
         ++c->handover_reruns;
@@ -1758,8 +1772,23 @@ struct GateDev {
     int* h_violation = nullptr;       // pinned: set by a workgroup of a masked chain that found itself in the OTHER half
     std::chrono::steady_clock::time_point last_busy{}; // when a chain last found another one in flight (ChainScope)
     bool ever_busy = false;
+    // Round 6: other PROCESSES on the same GPU.  The gate above orders the data-flow launches of this process by stream events;
+    // two processes have no events in common, and two data-flow launches resident together starve each other exactly as two
+    // streams did (bounded polls, full re-runs: 1 evaluation/s).  Two files per GPU under /dev/shm, named by its PCI bus id:
+    //   .users  every process that has a handle on the GPU write-locks ONE byte of it for its lifetime (POSIX record lock: the
+    //           kernel drops it when the process ends, however it ends); F_GETLK over the whole range answers "is anybody
+    //           else here?" in one system call (a process's own locks never conflict with itself);
+    //   .lock   flock(LOCK_EX) around a data-flow launch (or an evaluation's whole chain) AND the host wait for it, taken only
+    //           while somebody else is here: data-flow launches of different processes then never overlap on the device.
+    // A process that is alone pays one fcntl per launch scope and never touches the lock.
+    int xp_users = -1, xp_lock = -1, xp_byte = -1;
+    bool xp_tried = false, xp_held = false;
+    std::chrono::steady_clock::time_point xp_attach{};
+    bool xp_crowded_at_attach = false;
 };
 GateDev g_gate[16];
+std::atomic<int> g_live[16]; // live handles per physical device (gpe_create / gpe_destroy)
+std::atomic<long long> g_xproc_waits{0}; // data-flow scopes that ran under the inter-process lock (gpe_xproc_waits)
 bool gate_on()
 {
     static const bool on = !(getenv("GPE_FLOW_GATE") && atoi(getenv("GPE_FLOW_GATE")) == 0);
@@ -1770,6 +1799,124 @@ GateDev& gate_dev()
     int dev = 0;
     (void)hipGetDevice(&dev);
     return g_gate[dev & 15];
+}
+} // namespace
+namespace {
+bool xproc_on()
+{
+    static const bool on = !(getenv("GPE_XPROC_LOCK") && atoi(getenv("GPE_XPROC_LOCK")) == 0);
+    return on;
+}
+// is another process holding a byte of the users file?
+bool xproc_others(GateDev& g)
+{
+    if (g.xp_users < 0)
+        return false;
+    struct flock fl {};
+    fl.l_type = F_WRLCK;
+    fl.l_whence = SEEK_SET;
+    fl.l_start = 0;
+    fl.l_len = 4096;
+    return fcntl(g.xp_users, F_GETLK, &fl) == 0 && fl.l_type != F_UNLCK;
+}
+// once per process and device (under g.mu): open the two files, take a byte of the users file
+void xproc_attach(GateDev& g)
+{
+    if (g.xp_tried)
+        return;
+    g.xp_tried = true;
+    if (!xproc_on())
+        return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), dev) != hipSuccess || !bus[0])
+        return;
+    for (char* p = bus; *p; ++p)
+        if (*p == ':' || *p == '/')
+            *p = '_';
+    const char* dirs[2] = {"/dev/shm", "/tmp"};
+    for (const char* d : dirs) {
+        const std::string base = std::string(d) + "/limbo_amd.gpu-" + bus;
+        const mode_t um = umask(0);
+        const int fu = open((base + ".users").c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+        const int fl = open((base + ".lock").c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+        umask(um);
+        if (fu >= 0 && fl >= 0) {
+            g.xp_users = fu;
+            g.xp_lock = fl;
+            return;
+        }
+        if (fu >= 0)
+            close(fu);
+        if (fl >= 0)
+            close(fl);
+        g.xp_users = -1;
+    }
+}
+// the process's first live handle on the device appears / its last one goes (gpe_create, gpe_destroy; under g.mu): a byte of
+// the users file is held exactly while the process can have work on the GPU
+void xproc_show(GateDev& g)
+{
+    xproc_attach(g);
+    if (g.xp_users < 0 || g.xp_byte >= 0)
+        return;
+    g.xp_crowded_at_attach = xproc_others(g); // (before this process shows up in the file itself)
+    for (int k = 0; k < 4096 && g.xp_byte < 0; ++k) { // a byte of my own, starting from my pid's
+        struct flock fk {};
+        fk.l_type = F_WRLCK;
+        fk.l_whence = SEEK_SET;
+        fk.l_start = (getpid() + k) % 4096;
+        fk.l_len = 1;
+        if (fcntl(g.xp_users, F_SETLK, &fk) == 0)
+            g.xp_byte = (int)fk.l_start;
+    }
+    g.xp_attach = std::chrono::steady_clock::now();
+}
+void xproc_hide(GateDev& g)
+{
+    if (g.xp_users < 0 || g.xp_byte < 0)
+        return;
+    struct flock fk {};
+    fk.l_type = F_UNLCK;
+    fk.l_whence = SEEK_SET;
+    fk.l_start = g.xp_byte;
+    fk.l_len = 1;
+    (void)fcntl(g.xp_users, F_SETLK, &fk);
+    g.xp_byte = -1;
+}
+// outermost data-flow scope opens (under g.mu): take the inter-process lock while anybody else is on the GPU
+void xproc_enter(GateDev& g)
+{
+    if (g.xp_lock < 0 || g.xp_byte < 0 || !xproc_others(g))
+        return;
+    // somebody who was here before me may have a launch in flight that it started believing it was alone: not before 5 ms
+    // after I showed up in the users file (an evaluation is ~1 ms; it sees me from its next launch on)
+    if (g.xp_crowded_at_attach) {
+        const auto ready = g.xp_attach + std::chrono::milliseconds(5);
+        if (std::chrono::steady_clock::now() < ready)
+            std::this_thread::sleep_until(ready);
+        g.xp_crowded_at_attach = false;
+    }
+    while (flock(g.xp_lock, LOCK_EX) != 0 && errno == EINTR) {
+    }
+    g.xp_held = true;
+    g_xproc_waits.fetch_add(1, std::memory_order_relaxed);
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true))
+        fprintf(stderr, "limbo_amd: another process is using this GPU: data-flow launches take turns through %s (GPE_XPROC_LOCK=0 to disable)\n",
+                "/dev/shm/limbo_amd.gpu-*.lock");
+}
+// ... closes: what was enqueued must be THROUGH on the device before the next process may start its own
+void xproc_leave(GateDev& g, hipStream_t s, hipStream_t s2 = nullptr)
+{
+    if (!g.xp_held)
+        return;
+    (void)hipStreamSynchronize(s);
+    if (s2)
+        (void)hipStreamSynchronize(s2);
+    g.xp_held = false;
+    (void)flock(g.xp_lock, LOCK_UN);
 }
 } // namespace
 // a stream is about to be destroyed: nobody may record on it afterwards
@@ -1810,8 +1957,10 @@ void flow_gate_enter(hipStream_t s)
         return;
     GateDev& g = gate_dev();
     g.mu.lock(); // (held until flow_gate_leave: the launch in between is a few microseconds of host time)
-    if (g.depth++ == 0)
+    if (g.depth++ == 0) {
+        xproc_enter(g);
         gate_unmasked(g, s);
+    }
 }
 static bool partitions_on()
 {
@@ -1890,8 +2039,15 @@ static bool partition_streams(GateDev& g)
             uint32_t hi[8] = {0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; // CUs 16..31
             bool ok = hipExtStreamCreateWithCUMask(&g.part[0], 8, lo) == hipSuccess && hipExtStreamCreateWithCUMask(&g.part_aux[0], 8, lo) == hipSuccess
                 && hipExtStreamCreateWithCUMask(&g.part[1], 8, hi) == hipSuccess && hipExtStreamCreateWithCUMask(&g.part_aux[1], 8, hi) == hipSuccess;
+            auto drop_streams = [&g] { // (a partial or rejected set of masked streams is destroyed, not leaked)
+                for (hipStream_t* st : {&g.part[0], &g.part_aux[0], &g.part[1], &g.part_aux[1]}) {
+                    if (*st)
+                        (void)hipStreamDestroy(*st);
+                    *st = nullptr;
+                }
+            };
             if (!ok)
-                g.part[0] = g.part[1] = nullptr; // (whatever was created stays unused)
+                drop_streams();
             else {
                 // the runtime creates a stream's hardware queue at its FIRST launch (tens of milliseconds for a masked one):
                 // here, not inside the first evaluation that meets another one
@@ -1911,7 +2067,7 @@ static bool partition_streams(GateDev& g)
                     || hipMemcpy(g.d_owner, owner.data(), owner.size(), hipMemcpyHostToDevice) != hipSuccess
                     || hipHostMalloc(&g.h_violation, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
                     fprintf(stderr, "limbo_amd: the CU masks of the chain partitions are not honoured here: one chain at a time\n");
-                    g.part[0] = g.part[1] = nullptr;
+                    drop_streams();
                 }
                 else
                     *g.h_violation = 0;
@@ -1927,12 +2083,14 @@ ChainScope::ChainScope(gpe_ctx* c_, bool engage, bool may_partition) : c(c_), on
     GateDev& g = gate_dev();
     g.mu.lock(); // (held for the enqueue of the evaluation: ~50 us of host time)
     ++g.depth;   // the gates of the launches inside nest in this one
+    if (g.depth == 1)
+        xproc_enter(g); // (another PROCESS on the GPU: this chain runs under the inter-process lock, on the whole chip)
     if (g.h_violation && *g.h_violation) { // a masked chain saw one of its workgroups in the other half's CUs
         *g.h_violation = 0;
         g_masked_chains.fetch_add(1);
         partitions_give_up("a CU mask was not honoured");
     }
-    if (g.depth == 1 && may_partition && partitions_on() && !c->prof && partition_streams(g)) {
+    if (g.depth == 1 && may_partition && !g.xp_held && partitions_on() && !c->prof && partition_streams(g)) {
         // is another chain in flight on the device?  (A query, not a guarantee: it picks the mode; ORDER comes from the
         // events below.)
         const bool full_busy = g.last_stream && g.last_stream != c->stream && hipStreamQuery(g.last_stream) == hipErrorNotReady;
@@ -1994,6 +2152,8 @@ ChainScope::~ChainScope()
     }
     else if (g.depth == 1)
         g.last_stream = c->stream;
+    if (g.depth == 1)
+        xproc_leave(g, c->stream, c->stream2);
     --g.depth;
     g.mu.unlock();
 }
@@ -2002,8 +2162,10 @@ void flow_gate_leave(hipStream_t s)
     if (!gate_on())
         return;
     GateDev& g = gate_dev();
-    if (--g.depth == 0)
+    if (--g.depth == 0) {
         g.last_stream = s;
+        xproc_leave(g, s);
+    }
     g.mu.unlock();
 }
 
@@ -2056,13 +2218,18 @@ int gpe_create(int device_id, gpe_handle* out)
     }
     c->dHead = c->dScal + 1024;
     {
-        // the CU-masked stream pairs of the chain partitions (ChainScope) are created when a device gets its SECOND live handle:
-        // creating them takes tens of milliseconds, which must not fall into the first evaluation that meets another one
-        static std::atomic<int> live[16];
-        if (c->device < 16 && live[c->device].fetch_add(1) + 1 >= 2 && gate_on() && partitions_on()) {
+        // the CU-masked stream pairs of the chain partitions (ChainScope) are created when a device has TWO live handles for the
+        // first time: creating them takes tens of milliseconds, which must not fall into the first evaluation that meets another
+        // one.  (the count is of LIVE handles — gpe_destroy takes its handle off it again.)  The first live handle
+        // also shows the process in the GPU's users file (other processes then take turns with it, xproc_enter).
+        if (c->device < 16) {
+            const int now_live = g_live[c->device].fetch_add(1) + 1;
             GateDev& gd = gate_dev();
             std::lock_guard<std::recursive_mutex> lk(gd.mu);
-            (void)partition_streams(gd);
+            if (now_live >= 1)
+                xproc_show(gd);
+            if (now_live >= 2 && gate_on() && partitions_on())
+                (void)partition_streams(gd);
         }
     }
     // the polled X22 copies of k_panel256 (both buffers: a block from the pool may have been left in either state)
@@ -2153,6 +2320,12 @@ int gpe_destroy(gpe_handle c)
         flow_gate_forget(c->stream);
         hipStreamDestroy(c->stream2);
         hipStreamDestroy(c->stream);
+    }
+    if (c->device < 16 && g_live[c->device].fetch_sub(1) == 1) { // the process's last handle on this GPU: nothing of it can be in flight
+        GateDev& gd = gate_dev();
+        std::lock_guard<std::recursive_mutex> lk(gd.mu);
+        if (g_live[c->device].load() == 0)
+            xproc_hide(gd);
     }
     delete c;
     return GPE_OK;
@@ -3130,6 +3303,13 @@ int gpe_device_count(int* n)
     return *n > 0 ? GPE_OK : GPE_ERR_HIP;
 }
 
+int gpe_xproc_waits(int64_t* n)
+{
+    if (!n)
+        return GPE_ERR_ARG;
+    *n = g_xproc_waits.load();
+    return GPE_OK;
+}
 int gpe_epoch(gpe_handle c, uint64_t* epoch)
 {
     if (!c || !epoch)

@@ -79,7 +79,7 @@ def test_oracle_mirrors_the_abi(oracle_lib):
     skip = {"gpe_get_stream", "gpe_set_profiling", "gpe_get_phase_ms", "gpe_reset_phase_ms", "gpe_mfma_f64_peak",
             "gpe_hbm_stream_peak", "gpe_flow_retries", "gpe_small_calls", "gpe_handover_reruns", "gpe_trace", "gpe_trace_dump",
             "gpe_debug_tail_order", "gpe_debug_tail_plan", "gpe_debug_inv_plan", "gpe_debug_chain_split", "gpe_debug_ragged_split",
-            "gpe_epoch"}  # (engine bookkeeping, nothing of the reference's to restate)
+            "gpe_epoch", "gpe_xproc_waits"}  # (engine bookkeeping, nothing of the reference's to restate)
     for s in declared_symbols():
         if s in skip:
             continue
