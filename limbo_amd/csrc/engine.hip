@@ -156,6 +156,8 @@ struct gpe_ctx {
     bool panel256 = true;    // all steps of a 256-column outer panel in one data-flow launch (GPE_PANEL256=0: step by step)
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     double* dInvS = nullptr; // the recursive K^-1's scratch (inv2.hip): T-forms / W | three partial buffers, ld x cap each
+    int invS_bufs = 0;       // ... how many ld x cap buffers it holds: 1 + inv2_partials() for a single handle, 1 for a member of a
+                             // batch of >= 4 (whose plan cuts no k range: ADVICE r5 — 64 x N = 4096 used to reserve 26 GB it never touched)
     Inv2Plan* inv2 = nullptr; // ... and its plan, rebuilt when N, ld or a buffer changes
     int64_t inv_pad_n = -1;           // U and the T-form / W buffer read as zero beyond the inv_pad_n x inv_pad_n part (-1: unknown)
     Inv2Plan* inv2_batched = nullptr; // ... the plan of a batched sequence of >= 4 members led by this handle (no chunked k ranges)
@@ -329,6 +331,7 @@ void free_dev(gpe_ctx* c)
     if (c->dInvS)
         hipFree(c->dInvS);
     c->dInvS = nullptr;
+    c->invS_bufs = 0;
     c->inv_pad_n = -1;
     inv2_plan_free(c->inv2);
     inv2_plan_free(c->inv2_batched);
@@ -388,6 +391,7 @@ int grow_dev(gpe_ctx* c, int64_t need)
         if (p)
             hipFree(p);
     c->dInvS = nullptr;
+    c->invS_bufs = 0;
     c->dXt = nXt;
     c->dA = nA;
     c->dOm = nOm;
@@ -1365,8 +1369,15 @@ static int inv2_prepare(gpe_ctx* c)
     }
     if (!c->dKinv)
         HIPCHK(c, hipMalloc(&c->dKinv, sizeof(double) * (size_t)(ld * c->cap)));
+    const int bufs_needed = g_batch.G >= 4 ? 1 : 1 + inv2_partials(); // (the plan of a batch of >= 4 cuts no k range: no partial buffers)
+    if (c->dInvS && c->invS_bufs < bufs_needed) { // (a member of an earlier batch, now evaluated alone)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->dInvS);
+        c->dInvS = nullptr;
+    }
     if (!c->dInvS) {
-        HIPCHK(c, hipMalloc(&c->dInvS, sizeof(double) * (size_t)(ld * c->cap) * (size_t)(1 + inv2_partials())));
+        HIPCHK(c, hipMalloc(&c->dInvS, sizeof(double) * (size_t)(ld * c->cap) * (size_t)bufs_needed));
+        c->invS_bufs = bufs_needed;
         c->inv_pad_n = -1; // (fresh memory: the pads of the recursive K^-1 are to be zero-filled)
     }
     Inv2Plan*& slot = g_batch.G >= 4 ? c->inv2_batched : c->inv2;
@@ -1945,11 +1956,30 @@ static void gate_unmasked(GateDev& g, hipStream_t s)
     // that launch; nothing is recorded per launch — a batch of 64 members steps through ~60 gated launches on one stream)
     if (g.last_stream && g.last_stream != s)
         gate_order(g, s, g.last_stream);
-    for (int i = 0; i < 2; ++i)
-        if (g.part_dirty[i]) {
-            (void)hipStreamSynchronize(g.part[i]); // (a host wait, not an event the stream waits for: ChainScope's destructor says why)
-            g.part_dirty[i] = false;
-        }
+}
+// An unmasked data-flow launch can hold any CU: both masked halves must have drained before it.  A HOST wait (not an event the
+// stream waits for: ChainScope's destructor says why) — and NOT under the gate's mutex (one thread's query beside
+// threads running masked chains used to stall every other thread's enqueue for a whole chain): called with g.mu held ONCE by
+// this thread (depth as it was before this scope), returns with it held again and both halves clean.
+static void gate_drain_halves(GateDev& g)
+{
+    for (;;) {
+        hipStream_t w[2];
+        int nw = 0;
+        for (int i = 0; i < 2; ++i)
+            if (g.part_dirty[i]) {
+                if (hipStreamQuery(g.part[i]) != hipErrorNotReady)
+                    g.part_dirty[i] = false;
+                else
+                    w[nw++] = g.part[i];
+            }
+        if (nw == 0)
+            return;
+        g.mu.unlock();
+        for (int k = 0; k < nw; ++k)
+            (void)hipStreamSynchronize(w[k]);
+        g.mu.lock(); // (others may have dirtied a half again meanwhile: look again)
+    }
 }
 void flow_gate_enter(hipStream_t s)
 {
@@ -1957,6 +1987,8 @@ void flow_gate_enter(hipStream_t s)
         return;
     GateDev& g = gate_dev();
     g.mu.lock(); // (held until flow_gate_leave: the launch in between is a few microseconds of host time)
+    if (g.depth == 0)
+        gate_drain_halves(g);
     if (g.depth++ == 0) {
         xproc_enter(g);
         gate_unmasked(g, s);
@@ -2124,8 +2156,12 @@ ChainScope::ChainScope(gpe_ctx* c_, bool engage, bool may_partition) : c(c_), on
         static const bool fault = getenv("GPE_PARTITION_FAULT") && atoi(getenv("GPE_PARTITION_FAULT")) != 0; // (test hook: claims the other half)
         hipLaunchKernelGGL(k_partition_check, dim3(64), dim3(64), 0, P, g.d_owner, fault ? 1 - part : part, g.h_violation);
     }
-    else if (g.depth == 1)
+    else if (g.depth == 1) {
+        --g.depth; // (the mutex is released while the halves drain: the scope is not open yet)
+        gate_drain_halves(g);
+        ++g.depth;
         gate_unmasked(g, c->stream);
+    }
 }
 ChainScope::~ChainScope()
 {
@@ -3482,8 +3518,15 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
             }
             if (!c->dKinv)
                 HIPCHK(c, hipMalloc(&c->dKinv, mat));
+            const int bufs_needed = Gc >= 4 ? 1 : 1 + inv2_partials(); // (inv2_prepare's rule: a batch of >= 4 cuts no k range)
+            if (c->dInvS && c->invS_bufs < bufs_needed) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                hipFree(c->dInvS);
+                c->dInvS = nullptr;
+            }
             if (!c->dInvS && inv2_supported(c->N)) { // the recursive K^-1's scratch (inv2.hip)
-                HIPCHK(c, hipMalloc(&c->dInvS, mat * (size_t)(1 + inv2_partials())));
+                HIPCHK(c, hipMalloc(&c->dInvS, mat * (size_t)bufs_needed));
+                c->invS_bufs = bufs_needed;
                 c->inv_pad_n = -1; // (fresh memory: the pads of the recursive K^-1 are to be zero-filled)
             }
             if (inv2_supported(c->N))
@@ -3540,7 +3583,7 @@ static int batch_enqueue_fused(gpe_ctx** cs, int Gc, BatchTab** tab_out, const B
                                                (unsigned long long)(c0->dLinv ? dbl * c0->ld * c0->cap : 0), (unsigned long long)(c0->dKinv ? dbl * c0->ld * c0->cap : 0),
                                                (unsigned long long)(c0->dGradPartial ? dbl * c0->grad_partial_cap : 0),
                                                (unsigned long long)(c0->dTail ? dbl * 2 * (c0->tail_cap + c0->tall_cap) : 0),
-                                               (unsigned long long)(c0->dInvS ? dbl * c0->ld * c0->cap * (1 + inv2_partials()) : 0)};
+                                               (unsigned long long)(c0->dInvS ? dbl * c0->ld * c0->cap * (Gc >= 4 ? 1 : 1 + inv2_partials()) : 0)};
     for (int k = 0; k < GPE_BT_CLS; ++k) {
         t.base0[k] = t.base[k][0];
         t.size[k] = sz[k];

@@ -96,7 +96,8 @@ int make_tree(std::vector<Node>& nodes, int lo, int hi, bool is_right)
 }
 
 // one launch of products (+ the fold launch behind it when chunks or transposed copies call for one)
-void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extra_folds, int64_t ld, int nbins, double load, int te)
+void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extra_folds, int64_t ld, int nbins, double load, int te,
+          bool no_chunk = false)
 {
     if (prods.empty() && extra_folds.empty())
         return;
@@ -110,8 +111,10 @@ void emit(SymPlan& pl, const std::vector<Prod>& prods, std::vector<SymFold> extr
     // chunk length (in units of one tile edge of depth): no chunk much longer than a share of the launch, at most 1 + NPART
     // chunks per tile, never below 256 of depth (a fold launch costs more than it saves there)
     const double avg = (double)total / (double)nbins;
-    int ch = std::max(256 / te, (int)(load * avg + 0.5));
+    int ch = std::max(256 / te, (int)std::min(load * avg + 0.5, 1e9)); // (clamped before the cast: ADVICE r5)
     ch = std::max(ch, (lmax + NPART) / (NPART + 1));
+    if (no_chunk) // a batch of >= 4 members: whole k ranges, a workgroup per tile product
+        ch = std::max(ch, lmax);
     struct Chunk {
         SymItem it;
         int units;
@@ -200,10 +203,9 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load, int membe
 {
     // A batched sequence of at least four members fills the chip with whole tiles: no k range is cut (no partial buffers, no
     // fold launches but the transposed copies) and every tile product is a workgroup of its own.
-    if (members >= 4) {
-        load = 1e9;
+    const bool no_chunk = members >= 4; // (an explicit flag: ADVICE r5 — a magic load of 1e9 overflowed the chunk length's int from N ~ 32768 on)
+    if (no_chunk)
         nbins = 1 << 20;
-    }
     const int npan = (int)((N + LEAF - 1) / LEAF);
     const int64_t N64 = (N + 63) / 64 * 64; // how far a k range may run: the buffers hold zeros between N and their capacity
     std::vector<Node> nodes;
@@ -267,10 +269,10 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load, int membe
                     }
             }
         }
-        emit(pl, w_prods, {}, ld, nbins, load, TILE);
+        emit(pl, w_prods, {}, ld, nbins, load, TILE, no_chunk);
         if (h == 1)
             pl.prefix_steps = (int)pl.steps.size();
-        emit(pl, u_prods, t_folds, ld, nbins, load, TILE);
+        emit(pl, u_prods, t_folds, ld, nbins, load, TILE, no_chunk);
     }
     // K^-1[i, j] = sum_{k >= i} U[i, k] U[j, k], i >= j
     std::vector<Prod> k_prods;
@@ -287,7 +289,7 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load, int membe
             p.nc = (int)std::min<int64_t>(TILE, N - (int64_t)j * TILE);
             k_prods.push_back(p);
         }
-    emit(pl, k_prods, {}, ld, nbins, load, TILE);
+    emit(pl, k_prods, {}, ld, nbins, load, TILE, no_chunk);
 }
 
 // two resident workgroups per CU (74 KB of LDS each); chunks about as long as a share.  Measured around it
@@ -419,12 +421,14 @@ void inv2_run(hipStream_t s, Inv2Plan* p, const double* Xt_all, int part)
 //             0: 128 x 128 tiles, 2: 64 x 64 tiles)
 //   folds   : { step, 1 | 3, D buf, D off, P1 off | -1, P2 off | -1, P3 off | -1, T buf | -1, T off, 0 }
 // buffers: 0 L, 1 U, 2 K^-1, 3 T-forms / W, 4..6 partials.  Returns the number of rows (also when out is too small).
+// nbins < 0 asks for the plan of a batched sequence of -nbins members.
 int inv2_debug_plan(int64_t N, int64_t ld, int nbins, int load_pct, int64_t* out, int64_t cap_rows)
 {
     if (N <= 0 || ld < (N + 63) / 64 * 64)
         return -1;
     SymPlan sp;
-    build(sp, N, ld, nbins > 0 ? nbins : PLAN_BINS, load_pct > 0 ? load_pct / 100.0 : PLAN_LOAD, 1);
+    // nbins < 0: the plan of a BATCH of -nbins members (>= 4: no k range is cut, a workgroup per tile product)
+    build(sp, N, ld, nbins > 0 ? nbins : PLAN_BINS, load_pct > 0 ? load_pct / 100.0 : PLAN_LOAD, nbins < 0 ? -nbins : 1);
     int64_t row = 0;
     for (size_t s = 0; s < sp.steps.size(); ++s) {
         const SymStep& st = sp.steps[s];

@@ -115,9 +115,9 @@ def _run_plan(n, ld, nbins, load_pct, seed):
 
 @pytest.mark.parametrize("n,ld,nbins,load_pct", [(1024, 1024 + 32, 512, 100), (2048, 2048 + 32, 512, 100), (1536, 1536 + 16, 64, 100),
                                                   (1280, 1280 + 32, 16, 50), (768, 800, 8, 200), (512, 544, 512, 100), (256, 272, 4, 100),
-                                                  (1536, 1536 + 32, 1 << 20, 10 ** 8),  # what a batched sequence runs — no k range is cut
+                                                  (1536, 1536 + 32, -4, 100),  # what a batched sequence of >= 4 members runs — no k range is cut
                                                   (1100, 1152 + 32, 512, 100), (1700, 1728 + 16, 512, 100), (1025, 1088 + 32, 512, 100),
-                                                  (1344, 1344 + 32, 64, 100), (2047, 2048 + 32, 512, 100), (1281, 1344 + 16, 1 << 20, 10 ** 8),
+                                                  (1344, 1344 + 32, 64, 100), (2047, 2048 + 32, 512, 100), (1281, 1344 + 16, -8, 100),
                                                   (300, 320 + 16, 8, 100), (65, 128 + 16, 4, 100)])
 def test_inv_plan_executed_in_numpy(n, ld, nbins, load_pct):
     L, Kmat, U, Kinv, stats, plan = _run_plan(n, ld, nbins, load_pct, seed=n + nbins)
@@ -130,7 +130,8 @@ def test_inv_plan_executed_in_numpy(n, ld, nbins, load_pct):
     assert not np.isnan(Kinv[il]).any()
     assert np.max(np.abs(Kinv[il] - Kref[il])) <= 1e-9 * np.max(np.abs(Kref))
     assert stats["max_chunks"] <= 4
-    if load_pct >= 10 ** 8:
+    if nbins < 0:
+        assert stats["max_chunks"] == 1 and not (plan[plan[:, 1] & 1 == 0][:, 6] >= 4).any()  # no partial buffer is ever written
         assert stats["max_chunks"] == 1 and (plan[plan[:, 1] & 1 == 1][:, 4] == -1).all()  # folds only where a transposed copy is asked for
     # algorithmic flops: the products of the plan do 2 n^3 / 3 less what the leaves did, at tile granularity
     prods = plan[plan[:, 1] & 1 == 0]
@@ -138,6 +139,24 @@ def test_inv_plan_executed_in_numpy(n, ld, nbins, load_pct):
     nn = (n + 127) // 128 * 128  # (a ragged order pays for whole tiles)
     assert 0.55 * 2 * n ** 3 / 3 - 2.0 * 256 ** 3 <= flops <= 1.4 * 2 * nn ** 3 / 3 + 2.0 * 128 ** 3 * 3  # 2 n^3 / 3 less the leaves, whole tiles on the diagonals
     print(f"n={n}: {stats['launches']} launches after the leaves, {stats['products']} tile products, {stats['folds']} folds")
+
+
+def test_inv_plan_of_a_large_batch_cuts_nothing():
+    """the plan of a batch of >= 4 members used to switch chunking off through a magic load of 1e9, whose product with the
+    mean share overflowed the chunk length's int from N ~ 32768 on (undefined behaviour).  Now an explicit flag: at N = 40000
+    (planned, not executed) every tile product keeps its whole k range, no partial buffer appears, a share per product."""
+    n = 40000
+    ld = (n + 63) // 64 * 64 + 32
+    plan = _plan(n, ld, -4, 100)
+    prods = plan[plan[:, 1] & 1 == 0]
+    folds = plan[plan[:, 1] & 1 == 1]
+    assert len(prods) > 10000 and (prods[:, 8] >= 64).all() and (prods[:, 8] % 64 == 0).all()
+    assert not (prods[:, 6] >= 4).any() and (folds[:, 4] == -1).all()  # no partial buffers, folds only for transposed copies
+    for s_ in np.unique(prods[:, 0]):
+        rows = prods[prods[:, 0] == s_]
+        assert len(np.unique(rows[:, 9] >> 1)) == len(rows)  # every product a workgroup of its own
+    # the largest product of the top level reads half the matrix's depth
+    assert prods[:, 8].max() >= n // 2 - 256
 
 
 def test_inv_plan_shares_are_balanced():
