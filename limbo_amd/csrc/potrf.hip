@@ -2490,7 +2490,20 @@ bool launch_ragged_update(hipStream_t s, double* C, int64_t ldc, const double* A
 #include <vector>
 // the table itself, on the host: flat[2 w] = row strip, flat[2 w + 1] = tile column of workgroup w; false: a wait for a
 // higher-numbered workgroup somewhere (the caller then falls back to the column-by-column order)
-static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vector<int>& flat)
+// Round 6: the chain workgroups come TAIL_DLEAD columns earlier than their operands allow.  Stamps of a closing launch
+// (profiles/r06_closing_launch_stamps.log) show hops of 14-23 us at columns 19-28 where the chain workgroup's own catch-up
+// products ("earlier updates done") end late: it was dispatched behind the tiles of column c - 2, when the 256 resident
+// workgroups in front of it had retired, with 2 (c - 2) products still to do.  Dispatched four columns earlier it does most of
+// them while the chain is still four columns away: N = 4096 1.127 -> 1.108 ms, 3072 0.724 -> 0.707, 2560 0.542 -> 0.532, <= 2048
+// unchanged (profiles/r06_diag_lead.log; 2 ... 8 the same, 12 and 16 lose it again).  Such a workgroup may wait for a tile that
+// is dispatched AFTER it — the one exception to "every wait is for a lower-numbered workgroup".  It is harmless as long as
+// few of them can be in that state at once: at any point q of the dispatch order, the chain workgroups in front of q that
+// wait for something at or behind q hold a CU each while everything else in front of q waits only for lower-numbered
+// workgroups, i.e. makes progress on the other CUs; the table is accepted only if that number never exceeds TAIL_DLEAD_MAX_BLOCKED
+// (build_tail_order checks it).  Batched launches (every member has 256 / G resident workgroups) keep the strict order.
+#define TAIL_DLEAD 4
+#define TAIL_DLEAD_MAX_BLOCKED 16
+static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vector<int>& flat, int dlead = 0)
 {
     struct T {
         int key, c, b;
@@ -2503,7 +2516,7 @@ static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vect
         for (int b = c; b < nb; ++b) {
             int k;
             if (b == c)
-                k = paired(c) ? 2 * c - 4 : 2 * c - 3; // behind the tiles of slot c - 2 (its last operands: (c, c-2) and the diagonal workgroup c - 1)
+                k = (paired(c) ? 2 * c - 4 : 2 * c - 3) - 2 * dlead; // behind the tiles of slot c - 2 (its last operands: (c, c-2) and the diagonal workgroup c - 1)
             else if (b >= nt) // (a lag that shrinks along the launch — late columns' tiles started early for their catch-up
                               // products — measured slower at every slope: profiles/r04_lag_slope_negative.log)
                 k = 2 * (c + std::max(lag, 0));
@@ -2530,14 +2543,22 @@ static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vect
     auto dpos = [&](int c) { return (pair && (c & 1)) ? pos[tid(c - 1, c - 1)] : pos[tid(c, c)]; };
     auto owner = [&](int b, int s) { return (b == s + 1 && b < nt) ? dpos(b) : pos[tid(b, s)]; };
     bool legal = true;
+    std::vector<int> blocked(ts.size() + 1, 0); // difference array: chain workgroups in front of q waiting for something at / behind q
     for (const T& t : ts) {
         const int me = pos[tid(t.b, t.c)];
         if (t.b == t.c) {
             if (pair && (t.c & 1))
                 continue; // (no work: arms its slots and leaves)
             const bool two = paired(t.c);
-            for (int s2 = 0; s2 < t.c - 1 && legal; ++s2)
-                legal = owner(t.c, s2) < me && owner(t.c - 1, s2) < me && (!two || owner(t.c + 1, s2) < me);
+            int last = -1; // the latest-dispatched workgroup this one waits for
+            for (int s2 = 0; s2 < t.c - 1; ++s2)
+                last = std::max(last, std::max(std::max(owner(t.c, s2), owner(t.c - 1, s2)), two ? owner(t.c + 1, s2) : -1));
+            if (last > me) {
+                if (dlead <= 0)
+                    legal = false;
+                ++blocked[(size_t)me + 1]; // counts at q = me + 1 .. last
+                --blocked[(size_t)last + 1];
+            }
             if (t.c > 0)
                 legal = legal && dpos(t.c - 1) < me && (!two || owner(t.c + 1, t.c - 1) < me);
         }
@@ -2549,6 +2570,10 @@ static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vect
         if (!legal)
             break;
     }
+    for (size_t q = 1, run = 0; q < blocked.size() && legal; ++q) {
+        run += blocked[q];
+        legal = (int)run <= TAIL_DLEAD_MAX_BLOCKED;
+    }
     flat.assign(2 * ts.size(), 0);
     for (size_t i = 0; i < ts.size(); ++i) {
         flat[2 * i] = ts[i].b;
@@ -2556,22 +2581,23 @@ static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vect
     }
     return legal;
 }
-static const int* tail_order(int nt, int nb, int W, int lag, int pair)
+static const int* tail_order(int nt, int nb, int dlead, int lag, int pair)
 {
-    if (W <= 0 && lag <= 0 && !pair)
+    const int W = 0; // (the just-in-time window of the table: measured as a loss — kept in build_tail_order for the record)
+    if (dlead <= 0 && lag <= 0 && !pair)
         return nullptr;
     static std::mutex mu;
     static std::map<std::array<int, 6>, int*> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const std::array<int, 6> key{dev, nt, nb, W, lag, pair};
+    const std::array<int, 6> key{dev, nt, nb, dlead, lag, pair};
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it != cache.end())
         return it->second;
     std::vector<int> flat;
     int* d = nullptr;
-    if (build_tail_order(nt, nb, W, lag, pair, flat)) {
+    if (build_tail_order(nt, nb, W, lag, pair, flat, dlead) || (dlead > 0 && build_tail_order(nt, nb, W, lag, pair, flat, 0))) {
         if (hipMalloc(&d, sizeof(int) * flat.size()) != hipSuccess || hipMemcpy(d, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice) != hipSuccess)
             d = nullptr;
     }
@@ -2594,7 +2620,9 @@ int debug_tail_order(int nt, int nb, int lag, int pair)
     if (nt < 1 || nb < nt || nb > 4096)
         return -1;
     std::vector<int> flat;
-    if (!build_tail_order(nt, nb, 0, lag, pair, flat))
+    if (!build_tail_order(nt, nb, 0, lag, pair, flat, 0)) // the strict table (batched launches, the pair form)
+        return 0;
+    if (!pair && !build_tail_order(nt, nb, 0, lag, pair, flat, TAIL_DLEAD)) // ... and the one single launches use (checked below)
         return 0;
     std::vector<char> seen((size_t)nt * nb, 0);
     size_t n = 0;
@@ -2638,7 +2666,7 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
     // GPE_TAIL_PAIR=1: two diagonal blocks per chain workgroup (diag_flow2.h)
     static const int pair = getenv("GPE_TAIL_PAIR") ? atoi(getenv("GPE_TAIL_PAIR")) : 0;
     a.pair = pair && a.nt >= 2 ? 1 : 0;
-    a.order = tail_order(a.nt, a.nb, 0, ord_lag, a.pair); // (W: the just-in-time window of the table, measured as a loss — kept in tail_order for the record)
+    a.order = tail_order(a.nt, a.nb, g_batch.bt || a.pair ? 0 : TAIL_DLEAD, ord_lag, a.pair);
     const int64_t tiles = tail_tiles(a.nt, a.nb);
     if (gen) {
         a.Xg = gen->Xg;
