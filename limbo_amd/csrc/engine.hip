@@ -156,6 +156,10 @@ struct gpe_ctx {
     bool panel256 = true;    // all steps of a 256-column outer panel in one data-flow launch (GPE_PANEL256=0: step by step)
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     double* dInvS = nullptr; // the recursive K^-1's scratch (inv2.hip): T-forms / W | three partial buffers, ld x cap each
+    double* dSweep2 = nullptr;      // scratch of the chain-workgroup backward sweep (sweep2.hip): M tiles | f | flags, for cap / 64 blocks
+    int64_t sweep2_blocks = 0;      // ... blocks it was allocated for
+    bool sweep2_armed = false;      // ... holds the all-ones pattern where the launch expects it
+    unsigned long long sweep2_epoch = 0;
     int invS_bufs = 0;       // ... how many ld x cap buffers it holds: 1 + inv2_partials() for a single handle, 1 for a member of a
                              // batch of >= 4 (whose plan cuts no k range: ADVICE r5 — 64 x N = 4096 used to reserve 26 GB it never touched)
     Inv2Plan* inv2 = nullptr; // ... and its plan, rebuilt when N, ld or a buffer changes
@@ -332,6 +336,11 @@ void free_dev(gpe_ctx* c)
         hipFree(c->dInvS);
     c->dInvS = nullptr;
     c->invS_bufs = 0;
+    if (c->dSweep2)
+        hipFree(c->dSweep2);
+    c->dSweep2 = nullptr;
+    c->sweep2_blocks = 0;
+    c->sweep2_armed = false;
     c->inv_pad_n = -1;
     inv2_plan_free(c->inv2);
     inv2_plan_free(c->inv2_batched);
@@ -991,6 +1000,37 @@ void trsm_left_blocked(gpe_ctx* c, const double* L, double* B, int64_t ldb, int6
     }
 }
 
+// One right-hand side, a single GP: the backward sweep as a chain workgroup + helpers (sweep2.hip); false: not this shape, or
+// no scratch — the caller takes k_trsv_bwd_flow
+static bool bwd_chain_sweep(gpe_ctx* c, hipStream_t s, const double* y, int64_t ysi, double* al, int prefilled, const double* om, double* part)
+{
+    static const bool on = !(getenv("GPE_SWEEP_CHAIN") && atoi(getenv("GPE_SWEEP_CHAIN")) == 0);
+    const int64_t nblk = (c->N + NB - 1) / NB;
+    if (!on || g_batch.bt || g_batch.G != 1 || nblk < 4 || nblk > 255)
+        return false;
+    if (c->dSweep2 && c->sweep2_blocks < nblk) {
+        hipStreamSynchronize(c->stream);
+        hipFree(c->dSweep2);
+        c->dSweep2 = nullptr;
+    }
+    if (!c->dSweep2) {
+        const int64_t blocks = std::max<int64_t>(nblk, c->cap / NB);
+        if (hipMalloc(&c->dSweep2, sizeof(double) * (size_t)sweep2_scratch_doubles(blocks)) != hipSuccess) {
+            c->dSweep2 = nullptr;
+            return false;
+        }
+        c->sweep2_blocks = blocks;
+        c->sweep2_armed = false;
+    }
+    if (!c->sweep2_armed) {
+        hipMemsetAsync(c->dSweep2, 0xFF, sizeof(double) * (size_t)sweep2_scratch_doubles(c->sweep2_blocks), s);
+        c->sweep2_armed = true;
+    }
+    launch_trsv_bwd_chain(s, c->dA, c->ld, c->N, c->dXinv, y, ysi, al, c->dInfo + 1, prefilled, om, part, c->dSweep2, c->sweep2_blocks,
+                          ++c->sweep2_epoch);
+    return true;
+}
+
 // GP::_compute_alpha (gp.hpp:605-611): alpha = L^-T (L^-1 obs_mean)
 void solve_alpha(gpe_ctx* c)
 {
@@ -1005,8 +1045,9 @@ void solve_alpha(gpe_ctx* c)
         double* al = c->dAl + (int64_t)p0 * c->ld;
         if (flow) {
             launch_trsv_fwd_flow(s, c->dA, c->ld, c->N, c->dXinv, om, c->ld, c->dY, c->ld, pc, c->dInfo + 1);
-            launch_trsv_bwd_flow(s, c->dA, c->ld, c->N, c->dXinv, c->dY, 1, c->ld, al, c->ld, pc, c->dInfo + 1, 0, om, c->ld,
-                                 c->hScal + 8, p0 > 0 ? 1 : 0);
+            if (!(c->P == 1 && bwd_chain_sweep(c, s, c->dY, 1, al, 0, om, c->hScal + 8)))
+                launch_trsv_bwd_flow(s, c->dA, c->ld, c->N, c->dXinv, c->dY, 1, c->ld, al, c->ld, pc, c->dInfo + 1, 0, om, c->ld,
+                                     c->hScal + 8, p0 > 0 ? 1 : 0);
             continue;
         }
         launch_copy2d(s, om, c->ld, c->dW, c->ld, c->N, pc);
@@ -1026,10 +1067,12 @@ void solve_alpha_from_z(gpe_ctx* c)
     const bool flow = c->flow_solve && nblk <= 256; // every workgroup of the data-flow sweep must be resident
     for (int p0 = 0; p0 < c->P; p0 += GPE_MAX_P) {
         int pc = std::min(GPE_MAX_P, c->P - p0);
-        if (flow) // reads z straight from the appended rows, leaves the log-likelihood partial sums
-            launch_trsv_bwd_flow(s, c->dA, c->ld, c->N, c->dXinv, c->dA + c->N + p0, c->ld, 1, c->dAl + (int64_t)p0 * c->ld,
-                                 c->ld, pc, c->dInfo + 1, c->al_prefilled ? 1 : 0, c->dOm + (int64_t)p0 * c->ld, c->ld,
-                                 c->hScal + 8, p0 > 0 ? 1 : 0);
+        if (flow) { // reads z straight from the appended rows, leaves the log-likelihood partial sums
+            if (!(c->P == 1 && bwd_chain_sweep(c, s, c->dA + c->N, c->ld, c->dAl, c->al_prefilled ? 1 : 0, c->dOm, c->hScal + 8)))
+                launch_trsv_bwd_flow(s, c->dA, c->ld, c->N, c->dXinv, c->dA + c->N + p0, c->ld, 1, c->dAl + (int64_t)p0 * c->ld,
+                                     c->ld, pc, c->dInfo + 1, c->al_prefilled ? 1 : 0, c->dOm + (int64_t)p0 * c->ld, c->ld,
+                                     c->hScal + 8, p0 > 0 ? 1 : 0);
+        }
         else {
             launch_rows_to_cols(s, c->dA + c->N + p0, c->ld, c->N, pc, c->dY, c->ld);
             launch_trsv_sweep(s, c->dA, c->ld, c->N, c->dXinv, c->dY, c->dAl + (int64_t)p0 * c->ld, c->ld, pc, 1);
@@ -1219,8 +1262,10 @@ static bool flow_failed(gpe_ctx* c)
     if (c->hInfo[1] != 0)
         partitions_give_up("a sweep's hand-off timed out");
     c->hInfo[1] = 0;
-    if (bad)
+    if (bad) {
         ++c->flow_retries;
+        c->sweep2_armed = false; // (whatever state the chain sweep's slots are in: all-ones again before their next use)
+    }
     return bad;
 }
 
