@@ -354,13 +354,9 @@ void launch_trsv_sweep(hipStream_t s, const double* L, int64_t ld, int64_t N, co
 void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* y,
                           int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P, int* err, int prefilled, const double* om,
                           int64_t ldom, double* part, int part_acc);
-// the same for ONE right-hand side as a chain workgroup fed by helper workgroups (sweep2.hip, round 6): scratch =
-// sweep2_scratch_doubles(cap_blocks) doubles, all-ones before its first use (a launch leaves it armed; after an error: all-ones again);
-// epoch: a value no earlier launch on this scratch used (and never all-ones)
-int64_t sweep2_scratch_doubles(int64_t nblk);
-void launch_trsv_bwd_chain(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* y, int64_t ysi,
-                           double* a, int* err, int prefilled, const double* om, double* part, double* scratch, int64_t cap_blocks,
-                           unsigned long long epoch);
+// the same for ONE right-hand side with a_j = g_j - M_j a_{j+1}: the hop is one matrix-vector product (sweep2.hip, round 6)
+void launch_trsv_bwd_m(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* y, int64_t ysi, double* a,
+                       int* err, int prefilled, const double* om, double* part);
 // the whole forward sweep y = L^-1 b in one data-flow launch, nblk <= 256 (the caller checks); b: N x P (ldb),
 // y: N x P (ldy), must not alias b; err as above
 void launch_trsv_fwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all, const double* b,

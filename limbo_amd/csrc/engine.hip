@@ -156,10 +156,6 @@ struct gpe_ctx {
     bool panel256 = true;    // all steps of a 256-column outer panel in one data-flow launch (GPE_PANEL256=0: step by step)
     double* dXp = nullptr;   // inverses of the nbo x nbo diagonal panels of L, compact (ensure_inv with the overlapped product)
     double* dInvS = nullptr; // the recursive K^-1's scratch (inv2.hip): T-forms / W | three partial buffers, ld x cap each
-    double* dSweep2 = nullptr;      // scratch of the chain-workgroup backward sweep (sweep2.hip): M tiles | f | flags, for cap / 64 blocks
-    int64_t sweep2_blocks = 0;      // ... blocks it was allocated for
-    bool sweep2_armed = false;      // ... holds the all-ones pattern where the launch expects it
-    unsigned long long sweep2_epoch = 0;
     int invS_bufs = 0;       // ... how many ld x cap buffers it holds: 1 + inv2_partials() for a single handle, 1 for a member of a
                              // batch of >= 4 (whose plan cuts no k range: ADVICE r5 — 64 x N = 4096 used to reserve 26 GB it never touched)
     Inv2Plan* inv2 = nullptr; // ... and its plan, rebuilt when N, ld or a buffer changes
@@ -336,11 +332,6 @@ void free_dev(gpe_ctx* c)
         hipFree(c->dInvS);
     c->dInvS = nullptr;
     c->invS_bufs = 0;
-    if (c->dSweep2)
-        hipFree(c->dSweep2);
-    c->dSweep2 = nullptr;
-    c->sweep2_blocks = 0;
-    c->sweep2_armed = false;
     c->inv_pad_n = -1;
     inv2_plan_free(c->inv2);
     inv2_plan_free(c->inv2_batched);
@@ -1000,34 +991,16 @@ void trsm_left_blocked(gpe_ctx* c, const double* L, double* B, int64_t ldb, int6
     }
 }
 
-// One right-hand side, a single GP: the backward sweep as a chain workgroup + helpers (sweep2.hip); false: not this shape, or
-// no scratch — the caller takes k_trsv_bwd_flow
+// One right-hand side, a single GP: the backward sweep whose hop is one matrix-vector product (sweep2.hip); false: not this
+// shape — the caller takes k_trsv_bwd_flow
 static bool bwd_chain_sweep(gpe_ctx* c, hipStream_t s, const double* y, int64_t ysi, double* al, int prefilled, const double* om, double* part)
 {
-    static const bool on = !(getenv("GPE_SWEEP_CHAIN") && atoi(getenv("GPE_SWEEP_CHAIN")) == 0);
+    static const bool on = !(getenv("GPE_SWEEP_M") && atoi(getenv("GPE_SWEEP_M")) == 0);
     const int64_t nblk = (c->N + NB - 1) / NB;
-    if (!on || g_batch.bt || g_batch.G != 1 || nblk < 4 || nblk > 255)
+    // (below eight blocks the two matrix-core products in front of the chain cost what the shorter hops save: N = 256 0.077 against 0.075 ms)
+    if (!on || g_batch.bt || g_batch.G != 1 || nblk < 8 || nblk > 256)
         return false;
-    if (c->dSweep2 && c->sweep2_blocks < nblk) {
-        hipStreamSynchronize(c->stream);
-        hipFree(c->dSweep2);
-        c->dSweep2 = nullptr;
-    }
-    if (!c->dSweep2) {
-        const int64_t blocks = std::max<int64_t>(nblk, c->cap / NB);
-        if (hipMalloc(&c->dSweep2, sizeof(double) * (size_t)sweep2_scratch_doubles(blocks)) != hipSuccess) {
-            c->dSweep2 = nullptr;
-            return false;
-        }
-        c->sweep2_blocks = blocks;
-        c->sweep2_armed = false;
-    }
-    if (!c->sweep2_armed) {
-        hipMemsetAsync(c->dSweep2, 0xFF, sizeof(double) * (size_t)sweep2_scratch_doubles(c->sweep2_blocks), s);
-        c->sweep2_armed = true;
-    }
-    launch_trsv_bwd_chain(s, c->dA, c->ld, c->N, c->dXinv, y, ysi, al, c->dInfo + 1, prefilled, om, part, c->dSweep2, c->sweep2_blocks,
-                          ++c->sweep2_epoch);
+    launch_trsv_bwd_m(s, c->dA, c->ld, c->N, c->dXinv, y, ysi, al, c->dInfo + 1, prefilled, om, part);
     return true;
 }
 
@@ -1262,10 +1235,8 @@ static bool flow_failed(gpe_ctx* c)
     if (c->hInfo[1] != 0)
         partitions_give_up("a sweep's hand-off timed out");
     c->hInfo[1] = 0;
-    if (bad) {
+    if (bad)
         ++c->flow_retries;
-        c->sweep2_armed = false; // (whatever state the chain sweep's slots are in: all-ones again before their next use)
-    }
     return bad;
 }
 

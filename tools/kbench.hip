@@ -106,6 +106,32 @@ int main(int argc, char** argv)
         dump_flow_timing((int)(N / 64));
     }
 #endif
+#ifdef S2_TIMING
+    { // the backward sweep whose hop is one matrix-vector product (sweep2.hip), in-kernel stamps of every block's workgroup
+        int* err;
+        CHK(hipMalloc(&err, 8));
+        CHK(hipMemset(err, 0, 8));
+        double *a2, *yv;
+        CHK(hipMalloc(&a2, sizeof(double) * ld));
+        CHK(hipMalloc(&yv, sizeof(double) * ld));
+        CHK(hipMemset(yv, 0, sizeof(double) * ld));
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int rep = 0; rep < 3; ++rep) { // the last (warm) repetition is the one reported
+            CHK(hipMemsetAsync(a2, 0xFF, sizeof(double) * N, s));
+            hipEventRecord(e0, s);
+            launch_trsv_bwd_m(s, A0, ld, N, Xi, yv, 1, a2, err, 1, nullptr, nullptr);
+            hipEventRecord(e1, s);
+            CHK(hipStreamSynchronize(s));
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("k_trsv_bwd_m, N = %lld: %.2f us (events)\n", (long long)N, 1e3 * ms);
+        }
+        extern void dump_s2_timing(int);
+        dump_s2_timing((int)(N / 64));
+    }
+#endif
 #ifdef GEMM_TIMING
     extern void dump_gemm_timing();
     dump_gemm_timing();
