@@ -232,7 +232,6 @@ struct DiagRound<-1> {
 #define DIAG_LTB (4 * NB * 4)
 #define DIAG_RUN(a, Ltb, invd, sbad, r, w, Ls) DiagRound<15>::run(a, Ltb, invd, sbad, r, w, Ls)
 #include "diag_flow.h"
-#include "diag_flow2.h"
 #include "kfun_fast.h"
 #define DIAG_THREADS 512
 
@@ -1425,7 +1424,7 @@ void launch_panel256(hipStream_t s, double* A, int64_t lda, int64_t p0, int64_t 
 //                        step's operands are asked for before this step's product)
 //   step c, b == c:      the diagonal block is complete: factor it (diag_flow), its inverse leaves in polled quarters
 //   step c, b >  c:      L(b, c) = tile X_c^T in the half-block form, in two phases (tail_tile_solve; the chain workgroup:
-//                        tail_chain_updates_and_crossing; the pair form: p256_half_solve), published in two halves
+//                        tail_chain_updates_and_crossing), published in two halves
 // Workgroups are numbered column by column, the diagonal tile first: every wait is for a lower-numbered workgroup.  The chain
 // diag(c) -> X_c -> L(c+1, c) -> last update of tile (c+1, c+1) -> diag(c+1) is what k_panel256's is, without the fused
 // updates and launch boundaries in between.  Polled buffers: LP (a 4096-double slot per tile, blockIdx order) and SP (3072 doubles
@@ -1448,8 +1447,6 @@ struct TailArgs {
     double *LP, *SP, *LPn, *SPn;
     int spin_limit;
     const int* order; // dispatch order: workgroup w works on tile (b, c) = (order[2 w], order[2 w + 1]); null: column by column
-    int pair;         // 1: the diagonal workgroup of an even column factors ITS block, the tile below and the next diagonal block
-                      // as one 128 x 128 block (diag_flow2.h); the diagonal tile of the odd column has no workgroup of its own
     // gen (Xg != null): the launch GENERATES its tiles of K from the samples instead of reading them from A — the kernel matrix
     // is never written for the columns this launch factors (kernel/kernel.hpp:81-84 with the functors of kfun_fast.h, the
     // pair formula and summation order of kbuild.hip); rows >= Ns of the last strip are obs_mean's rows, read from Om
@@ -1462,10 +1459,9 @@ struct TailArgs {
     int P;
 };
 // LDS of a k_tail workgroup: two pairs of operand tiles [A0 | B0 | A1 | B1] (40 KB each: all of the CU's 160 KB) for the pipelined
-// products of the update loop; behind it the carve of the solve and the factorisation (CH_*, further down; the pair form of
-// diag_flow2.h keeps round 4's [Bx | T0 | T1 | T2])
+// products of the update loop; behind it the carve of the solve and the factorisation (CH_*, further down)
 #define TAIL_LDS_DOUBLES (4 * NB * PS)
-static_assert(TAIL_LDS_DOUBLES >= NB * XS + 3 * NB * PS && TAIL_LDS_DOUBLES >= D2_LDS_DOUBLES && TAIL_LDS_DOUBLES * 8 <= 160 * 1024, "k_tail LDS carve");
+static_assert(TAIL_LDS_DOUBLES >= NB * XS + 3 * NB * PS && TAIL_LDS_DOUBLES * 8 <= 160 * 1024, "k_tail LDS carve");
 static __device__ __forceinline__ int tail_tile_id(int nb, int b, int c) { return c * nb - (c * (c - 1)) / 2 + (b - c); }
 
 // element it of a thread's tile slice: global row I (clamped into the strip by the caller), global columns J0 + 2 it
@@ -2075,8 +2071,6 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
     }
     if (b == c + 1 && b < a.nt)
         return; // the sub-diagonal tile (c + 1, c) belongs to the workgroup of the diagonal tile of its row (below)
-    if (a.pair && b == c && (c & 1))
-        return; // ... and an odd diagonal block to the workgroup of the block before it (pair, below)
     // the tile, lane = row layout
     const int crc = crow < x.nrows ? crow : x.nrows - 1;
     double cv[8];
@@ -2090,154 +2084,6 @@ static __device__ __forceinline__ void tail_body(const TailArgs& a, const int wg
 #pragma unroll
         for (int it = 0; it < 8; ++it)
             cv[it] = a.A[x.R0 + crc + (a.t0 + (int64_t)NB * c + ccol + 2 * it) * a.lda];
-    }
-    if (b == c && a.pair && c + 1 < a.nt) {
-        // ---- the chain, two blocks at a time (c even): this workgroup owns the diagonal blocks c and c + 1, the tile (c+1, c)
-        // between them — all three factored as ONE 128 x 128 block (diag_flow2.h) — and, as before, its left neighbour (c, c-1).
-        const int64_t R1 = x.R0 + NB, C0 = a.t0 + (int64_t)NB * c;
-        double a2r[8];
-        double aLf[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, aD0[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-        double aTm[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, aD1[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-        if (c > 1) { // steps s < c-1: L(c, s), L(c-1, s), L(c+1, s) -> four products (three operand tiles: single-buffered)
-            PolledTile pa, pb, pc;
-            pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, 0) * (NB * NB));
-            pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, 0) * (NB * NB));
-            pc.issue(a.LP + (int64_t)tail_tile_id(a.nb, c + 1, 0) * (NB * NB));
-#pragma unroll 1
-            for (int s = 0; s < c - 1; ++s) {
-                // (the operand tiles' offsets are opaque to the compiler: with constant bases it lifts the LDS addresses of all four
-                // products out of the loop — a few hundred registers, spilled)
-                int oA = 0, oB = NB * PS, oC = 2 * NB * PS;
-                asm volatile("" : "+v"(oA), "+v"(oB), "+v"(oC));
-                double* const opA = lds + oA;
-                double* const opB = lds + oB;
-                double* const opC = lds + oC;
-                pa.finish(a.LP + (int64_t)tail_tile_id(a.nb, c, s) * (NB * NB), x.spin_limit, x.info);
-                pa.store(opA);
-                pb.finish(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s) * (NB * NB), x.spin_limit, x.info);
-                pb.store(opB);
-                pc.finish(a.LP + (int64_t)tail_tile_id(a.nb, c + 1, s) * (NB * NB), x.spin_limit, x.info);
-                pc.store(opC);
-                if (s + 1 < c - 1) {
-                    pa.issue(a.LP + (int64_t)tail_tile_id(a.nb, c, s + 1) * (NB * NB));
-                    pb.issue(a.LP + (int64_t)tail_tile_id(a.nb, c - 1, s + 1) * (NB * NB));
-                    pc.issue(a.LP + (int64_t)tail_tile_id(a.nb, c + 1, s + 1) * (NB * NB));
-                }
-                __syncthreads();
-                mm64<false>(opA, opB, wm, wn, lane, aLf);
-                __builtin_amdgcn_sched_barrier(0); // (one product at a time: interleaved, their operand registers add up)
-                mm64<false>(opA, opA, wm, wn, lane, aD0);
-                __builtin_amdgcn_sched_barrier(0);
-                mm64<false>(opC, opA, wm, wn, lane, aTm);
-                __builtin_amdgcn_sched_barrier(0);
-                mm64<false>(opC, opC, wm, wn, lane, aD1);
-                __syncthreads(); // the operand tiles are free again
-            }
-        }
-        // the other tiles of this workgroup, (c+1, c), (c+1, c+1) and (c, c-1) — cv is (c, c) —, only now: the loop above needs the registers
-        double tm[8], d1[8], lf[8];
-        if (kp) {
-            tail_gen_tile(a, kp, R1 + crow, C0 + ccol, tm);
-            tail_gen_tile(a, kp, R1 + crow, C0 + NB + ccol, d1);
-            if (c > 0)
-                tail_gen_tile(a, kp, x.R0 + crow, C0 - NB + ccol, lf);
-        }
-        else {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                tm[it] = a.A[R1 + crow + (C0 + ccol + 2 * it) * a.lda];
-                d1[it] = a.A[R1 + crow + (C0 + NB + ccol + 2 * it) * a.lda];
-                if (c > 0)
-                    lf[it] = a.A[x.R0 + crow + (C0 - NB + ccol + 2 * it) * a.lda];
-            }
-        }
-        if (c > 1) {
-            wave_tile_to_rows(aLf, a2r, lane);
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                lf[it] -= a2r[it];
-            wave_tile_to_rows(aD0, a2r, lane);
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                cv[it] -= a2r[it];
-            wave_tile_to_rows(aTm, a2r, lane);
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                tm[it] -= a2r[it];
-            wave_tile_to_rows(aD1, a2r, lane);
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                d1[it] -= a2r[it];
-        }
-        TTS(c, 0);
-        TileRegs keep; // L(c, c-1): into the matrix behind the factorisation
-        if (c > 0) {
-            // step c-1: L(c, c-1) = tile X_{c-1}^T in two phases, its square accumulated on the way (as the single-block workgroup);
-            // L(c+1, c-1) comes from its own tile's workgroup and updates the two tiles of row c + 1
-            PolledTile pt;
-            pt.issue(a.LP + (int64_t)tail_tile_id(a.nb, c + 1, c - 1) * (NB * NB));
-            double a2c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            p256_half_solve<0, true>(x, x.T1, x.T0, lf, a2c, true, a.SP + (int64_t)(c - 1) * 3072,
-                                     a.LP + (int64_t)tail_tile_id(a.nb, c, c - 1) * (NB * NB));
-            wave_tile_to_rows(a2c, a2r, lane);
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                cv[it] -= a2r[it];
-            pt.finish(a.LP + (int64_t)tail_tile_id(a.nb, c + 1, c - 1) * (NB * NB), x.spin_limit, x.info);
-            __syncthreads(); // [Bx | T0] have no readers left
-            pt.store(x.T0);
-            keep.v[0] = 0.0;
-            {
-                const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    keep.v[q] = x.T1[(kk0 + 8 * q) * PS + i];
-            }
-            __syncthreads();
-            double bTm[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, bD1[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            mm64<false>(x.T0, x.T1, wm, wn, lane, bTm);
-            mm64<false>(x.T0, x.T0, wm, wn, lane, bD1);
-            wave_tile_to_rows(bTm, a2r, lane);
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                tm[it] -= a2r[it];
-            wave_tile_to_rows(bD1, a2r, lane);
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                d1[it] -= a2r[it];
-            __syncthreads(); // T0 / T1 are free: the factorisation re-carves the whole block
-        }
-        TTS(c, 1);
-        double* L1 = lds;
-        double* L2 = lds + D2_OFF_L2;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            L1[crow * XS + ccol + 2 * it] = cv[it];
-            L1[(NB + crow) * XS + ccol + 2 * it] = tm[it];
-            L2[crow * XS + ccol + 2 * it] = d1[it];
-        }
-        diag_flow_init(reinterpret_cast<DiagSync*>(lds + D2_OFF_SY));
-        __syncthreads();
-        Diag2Out o;
-        o.lda = a.lda;
-        o.Ad0 = a.A + x.R0 + x.R0 * a.lda;
-        o.Atm = a.A + R1 + x.R0 * a.lda;
-        o.Ad1 = a.A + R1 + R1 * a.lda;
-        o.LPtm = mute ? nullptr : a.LP + (int64_t)tail_tile_id(a.nb, c + 1, c) * (NB * NB);
-        o.SL21_0 = mute ? nullptr : a.SP + (int64_t)c * 3072 + 1024;
-        o.SL21_1 = mute ? nullptr : a.SP + (int64_t)(c + 1) * 3072 + 1024;
-        TTS(c, 2);
-        diag_flow2(lds, o, a.Xt + (int64_t)c * (NB * NB), a.Xt + (int64_t)(c + 1) * (NB * NB), a.info, x.R0, wave, lane,
-                   mute ? nullptr : a.SP + (int64_t)c * 3072, mute ? nullptr : a.SP + (int64_t)(c + 1) * 3072);
-        TTS(c, 3);
-        if (c > 0) { // L(c, c-1) into the matrix: nobody reads it there before the launch ends
-            const int i = threadIdx.x & 63, kk0 = threadIdx.x >> 6;
-            double* Ag = a.A + x.R0 + (C0 - NB) * a.lda;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                Ag[i + (int64_t)(kk0 + 8 * q) * a.lda] = keep.v[q];
-        }
-        return;
     }
     if (b == c) {
         // ---- a diagonal tile's workgroup: the chain.  It also owns the tile to the left, (c, c-1): L(c, c-1) never has to
@@ -2503,27 +2349,22 @@ bool launch_ragged_update(hipStream_t s, double* C, int64_t ldc, const double* A
 // (build_tail_order checks it).  Batched launches (every member has 256 / G resident workgroups) keep the strict order.
 #define TAIL_DLEAD 4
 #define TAIL_DLEAD_MAX_BLOCKED 16
-static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vector<int>& flat, int dlead = 0)
+static bool build_tail_order(int nt, int nb, int W, int lag, std::vector<int>& flat, int dlead = 0)
 {
     struct T {
         int key, c, b;
     };
-    // pair: the diagonal workgroup of an even column c also factors block c + 1 (k_tail, diag_flow2.h) and needs L(c+1, c-1)
-    // from that tile's own workgroup for it: both move one slot forward, the tile first
-    auto paired = [&](int c) { return pair && (c & 1) == 0 && c + 1 < nt; };
     std::vector<T> ts;
     for (int c = 0; c < nt; ++c)
         for (int b = c; b < nb; ++b) {
             int k;
             if (b == c)
-                k = (paired(c) ? 2 * c - 4 : 2 * c - 3) - 2 * dlead; // behind the tiles of slot c - 2 (its last operands: (c, c-2) and the diagonal workgroup c - 1)
+                k = 2 * c - 3 - 2 * dlead; // behind the tiles of slot c - 2 (its last operands: (c, c-2) and the diagonal workgroup c - 1)
             else if (b >= nt) // (a lag that shrinks along the launch — late columns' tiles started early for their catch-up
                               // products — measured slower at every slope: profiles/r04_lag_slope_negative.log)
                 k = 2 * (c + std::max(lag, 0));
             else if (b == c + 1)
                 k = 2 * c; // (owned by the diagonal workgroup of its row: this workgroup only arms its slot)
-            else if (b == c + 2 && (c & 1) && paired(c + 1))
-                k = 2 * c - 2; // L(c+2, c) for the pair that starts at column c + 1
             else
                 k = 2 * (W > 0 ? std::max(c, b - W) : c);
             ts.push_back(T{k, c, b});
@@ -2540,19 +2381,16 @@ static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vect
     for (size_t i = 0; i < ts.size(); ++i)
         pos[tid(ts[i].b, ts[i].c)] = (int)i;
     // which workgroup factors diagonal block c / publishes the slot of tile (b, s)?
-    auto dpos = [&](int c) { return (pair && (c & 1)) ? pos[tid(c - 1, c - 1)] : pos[tid(c, c)]; };
+    auto dpos = [&](int c) { return pos[tid(c, c)]; };
     auto owner = [&](int b, int s) { return (b == s + 1 && b < nt) ? dpos(b) : pos[tid(b, s)]; };
     bool legal = true;
     std::vector<int> blocked(ts.size() + 1, 0); // difference array: chain workgroups in front of q waiting for something at / behind q
     for (const T& t : ts) {
         const int me = pos[tid(t.b, t.c)];
         if (t.b == t.c) {
-            if (pair && (t.c & 1))
-                continue; // (no work: arms its slots and leaves)
-            const bool two = paired(t.c);
             int last = -1; // the latest-dispatched workgroup this one waits for
             for (int s2 = 0; s2 < t.c - 1; ++s2)
-                last = std::max(last, std::max(std::max(owner(t.c, s2), owner(t.c - 1, s2)), two ? owner(t.c + 1, s2) : -1));
+                last = std::max(last, std::max(owner(t.c, s2), owner(t.c - 1, s2)));
             if (last > me) {
                 if (dlead <= 0)
                     legal = false;
@@ -2560,7 +2398,7 @@ static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vect
                 --blocked[(size_t)last + 1];
             }
             if (t.c > 0)
-                legal = legal && dpos(t.c - 1) < me && (!two || owner(t.c + 1, t.c - 1) < me);
+                legal = legal && dpos(t.c - 1) < me;
         }
         else if (!(t.b == t.c + 1 && t.b < nt)) {
             for (int s2 = 0; s2 < t.c && legal; ++s2)
@@ -2581,28 +2419,28 @@ static bool build_tail_order(int nt, int nb, int W, int lag, int pair, std::vect
     }
     return legal;
 }
-static const int* tail_order(int nt, int nb, int dlead, int lag, int pair)
+static const int* tail_order(int nt, int nb, int dlead, int lag)
 {
     const int W = 0; // (the just-in-time window of the table: measured as a loss — kept in build_tail_order for the record)
-    if (dlead <= 0 && lag <= 0 && !pair)
+    if (dlead <= 0 && lag <= 0)
         return nullptr;
     static std::mutex mu;
     static std::map<std::array<int, 6>, int*> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const std::array<int, 6> key{dev, nt, nb, dlead, lag, pair};
+    const std::array<int, 6> key{dev, nt, nb, dlead, lag, 0};
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it != cache.end())
         return it->second;
     std::vector<int> flat;
     int* d = nullptr;
-    if (build_tail_order(nt, nb, W, lag, pair, flat, dlead) || (dlead > 0 && build_tail_order(nt, nb, W, lag, pair, flat, 0))) {
+    if (build_tail_order(nt, nb, W, lag, flat, dlead) || (dlead > 0 && build_tail_order(nt, nb, W, lag, flat, 0))) {
         if (hipMalloc(&d, sizeof(int) * flat.size()) != hipSuccess || hipMemcpy(d, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice) != hipSuccess)
             d = nullptr;
     }
     else
-        fprintf(stderr, "gpe: tail_order(%d, %d, W %d, lag %d, pair %d) violates a dependency — column-by-column order used\n", nt, nb, W, lag, pair);
+        fprintf(stderr, "gpe: tail_order(%d, %d, lead %d, lag %d) violates a dependency — column-by-column order used\n", nt, nb, dlead, lag);
     cache[key] = d;
     return d;
 }
@@ -2617,12 +2455,14 @@ void debug_chain_split(int wave, int* units10, int* cols)
 // strips is a permutation of its tiles in which every wait is for a lower-numbered workgroup, 0 if not; host only
 int debug_tail_order(int nt, int nb, int lag, int pair)
 {
+    if (pair)
+        return -1; // (the two-blocks-per-chain-workgroup form of round 4 was removed in round 6)
     if (nt < 1 || nb < nt || nb > 4096)
         return -1;
     std::vector<int> flat;
-    if (!build_tail_order(nt, nb, 0, lag, pair, flat, 0)) // the strict table (batched launches, the pair form)
+    if (!build_tail_order(nt, nb, 0, lag, flat, 0)) // the strict table (batched launches)
         return 0;
-    if (!pair && !build_tail_order(nt, nb, 0, lag, pair, flat, TAIL_DLEAD)) // ... and the one single launches use (checked below)
+    if (!build_tail_order(nt, nb, 0, lag, flat, TAIL_DLEAD)) // ... and the one single launches use (checked below)
         return 0;
     std::vector<char> seen((size_t)nt * nb, 0);
     size_t n = 0;
@@ -2663,10 +2503,7 @@ void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, 
     // just-in-time window W > 0 LOSES (6: 675, 8: 694, 12: 738, 16: 770): a tile dispatched late has its catch-up products still
     // to do when its row's diagonal workgroup asks for it; waiting workgroups are not what limits the closing launch
     static const int ord_lag = getenv("GPE_TAIL_LAG") ? atoi(getenv("GPE_TAIL_LAG")) : 3;
-    // GPE_TAIL_PAIR=1: two diagonal blocks per chain workgroup (diag_flow2.h)
-    static const int pair = getenv("GPE_TAIL_PAIR") ? atoi(getenv("GPE_TAIL_PAIR")) : 0;
-    a.pair = pair && a.nt >= 2 ? 1 : 0;
-    a.order = tail_order(a.nt, a.nb, g_batch.bt || a.pair ? 0 : TAIL_DLEAD, ord_lag, a.pair);
+    a.order = tail_order(a.nt, a.nb, g_batch.bt ? 0 : TAIL_DLEAD, ord_lag);
     const int64_t tiles = tail_tiles(a.nt, a.nb);
     if (gen) {
         a.Xg = gen->Xg;

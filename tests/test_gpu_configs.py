@@ -611,38 +611,6 @@ def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, t
     h.close()
 
 
-def test_gpu_pair_blocks_vs_lapack():
-    """GPE_TAIL_PAIR=1 (diag_flow2.h, experimental, off by default): the chain workgroup of an even tile column factors its
-    diagonal block, the tile below and the NEXT diagonal block as one 128 x 128 block — the panel wave holds two rows per lane —
-    and the odd column's diagonal tile has no workgroup of its own.  L, alpha and the log-likelihood against LAPACK for an even
-    and an odd number of tile columns, a ragged order with three outputs, and the tall launch + update + closing launch of
-    N = 4096; every size twice (both pairs of polled buffers).  Child process: the switch is read once."""
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "import numpy as np, scipy.linalg as sl\n"
-            "from limbo_amd import _capi, synth as O\n"
-            "eng = _capi.load_engine()\n"
-            "for N, P in [(128, 1), (1024, 1), (1088, 2), (1407, 3), (2048, 1), (4096, 1)]:\n"
-            "    rng = np.random.default_rng(N + P)\n"
-            "    X = rng.uniform(0, 1, size=(N, 4))\n"
-            "    Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.05 * rng.normal(size=(N, P))\n"
-            "    om, _ = O.obs_mean_data(Y)\n"
-            "    h = _capi.Handle(eng); h.set_data(X, om); h.set_kernel(int(O.SE_ARD), rng.uniform(-0.3, 0.2, size=5), 0.01)\n"
-            "    for rep in range(2):\n"
-            "        assert h.compute() == 0 and h.flow_retries() == 0, (N, P)\n"
-            "        L = np.tril(h.get_L()); K = h.get_K()\n"
-            "        Lref = sl.cholesky(np.tril(K) + np.tril(K, -1).T, lower=True)\n"
-            "        assert np.max(np.abs(L - Lref)) <= 1e-10 * np.max(np.abs(Lref)), (N, P)\n"
-            "        aref = sl.cho_solve((Lref, True), om)\n"
-            "        assert np.linalg.norm(h.get_alpha() - aref) < 1e-7 * np.linalg.norm(aref), (N, P)\n"
-            "        llref = -0.5 * np.sum(om * aref) - np.sum(np.log(np.diag(Lref))) - 0.5 * N * np.log(2 * np.pi)\n"
-            "        assert abs(h.log_lik() - llref) <= 1e-10 * abs(llref), (N, P)\n"
-            "    h.close()\n"
-            "print('pair ok')\n") % str(ROOT)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPE_TAIL_PAIR="1"), capture_output=True, text=True,
-                       timeout=900, cwd=str(ROOT))
-    assert r.returncode == 0 and "pair ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-
-
 @pytest.mark.parametrize("threads,per", [(4, 6), (8, 200)])
 def test_gpu_concurrent_handles_do_not_starve_each_other(engine_lib, threads, per):
     """Round 4: data-flow launches wait inside the launch for lower-numbered workgroups, which is deadlock-free for ONE such
