@@ -105,6 +105,10 @@ struct gpe_ctx {
     int64_t tail_max = 2816;           // the last <= this many columns by one launch (k_tail; GPE_TAIL_MAX=0: by panels to the end);
                                        // 2816 against 2560: the one update in front of it has 253 tiles instead of 230 for the 256 CUs
                                        // (0.64 against 0.57 of the fp64 peak), profiles/r04_tail_max_sizes.log
+    int64_t tail_single = 3328;        // round 6: an order up to this is ONE data-flow launch, whatever tail_max says (measured after the
+                                       // chain work of rounds 5-6, profiles/r06_split_retune.log: N = 2880 0.657 -> 0.600 ms, 3072 0.689 ->
+                                       // 0.646, 3200 0.792 -> 0.688, 3328 0.776 -> 0.732; 3584 and up: the three launches); 0 when
+                                       // GPE_TAIL_MAX is set (the switch then means what it says)
     int64_t tall_max = 1536;           // ... and up to this many columns in FRONT of them as one tall data-flow launch (all rows
                                        // below ride along) followed by ONE update with k = its width (GPE_TALL=0: 256-column panels
                                        // with look-ahead all the way to the closing launch, the round-3 schedule)
@@ -475,7 +479,9 @@ static TailPlan tail_plan(const gpe_ctx* c, int64_t N, int64_t M)
     // holds its CU from dispatch to its last store, mostly waiting — measured (profiles/r04_dispatch_order.log): 8 x N = 2048
     // 1.45 ms per batch against 1.59 through the step-by-step panels, but 64 x 2048 9.0 against 7.0 and 10 x 4096 7.9 against 7.6
     static const int64_t batch_tiles = getenv("GPE_BATCH_TAIL_TILES") ? atoll(getenv("GPE_BATCH_TAIL_TILES")) : 4608;
-    const int64_t tmax = g_batch.bt ? c->batch_tail_max : c->tail_max;
+    int64_t tmax = g_batch.bt ? c->batch_tail_max : c->tail_max;
+    if (!g_batch.bt && tmax >= 2 * NB && pl.N64 <= c->tail_single)
+        tmax = std::max(tmax, pl.N64);
     if (!(tmax >= 2 * NB && c->panel256 && c->fuse_panel && c->panel_handover && nbo == 4 * NB && M - pl.N64 <= NB))
         return pl;
     const int64_t t0 = pl.N64 > tmax ? (pl.N64 - tmax + nbo - 1) / nbo * nbo : 0;
@@ -511,8 +517,10 @@ static TailPlan tail_plan(const gpe_ctx* c, int64_t N, int64_t M)
 static void debug_tail_plan(int64_t N, int P, int G, int64_t tail_max, int64_t tall_max, int64_t batch_tail_max, int64_t* out)
 {
     gpe_ctx c;
-    if (tail_max > 0)
+    if (tail_max > 0) {
         c.tail_max = tail_max;
+        c.tail_single = 0; // (as GPE_TAIL_MAX: the width given is the width used)
+    }
     if (tall_max > 0)
         c.tall_max = tall_max;
     c.batch_tail_max = std::min(batch_tail_max > 0 ? batch_tail_max : c.batch_tail_max, c.tail_max);
@@ -2304,8 +2312,10 @@ int gpe_create(int device_id, gpe_handle* out)
         c->panel256 = atoi(f) != 0;
     if (const char* f = getenv("GPE_EARLY_BULK_TILES"))
         c->early_bulk = atoll(f);
-    if (const char* f = getenv("GPE_TAIL_MAX"))
+    if (const char* f = getenv("GPE_TAIL_MAX")) {
         c->tail_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), GPE_TAIL_MAX);
+        c->tail_single = 0;
+    }
     if (const char* f = getenv("GPE_TALL"))
         c->tall_max = std::min<int64_t>(std::max<int64_t>(atoll(f), 0), GPE_TAIL_MAX);
     c->batch_tail_max = std::min(c->batch_tail_max, c->tail_max);

@@ -175,7 +175,7 @@ def test_ragged_block_update_deals_its_k_range_completely():
 
 
 def test_schedule_of_the_factorisation_by_size():
-    """engine.hip: tail_plan (host logic, no device).  N <= 2816: ONE data-flow launch from column 0; up to tall_max + tail_max =
+    """engine.hip: tail_plan (host logic, no device).  N <= 3328 (round 6; 2816 before): ONE data-flow launch from column 0; up to tall_max + tail_max =
     4352: tall launch from column 0 | one update | closing launch; larger: 256-column panels in front of the closing launch;
     the panels end on a panel boundary, the closing launch is never wider than tail_max, a ragged order rides as one more row
     strip.  Batched sequences: data-flow launches from column 0 or not at all, and only while the members' tiles fit."""
@@ -193,7 +193,9 @@ def test_schedule_of_the_factorisation_by_size():
 
     assert plan(4096) == dict(t0=1280, e0=0, nt_tail=44, nb_tail=45, nt_tall=20, nb_tall=65, n64=4096, nbo=256)
     assert plan(2048)["t0"] == 0 and plan(2048)["e0"] == -1 and plan(2048)["nt_tail"] == 32
-    assert plan(2816)["t0"] == 0 and plan(2880)["t0"] == 256 and plan(2880)["e0"] == 0
+    assert plan(2816)["t0"] == 0 and plan(2880)["t0"] == 0 and plan(3328)["t0"] == 0 and plan(3328)["nt_tail"] == 52
+    assert plan(3392)["t0"] == 768 and plan(3392)["e0"] == 0  # (above the one-launch range: closing launch <= 2816 columns again)
+    assert plan(2880, tail=2816)["t0"] == 256 and plan(2880, tail=2816)["e0"] == 0  # (an explicit width is the width used)
     assert plan(5000)["t0"] == 2304 and plan(5000)["e0"] == -1  # (the tall launch only from column 0 and <= 1536 wide)
     assert plan(100)["t0"] == -1 and plan(128)["t0"] == 0
     assert plan(4096, tail=2560)["t0"] == 1536 and plan(4096, tail=2560, tall=1024)["e0"] == -1
@@ -208,7 +210,7 @@ def test_schedule_of_the_factorisation_by_size():
                 continue
             assert n - n // 64 * 64 + p <= 64
             assert pl["n64"] == n // 64 * 64 and pl["t0"] % pl["nbo"] == 0
-            assert 2 <= pl["nt_tail"] == (pl["n64"] - pl["t0"]) // 64 <= 2816 // 64
+            assert 2 <= pl["nt_tail"] == (pl["n64"] - pl["t0"]) // 64 <= (3328 if pl["t0"] == 0 else 2816) // 64
             assert pl["nb_tail"] == pl["nt_tail"] + 1  # (obs_mean's rows, and a ragged last block, as one more row strip)
             if pl["e0"] >= 0:
                 assert pl["e0"] == 0 and 2 <= pl["nt_tall"] == pl["t0"] // 64 <= 1536 // 64 and pl["nb_tall"] == pl["n64"] // 64 + 1
