@@ -235,6 +235,11 @@ int gpe_debug_chain_split(int wave, int* units10, int* cols);
  * launch_ragged_update): returns the number of workgroups (0: the general product runs instead — k < 256 or no room for two
  * 64 x 64 slots in scratch_doubles) and *kc = the k rows of each; -1: bad arguments. */
 int gpe_debug_ragged_split(int64_t k, int64_t scratch_doubles, int* kc);
+/* Test hook, host only: which workgroup takes which 128 x 128 tile of a triangular trailing update C[m x n] -= A B^T whose
+ * element (0, 0) is element (grow0, gcol0) of the symmetric matrix (csrc/gemm.hip: tri_tile_map; the updates behind
+ * gp.hpp:565's factorisation).  out[b] = ti | tj << 16 for workgroup b (XCD b mod 8), -1: none; returns the table's length
+ * (a multiple of 8; at most cap entries are written), -1: bad arguments. */
+int gpe_debug_tri_tile_map(int64_t m, int64_t n, int64_t grow0, int64_t gcol0, int* out, int cap);
 /* ... and the schedule the engine picks for n samples, p outputs and a batched sequence of g members (g <= 1: one handle) under
  * the given widths (<= 0: the defaults GPE_TAIL_MAX / GPE_TALL / GPE_BATCH_TAIL_MAX): out8 = { t0 (first column of the closing
  * data-flow launch; -1: panels to the end), e0 (first column of the tall launch in front of it; -1: none), tile columns and row

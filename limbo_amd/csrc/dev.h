@@ -288,6 +288,8 @@ struct GemmArgs {
     int rhs_rows;  // the LAST rhs_rows of the m rows of C / A are right-hand-side rows (engine.hip): the direct-to-LDS
                    // kernels update them with plain FMAs instead of a tile row (gemm_glds64.h: gemm_rhs_rows); inside those
                    // kernels m counts the main rows only
+    const int* tile_map; // set by launch_gemm_sub (tri, 128 x 128 direct-to-LDS kernel): workgroup -> tile (ti | tj << 16, or -1: none)
+                         // in an order that keeps the operand panels of an XCD's resident workgroups few (gemm.hip: tri_tile_map)
     void* stop_event; // host side only: hipEvent_t completed by this launch (null: none)
     const BatchTab* bt; // batched launch (gridDim.z GPs): set by the launch wrapper, null otherwise
 };
@@ -301,6 +303,7 @@ static __device__ __forceinline__ void gemm_rebase(GemmArgs& g)
     }
 }
 void launch_gemm_sub(hipStream_t s, const GemmArgs& g);
+int debug_tri_tile_map(int64_t m, int64_t n, int64_t grow0, int64_t gcol0, int* out, int cap); // gemm.hip (host only)
 // the next-panel update g (as for launch_gemm_sub: C = A[pe:, pe:pe2], k = pe - p0, tri) and, in the same launch, the
 // update + factorisation + half-inversion of the next diagonal block A[pe:pe+64, pe:pe+64] (-> Xt_next)
 // (Dacc: sum of the pieces the panel steps already formed, subtracted as well; p0 == pe: no products here)

@@ -1700,6 +1700,12 @@ int gpe_debug_ragged_split(int64_t k, int64_t scratch_doubles, int* kc)
     *kc = 0;
     return ragged_split(k, scratch_doubles, kc);
 }
+int gpe_debug_tri_tile_map(int64_t m, int64_t n, int64_t grow0, int64_t gcol0, int* out, int cap)
+{
+    if (m <= 0 || n <= 0 || !out || cap <= 0 || (m + 127) / 128 >= 65536 || (n + 127) / 128 >= 32768)
+        return -1;
+    return debug_tri_tile_map(m, n, grow0, gcol0, out, cap);
+}
 int gpe_debug_chain_split(int wave, int* units10, int* cols)
 {
     if (wave < 0 || wave > 7 || !units10 || !cols)

@@ -38,6 +38,11 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+#include <algorithm>
 
 #ifdef GEMM_TIMING
 __device__ long long g_gemm_ts[16];
@@ -377,7 +382,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g_)
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     int ti, tj;
-    if (g.tri) {
+    if (g.tile_map) { // (host-built order: tri_tile_map below)
+        const int pk = g.tile_map[lwg];
+        if (pk < 0)
+            continue;
+        ti = pk & 0xffff;
+        tj = pk >> 16;
+    }
+    else if (g.tri) {
         const int sc = wg / g.fold_len;
         int rr = wg % g.fold_len;
         const int t0 = first_live_tile<TM, TN>(g, sc), c0 = tiles_m - t0;
@@ -585,13 +597,102 @@ static bool glds_ok(const GemmArgs& g)
         && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0;
 }
 
+// ---- which workgroup takes which tile of a triangular update (round 6) ------------------------------------------------------
+// Workgroup b runs on XCD b mod 8, each XCD has its own L2, and the workgroups resident on an XCD walk their k ranges together:
+// what an XCD fetches from memory is the set of DISTINCT operand panels (128 rows x k) of its resident tiles.  The folded
+// column enumeration (k_gemm4) gives an XCD a tile column and a half — one B panel, some thirty A panels: 139 panel fetches
+// for the 253 tiles of N = 4096's update (the PMC's 308 MB, 3.35 x the algorithmic bytes).  Here: the live tiles in bands of
+// TRI_BAND tile rows, column by column inside a band, the sequence cut into eight runs, run x dealt to the workgroups
+// x, x + 8, .. — 32 consecutive tiles are a 8 x 4 block, 12 panels, fewer where the band meets the diagonal (A and B are the
+// same matrix there): 91 panel fetches.  The table is built once per shape and device and kept.
+#define TRI_BAND 8
+struct TriMapKey {
+    int dev, tiles_m, tiles_n;
+    int64_t off; // (gcol0 - grow0: where the diagonal runs)
+    bool operator<(const TriMapKey& o) const
+    {
+        return std::tie(dev, tiles_m, tiles_n, off) < std::tie(o.dev, o.tiles_m, o.tiles_n, o.off);
+    }
+};
+// host part (also the test hook gpe_debug_tri_tile_map): the table for a launch of shape g; returns its length
+static int tri_tile_map_host(const GemmArgs& g, std::vector<int>& tab)
+{
+    constexpr int TM = 128, TN = 128;
+    const int tiles_m = (int)((g.m + TM - 1) / TM), tiles_n = (int)((g.n + TN - 1) / TN);
+    std::vector<int> first(tiles_n);
+    for (int tj = 0; tj < tiles_n; ++tj)
+        first[tj] = first_live_tile<TM, TN>(g, tj);
+    std::vector<int> seq;
+    for (int r0 = 0; r0 < tiles_m; r0 += TRI_BAND) {
+        const int r1 = std::min(tiles_m, r0 + TRI_BAND);
+        for (int tj = 0; tj < tiles_n; ++tj)
+            for (int ti = std::max(r0, first[tj]); ti < r1; ++ti)
+                seq.push_back(ti | (tj << 16));
+    }
+    const int T = (int)seq.size(), q = T / 8, r = T % 8, slots = q + (r ? 1 : 0);
+    tab.assign((size_t)slots * 8, -1);
+    int pos = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int len = q + (x < r ? 1 : 0);
+        for (int i = 0; i < len; ++i)
+            tab[(size_t)i * 8 + x] = seq[pos + i];
+        pos += len;
+    }
+    return (int)tab.size();
+}
+int debug_tri_tile_map(int64_t m, int64_t n, int64_t grow0, int64_t gcol0, int* out, int cap)
+{
+    GemmArgs g{};
+    g.m = m;
+    g.n = n;
+    g.tri = 1;
+    g.grow0 = grow0;
+    g.gcol0 = gcol0;
+    std::vector<int> tab;
+    const int len = tri_tile_map_host(g, tab);
+    for (int i = 0; i < len && i < cap; ++i)
+        out[i] = tab[i];
+    return len;
+}
+static const int* tri_tile_map(const GemmArgs& g, int* total)
+{
+    static std::mutex mu;
+    static std::map<TriMapKey, std::pair<int*, int>> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const TriMapKey key{dev, (int)((g.m + 127) / 128), (int)((g.n + 127) / 128), g.gcol0 - g.grow0};
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        std::vector<int> tab;
+        const int len = tri_tile_map_host(g, tab);
+        int* d = nullptr;
+        if (hipMalloc(&d, sizeof(int) * (size_t)len) != hipSuccess)
+            return nullptr;
+        if (hipMemcpy(d, tab.data(), sizeof(int) * (size_t)len, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return nullptr;
+        }
+        it = cache.emplace(key, std::make_pair(d, len)).first;
+    }
+    *total = it->second.second;
+    return it->second.first;
+}
+
 static void launch_glds128(hipStream_t s, const GemmArgs& g0)
 {
     constexpr int TM = 128, TN = 128;
     GemmArgs g = g0;
     const int tiles_m = (int)((g.m + TM - 1) / TM), tiles_n = (int)((g.n + TN - 1) / TN);
     int64_t tiles = (int64_t)tiles_m * tiles_n;
-    if (g.tri) {
+    g.tile_map = nullptr;
+    static const bool tri_map = !(getenv("GPE_TRI_MAP") && atoi(getenv("GPE_TRI_MAP")) == 0);
+    int mapped = 0;
+    if (g.tri && tri_map && tiles_m < 65536 && tiles_n < 32768)
+        g.tile_map = tri_tile_map(g, &mapped);
+    if (g.tile_map)
+        tiles = mapped;
+    else if (g.tri) {
         int fold = 1;
         const int nsup = (tiles_n + 1) / 2;
         for (int sc = 0; sc < nsup; ++sc) {

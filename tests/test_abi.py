@@ -79,7 +79,7 @@ def test_oracle_mirrors_the_abi(oracle_lib):
     skip = {"gpe_get_stream", "gpe_set_profiling", "gpe_get_phase_ms", "gpe_reset_phase_ms", "gpe_mfma_f64_peak",
             "gpe_hbm_stream_peak", "gpe_flow_retries", "gpe_small_calls", "gpe_handover_reruns", "gpe_trace", "gpe_trace_dump",
             "gpe_debug_tail_order", "gpe_debug_tail_plan", "gpe_debug_inv_plan", "gpe_debug_chain_split", "gpe_debug_ragged_split",
-            "gpe_epoch", "gpe_xproc_waits"}  # (engine bookkeeping, nothing of the reference's to restate)
+            "gpe_debug_tri_tile_map", "gpe_epoch", "gpe_xproc_waits"}  # (engine bookkeeping, nothing of the reference's to restate)
     for s in declared_symbols():
         if s in skip:
             continue
@@ -172,6 +172,41 @@ def test_ragged_block_update_deals_its_k_range_completely():
             assert kc.value % 32 == 0 and G * kc.value >= k and (G - 1) * kc.value < k, (k, scratch, G, kc.value)
     G = f(1664, 1 << 22, ctypes.byref(kc))  # N = 1700: 26 workgroups of 64 rows
     assert (G, kc.value) == (26, 64)
+
+
+def test_triangular_update_tile_order_covers_every_tile_once_and_keeps_panels_few():
+    """csrc/gemm.hip: tri_tile_map (round 6).  The 128 x 128 tiles of a triangular trailing update are dealt to the workgroups
+    through a host-built table: every live tile (one that touches the lower triangle) exactly once, no other; the table is a whole
+    number of rounds of the eight XCDs (workgroup b runs on XCD b mod 8); the tiles of an XCD are a run of the band order — for
+    the update of N = 4096 (2816 + 1 rows behind column 1280, k = 1280) the eight XCDs fetch at most 96 distinct 128-row panels
+    between them against 139 of the folded column order it replaces; shapes: square, ragged, with right-hand-side rows as a
+    tile row, a diagonal that does not start at a tile corner (a ragged order's last block), more than one round."""
+    from limbo_amd import _capi
+
+    lib = ctypes.CDLL(str(_capi.ENGINE_SO))
+    f = lib.gpe_debug_tri_tile_map
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int64] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    buf = (ctypes.c_int * 65536)()
+    assert f(0, 128, 0, 0, buf, 65536) == -1 and f(128, 128, 0, 0, None, 0) == -1
+    for m, n, r0, c0 in [(2817, 2816, 1280, 1280), (2816, 2816, 0, 0), (128, 128, 0, 0), (130, 100, 64, 64), (3000, 2900, 1024, 1024),
+                         (2945, 2880, 1536, 1600), (14849, 14848, 1536, 1536), (700, 300, 4096, 4096), (257, 256, 64, 0)]:
+        ln = f(m, n, r0, c0, buf, 65536)
+        tm, tn = -(-m // 128), -(-n // 128)
+        live = {(ti, tj) for tj in range(tn) for ti in range(tm) if r0 + ti * 128 + 127 >= c0 + tj * 128}
+        assert ln % 8 == 0 and 0 < ln <= 65536 and ln < len(live) + 8, (m, n, ln)
+        got = [(buf[b] & 0xffff, buf[b] >> 16) for b in range(ln) if buf[b] >= 0]
+        assert len(got) == len(live) and set(got) == live, (m, n)
+        per_xcd = [[(buf[b] & 0xffff, buf[b] >> 16) for b in range(x, ln, 8) if buf[b] >= 0] for x in range(8)]
+        assert max(map(len, per_xcd)) - min(map(len, per_xcd)) <= 1
+        if (m, n) == (2817, 2816):
+            panels = sum(len({i for i, _ in t} | {j for _, j in t}) for t in per_xcd)
+            assert len(live) == 253 + 22 and panels <= 110, panels  # (with the right-hand-side row as a tile row: 23 tile rows)
+    # the same update with its right-hand-side row as FMAs in front of the tiles (what the engine launches): 253 tiles
+    ln = f(2816, 2816, 1280, 1280, buf, 65536)
+    per_xcd = [[(buf[b] & 0xffff, buf[b] >> 16) for b in range(x, ln, 8) if buf[b] >= 0] for x in range(8)]
+    assert ln == 256 and sum(map(len, per_xcd)) == 253
+    assert sum(len({i for i, _ in t} | {j for _, j in t}) for t in per_xcd) <= 96
 
 
 def test_schedule_of_the_factorisation_by_size():
