@@ -247,12 +247,14 @@ int gpe_debug_tri_tile_map(int64_t m, int64_t n, int64_t grow0, int64_t gcol0, i
 int gpe_debug_tail_plan(int64_t n, int p, int g, int64_t tail_max, int64_t tall_max, int64_t batch_tail_max, int64_t* out8);
 /* Test hook, host only: the launch plan of the recursive K^-1 (csrc/inv2.hip; replaces the dense solves of gp.hpp:254-264) for
  * order n and leading dimension ld (>= n rounded up to 64), dealt into nbins shares (<= 0: 512) with chunk-length factor
- * load_pct / 100 (<= 0: 1.0).  Rows of 12 int64 in launch order (the last two: the valid rows and columns of the tile — a ragged
- * order's last strip):
- *   tile product { step, 0 | 2 (64 x 64 tiles), A buf, A offset, B buf, B offset, C buf, C offset, k, negate | share << 1 }  (share = the
- *                  persistent workgroup of the launch that runs it; workgroup b sits on XCD b % 8)
- *   tile fold    { step, 1 | 3, D buf, D offset, P1 offset | -1, P2 offset | -1, P3 offset | -1, T buf | -1, T offset, 0 }
- * buffers: 0 L, 1 U = L^-T, 2 K^-1, 3 T-forms / W, 4..6 partial sums; offsets in doubles.  Returns the number of rows of the
+ * load_pct / 100 (<= 0: 1.0); nbins < 0: the plan of a batched sequence of -nbins members.  One row of 16 int64 per tile product, in
+ * launch order, share by share:
+ *   { step (= launch), 0 | 2 (128 x 128 | 64 x 64 tiles), A buf, A offset, B buf, B offset, C buf, C offset, k, negate | share << 1,
+ *     valid rows, valid columns (a ragged order's last strip), chunk number | chunks of the tile's k range << 8, flag word of the
+ *     tile, T buf | -1, T offset }
+ *   share = the persistent workgroup of the launch that runs it (workgroup b sits on XCD b % 8); chunk 0 stores C, chunk c > 0 adds
+ *   to it once chunk c - 1 has stored (it sits in no lower a share, behind it inside one); the last chunk also stores C^T at T.
+ * buffers: 0 L, 1 U = L^-T, 2 K^-1, 3 T-forms / W; offsets in doubles.  Returns the number of rows of the
  * plan (out may be too small or null: nothing beyond cap_rows is written), -1 for bad arguments.  tests/test_inv_plan.py
  * executes the plan in numpy. */
 int gpe_debug_inv_plan(int64_t n, int64_t ld, int nbins, int load_pct, int64_t* out, int64_t cap_rows);

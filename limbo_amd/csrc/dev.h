@@ -319,19 +319,22 @@ double gemm_flops(const GemmArgs& g);
 struct GemmItem {
     const double* A; // tile row origin at the first k of the chunk: A[r + kk * ld]
     const double* B; // tile column origin likewise: B[c + kk * ld]
-    double* C;       // tile origin, overwritten (its first mr rows x nc columns: a ragged last tile stores nothing else)
+    double* C;       // where THIS chunk's product goes (its first mr rows x nc columns: a ragged last tile stores nothing else); never
+                     // read by the product: the tile itself for chunk 0 (and for a whole k range), partial buffer c for chunk c > 0
+    double* T;       // optional: the finished tile transposed as well, T[c + r * ld] = D[r + c * ld]
+    double* D;       // a cut k range: the tile (= chunk 0's C)
+    const double* P1; // ... and its place in partial buffer 1 (buffer c: P1 + (c - 1) * pstride)
     int32_t k;       // multiple of 16
-    int32_t flags;   // bit 0: C = -A B^T; bits 8..15: mr, bits 16..23: nc — valid rows / columns of the tile (1 .. tile edge)
+    int32_t flags;   // bit 0: the product enters negated; bits 8..15: mr, bits 16..23: nc — valid rows / columns (1 .. tile edge)
+    int32_t slot, nch; // nch > 1: one of the nch chunks of a cut k range; `slot` = the tile's counter word.  Every chunk stores its
+                     // product write-through and counts; the one that counts LAST adds them up, D + P1 + P2 + .. in that order
+                     // whoever it is (bitwise reproducible), stores the tile and its transposed copy: nobody waits for anybody
 };
-struct FoldItem {
-    double* D;          // tile (128 x 128, or 64 x 64): D += P[0] + P[1] + P[2] (null entries skipped; D is not rewritten without any)
-    const double* P[3];
-    double* T;          // optional: the resulting tile transposed, T[c + r * ld] = D[r + c * ld]
-    int32_t mr, nc;     // valid rows / columns of D's tile
-};
-// (batched launches, g_batch: the lists hold member 0's pointers, workgroup z rebases them — dev.h: bt_rebase)
-void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld, int tile = 128); // tile: 128 or 64
-void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld, int tile = 128);
+#define GEMM_ITEM_NEG 1
+// (batched launches, g_batch: the lists hold member 0's pointers, workgroup z rebases them — dev.h: bt_rebase; member z counts in
+// the words z * nslots ..)
+void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld, int tile, int* counters,
+                       int nslots, int64_t pstride); // tile: 128 or 64
 // the plan of one inversion (inv2.hip): host-built once per (N, ld, buffers), resident on the device
 struct Inv2Plan;
 Inv2Plan* inv2_plan_get(Inv2Plan* old, int64_t N, int64_t ld, const double* L, double* U, double* Kinv, double* S, int64_t pstride,

@@ -732,7 +732,8 @@ static void launch_glds128(hipStream_t s, const GemmArgs& g0)
 // ---------------------------------------------------------------------------------------------
 template <int BKT, int NST, int EPC, int MINB>
 __global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __restrict__ items, const int32_t* __restrict__ bin_start,
-                                                          int64_t ld, const BatchTab* __restrict__ bt)
+                                                          int64_t ld, const BatchTab* __restrict__ bt, int* __restrict__ counters, int nslots,
+                                                          int64_t pstride)
 {
     constexpr int TM = 128, TN = 128, WM = 2, WN = 4, NWV = WM * WN;
     constexpr int SA = TM + 16, SB = TN + 16;
@@ -740,6 +741,7 @@ __global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __rest
     constexpr int RA = TM / WM / 16, RB = TN / WN / 4;
     constexpr int LPW = 2 * BKT / NWV;
     __shared__ __attribute__((aligned(16))) double lds[NST * STAGE];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave % WM) * (TM / WM), wn = (wave / WM) * (TN / WN);
@@ -752,6 +754,12 @@ __global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __rest
             item.A = bt_rebase(bt, (int)blockIdx.z, item.A);
             item.B = bt_rebase(bt, (int)blockIdx.z, item.B);
             item.C = bt_rebase(bt, (int)blockIdx.z, item.C);
+            if (item.T)
+                item.T = bt_rebase(bt, (int)blockIdx.z, item.T);
+            if (item.nch > 1) {
+                item.D = bt_rebase(bt, (int)blockIdx.z, item.D);
+                item.P1 = bt_rebase(bt, (int)blockIdx.z, item.P1);
+            }
         }
         // this lane's 16-byte piece of every k-row: rows (2 lane, 2 lane + 1), clamped into the tile's valid rows (copies of
         // valid rows only feed outputs the epilogue does not store); wave w moves k-rows w, w + 8, ..
@@ -825,8 +833,22 @@ __global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __rest
             static_assert(NWV * SCR <= NST * STAGE, "transposition scratch must fit in the operand stages");
             // the k loop ended with a barrier: the stages are free, each wave uses a private slice
             const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
+            double* const Tw = item.T ? item.T + wn + (int64_t)wm * ld : nullptr;
+            const bool cut = item.nch > 1; // one of the chunks of a cut k range (dev.h: GemmItem)
             if (rlim > 0 && clim > 0)
-                WT::template rmw_chunked<EPC>(acc, lds + wave * SCR, item.C + (int64_t)wn * ld + wm, ld, rlim, clim, 1, lane);
+                WT::template store_item<EPC>(acc, lds + wave * SCR, item.C + (int64_t)wn * ld + wm, cut ? nullptr : Tw, ld, rlim, clim, cut, lane);
+            if (cut) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's part of the chunk is acknowledged
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    s_last = (__hip_atomic_fetch_add(counters + item.slot + (int)blockIdx.z * nslots, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1)
+                            % item.nch
+                        == 0;
+                __syncthreads();
+                if (s_last && rlim > 0 && clim > 0) // every chunk of the tile is out: this workgroup adds them up
+                    WT::template fold_item<EPC>(lds + wave * SCR, item.D + (int64_t)wn * ld + wm, item.P1 + (int64_t)wn * ld + wm, pstride,
+                                                item.nch - 1, Tw, ld, rlim, clim, lane);
+            }
         }
         __syncthreads(); // the next item's prologue overwrites the LDS stages
     }
@@ -837,14 +859,16 @@ __global__ __launch_bounds__(512, MINB) void k_gemm_items(const GemmItem* __rest
 // (a launch of 32 tile products of k = 256: 38 us with 128 x 128 tiles).  The k loop is gemm_glds64_body's with eight waves
 // on the tile (2 x 4 waves of 32 x 16: two per SIMD cover each other's fragment reads), BKT 16, four LDS stages (74 KB).
 template <int BKT, int NST, int NWV>
-__global__ __launch_bounds__(64 * NWV, 1) void k_gemm_items64(const GemmItem* __restrict__ items, const int32_t* __restrict__ bin_start,
-                                                               int64_t ld, const BatchTab* __restrict__ bt)
+__global__ __launch_bounds__(64 * NWV, 4) void k_gemm_items64(const GemmItem* __restrict__ items, const int32_t* __restrict__ bin_start,
+                                                               int64_t ld, const BatchTab* __restrict__ bt, int* __restrict__ counters, int nslots,
+                                                               int64_t pstride)
 {
     static_assert(NWV == 8, "2 x 4 waves of 32 x 16");
     constexpr int PAIR = 144, OPER = (BKT / 2) * PAIR, STAGE = 2 * OPER;
     constexpr int RA = 2, RB = 64 / (NWV / 2) / 4;
     constexpr int LPW = 2 * (BKT / 2) / NWV;
     __shared__ __attribute__((aligned(16))) double lds[NST * STAGE];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * (4 * RB);
@@ -859,6 +883,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_gemm_items64(const GemmItem* __
             item.A = bt_rebase(bt, (int)blockIdx.z, item.A);
             item.B = bt_rebase(bt, (int)blockIdx.z, item.B);
             item.C = bt_rebase(bt, (int)blockIdx.z, item.C);
+            if (item.T)
+                item.T = bt_rebase(bt, (int)blockIdx.z, item.T);
+            if (item.nch > 1) {
+                item.D = bt_rebase(bt, (int)blockIdx.z, item.D);
+                item.P1 = bt_rebase(bt, (int)blockIdx.z, item.P1);
+            }
         }
         // this lane's 16-byte piece: rows (2 l', 2 l' + 1) of k-row kk + (lane >> 5), l' = lane & 31, clamped into the tile's valid
         // rows; wave w moves k-row pairs w, w + NWV, ..
@@ -932,30 +962,41 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_gemm_items64(const GemmItem* __
         {
             using WT = WaveTileC<RA, RB>;
             static_assert(NWV * WT::SCRATCH <= NST * STAGE, "transposition scratch must fit in the operand stages");
-            double cv[WT::NIT];
-#pragma unroll
-            for (int q = 0; q < WT::NIT; ++q)
-                cv[q] = 0.0; // (overwrite: C is not read)
             const int rlim = mr - wm < WT::R ? mr - wm : WT::R, clim = nc - wn < WT::CN ? nc - wn : WT::CN;
+            double* const Tw = item.T ? item.T + wn + (int64_t)wm * ld : nullptr;
+            const bool cut = item.nch > 1; // (as in k_gemm_items)
             if (rlim > 0 && clim > 0)
-                WT::store(acc, cv, lds + wave * WT::SCRATCH, item.C + (int64_t)wn * ld + wm, ld, rlim, clim, 1, lane);
+                WT::template store_item<1>(acc, lds + wave * WT::SCRATCH, item.C + (int64_t)wn * ld + wm, cut ? nullptr : Tw, ld, rlim, clim, cut, lane);
+            if (cut) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    s_last = (__hip_atomic_fetch_add(counters + item.slot + (int)blockIdx.z * nslots, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1)
+                            % item.nch
+                        == 0;
+                __syncthreads();
+                if (s_last && rlim > 0 && clim > 0)
+                    WT::template fold_item<1>(lds + wave * WT::SCRATCH, item.D + (int64_t)wn * ld + wm, item.P1 + (int64_t)wn * ld + wm, pstride,
+                                              item.nch - 1, Tw, ld, rlim, clim, lane);
+            }
         }
         __syncthreads(); // the next item's prologue overwrites the LDS stages
     }
 }
 
-void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld, int tile)
+void launch_gemm_items(hipStream_t s, const GemmItem* items, const int32_t* bin_start, int nbins, int64_t ld, int tile, int* counters, int nslots,
+                       int64_t pstride)
 {
     if (nbins > 0 && tile == 64) {
         GPE_LAUNCH_NAMED("k_gemm_items64", (k_gemm_items64<16, 4, 8>), dim3((unsigned)nbins, 1, (unsigned)g_batch.G), dim3(512), 0, s, items,
-                         bin_start, ld, g_batch.bt);
+                         bin_start, ld, g_batch.bt, counters, nslots, pstride);
         return;
     }
 
     if (nbins <= 0)
         return;
-    GPE_LAUNCH_NAMED("k_gemm_items", (k_gemm_items<16, 2, 4, 2>), dim3((unsigned)nbins, 1, (unsigned)g_batch.G), dim3(512), 0, s, items, bin_start,
-                     ld, g_batch.bt);
+    GPE_LAUNCH_NAMED("k_gemm_items", (k_gemm_items<16, 2, 4, 4>), dim3((unsigned)nbins, 1, (unsigned)g_batch.G), dim3(512), 0, s, items, bin_start,
+                     ld, g_batch.bt, counters, nslots, pstride);
 }
 
 // number of TM x TN tiles that do work (triangular skipping accounted for)

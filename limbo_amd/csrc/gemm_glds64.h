@@ -152,6 +152,120 @@ struct WaveTileC {
             }
         }
     }
+    // The epilogue of a tile product of a LIST (dev.h: GemmItem; k_gemm_items / k_gemm_items64), in NCH passes over column chunks:
+    // C = acc, never read; `through`: with device-scope (write-through) stores — a chunk of a cut k range, which another
+    // workgroup may add up; Tw (null: no): the tile transposed as well, Tw[c + r * ld] = C[r + c * ld], lanes along c.
+    template <int NCH>
+    static __device__ __forceinline__ void store_item(const double (&acc)[RA][RB], double* __restrict__ W, double* __restrict__ Cw,
+                                                      double* __restrict__ Tw, int64_t ld, int rlim, int clim, bool through, int lane)
+    {
+        static_assert(RB % NCH == 0 && (4 * RB / NCH) % CPI == 0, "chunking");
+        constexpr int RBC = RB / NCH, CNC = 4 * RBC, NITC = CNC / CPI;
+        const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+        const int row = lane % R, cl = lane / R;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            double t[NITC];
+#pragma unroll
+            for (int n = 0; n < RBC; ++n)
+#pragma unroll
+                for (int m = 0; m < RA; ++m)
+                    W[(4 * n + dcol) * SW + 16 * m + drow] = acc[m][ch * RBC + n];
+#pragma unroll
+            for (int it = 0; it < NITC; ++it)
+                t[it] = W[(it * CPI + cl) * SW + row];
+#pragma unroll
+            for (int it = 0; it < NITC; ++it) {
+                const int col = ch * CNC + it * CPI + cl;
+                if (row < rlim && col < clim) {
+                    if (through)
+                        __hip_atomic_store(Cw + (int64_t)col * ld + row, t[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        Cw[(int64_t)col * ld + row] = t[it];
+                }
+            }
+            if (Tw) { // (wave-uniform)
+#pragma unroll
+                for (int q = 0; q < R * CNC / 64; ++q) {
+                    const int e = q * 64 + lane, c = e % CNC, r = e / CNC;
+                    if (r < rlim && ch * CNC + c < clim)
+                        Tw[(int64_t)r * ld + ch * CNC + c] = W[c * SW + r];
+                }
+            }
+        }
+    }
+    // ... and what the workgroup that counted last does for a cut k range: D = D + P1 + .. + P(nparts), in that order, every
+    // operand read device-wide (the chunks went out write-through from wherever they ran); D stored, and D^T at Tw
+    template <int NCH>
+    static __device__ __forceinline__ void fold_item(double* __restrict__ W, double* __restrict__ Dw, const double* __restrict__ P1w,
+                                                     int64_t pstride, int nparts, double* __restrict__ Tw, int64_t ld, int rlim,
+                                                     int clim, int lane)
+    {
+        constexpr int RBC = RB / NCH, CNC = 4 * RBC, NITC = CNC / CPI;
+        const int row = lane % R, cl = lane / R;
+        const int rr = row < rlim ? row : rlim - 1;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            double v[NITC];
+            int64_t off[NITC];
+#pragma unroll
+            for (int it = 0; it < NITC; ++it) {
+                const int col = ch * CNC + it * CPI + cl;
+                off[it] = (int64_t)(col < clim ? col : clim - 1) * ld + rr;
+                v[it] = __hip_atomic_load(Dw + off[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // (every load of the pass in flight before the first sum: the device-wide loads are 2-3 us each way, and this workgroup
+            // is the only one working on the tile)
+            double u1[NITC], u2[NITC], u3[NITC];
+            if (nparts > 0) {
+#pragma unroll
+                for (int it = 0; it < NITC; ++it)
+                    u1[it] = __hip_atomic_load(P1w + off[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (nparts > 1) {
+#pragma unroll
+                for (int it = 0; it < NITC; ++it)
+                    u2[it] = __hip_atomic_load(P1w + pstride + off[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (nparts > 2) {
+#pragma unroll
+                for (int it = 0; it < NITC; ++it)
+                    u3[it] = __hip_atomic_load(P1w + 2 * pstride + off[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (nparts > 0) {
+#pragma unroll
+                for (int it = 0; it < NITC; ++it)
+                    v[it] += u1[it];
+            }
+            if (nparts > 1) {
+#pragma unroll
+                for (int it = 0; it < NITC; ++it)
+                    v[it] += u2[it];
+            }
+            if (nparts > 2) {
+#pragma unroll
+                for (int it = 0; it < NITC; ++it)
+                    v[it] += u3[it];
+            }
+#pragma unroll
+            for (int it = 0; it < NITC; ++it) {
+                const int col = ch * CNC + it * CPI + cl;
+                if (row < rlim && col < clim)
+                    Dw[(int64_t)col * ld + row] = v[it];
+            }
+            if (Tw) {
+#pragma unroll
+                for (int it = 0; it < NITC; ++it)
+                    W[(it * CPI + cl) * SW + row] = v[it];
+#pragma unroll
+                for (int q = 0; q < R * CNC / 64; ++q) {
+                    const int e = q * 64 + lane, c = e % CNC, r = e / CNC;
+                    if (r < rlim && ch * CNC + c < clim)
+                        Tw[(int64_t)r * ld + ch * CNC + c] = W[c * SW + r];
+                }
+            }
+        }
+    }
     // the same in NCH passes over column chunks: 1/NCH of the registers and of the LDS scratch
     // (SCRATCH / NCH doubles per wave) — for kernels that keep two workgroups per CU
     template <int NCH>

@@ -176,82 +176,3 @@ void launch_zero2d(hipStream_t s, double* A, int64_t lda, int64_t rows, int64_t 
     GPE_LAUNCH(k_zero2d, dim3(gx, (unsigned)cols, (unsigned)g_batch.G), dim3(256), 0, s, A, lda, rows, cols, g_batch.bt);
 }
 
-// ---- tile folds of the recursive K^-1 (inv2.hip; dev.h: FoldItem) ------------------------------------------------------
-// One workgroup per 128 x 128 tile: D += P[0] + P[1] + P[2] in that order (the chunks of a product whose k range was cut:
-// bitwise reproducible), and / or the tile transposed into T through LDS (both sides coalesced: lanes along the rows of D
-// when reading, along the rows of T when writing).  A bandwidth kernel: four 64 x 64 quarters, 16 elements per thread each.
-template <int QUARTERS> // 4: a 128 x 128 tile, 1: a 64 x 64 tile
-__global__ __launch_bounds__(256) void k_fold_items(const FoldItem* __restrict__ items, int64_t ld, const BatchTab* __restrict__ bt)
-{
-    __shared__ double sh[64 * 65];
-    FoldItem it = items[blockIdx.x];
-    if (bt) { // batched launch: the list holds member 0's pointers (null stays null: no buffer starts at 0)
-        const int z = (int)blockIdx.z;
-        it.D = bt_rebase(bt, z, it.D);
-        for (int p = 0; p < 3; ++p)
-            if (it.P[p])
-                it.P[p] = bt_rebase(bt, z, it.P[p]);
-        if (it.T)
-            it.T = bt_rebase(bt, z, it.T);
-    }
-    const int r = threadIdx.x & 63, c4 = threadIdx.x >> 6;
-    const bool sum = it.P[0] != nullptr;
-    // one 64 x 64 quarter; MASKED (a ragged last tile: block-uniform) guards every element, the full form keeps its 16 loads in flight
-    auto quarter = [&](int r0, int c0, auto masked) {
-        constexpr bool MASKED = decltype(masked)::value;
-        const bool rok = !MASKED || r0 + r < it.mr;
-        auto ok = [&](int j) { return !MASKED || (rok && c0 + c4 + 4 * j < it.nc); };
-        double v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            v[j] = ok(j) ? it.D[(int64_t)(c0 + c4 + 4 * j) * ld + r0 + r] : 0.0;
-        if (sum) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                if (it.P[p] == nullptr)
-                    break;
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (ok(j))
-                        v[j] += it.P[p][(int64_t)(c0 + c4 + 4 * j) * ld + r0 + r];
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (ok(j))
-                    it.D[(int64_t)(c0 + c4 + 4 * j) * ld + r0 + r] = v[j];
-        }
-        if (it.T) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                sh[(c4 + 4 * j) * 65 + r] = v[j]; // sh[col][row]
-            __syncthreads();
-            // T[(c0 + x) + (r0 + y) * ld] = D[(r0 + y) + (c0 + x) * ld]: lanes along x
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int y = c4 + 4 * j;
-                if (!MASKED || (r0 + y < it.mr && c0 + r < it.nc))
-                    it.T[(int64_t)(r0 + y) * ld + c0 + r] = sh[r * 65 + y];
-            }
-            __syncthreads();
-        }
-    };
-#pragma unroll 1
-    for (int q = 0; q < QUARTERS; ++q) {
-        const int r0 = (q & 1) * 64, c0 = (q >> 1) * 64;
-        if (r0 >= it.mr || c0 >= it.nc)
-            continue;
-        if (r0 + 64 <= it.mr && c0 + 64 <= it.nc)
-            quarter(r0, c0, std::false_type{});
-        else
-            quarter(r0, c0, std::true_type{});
-    }
-}
-void launch_fold_items(hipStream_t s, const FoldItem* items, int n, int64_t ld, int tile)
-{
-    if (n <= 0)
-        return;
-    if (tile == 64)
-        GPE_LAUNCH_NAMED("k_fold_items64", (k_fold_items<1>), dim3((unsigned)n, 1, (unsigned)g_batch.G), dim3(256), 0, s, items, ld, g_batch.bt);
-    else
-        GPE_LAUNCH_NAMED("k_fold_items", (k_fold_items<4>), dim3((unsigned)n, 1, (unsigned)g_batch.G), dim3(256), 0, s, items, ld, g_batch.bt);
-}
