@@ -189,13 +189,19 @@ static void launch_build(hipStream_t s, const double* Xt, int64_t ldx, int64_t N
 // ---------------------------------------------------------------------------------------------------------------------
 #include "kfun_fast.h"
 
-// k_build_wide<KIND, DMAX, BATCH> — shaped for the memory side: a workgroup owns 128 rows x 64
+// k_build_wide<KIND, DMAX, BATCH, CW> — shaped for the memory side: a workgroup owns 128 rows x CW
 // columns, a lane owns TWO consecutive rows and stores them as one 16-byte double2 (1 KiB contiguous per wave store
-// instead of 512 B), the 64 column samples are staged once through LDS (wave-uniform LDS reads: broadcasts).
+// instead of 512 B), the CW column samples are staged once through LDS (wave-uniform LDS reads: broadcasts).
+// Round 6, 32-34 -> 23-24 us at N = 4096 (2.8-2.9 TB/s of the 67 MB it writes; profiles/r06_kernel_build.log), three things the
+// ISA showed: (1) `if (d < D)` inside the pair loop was a branch + an LDS read + a full wait per dimension per column — the loop now
+// runs over DMAX dimensions unconditionally, the padded ones add exact zeros (DMAX 2, 4, 6, 8, 16 ..: no padding at D = 6);
+// (2) with the triangle's masks in the loop the compiler split the 16-byte store into two predicated 8-byte ones and computed the
+// second row's exp behind the first row's store — tiles strictly below the diagonal take a loop of their own without masks;
+// (3) smaller workgroups (CW 32 instead of 64; 128 was slower still: 40 us).
 // rt (single-GP launches): the workgroups from rt.first on do what k_cols_to_rows (solve.hip) does — obs_mean^T into the rows
 // under the matrix, the backward sweep's output pre-filled with its sentinel — instead of a launch of its own behind this one
 // (4.6 us + a launch boundary at the head of every evaluation).
-template <int KIND, int DMAX, bool BATCH>
+template <int KIND, int DMAX, bool BATCH, int CW = 64>
 __global__ __launch_bounds__(256) void k_build_wide(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp_,
                                                      double* __restrict__ A, int64_t lda, const BatchTab* __restrict__ bt,
                                                      BuildRowsTail rt)
@@ -218,25 +224,29 @@ __global__ __launch_bounds__(256) void k_build_wide(const double* __restrict__ X
 #define KPF(field) (BATCH ? bt->kp[blockIdx.z].field : kp_.field)
     const int D = KPF(D);
     const double sf2 = KPF(sf2), diag_add = KPF(diag_add);
-    // tile (ti: 128-row block, tj: 64-column block), live iff 128 ti + 127 >= 64 tj  <=>  tj <= 2 ti + 1
+    // tile (ti: 128-row block, tj: CW-column block), live iff 128 ti + 127 >= CW tj  <=>  tj <= 2 ti + 1 (CW 64) / tj <= ti (CW 128)
     int ti, tj;
     {
-        const long long b = blockIdx.x; // b = ti (ti + 1) + tj
-        long long t = (long long)((sqrt(4.0 * (double)b + 1.0) - 1.0) * 0.5);
-        while ((t + 1) * (t + 2) <= b)
+        constexpr int R = 128 / CW; // column blocks per 128 rows: block-row ti has R (ti + 1) live ones, b = R ti (ti + 1) / 2 + tj
+        const long long b = blockIdx.x;
+        long long t = (long long)((sqrt(8.0 * (double)b / R + 1.0) - 1.0) * 0.5);
+        while (R * (t + 1) * (t + 2) / 2 <= b)
             ++t;
-        while (t * (t + 1) > b)
+        while (R * t * (t + 1) / 2 > b)
             --t;
         ti = (int)t;
-        tj = (int)(b - t * (t + 1));
+        tj = (int)(b - R * t * (t + 1) / 2);
     }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t i0 = (int64_t)ti * 128 + 2 * tx; // rows i0, i0 + 1
-    const int64_t j0 = (int64_t)tj * TILE;
-    for (int e = threadIdx.x; e < D * TILE; e += 256) {
-        const int d = e >> 6, c = e & 63;
+    const int64_t j0 = (int64_t)tj * CW;
+    // (rows D .. DMAX - 1 of the staged samples are zeros and so are their 1 / ell: the pair loop below runs over DMAX
+    // dimensions without a condition — with `if (d < D)` inside it the compiler made a branch, an LDS read and a full wait of every
+    // dimension of every column: 32 -> 28 us at N = 4096 went with the smaller workgroups, the rest with this)
+    for (int e = threadIdx.x; e < DMAX * CW; e += 256) {
+        const int d = e / CW, c = e % CW;
         const int64_t j = j0 + c;
-        smem[e] = (j < N) ? Xt[(int64_t)d * ldx + j] : 0.0;
+        smem[e] = (d < D && j < N) ? Xt[(int64_t)d * ldx + j] : 0.0;
     }
     double xa[DMAX], xb[DMAX], ie[DMAX];
     const int64_t ia = i0 < N ? i0 : N - 1, ib = i0 + 1 < N ? i0 + 1 : N - 1;
@@ -248,21 +258,43 @@ __global__ __launch_bounds__(256) void k_build_wide(const double* __restrict__ X
     }
 #undef KPF
     __syncthreads();
+    // A tile strictly below the diagonal and inside N (all but the 128 / CW last ones of a block row): no masks, no diagonal term, ONE
+    // 16-byte store of the two rows per lane — 1 KiB contiguous per wave store.  (Written with the masks in the same loop the compiler
+    // turned the 16-byte store into two predicated 8-byte ones and computed the second row's exp behind the first row's store.)
+    const bool interior = (int64_t)ti * 128 >= j0 + CW && (int64_t)ti * 128 + 128 <= N;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    if (interior) {
+#pragma unroll 4
+        for (int c = 0; c < CW / 4; ++c) {
+            const int cc = ty * (CW / 4) + c;
+            double za = 0.0, zb = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const double xj = smem[d * CW + cc];
+                const double qa = (xa[d] - xj) * ie[d], qb = (xb[d] - xj) * ie[d];
+                za = fma(qa, qa, za); // (a padded dimension adds an exact zero)
+                zb = fma(qb, qb, zb);
+            }
+            d2_t v;
+            v.x = kfun_fast<KIND>(za, sf2);
+            v.y = kfun_fast<KIND>(zb, sf2);
+            *reinterpret_cast<d2_t*>(A + i0 + (j0 + cc) * lda) = v; // (i0 and lda are even)
+        }
+        return;
+    }
 #pragma unroll 2
-    for (int c = 0; c < 16; ++c) {
-        const int cc = ty * 16 + c;
+    for (int c = 0; c < CW / 4; ++c) {
+        const int cc = ty * (CW / 4) + c;
         const int64_t j = j0 + cc; // wave-uniform
         if (j >= N)
             break;
         double za = 0.0, zb = 0.0;
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
-            if (d < D) {
-                const double xj = smem[d * TILE + cc];
-                const double qa = (xa[d] - xj) * ie[d], qb = (xb[d] - xj) * ie[d];
-                za = fma(qa, qa, za);
-                zb = fma(qb, qb, zb);
-            }
+            const double xj = smem[d * CW + cc];
+            const double qa = (xa[d] - xj) * ie[d], qb = (xb[d] - xj) * ie[d];
+            za = fma(qa, qa, za);
+            zb = fma(qb, qb, zb);
         }
         double va = kfun_fast<KIND>(za, sf2), vb = kfun_fast<KIND>(zb, sf2);
         if (i0 == j)
@@ -270,14 +302,10 @@ __global__ __launch_bounds__(256) void k_build_wide(const double* __restrict__ X
         if (i0 + 1 == j)
             vb += diag_add;
         double* dst = A + i0 + j * lda;
-        if (i0 + 1 < N && j <= i0) // both rows on/below the diagonal: one 16-byte store (i0 and lda are even)
-            *reinterpret_cast<double2*>(dst) = double2{va, vb};
-        else {
-            if (i0 < N && j <= i0)
-                dst[0] = va;
-            if (i0 + 1 < N && j <= i0 + 1)
-                dst[1] = vb;
-        }
+        if (i0 < N && j <= i0)
+            dst[0] = va;
+        if (i0 + 1 < N && j <= i0 + 1)
+            dst[1] = vb;
     }
 }
 
@@ -286,25 +314,32 @@ static void launch_build_wide_kind(hipStream_t s, const double* Xt, int64_t ldx,
                                    BuildRowsTail rt)
 {
     const int64_t nt = (N + 127) / 128;
+    // columns per workgroup: 32 for a single GP (2128 workgroups at N = 4096: measured 23.0-24.2 us against 24.2-24.4 with 64 and
+    // 24.0-24.4 with 16), 64 for the members of a batch (gridDim.z fills the chip)
+    const int cwx = g_batch.bt ? 64 : 32;
     // live tiles: sum over ti of min(2 ti + 2, column blocks)
     const int64_t ncb = (N + TILE - 1) / TILE;
-    int64_t tiles = nt * (nt + 1); // the last block-row may count a column block past N: those workgroups find j >= N and leave
+    int64_t tiles = (128 / cwx) * nt * (nt + 1) / 2; // the last block-row may count a column block past N: those workgroups find j >= N and leave
     (void)ncb;
     rt.first = tiles;
     if (rt.V)
         tiles += (N + 255) / 256;
     dim3 grid((unsigned)tiles, 1, (unsigned)g_batch.G);
     const BatchTab* bt = g_batch.bt;
-    const size_t sh = (size_t)kp.D * TILE * sizeof(double);
 #define LBW(DM)                                                                                                     \
     do {                                                                                                            \
+        const size_t sh = (size_t)(DM) * cwx * sizeof(double);                                                      \
         if (bt)                                                                                                     \
             GPE_LAUNCH((k_build_wide<KIND, DM, true>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt, rt);  \
         else                                                                                                        \
-            GPE_LAUNCH((k_build_wide<KIND, DM, false>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt, rt); \
+            GPE_LAUNCH((k_build_wide<KIND, DM, false, 32>), grid, dim3(256), sh, s, Xt, ldx, N, kp, A, lda, bt, rt); \
     } while (0)
-    if (kp.D <= 4)
+    if (kp.D <= 2)
+        LBW(2);
+    else if (kp.D <= 4)
         LBW(4);
+    else if (kp.D <= 6)
+        LBW(6);
     else if (kp.D <= 8)
         LBW(8);
     else if (kp.D <= 16)
