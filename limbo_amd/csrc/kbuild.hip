@@ -100,11 +100,12 @@ __global__ __launch_bounds__(256) void k_build(const double* __restrict__ Xt, in
     const int64_t ldc = (MODE == 2) ? ldq : ldx;
     const int64_t ncol = (MODE == 2) ? M : N;
 
-    // stage the column-sample panel: D x 64, coalesced
-    for (int e = threadIdx.x; e < D * TILE; e += 256) {
+    // stage the column-sample panel: DMAX x 64, coalesced (rows D .. DMAX - 1 are zeros, and so are their xi and 1 / ell: the pair
+    // loop runs over DMAX dimensions without a condition, see k_build_wide)
+    for (int e = threadIdx.x; e < DMAX * TILE; e += 256) {
         int d = e >> 6, c = e & 63;
         int64_t j = j0 + c;
-        smem[e] = (j < ncol) ? Cs[(int64_t)d * ldc + j] : 0.0;
+        smem[e] = (d < D && j < ncol) ? Cs[(int64_t)d * ldc + j] : 0.0;
     }
     double xi[DMAX];
 #pragma unroll
@@ -124,10 +125,8 @@ __global__ __launch_bounds__(256) void k_build(const double* __restrict__ Xt, in
         double z = 0.0;
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
-            if (d < D) {
-                double q = (xi[d] - smem[d * TILE + cc]) * ie[d]; // cwiseQuotient(_ell)
-                z = fma(q, q, z);
-            }
+            double q = (xi[d] - smem[d * TILE + cc]) * ie[d]; // cwiseQuotient(_ell); a padded dimension adds an exact zero
+            z = fma(q, q, z);
         }
         double v = kfun(kp_kind, z, kp_sf2);
         if (MODE != 2 && i == j)
@@ -150,19 +149,21 @@ static void launch_build(hipStream_t s, const double* Xt, int64_t ldx, int64_t N
         grid = dim3((unsigned)nt, (unsigned)nt);
     else
         grid = dim3((unsigned)nt, (unsigned)((M + TILE - 1) / TILE));
-    size_t sh = (size_t)kp.D * TILE * sizeof(double);
     int D = kp.D;
     const BatchTab* bt = (MODE == 0) ? g_batch.bt : nullptr;
     if (bt)
         grid.z = (unsigned)g_batch.G;
 #define LB(DM)                                                                                                                  \
     do {                                                                                                                        \
+        const size_t sh = (size_t)(DM) * TILE * sizeof(double);                                                                 \
         if (bt)                                                                                                                 \
             GPE_LAUNCH((k_build<DM, MODE, true>), grid, dim3(256), sh, s, Xt, ldx, N, Qt, ldq, M, kp, A, lda, bt);      \
         else                                                                                                                    \
             GPE_LAUNCH((k_build<DM, MODE, false>), grid, dim3(256), sh, s, Xt, ldx, N, Qt, ldq, M, kp, A, lda, bt);     \
     } while (0)
-    if (D <= 4)
+    if (D <= 2)
+        LB(2);
+    else if (D <= 4)
         LB(4);
     else if (D <= 8)
         LB(8);
