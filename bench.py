@@ -697,9 +697,10 @@ def main():
             out["kernel_build"] = {"kernel": "k_build_wide (kbuild.hip): lower triangle of K + obs_mean's rows under it, fp64 exp per pair",
                                    "us": kb["us"], "launches": kb["launches"], "bytes": kb_bytes, "GBps": gbps, "frac_of_hbm_spec": gbps / 8000.0,
                                    "measured_write_stream_GBps": ws.value, "frac_of_measured_write_stream": gbps / ws.value if ws.value > 0 else None,
-                                   "note": "8.4 M pairs x (3 D + ~25 fp64 operations of the branch-free exp): the launch is at ~2.5x BOTH of its "
-                                           "floors (write stream 14 us, fp64 VALU ~10 us) — short workgroups (32 pairs a thread) behind a 18-load "
-                                           "prologue; 3 % of the step"}
+                                   "note": "8.4 M pairs x (3 D + ~25 fp64 operations of the branch-free exp); floors: write stream 14 us, fp64 VALU "
+                                           "~10 us.  Round 6 (profiles/r06_kernel_build.log): 32-34 -> 23-24 us (the profiled launch carries events: "
+                                           "+2) by an unconditional pair loop over padded dimensions, a mask-free loop with 16-byte stores below the "
+                                           "diagonal and 32-column workgroups; 2 % of the step"}
         sw = ph.get("solve")
         if sw and sw["us"] > 0:
             nblk_ = (N + 63) // 64
