@@ -1365,7 +1365,10 @@ def test_gpu_bench_one_rank_rccl():
 
 
 @pytest.mark.parametrize("N,G,kind,on,P", [(2048, 8, O.SE_ARD, False, 1), (700, 5, O.MATERN52, True, 2), (1100, 18, O.SE_ARD, True, 1),
-                                            (300, 3, O.SE_ARD, False, 1)])
+                                            (300, 3, O.SE_ARD, False, 1),
+                                            # round 6: a batch of fewer than four members CUTS k ranges — every member counts its chunks in
+                                            # counter words of its own (inv2.hip), ragged order
+                                            (2100, 3, O.SE_ARD, True, 1)])
 def test_gpu_batch_hp_objective_vs_single_and_oracle(engine_lib, oracle_lib, N, G, kind, on, P):
     """gpe_batch_hp_objective — G restarts of KernelLFOptimization::operator() (kernel_lf_opt.hpp:77-92,
     parallel_repeater.hpp:84-105) stepped by one launch sequence: every member's (log-lik, gradient) equals the
