@@ -26,7 +26,11 @@
 // LAM = false: the length-scale / sigma_f / noise entries (n_theta = number of those without the noise).
 // LAM = true : the Din entries of column `lam_col` of Lambda (squared_exp_ard.hpp:118-121):
 //              g = -((x1-x2)^T Lambda_col) (x1-x2) k;  n_theta = Din, optimize_noise = 0.
-template <int DMAX, bool LAM>
+// (Round 6, after the kernel-matrix build: the pair loop runs over DMAX dimensions and PM outputs WITHOUT conditions — the padded ones
+// are zeros in registers and in LDS and add exact zeros, same sums bit for bit —, 1 / ell_d sits in registers, and tiles strictly
+// below the diagonal take a loop without the triangle's tests; DMAX 2 and 6 and PM = 1 (one output: config 2) are instantiated.
+// N = 4096, D = 6: 102 -> see profiles/r06_grad_tiles.log.)
+template <int DMAX, bool LAM, int PM>
 __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ Xt, int64_t ldx, int64_t N, KParams kp_,
                                                     const double* __restrict__ Kinv, int64_t ldk,
                                                     const double* __restrict__ alpha, int64_t lda,
@@ -49,9 +53,9 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
     const int D = kp.D;
     const int T = n_theta + (optimize_noise ? 1 : 0);
     double* xj = smem;
-    double* aj = smem + D * TILE;
-    double* uj = aj + GPE_MAX_P * TILE;
-    double* red = uj + GPE_MAX_P * TILE;
+    double* aj = smem + DMAX * TILE;
+    double* uj = aj + PM * TILE;
+    double* red = uj + PM * TILE;
 
     long long b = blockIdx.x;
     long long t = (long long)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
@@ -64,24 +68,27 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
     const int64_t i = (int64_t)ti * TILE + tx;
     const int64_t j0 = (int64_t)tj * TILE;
 
-    for (int e = threadIdx.x; e < D * TILE; e += 256) {
+    const int xrows = LAM ? (D > DMAX ? D : DMAX) : DMAX; // (LAM reads the projection row lrow >= Din as well: all D rows are staged)
+    for (int e = threadIdx.x; e < xrows * TILE; e += 256) {
         const int d = e >> 6, c = e & 63;
-        xj[e] = (j0 + c < N) ? Xt[(int64_t)d * ldx + j0 + c] : 0.0;
+        xj[e] = (d < D && j0 + c < N) ? Xt[(int64_t)d * ldx + j0 + c] : 0.0;
     }
-    for (int e = threadIdx.x; e < P * TILE; e += 256) {
+    for (int e = threadIdx.x; e < PM * TILE; e += 256) {
         const int p = e >> 6, c = e & 63;
-        aj[e] = (j0 + c < N) ? alpha[(int64_t)p * lda + j0 + c] : 0.0;
-        uj[e] = (j0 + c < N) ? 0.5 * uvec[(int64_t)p * lda + j0 + c] : 0.0;
+        aj[e] = (p < P && j0 + c < N) ? alpha[(int64_t)p * lda + j0 + c] : 0.0;
+        uj[e] = (p < P && j0 + c < N) ? 0.5 * uvec[(int64_t)p * lda + j0 + c] : 0.0;
     }
-    double xi[DMAX], ai[GPE_MAX_P], ui[GPE_MAX_P];
+    double xi[DMAX], ie[DMAX], ai[PM], ui[PM];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d)
+    for (int d = 0; d < DMAX; ++d) {
         xi[d] = (d < D && i < N) ? Xt[(int64_t)d * ldx + i] : 0.0;
+        ie[d] = d < D ? kp.inv_ell[d] : 0.0;
+    }
 #pragma unroll
-    for (int p = 0; p < GPE_MAX_P; ++p)
+    for (int p = 0; p < PM; ++p)
         ai[p] = (p < P && i < N) ? alpha[(int64_t)p * lda + i] : 0.0;
 #pragma unroll
-    for (int p = 0; p < GPE_MAX_P; ++p)
+    for (int p = 0; p < PM; ++p)
         ui[p] = (p < P && i < N) ? 0.5 * uvec[(int64_t)p * lda + i] : 0.0;
     double acc[DMAX + 2];
 #pragma unroll
@@ -91,26 +98,29 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
     const double fi = (LAM && i < N) ? Xt[(int64_t)lrow * ldx + i] : 0.0;
     __syncthreads();
 
-    if (i < N) {
+    // a tile strictly below the diagonal with all its rows and columns inside N: no tests in the pair loop
+    const bool interior_tile = ti > tj && (int64_t)(ti + 1) * TILE <= N;
+    auto pairs = [&](auto interior_c) {
+        constexpr bool INTERIOR = decltype(interior_c)::value;
+#pragma unroll 2
         for (int c = 0; c < 16; ++c) {
             const int cc = ty * 16 + c;
             const int64_t j = j0 + cc;
-            if (j >= N || j > i)
+            if (!INTERIOR && (j >= N || j > i))
                 break;
             double w = 0.0; // gp.hpp:293-296
 #pragma unroll
-            for (int p = 0; p < GPE_MAX_P; ++p)
-                if (p < P)
-                    w = fma(ai[p], uj[p * TILE + cc], fma(ui[p], aj[p * TILE + cc], w));
+            for (int p = 0; p < PM; ++p)
+                w = fma(ai[p], uj[p * TILE + cc], fma(ui[p], aj[p * TILE + cc], w));
             w = fma(-kinv_scale, Kinv[i + j * ldk], w); // 0 for the 2nd.. chunk of outputs when P > GPE_MAX_P
-            if (i == j)
+            if (!INTERIOR && i == j)
                 w *= 0.5; // gp.hpp:303-304
             double z[DMAX];
             double zs = 0.0;
 #pragma unroll
             for (int d = 0; d < DMAX; ++d) {
-                const double dd = (d < D) ? xi[d] - xj[d * TILE + cc] : 0.0;
-                const double q = dd * kp.inv_ell[d];
+                const double dd = xi[d] - xj[d * TILE + cc]; // (a padded dimension: 0 - 0)
+                const double q = dd * ie[d];
                 z[d] = LAM ? dd : q * q;
                 zs += q * q;
             }
@@ -152,10 +162,14 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const double* __restrict__ X
                 acc[0] = fma(w * k, zs, acc[0]);
                 acc[1] = fma(w * k, 2.0, acc[1]);
             }
-            if (i == j) // kernel.hpp:90-93: 2 * noise on the diagonal
+            if (!INTERIOR && i == j) // kernel.hpp:90-93: 2 * noise on the diagonal
                 acc[DMAX + 1] = fma(w, 2.0 * kp.noise, acc[DMAX + 1]);
         }
-    }
+    };
+    if (interior_tile)
+        pairs(std::true_type{});
+    else if (i < N)
+        pairs(std::false_type{});
     // block reduction of the T sums: wave shuffles, then 4 waves through LDS in fixed order
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -252,28 +266,46 @@ static void launch_grad_chunk(hipStream_t s, const double* Xt, int64_t ldx, int6
     const int64_t nblk = nt * (nt + 1) / 2;
     const int D = kp.D;
     dim3 grid((unsigned)nblk, 1, (unsigned)g_batch.G), block(256);
-#define LG(DM, LAM)                                                                                              \
-    GPE_LAUNCH((k_grad_tiles<DM, LAM>), grid, block,                                                     \
-                       (size_t)(D * TILE + 2 * GPE_MAX_P * TILE + 4 * (DM + 2)) * sizeof(double), s, Xt, ldx, N, \
+#define LG(DM, LAM, PMV)                                                                                         \
+    GPE_LAUNCH((k_grad_tiles<DM, LAM, PMV>), grid, block,                                                        \
+                       (size_t)(((LAM) && D > DM ? D : DM) * TILE + 2 * PMV * TILE + 4 * (DM + 2)) * sizeof(double), s, Xt, ldx, N, \
                        kp, Kinv, ldk, alpha, lda, uvec, P, kinv_scale, n_theta, optimize_noise, lam_col, partial, g_batch.bt)
-#define LGD(LAM)      \
-    if (D <= 4)       \
-        LG(4, LAM);   \
-    else if (D <= 8)  \
-        LG(8, LAM);   \
-    else if (D <= 16) \
-        LG(16, LAM);  \
-    else if (D <= 32) \
-        LG(32, LAM);  \
-    else              \
-        LG(64, LAM)
+#define LGP(DM)                   \
+    do {                          \
+        if (P == 1)               \
+            LG(DM, false, 1);     \
+        else                      \
+            LG(DM, false, GPE_MAX_P); \
+    } while (0)
     if (lam_col >= 0) {
-        LGD(true);
+        if (D <= 4)
+            LG(4, true, GPE_MAX_P);
+        else if (D <= 8)
+            LG(8, true, GPE_MAX_P);
+        else if (D <= 16)
+            LG(16, true, GPE_MAX_P);
+        else if (D <= 32)
+            LG(32, true, GPE_MAX_P);
+        else
+            LG(64, true, GPE_MAX_P);
     }
     else {
-        LGD(false);
+        if (D <= 2)
+            LGP(2);
+        else if (D <= 4)
+            LGP(4);
+        else if (D <= 6)
+            LGP(6);
+        else if (D <= 8)
+            LGP(8);
+        else if (D <= 16)
+            LGP(16);
+        else if (D <= 32)
+            LGP(32);
+        else
+            LGP(64);
     }
-#undef LGD
+#undef LGP
 #undef LG
     GPE_LAUNCH(k_grad_final, dim3((unsigned)T, 1, (unsigned)g_batch.G), dim3(256), 0, s, partial, nblk, T, grad, accumulate,
                        out_off, tail_from, tail_to, g_batch.bt);
