@@ -110,12 +110,13 @@ __global__ __launch_bounds__(512) void k_trsv_bwd_m(const double* __restrict__ L
         const int64_t t0 = tt * NB;
         const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
         const int kc = lane < tb ? lane : tb - 1;
-        const double rowmask = lane < tb ? 1.0 : 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { // (unconditional loads from clamped addresses, masked by a multiplication: solve.hip says why)
+        for (int q = 0; q < 8; ++q) { // (unconditional loads from clamped addresses; the mask is applied where the tile is used — fold —: with
+            // the multiplication here the compiler issued load, wait, multiply, load, .. one at a time in front of the loop, and the loop's
+            // own fetches came out worse too: 98.6 -> 90.5 us, profiles/r06_sweep_m_stamps.log)
             const int c = wvu + 8 * q;
             const int cc = c < jb ? c : jb - 1;
-            dst[q] = L[t0 + kc + (j0 + cc) * ld] * (c < jb ? rowmask : 0.0);
+            dst[q] = L[t0 + kc + (j0 + cc) * ld];
         }
         peek = __hip_atomic_load((const unsigned long long*)(a + t0 + kc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -147,9 +148,11 @@ __global__ __launch_bounds__(512) void k_trsv_bwd_m(const double* __restrict__ L
     };
     auto fold = [&](const double (&src)[8], unsigned long long peek, int64_t t) {
         __syncthreads();
+        const int tbf = (int)((N - t * NB < NB) ? N - t * NB : NB);
+        const double rowmask = lane < tbf ? 1.0 : 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            Stg[(wv + 8 * q) * 65 + lane] = src[q];
+            Stg[(wv + 8 * q) * 65 + lane] = src[q] * (wvu + 8 * q < jb ? rowmask : 0.0);
         if (threadIdx.x < NB)
             xs[lane] = await(peek, t);
         __syncthreads();
