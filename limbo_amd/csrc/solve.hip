@@ -252,7 +252,6 @@ static __device__ __forceinline__ void trsv_bwd_flow_body(const double* __restri
             const int64_t t0 = tt * NB;
             const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
             const int kc = lane < tb ? lane : tb - 1;
-            const double rowmask = lane < tb ? 1.0 : 0.0;
 #pragma unroll
             for (int q = 0; q < FQ; ++q) {
                 // Unconditional load from a clamped (valid) address, masked by a multiplication: written as
@@ -263,7 +262,8 @@ static __device__ __forceinline__ void trsv_bwd_flow_body(const double* __restri
                 const int c = wvu + FW * q;
                 const int cc = c < jb ? c : jb - 1;
                 const double* col = L + t0 + (j0 + cc) * ld;
-                dst[q] = col[kc] * (c < jb ? rowmask : 0.0);
+                dst[q] = col[kc]; // (the mask of a ragged tile: in fold, where the tile is used — with the multiplication here the compiler
+                                  // serialised the loads in front of the loop, sweep2.hip)
             }
             // first look at a_t (clamped address; lanes past the block read a valid neighbour and ignore it)
 #ifdef FLOW_NOPOLL
@@ -274,9 +274,10 @@ static __device__ __forceinline__ void trsv_bwd_flow_body(const double* __restri
         };
         auto fold = [&](const double (&src)[FQ], unsigned long long peek, int64_t t) {
             __syncthreads(); // Stg / xs of the previous contributor are consumed
+            const double rowmask = lane < ((N - t * NB < NB) ? (int)(N - t * NB) : NB) ? 1.0 : 0.0;
 #pragma unroll
             for (int q = 0; q < FQ; ++q)
-                Stg[(wv + FW * q) * LSTR + lane] = src[q]; // Stg[c][k]
+                Stg[(wv + FW * q) * LSTR + lane] = src[q] * (wvu + FW * q < jb ? rowmask : 0.0); // Stg[c][k]
             if (threadIdx.x < NB) {
                 const int64_t t0 = t * NB;
                 const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
