@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_fwd_flow(const double* __restr
 #pragma unroll
             for (int q = 0; q < FQ; ++q) {
                 const double* col = L + j0 + (t0 + wvu + FW * q) * ld; // wave-uniform column base
-                dst[q] = col[rc] * rowmask; // clamped row, masked by a multiplication (no predicated loads)
+                dst[q] = col[rc]; // clamped row (no predicated loads); the mask where the tile is used, fold (sweep2.hip says why)
             }
             peek = __hip_atomic_load((const unsigned long long*)(yp + t0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_fwd_flow(const double* __restr
             double acc = 0.0;
 #pragma unroll
             for (int q = 0; q < FQ; ++q)
-                acc = fma(src[q], xs[wvu + FW * q], acc);
+                acc = fma(src[q] * rowmask, xs[wvu + FW * q], acc);
             part_s[wv][lane] = acc;
             __syncthreads();
             if (threadIdx.x < NB)
