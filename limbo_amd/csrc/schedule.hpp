@@ -197,13 +197,17 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 g.lda = ld;
                 g.B = A + t0 + e0 * ld;
                 g.ldb = ld;
+                // (A ragged order: the columns of its last block, N64 .. N, stay out of this launch — they would be a 23rd column of
+                // 128 x 128 tiles at N = 4100, a second round of the chip, 214 -> 337 us — and take the tall launch's columns together
+                // with the closing launch's in their own update below.  The rows under N64 — the ragged rows and the right-hand sides —
+                // are the launch's "right-hand-side rows": plain FMAs in front of the tiles where that saves the round, gemm.hip.)
                 g.m = M - t0;
-                g.n = N - t0;
+                g.n = N64 - t0;
                 g.k = t0 - e0;
                 g.tri = 1;
                 g.grow0 = t0;
                 g.gcol0 = t0;
-                g.rhs_rows = (int)(M - N);
+                g.rhs_rows = (int)(M - N64);
                 PhaseScope ps(c, GPE_PH_POTRF_UPDATE, gemm_flops(g));
                 launch_gemm_sub(s, g);
             }
@@ -226,15 +230,16 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 break;
             { // the ragged block and what lies under it: -= L[N64:M, t0:N64] L[N64:N, t0:N64]^T, then the panel code factors it
                 GemmArgs g{};
+                const int64_t k0 = e0 >= 0 ? e0 : t0; // (behind a tall launch: its columns too, see the update above)
                 g.C = A + N64 + N64 * ld;
                 g.ldc = ld;
-                g.A = A + N64 + t0 * ld;
+                g.A = A + N64 + k0 * ld;
                 g.lda = ld;
-                g.B = A + N64 + t0 * ld;
+                g.B = A + N64 + k0 * ld;
                 g.ldb = ld;
                 g.m = M - N64;
                 g.n = N - N64;
-                g.k = N64 - t0;
+                g.k = N64 - k0;
                 g.tri = 1;
                 g.grow0 = N64;
                 g.gcol0 = N64;

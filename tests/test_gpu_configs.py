@@ -570,6 +570,14 @@ def test_gpu_panel_hand_over_timeout_is_answered_by_a_full_rerun(engine_lib, mon
                                            (2000, 3, "512", "256"),    # (tall only from column 0: here panels to 1536, closing 7, ragged, P = 3)
                                            (3200, 1, "1024", "2304"),  # tall 0..2304 (36 x 50 row strips), closing 14
                                            (3000, 2, "1280", "1536"),  # tall 0..1792 (28 x 46 strips + ragged/rhs strip), closing 18
+                                           # round 6: the default three-launch orders (N64 3392 .. 4352) at ragged sizes — the ragged block's
+                                           # columns stay out of the one update (they take all their columns in their own, behind the closing
+                                           # launch), its rows and the right-hand sides are that update's FMA rows or a tile row
+                                           (3400, 2, None, None),      # tall 0..768, update 21 tile columns, 8 ragged rows + 2 outputs
+                                           (3600, 1, None, None),      # 16 ragged rows
+                                           (4100, 1, None, None),      # 4 ragged rows + 1: FMAs in front of 253 tiles
+                                           (4159, 3, None, None),      # 63 ragged rows + 3 outputs
+                                           (4352, 1, None, None),      # the largest three-launch order
                                            ])
 def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, tail, tall):
     """k_tail: the last <= 2816 columns (GPE_TAIL_MAX; all of them when N is no larger) of a factorisation whose order is a
