@@ -371,7 +371,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void k_gemm_glds(GemmArgs g_)
     const int tiles_m = (int)((g.m + TM - 1) / TM);
     const int tiles_n = (int)((g.n + TN - 1) / TN);
     if (g.rhs_rows > 0) // the right-hand-side rows under the matrix: this workgroup's n / G columns of them (gemm_glds64.h)
-        gemm_rhs_rows<64 * NWV>(g, g.rhs_rows, (int)gridDim.x, lds);
+        gemm_rhs_rows<64 * NWV, MINB == 1>(g, g.rhs_rows, (int)gridDim.x, lds);
     // g.total logical workgroups; a launch with fewer physical ones (gridDim.x < g.total: the
     // look-ahead update, which must leave CUs free for the panel on the other stream) loops.
     for (int lwg = blockIdx.x; lwg < g.total; lwg += gridDim.x) {

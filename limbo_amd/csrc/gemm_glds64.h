@@ -35,9 +35,16 @@ static __host__ __device__ __forceinline__ int first_live_tile(const GemmArgs& g
 // 16 columns at a time, thread = (column tid & 15, k-group tid >> 4); every thread has 4 loads of B and 16 of the rows in
 // flight together, then the NT / 16 k-groups are added in order through LDS (red: 4 x NT / 16 x 16 doubles): bitwise
 // reproducible.  Four rows per pass.
-template <int NT>
+static __device__ __forceinline__ void gemm_rhs_rows_mfma(const GemmArgs& g, int R, int G, double* lds, int b);
+template <int NT, bool MANY = false> // MANY: the kernel shapes with one workgroup per CU (the other ones must stay within 128 VGPRs)
 static __device__ __forceinline__ void gemm_rhs_rows(const GemmArgs& g, int rhs_rows, int G, double* red)
 {
+    if constexpr (MANY && NT == 512) {
+        if (rhs_rows > 4 && rhs_rows <= 80) { // many rows (a ragged order's last ones): as a matrix-core product, below
+            gemm_rhs_rows_mfma(g, rhs_rows, G, red, (int)blockIdx.x);
+            return;
+        }
+    }
     constexpr int KG = NT / 16;
     const int tid = threadIdx.x, cl = tid & 15, kg = tid >> 4, b = blockIdx.x;
     const int nc = (int)((g.n + G - 1) / G);
@@ -92,6 +99,114 @@ static __device__ __forceinline__ void gemm_rhs_rows(const GemmArgs& g, int rhs_
             }
             __syncthreads();
         }
+    }
+}
+
+// ... and the same rows when there are MANY of them (round 6): a ragged order's last rows ride under the matrix like right-hand sides
+// (up to 63 + P rows), and as FMAs they cost ~3 us a row in front of every tile (N = 4130: the update 214 -> 320 us).  Here the
+// workgroup's share — R rows x <= 16 columns at a time x k — is a small matrix-core product: the k range in chunks of 64 through
+// LDS (A: R x 64, lane = row: contiguous; B: 16 x 64), wave w takes k-rows 8 w .. 8 w + 7 of a chunk for all (16-row, 4-column)
+// blocks, the eight waves' sums are added in order through LDS at the end (bitwise reproducible).  512 threads; LDS: 8448 doubles.
+static __device__ __forceinline__ void gemm_rhs_rows_mfma(const GemmArgs& g, int R, int G, double* lds, int b)
+{
+    constexpr int RS = 80, BS = 20, KC = 64; // strides of the staged chunks: As[kk][row], Bs[kk][col]
+    double* const As = lds;
+    double* const Bs = lds + KC * RS;
+    double* const red = Bs + KC * BS; // [8 waves][4][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4;
+    const int MB = (R + 15) / 16; // 16-row blocks (<= 5)
+    const int nc = (int)((g.n + G - 1) / G);
+    const int64_t c_lo = (int64_t)b * nc;
+    int64_t c_hi = c_lo + nc;
+    c_hi = c_hi < g.n ? c_hi : g.n;
+    const double* Ab = g.A + g.m; // the rows under the main ones
+    // this thread's elements of a chunk: ten of A (row ap, k-rows ak + 6.4 i: idx = tid + 512 i -> row idx % 80, k idx / 80), two of B
+    for (int64_t cb = c_lo; cb < c_hi; cb += 16) {
+        double acc[5][4];
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                acc[mb][nb] = 0.0;
+        double pa[10], pbv[2];
+        auto fetch = [&](int64_t kb) { // (unconditional loads from clamped addresses; masks where the values are used)
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int idx = tid + 512 * i, p = idx % RS, kk = idx / RS;
+                int64_t kc = kb + kk;
+                kc = kc < g.k ? kc : g.k - 1;
+                pa[i] = Ab[(p < R ? p : R - 1) + kc * g.lda];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 512 * i, c = idx & 15, kk = idx >> 4;
+                int64_t kc = kb + kk;
+                kc = kc < g.k ? kc : g.k - 1;
+                const int64_t cc = cb + c < c_hi ? cb + c : c_hi - 1;
+                pbv[i] = g.B[cc + kc * g.ldb];
+            }
+        };
+        fetch(0);
+        for (int64_t kb = 0; kb < g.k; kb += KC) {
+            __syncthreads(); // the previous chunk is consumed
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int idx = tid + 512 * i, p = idx % RS, kk = idx / RS;
+                As[kk * RS + p] = (p < R && kb + kk < g.k) ? pa[i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 512 * i, c = idx & 15, kk = idx >> 4;
+                Bs[kk * BS + c] = (kb + kk < g.k) ? pbv[i] : 0.0;
+            }
+            fetch(kb + KC < g.k ? kb + KC : kb); // (the last one fetches its own chunk again: unconditional, counted)
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 8; ks += 4) {
+                const int k = 8 * wv + ks + kq;
+                double bf[4];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    bf[nb] = Bs[k * BS + 4 * nb + (lane & 3)];
+#pragma unroll
+                for (int mb = 0; mb < 5; ++mb) {
+                    if (mb < MB) { // (wave-uniform)
+                        const double af = As[k * RS + 16 * mb + (lane & 15)];
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb)
+                            acc[mb][nb] = mfma4(af, bf[nb], acc[mb][nb]);
+                    }
+                }
+            }
+        }
+        // the eight waves' sums, 16 rows at a time, in order
+        const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4), dcol = lane & 3;
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) {
+            if (mb < MB) {
+                __syncthreads();
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    red[(wv * 4 + nb) * 64 + lane] = acc[mb][nb];
+                __syncthreads();
+                if (tid < 256) {
+                    const int nb = tid >> 6;
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w)
+                        sacc += red[(w * 4 + nb) * 64 + lane];
+                    const int row = 16 * mb + drow;
+                    const int64_t c = cb + 4 * nb + dcol;
+                    if (row < R && c < c_hi) {
+                        double* Cp = g.C + (g.m + row) + c * g.ldc;
+                        *Cp = *Cp - sacc;
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -343,7 +458,7 @@ static __device__ __forceinline__ void gemm_glds64_body(const GemmArgs& g, doubl
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (g.rhs_rows > 0 && !skip00) // (the fused next-panel update keeps its right-hand-side rows as a tile row)
-        gemm_rhs_rows<64 * NWV>(g, g.rhs_rows, n_wg, lds);
+        gemm_rhs_rows<64 * NWV, NWV == 8>(g, g.rhs_rows, n_wg, lds);
     for (int lwg = first_wg; lwg < g.total; lwg += n_wg) {
         int wg = lwg;
         {
