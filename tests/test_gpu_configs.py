@@ -619,6 +619,30 @@ def test_gpu_tiled_tail_factorisation_vs_lapack(engine_lib, monkeypatch, N, P, t
     h.close()
 
 
+def test_gpu_ragged_orders_of_the_three_launch_range_vs_lapack(engine_lib):
+    """Round 6: orders around the three-launch range (N64 3392 .. 4352) that are NOT multiples of 64, one to three outputs — the
+    ragged block's columns stay out of the one trailing update, its rows (1 .. 63) and the right-hand sides ride under it as FMA
+    rows (<= 4), as a small matrix-core product of every workgroup's column share (more: gemm_glds64.h, gemm_rhs_rows_mfma) or as a
+    tile row (where that does not cost a round of the chip); the tiles of the update come from the host-built table (gemm.hip:
+    tri_tile_map).  Every size: L against LAPACK 1e-10 of max|L|, alpha 1e-7, no re-run."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(5)
+    for N in (3393, 3455, 3519, 3585, 3841, 4033, 4095, 4097, 4130, 4223, 4289, 4351, 4353):
+        P = int(rng.integers(1, 4))
+        X = rng.uniform(0, 1, size=(N, 4))
+        Y = np.stack([np.cos((p + 1) * X.sum(axis=1)) for p in range(P)], axis=1) + 0.05 * rng.normal(size=(N, P))
+        om, _ = O.obs_mean_data(Y)
+        h = new_gp(engine_lib, O.SE_ARD, X, om, rng.uniform(-0.3, 0.2, size=5), 0.01)
+        assert h.compute() == 0 and h.flow_retries() == 0, N
+        L = np.tril(h.get_L())
+        K = h.get_K()
+        Lref = sl.cholesky(np.tril(K) + np.tril(K, -1).T, lower=True)
+        assert np.max(np.abs(L - Lref)) <= 1e-10 * np.max(np.abs(Lref)), N
+        aref = sl.cho_solve((Lref, True), om)
+        assert relerr_norm(h.get_alpha(), aref) < 1e-7, N
+        h.close()
+
+
 @pytest.mark.parametrize("threads,per", [(4, 6), (8, 200)])
 def test_gpu_concurrent_handles_do_not_starve_each_other(engine_lib, threads, per):
     """Round 4: data-flow launches wait inside the launch for lower-numbered workgroups, which is deadlock-free for ONE such
