@@ -249,6 +249,8 @@ struct TailGen {
     const KParams* kp; // host copy (single launches pass it by value; batched ones read the batch table)
 };
 int ragged_split(int64_t k, int64_t scratch_doubles, int* kc_out); // potrf.hip (host only)
+bool launch_ragged_finish(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t ld, int64_t jb, int64_t P, int64_t k,
+                          double* scratch, int64_t scratch_doubles, double* Xt, int* info, int64_t goff); // potrf.hip: update + factor + solve
 bool launch_ragged_update(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t ld, int64_t m, int64_t n, int64_t k,
                           double* scratch, int64_t scratch_doubles); // potrf.hip: a ragged order's last block behind k_tail
 void launch_tail(hipStream_t s, double* A, int64_t lda, int64_t t0, int64_t t1, int64_t N64, int64_t M, double* Xt_all, int* info,

@@ -2301,6 +2301,103 @@ int ragged_split(int64_t k, int64_t scratch_doubles, int* kc_out)
     *kc_out = (int)kc;
     return (int)G;
 }
+// ... and the rest of a ragged order's last block in ONE more launch (round 6, later): the slots are added in order and subtracted,
+// the block (jb < 64 columns, padded with the identity) is factored and inverted by diag_flow, the right-hand-side rows under it are
+// solved with its inverse — what k_ragged_fold, k_diag_full and a k_gemm4 launch did one after the other with a launch gap each
+// (4 + 21 + 5 us and three gaps at N = 1100: profiles/r06_ragged_orders.log).  One workgroup of 512 threads.
+//   C = A[N64 .., N64 ..]: rows 0 .. jb-1 the block (lower triangle), rows jb .. jb+P-1 the right-hand-side rows; part: G slots of
+//   64 x 64 (i + 64 j); Lscr: 64 x 64 doubles of scratch (diag_flow stores whole columns: into the matrix they would run over the
+//   right-hand-side rows); Xt: the block's inverse, transposed, identity-padded (what the sweeps read).
+__global__ __launch_bounds__(DIAG_THREADS) void k_ragged_finish(double* __restrict__ C, int64_t ldc, int jb, int P, int G,
+                                                                const double* __restrict__ part, double* __restrict__ Lscr,
+                                                                double* __restrict__ Xt, int* __restrict__ info, int64_t goff)
+{
+    __shared__ __attribute__((aligned(16))) double Ls[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Ltb[DIAG_LTB];
+    __shared__ __attribute__((aligned(16))) double invd[NB];
+    __shared__ DiagSync sy;
+    __shared__ __attribute__((aligned(16))) double Xw[DIAG_XW_DOUBLES];
+    __shared__ double Rr[NB * 65]; // the right-hand-side rows: Rr[p * 65 + k]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = jb + P;
+    for (int e = threadIdx.x; e < NB * 65; e += DIAG_THREADS)
+        Rr[e] = 0.0;
+    for (int e = threadIdx.x; e < NB * NB; e += DIAG_THREADS) // the identity the short block is padded with; zeros above the diagonal
+        Ls[(e & 63) * XS + (e >> 6)] = (e & 63) == (e >> 6) ? 1.0 : 0.0;
+    __syncthreads();
+    // the jb live columns only (64 jb elements, i + 64 j): every slot's value of TWO elements requested before the first is added,
+    // then the sums in slot order (k_ragged_fold's)
+#pragma unroll 1
+    for (int e0 = 0; e0 < NB * jb; e0 += 2 * DIAG_THREADS) {
+        double v[2][RAGGED_MAX_G], c0[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int e = e0 + u * DIAG_THREADS + (int)threadIdx.x;
+            e = e < NB * jb ? e : NB * jb - 1;
+            const int i = e & 63, j = e >> 6;
+#pragma unroll
+            for (int g = 0; g < RAGGED_MAX_G; ++g)
+                v[u][g] = part[(int64_t)(g < G ? g : G - 1) * (NB * NB) + e];
+            c0[u] = C[(i < m ? i : m - 1) + (int64_t)j * ldc];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = e0 + u * DIAG_THREADS + (int)threadIdx.x;
+            const int i = e & 63, j = e >> 6;
+            double sum = 0.0;
+#pragma unroll
+            for (int g = 0; g < RAGGED_MAX_G; ++g)
+                sum += g < G ? v[u][g] : 0.0;
+            const double val = c0[u] - sum;
+            if (e < NB * jb && i < m && i >= j) {
+                if (i < jb)
+                    Ls[i * XS + j] = val;
+                else
+                    Rr[(i - jb) * 65 + j] = val;
+            }
+        }
+    }
+    diag_flow_init(&sy);
+    __syncthreads();
+    diag_flow(Ls, Ltb, invd, &sy, Lscr, NB, Xt, info, goff, w, lane, Xw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores of L and X^T are acknowledged
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += DIAG_THREADS) {
+        const int i = e & 63, j = e >> 6;
+        if (i < jb && j <= i)
+            C[i + (int64_t)j * ldc] = __hip_atomic_load(Lscr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // z[p][c] = sum_k r[p][k] X[c][k]   (X^T[k + 64 c], staged through LDS: Ls is free; zero above the diagonal)
+    if (P > 0) {
+        for (int e = threadIdx.x; e < NB * NB; e += DIAG_THREADS)
+            Ls[(e >> 6) * XS + (e & 63)] = __hip_atomic_load(Xt + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // Ls[c][k]
+        __syncthreads();
+        for (int e = threadIdx.x; e < P * NB; e += DIAG_THREADS) {
+            const int c = e & 63, p = e >> 6;
+            if (c < jb) {
+                double z = 0.0;
+                for (int k = 0; k <= c; ++k)
+                    z = fma(Rr[p * 65 + k], Ls[c * XS + k], z);
+                C[jb + p + (int64_t)c * ldc] = z;
+            }
+        }
+    }
+}
+bool launch_ragged_finish(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t ld, int64_t jb, int64_t P, int64_t k,
+                          double* scratch, int64_t scratch_doubles, double* Xt, int* info, int64_t goff)
+{
+    const int64_t m = jb + P;
+    if (g_batch.bt || g_batch.G != 1 || jb < 1 || jb >= NB || P < 0 || m > NB || !scratch || scratch_doubles < 3 * NB * NB)
+        return false;
+    int kc = 0;
+    const int G = ragged_split(k, scratch_doubles - NB * NB, &kc); // (one slot is diag_flow's scratch)
+    if (G < 2)
+        return false;
+    GPE_LAUNCH(k_ragged_partial, dim3((unsigned)G), dim3(256), 0, s, A, ld, (int)m, (int)jb, k, kc, scratch);
+    GPE_LAUNCH(k_ragged_finish, dim3(1), dim3(DIAG_THREADS), 0, s, C, ldc, (int)jb, (int)P, G, (const double*)scratch,
+               scratch + (int64_t)G * (NB * NB), Xt, info, goff);
+    return true;
+}
 // false: not this shape (the caller takes the general product)
 bool launch_ragged_update(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t ld, int64_t m, int64_t n, int64_t k,
                           double* scratch, int64_t scratch_doubles)

@@ -247,6 +247,15 @@ void potrf_blocked(gpe_ctx* c, double* A, int64_t N, int64_t M)
                 // ONE tile with k up to 2816: dealt to up to 32 workgroups + an ordered fold (potrf.hip); its scratch is the pair of polled
                 // buffers the closing launch has just used — dead until the next launch arms all of them again
                 double* const used = c->dTail + ((c->tail_count - 1) & 1) * c->tail_cap;
+                // ... and factored, inverted and its right-hand-side rows solved by the same two launches where that form serves
+                // (GPE_RAGGED_FINISH=0: the update alone, then the panel code below)
+                static const bool finish = !(getenv("GPE_RAGGED_FINISH") && atoi(getenv("GPE_RAGGED_FINISH")) == 0);
+                // (one workgroup adds the slots up here: worth it while the block is narrow — N = 520 0.156 -> 0.149 ms, 1100 0.269 ->
+                // 0.258; from ~40 columns on the sixteen workgroups of k_ragged_fold are quicker than the launches they cost)
+                if (finish && !c->prof && N - N64 <= 40
+                    && launch_ragged_finish(s, g.C, ld, g.A, ld, N - N64, M - N, g.k, used, pl.need_tail, c->dXinv + (N64 / NB) * (NB * NB),
+                                            c->dInfo, N64))
+                    break;
                 if (!launch_ragged_update(s, g.C, ld, g.A, ld, g.m, g.n, g.k, used, pl.need_tail))
                     launch_gemm_sub(s, g);
             }

@@ -515,7 +515,7 @@ def _switch_memo_dir(tmp_path_factory):
                                  {"GPE_FLOW_PARTITIONS": "0", "GPE_FLOW_XCD": "0", "GPE_FLOW_GATE": "0"},
                                  {"GPE_STREAM_PRIO": "0", "GPE_TAIL_GEN": "0", "GPE_TRACE": "1", "GPE_ROCTX": "1"},
                                  {"GPE_BATCH_SPLIT": "0", "GPE_BATCH_TAIL_TILES": "0", "GPE_BATCH_TAIL_MAX": "512"}, {"GPE_BATCH": "0"},
-                                 {"GPE_SWEEP_M": "0", "GPE_XPROC_LOCK": "0", "GPE_TRI_MAP": "0"}],
+                                 {"GPE_SWEEP_M": "0", "GPE_XPROC_LOCK": "0", "GPE_TRI_MAP": "0", "GPE_RAGGED_FINISH": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_process_wide_switches(env, tmp_path_factory):
     """Switches that are read once per process (the blocked point-query solve, the in-panel substitution chain for K^-1; round 3:
