@@ -92,21 +92,21 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow_mp(const double* __re
         const int64_t t0 = tt * NB;
         const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
         const int kc = lane < tb ? lane : tb - 1;
-        const double rowmask = lane < tb ? 1.0 : 0.0;
 #pragma unroll
-        for (int q = 0; q < FQ; ++q) {
+        for (int q = 0; q < FQ; ++q) { // (the ragged tile's mask: in fold, where the tile is used — sweep2.hip says why)
             const int c = wvu + FW * q;
             const int cc = c < jb ? c : jb - 1;
             const double* col = L + t0 + (j0 + cc) * ld;
-            dst[q] = col[kc] * (c < jb ? rowmask : 0.0);
+            dst[q] = col[kc];
         }
         peek = __hip_atomic_load((const unsigned long long*)(ap + t0 + kc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto fold = [&](const double (&src)[FQ], unsigned long long peek, int64_t t) {
         __syncthreads(); // Stg / xs / part_s of the previous contributor are consumed
+        const double rowmask = lane < ((N - t * NB < NB) ? (int)(N - t * NB) : NB) ? 1.0 : 0.0;
 #pragma unroll
         for (int q = 0; q < FQ; ++q)
-            Stg[(wv + FW * q) * LSTR + lane] = src[q]; // Stg[c][k]
+            Stg[(wv + FW * q) * LSTR + lane] = src[q] * (wvu + FW * q < jb ? rowmask : 0.0); // Stg[c][k]
         if (wvu < NP) {
             const int64_t t0 = t * NB;
             const int tb = (int)((N - t0 < NB) ? N - t0 : NB);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_fwd_flow_mp(const double* __re
 #pragma unroll
         for (int q = 0; q < FQ; ++q) {
             const double* col = L + j0 + (t0 + wvu + FW * q) * ld;
-            dst[q] = col[rc] * rowmask;
+            dst[q] = col[rc]; // (masked where it is used, below)
         }
         peek = __hip_atomic_load((const unsigned long long*)(yp + t0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_fwd_flow_mp(const double* __re
         for (int q = 0; q < FQ; ++q) {
 #pragma unroll
             for (int p = 0; p < NP; ++p)
-                acc[p] = fma(src[q], xs[p][wvu + FW * q], acc[p]);
+                acc[p] = fma(src[q] * rowmask, xs[p][wvu + FW * q], acc[p]);
         }
 #pragma unroll
         for (int p = 0; p < NP; ++p)
