@@ -87,11 +87,20 @@ __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L
         }
     };
     // left operand <- X_i (lower triangular, explicit zeros above the diagonal)
+    // (Round 6: every load of a staging pass unconditional and in flight together, the zero written where the value is used —
+    // `cond ? load : 0` made a predicated load with a wait of its own of each: sixteen memory round trips per 64 x 64 tile,
+    // 73 us for the launch; profiles/r06_inv_panels.log.)
     auto stage_X = [&](int i) {
         const double* Xt = Xt_all + (gb0 + i) * (NB * NB);
-        for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            v[q] = Xt[threadIdx.x + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = threadIdx.x + 256 * q;
             const int kk = e & 63, row = e >> 6; // Xt[kk + 64 row] = X[row][kk]
-            As[kk * AST + row] = (row >= kk) ? Xt[e] : 0.0;
+            As[kk * AST + row] = (row >= kk) ? v[q] : 0.0;
         }
     };
     // left operand <- L tile (block row i, block column k of the panel); rows past N read as zero (rows N.. of the
@@ -99,10 +108,15 @@ __global__ __launch_bounds__(256) void k_inv_panels(const double* __restrict__ L
     auto stage_L = [&](int i, int k) {
         const double* Lt = L + (o0 + (int64_t)i * NB) + (o0 + (int64_t)k * NB) * ld;
         const int64_t rmax = N - (o0 + (int64_t)i * NB); // valid rows in this block
-        for (int e = threadIdx.x; e < NB * NB; e += 256) {
-            const int row = e & 63, kk = e >> 6;
-            As[kk * AST + row] = (row < rmax) ? Lt[row + (int64_t)kk * ld] : 0.0;
-        }
+        const int row = threadIdx.x & 63, k0 = threadIdx.x >> 6;
+        const int rc = row < rmax ? row : (int)(rmax > 0 ? rmax - 1 : 0);
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            v[q] = Lt[rc + (int64_t)(k0 + 4 * q) * ld];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            As[(k0 + 4 * q) * AST + row] = (row < rmax) ? v[q] : 0.0;
     };
     const double zero[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     for (int i = 0; i < s; ++i)

@@ -59,7 +59,7 @@ struct SymStep {
     double flops = 0.0;
 };
 struct SymPlan {
-    int prefix_steps = 0; // the first product launch of the lowest tree level (inv2_run, part 1)
+    int prefix_steps = 0; // the product launches of the lowest tree level (inv2_run, part 1)
     int nslots = 0;       // counter words: one per tile whose k range is cut
     std::vector<SymItem> items;
     std::vector<int32_t> bin_start; // per step: bins + 1 entries (absolute item indices)
@@ -248,9 +248,10 @@ void build(SymPlan& pl, int64_t N, int64_t ld, int nbins, double load, int membe
                 }
         }
         emit(pl, w_prods, ld, nbins, load, TILE, no_chunk);
-        if (h == 1)
-            pl.prefix_steps = (int)pl.steps.size();
         emit(pl, u_prods, ld, nbins, load, TILE, no_chunk);
+        if (h == 1) // (round 6: both launches of the lowest level — k_inv_panels in front of them went 73 -> 44 us, the second one fits
+            // beside the sweep too: profiles/r06_inv_panels.log)
+            pl.prefix_steps = (int)pl.steps.size();
     }
     // K^-1[i, j] = sum_{k >= i} U[i, k] U[j, k], i >= j
     std::vector<Prod> k_prods;
