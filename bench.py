@@ -440,6 +440,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if dist is not None:
+        # the collectives of the timed region once outside it: the first all_gather / all_reduce of a process group loads RCCL's
+        # kernels and sets up its channels (milliseconds — 10 % of a 20-step region, profiles/r06_bench_ranks.log), which is
+        # warm-up, not arg-max
+        argmax([0.0], [theta])
+        max_over_ranks(0.0)
     sync()
     t0 = time.perf_counter()
     ll = 0.0
