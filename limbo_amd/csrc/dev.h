@@ -101,16 +101,22 @@ static __device__ __forceinline__ double kfun(int kind, double z, double sf2)
 // for the forward sweep, nblk-1-s for the backward one); only the one that sits on the XCD owning that block's
 // contiguous range of the chain works, the other seven return at once (-1).
 #define GPE_FLOW_SPIN_LIMIT (1 << 22) // bounded poll: ~a second; raises *err, and the host re-runs block by block
-static __device__ __forceinline__ int64_t flow_block_of(int64_t nblk, bool backward)
+// (bx of gx: the workgroup's place in ITS chain's grid — blockIdx.x of gridDim.x for a single GP; a batched sweep interleaves its
+// members' chains in one 1-D grid, batch.hpp / solve.hip)
+static __device__ __forceinline__ int64_t flow_block_of_at(int64_t nblk, bool backward, int64_t bx, int64_t gx)
 {
-    if ((int64_t)gridDim.x == nblk) // plain form (GPE_FLOW_XCD=0): chain position = dispatch position, no XCD locality
-        return backward ? nblk - 1 - (int64_t)blockIdx.x : (int64_t)blockIdx.x;
-    const int64_t s = blockIdx.x >> 3;
-    const int64_t x = blockIdx.x & 7;
+    if (gx == nblk) // plain form (GPE_FLOW_XCD=0, batched sweeps): chain position = dispatch position, no XCD locality
+        return backward ? nblk - 1 - bx : bx;
+    const int64_t s = bx >> 3;
+    const int64_t x = bx & 7;
     const int64_t j = backward ? nblk - 1 - s : s;
     const int64_t q = nblk / 8, r = nblk % 8, split = r * (q + 1);
     const int64_t owner = j < split ? j / (q + 1) : r + (j - split) / (q > 0 ? q : 1);
     return x == owner ? j : -1;
+}
+static __device__ __forceinline__ int64_t flow_block_of(int64_t nblk, bool backward)
+{
+    return flow_block_of_at(nblk, backward, (int64_t)blockIdx.x, (int64_t)gridDim.x);
 }
 unsigned flow_grid(int64_t nblk); // 8 nblk (XCD-local chains) or nblk (GPE_FLOW_XCD=0)
 #define GPE_FLOW_GRID(nblk) flow_grid(nblk)

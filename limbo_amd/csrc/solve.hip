@@ -218,7 +218,7 @@ static __device__ __forceinline__ void trsv_bwd_flow_body(const double* __restri
                                                            const double* __restrict__ Xt_all, const double* __restrict__ y,
                                                            int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
                                                            int* __restrict__ err, const double* __restrict__ om,
-                                                           int64_t ldom, double* __restrict__ part, int part_acc)
+                                                           int64_t ldom, double* __restrict__ part, int part_acc, int64_t bx, int64_t gx)
 {
     __shared__ double Stg[NB * LSTR];
     __shared__ double xs[NB];
@@ -228,7 +228,7 @@ static __device__ __forceinline__ void trsv_bwd_flow_body(const double* __restri
     const int wvu = __builtin_amdgcn_readfirstlane(wv); // the same value, known to be wave-uniform
     const int64_t nblk = (N + NB - 1) / NB;
     // workgroup -> unknown block: dependencies only on lower blockIdx.x, consecutive blocks on one XCD (dev.h)
-    const int64_t j = flow_block_of(nblk, true);
+    const int64_t j = flow_block_of_at(nblk, true, bx, gx);
     if (j < 0)
         return;
     const int64_t j0 = j * NB;
@@ -401,8 +401,13 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow(const double* __restr
                                                        int* __restrict__ err, const double* __restrict__ om,
                                                        int64_t ldom, double* __restrict__ part, int part_acc)
 {
-    trsv_bwd_flow_body(L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err, om, ldom, part, part_acc);
+    trsv_bwd_flow_body(L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err, om, ldom, part, part_acc, (int64_t)blockIdx.x, (int64_t)gridDim.x);
 }
+// G members in ONE 1-D grid, position by position: blockIdx.x = position * G + member, every member's chain in the plain form (a
+// workgroup per block: the eight-per-position form of a single GP would put 8 G nblk workgroups through the dispatcher, seven of
+// eight to return at once — 2048 at G = 8, N = 2048, 40 us of a 97 us launch), so that all members' chains advance side by side
+// whatever number of workgroups is resident (member after member, gridDim.z, the second half of a batch of 32 started when the first
+// had finished).  A wait is for a lower position of the same member: a lower-numbered workgroup.
 __global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow_b(const double* __restrict__ L, int64_t ld, int64_t N,
                                                          const double* __restrict__ Xt_all, const double* __restrict__ y,
                                                          int64_t ysi, int64_t ysp, double* a, int64_t ldw, int P,
@@ -410,14 +415,15 @@ __global__ __launch_bounds__(64 * FW) void k_trsv_bwd_flow_b(const double* __res
                                                          int64_t ldom, double* __restrict__ part, int part_acc,
                                                          const BatchTab* __restrict__ bt)
 {
-    BT_REBASE(bt, L);
-    BT_REBASE(bt, Xt_all);
-    BT_REBASE(bt, y);
-    BT_REBASE(bt, a);
-    BT_REBASE(bt, err);
-    BT_REBASE(bt, om);
-    BT_REBASE(bt, part);
-    trsv_bwd_flow_body(L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err, om, ldom, part, part_acc);
+    const int G = bt->G, gp = (int)(blockIdx.x % G);
+    L = bt_rebase(bt, gp, L);
+    Xt_all = bt_rebase(bt, gp, Xt_all);
+    y = bt_rebase(bt, gp, y);
+    a = bt_rebase(bt, gp, a);
+    err = bt_rebase(bt, gp, err);
+    om = bt_rebase(bt, gp, om);
+    part = bt_rebase(bt, gp, part);
+    trsv_bwd_flow_body(L, ld, N, Xt_all, y, ysi, ysp, a, ldw, P, err, om, ldom, part, part_acc, (int64_t)(blockIdx.x / G), (int64_t)(gridDim.x / G));
 }
 
 #ifdef FLOW_TIMING
@@ -455,7 +461,7 @@ void launch_trsv_bwd_flow(hipStream_t s, const double* L, int64_t ld, int64_t N,
         if (pc == 1)
         {
             if (g_batch.bt)
-                GPE_LAUNCH(k_trsv_bwd_flow_b, dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc,
+                GPE_LAUNCH(k_trsv_bwd_flow_b, dim3((unsigned)(nblk * g_batch.G)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc,
                                    ysi, ysp, ac, ldw, 1, err, omc, ldom, part, acc, g_batch.bt);
             else
                 GPE_LAUNCH(k_trsv_bwd_flow, dim3(GPE_FLOW_GRID(nblk)), dim3(64 * FW), 0, s, L, ld, N, Xt_all, yc, ysi, ysp, ac,

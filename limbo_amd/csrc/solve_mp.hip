@@ -331,10 +331,10 @@ void launch_trsv_bwd_flow_mp(hipStream_t s, const double* L, int64_t ld, int64_t
 {
     const unsigned nblk = (unsigned)((N + NB - 1) / NB);
     if (P <= 2)
-        GPE_LAUNCH((k_trsv_bwd_flow_mp<2>), dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi,
+        GPE_LAUNCH((k_trsv_bwd_flow_mp<2>), dim3(g_batch.bt ? (unsigned)nblk : GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi,
                            ysp, a, ldw, P, err, om, ldom, part, part_acc, g_batch.bt);
     else
-        GPE_LAUNCH((k_trsv_bwd_flow_mp<4>), dim3(GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi,
+        GPE_LAUNCH((k_trsv_bwd_flow_mp<4>), dim3(g_batch.bt ? (unsigned)nblk : GPE_FLOW_GRID(nblk), 1, g_batch.G), dim3(64 * FW), 0, s, L, ld, N, Xt_all, y, ysi,
                            ysp, a, ldw, P, err, om, ldom, part, part_acc, g_batch.bt);
 }
 void launch_trsv_fwd_flow_mp(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* Xt_all,
